@@ -1,0 +1,34 @@
+"""Deterministic weight builders shared by the golden generator and the tests
+(pure functions of a seed, built on eav_amd.synth - no reference code)."""
+import numpy as np
+
+from eav_amd import synth
+
+
+def eegnet_weights(seed, samples, chans=30, klen=300, F1=8, D=8, F2=64, nb=5, scale=1.0):
+    nflat = F2 * (samples // 4 // 8)
+    u = synth.uniform
+
+    def ku(s, shape, fan_in):
+        b = 1.0 / np.sqrt(fan_in)
+        return u(s, shape, -b, b) * np.float32(scale)
+
+    return {
+        "firstConv.weight": ku(seed + 1, (F1, 1, 1, klen), klen),
+        "firstBN.weight": u(seed + 2, (F1,), 0.8, 1.2),
+        "firstBN.bias": u(seed + 3, (F1,), -0.1, 0.1),
+        "depthwiseConv.weight": ku(seed + 4, (F1 * D, 1, chans, 1), chans),
+        "depthwiseBN.weight": u(seed + 5, (F1 * D,), 0.8, 1.2),
+        "depthwiseBN.bias": u(seed + 6, (F1 * D,), -0.1, 0.1),
+        "separableConv.weight": ku(seed + 7, (F2, F1 * D, 1, 16), F1 * D * 16),
+        "separableBN.weight": u(seed + 8, (F2,), 0.8, 1.2),
+        "separableBN.bias": u(seed + 9, (F2,), -0.1, 0.1),
+        "dense.weight": ku(seed + 10, (nb, nflat), nflat),
+        "dense.bias": ku(seed + 11, (nb,), nflat),
+        "firstBN.running_mean": u(seed + 12, (F1,), -0.05, 0.05),
+        "firstBN.running_var": u(seed + 13, (F1,), 0.5, 1.5),
+        "depthwiseBN.running_mean": u(seed + 14, (F1 * D,), -0.05, 0.05),
+        "depthwiseBN.running_var": u(seed + 15, (F1 * D,), 0.5, 1.5),
+        "separableBN.running_mean": u(seed + 16, (F2,), -0.05, 0.05),
+        "separableBN.running_var": u(seed + 17, (F2,), 0.5, 1.5),
+    }

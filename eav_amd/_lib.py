@@ -1,0 +1,106 @@
+"""ctypes binding of libeav_hip.so (the C ABI declared in include/eav_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing or a symbol
+cannot be resolved the import of the calling module fails loudly, and every
+call checks the integer status and raises ``EavError`` with the library's own
+message.  PyTorch is used only to own device memory and streams; tensors cross
+the boundary as raw device pointers (``Tensor.data_ptr()``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libeav_hip.so")
+
+
+class EavError(RuntimeError):
+    pass
+
+
+_p = C.c_void_p
+_i = C.c_int
+_i64 = C.c_int64
+_u64 = C.c_uint64
+_f = C.c_float
+_d = C.c_double
+
+# name -> argtypes (all return an int status)
+SIGNATURES = {
+    "eav_reduce_partials": [_p, _i, _i64, _i, _f, _p, _p],
+    "eav_bn_finalize": [_p, _i, _i, _d, _p, _p, _p, _p, _i, _f, _f, _p, _p, _p, _p, _p],
+    "eav_bn_bwd_finalize": [_p, _i, _i, _d, _i, _p, _p, _p, _p, _p],
+    "eav_renorm_rows": [_p, _i, _i, _f, _p],
+    "eav_eegnet_fir_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "eav_eegnet_fir_wgrad": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "eav_eegnet_dw_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _p],
+    "eav_eegnet_dw_bwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
+    "eav_bn_elu_pool_fwd": [_p, _p, _p, _i, _i, _i, _i, _f, _u64, _p, _p],
+    "eav_bn_elu_pool_bwd_reduce": [_p, _p, _p, _p, _i, _i, _i, _i, _f, _u64, _p, _p],
+    "eav_bn_elu_pool_bwd_apply": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _u64, _p, _p],
+    "eav_conv64_prep_weights": [_p, _p, _p, _p],
+    "eav_conv64_fwd": [_p, _p, _p, _p, _i, _i, _i, _p],
+    "eav_conv64_wgrad": [_p, _p, _p, _i, _i, _i, _p],
+    "eav_dense_softmax_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _p],
+    "eav_dense_softmax_bwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
+    "eav_ce_fwd_bwd": [_p, _p, _p, _p, _p, _i, _i, _p],
+    "eav_adam_step": [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _i64, _i, _p],
+}
+# helpers that return a plain value (no status)
+PLAIN = {
+    "eav_abi_version": ([], _i),
+    "eav_last_error": ([], C.c_char_p),
+    "eav_eegnet_fir_fwd_nparts": ([_i, _i, _i], _i),
+    "eav_eegnet_fir_wgrad_nparts": ([_i, _i, _i], _i),
+    "eav_conv64_ntiles": ([_i], _i),
+    "eav_conv64_wgrad_nparts": ([_i, _i], _i),
+}
+
+EXPORTS = sorted(list(SIGNATURES) + list(PLAIN))
+
+_lib = None
+
+
+def load():
+    """Load (once) and type the shared library.  Raises EavError if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EavError(
+            f"{LIB_PATH} is missing - the HIP extension is not built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C eav_amd/csrc`). "
+            "There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = _i
+    for name, (args, res) in PLAIN.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = res
+    _lib = lib
+    return lib
+
+
+def ptr(t):
+    """Raw pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise EavError(f"{name} failed ({rc}): {lib.eav_last_error().decode()}")
+
+
+def plain(name, *args):
+    return getattr(load(), name)(*args)

@@ -1,0 +1,77 @@
+// Shared helpers for the gfx950 kernels of libeav_hip.so (wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define EAV_OK 0
+#define EAV_EINVAL (-1)
+#define EAV_ELAUNCH (-2)
+#define EAV_EUNSUPPORTED (-3)
+
+int eav_set_error(int code, const char* fmt, ...);
+
+#define EAV_REQUIRE(cond, ...)                                   \
+  do {                                                           \
+    if (!(cond)) return eav_set_error(EAV_EINVAL, __VA_ARGS__);  \
+  } while (0)
+
+#define EAV_CHECK_LAUNCH(name)                                                        \
+  do {                                                                                \
+    hipError_t e__ = hipGetLastError();                                               \
+    if (e__ != hipSuccess)                                                            \
+      return eav_set_error(EAV_ELAUNCH, "%s: %s", name, hipGetErrorString(e__));      \
+  } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ELU(alpha=1) as torch computes it (expm1 for v<=0) and its derivative.
+__device__ __forceinline__ float elu_f(float v) { return v > 0.f ? v : expm1f(v); }
+__device__ __forceinline__ float elu_grad_from_out(float v, float a) { return v > 0.f ? 1.f : a + 1.f; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// sum over the 32 lanes of each wave half (lanes 0-31 / 32-63 reduce separately)
+__device__ __forceinline__ float half_sum(float v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Block-wide sum of NV values per thread (256 threads = 4 waves).  red: LDS, >= 4*NV floats.
+// Result valid in thread 0..NV-1 order: returns total of value k in out[k] for threadIdx.x == 0 only
+template <int NV>
+__device__ __forceinline__ void block_sum_256(float (&v)[NV], float* red) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    float s = wave_sum(v[k]);
+    if (lane == 0) red[wave * NV + k] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < NV) {
+    v[0] = red[threadIdx.x] + red[NV + threadIdx.x] + red[2 * NV + threadIdx.x] + red[3 * NV + threadIdx.x];
+  }
+  __syncthreads();
+}
+
+// counter-based dropout keep decision: pure function of (seed, element index)
+__device__ __forceinline__ uint32_t eav_hash32(uint64_t seed, uint64_t idx) {
+  uint64_t z = seed + (idx + 1) * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (uint32_t)(z >> 40);  // 24 random bits
+}
+// returns the multiplier applied to the pooled value: 0 or 1/(1-p); 1 when dropout is off
+__device__ __forceinline__ float dropout_mult(float drop_p, uint64_t seed, const uint8_t* mask, uint64_t idx) {
+  if (drop_p <= 0.f) return 1.f;
+  bool keep = mask ? (mask[idx] != 0) : ((float)eav_hash32(seed, idx) * (1.0f / 16777216.0f) >= drop_p);
+  return keep ? 1.f / (1.f - drop_p) : 0.f;
+}

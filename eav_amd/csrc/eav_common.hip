@@ -1,0 +1,151 @@
+// Error reporting + tiny generic kernels (partial-sum reduction, BatchNorm finalisers).
+#include "eav_common.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "../../include/eav_hip.h"
+
+static thread_local char g_err[512] = "";
+
+int eav_set_error(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+extern "C" const char* eav_last_error(void) { return g_err; }
+extern "C" int eav_abi_version(void) { return EAV_ABI_VERSION; }
+
+// ---------------------------------------------------------------------------------------------
+// out[i] = scale * sum_p part[p*stride + i]   (fp64 accumulation; deterministic order)
+__global__ void reduce_partials_kernel(const float* __restrict__ part, int nparts, int64_t stride, int n,
+                                       float scale, float* __restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s = 0.0;
+  for (int p = 0; p < nparts; ++p) s += (double)part[(int64_t)p * stride + i];
+  out[i] = (float)(s * (double)scale);
+}
+
+extern "C" int eav_reduce_partials(const float* part, int nparts, int64_t stride, int n, float scale, float* out,
+                                   void* stream) {
+  EAV_REQUIRE(part && out && nparts > 0 && n > 0, "eav_reduce_partials: bad arguments");
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, part, nparts,
+                     stride, n, scale, out);
+  EAV_CHECK_LAUNCH("eav_reduce_partials");
+  return EAV_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm forward finaliser.  part[p][0..nch) = sum x, part[p][nch..2nch) = sum x^2.
+// training: batch mean / biased var normalise; running stats updated with the unbiased var
+// (momentum 0.1 in the reference's nn.BatchNorm2d, EEGNet_tor.py:25,29,38).  eval: running stats.
+// Emits mean, invstd and the fused affine  y = scale*x + shift.
+__global__ void bn_finalize_kernel(const float* __restrict__ part, int nparts, int nch, double count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ rmean, float* __restrict__ rvar, int training, float momentum,
+                                   float eps, float* __restrict__ mean_o, float* __restrict__ invstd_o,
+                                   float* __restrict__ scale_o, float* __restrict__ shift_o) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nch) return;
+  float mean, var;
+  if (training) {
+    double s = 0.0, q = 0.0;
+    for (int p = 0; p < nparts; ++p) {
+      s += (double)part[(int64_t)p * 2 * nch + c];
+      q += (double)part[(int64_t)p * 2 * nch + nch + c];
+    }
+    double m = s / count;
+    double v = q / count - m * m;
+    if (v < 0.0) v = 0.0;
+    mean = (float)m;
+    var = (float)v;
+    double unb = count > 1.0 ? v * (count / (count - 1.0)) : v;
+    rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+    rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+  } else {
+    mean = rmean[c];
+    var = rvar[c];
+  }
+  float invstd = 1.0f / sqrtf(var + eps);
+  float sc = gamma[c] * invstd;
+  mean_o[c] = mean;
+  invstd_o[c] = invstd;
+  scale_o[c] = sc;
+  shift_o[c] = beta[c] - mean * sc;
+}
+
+extern "C" int eav_bn_finalize(const float* part, int nparts, int nch, double count, const float* gamma,
+                               const float* beta, float* running_mean, float* running_var, int training,
+                               float momentum, float eps, float* mean, float* invstd, float* scale, float* shift,
+                               void* stream) {
+  EAV_REQUIRE(nch > 0 && gamma && beta && running_mean && running_var && mean && invstd && scale && shift,
+              "eav_bn_finalize: bad arguments");
+  EAV_REQUIRE(!training || (part && nparts > 0 && count > 0), "eav_bn_finalize: training needs partials");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(nch, 64)), dim3(64), 0, (hipStream_t)stream, part, nparts, nch,
+                     count, gamma, beta, running_mean, running_var, training, momentum, eps, mean, invstd, scale,
+                     shift);
+  EAV_CHECK_LAUNCH("eav_bn_finalize");
+  return EAV_OK;
+}
+
+// BatchNorm backward finaliser.  part[p][0..nch) = sum g, part[p][nch..2nch) = sum g*xhat
+// (g = gradient w.r.t. the BN output).  dbeta = sum g, dgamma = sum g*xhat; in training mode the
+// input gradient is scale*(g - m1 - xhat*m2) with m1 = mean g, m2 = mean g*xhat; in eval mode
+// (running statistics are constants) m1 = m2 = 0.
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nparts, int nch, double count,
+                                       int training, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                       float* __restrict__ m1, float* __restrict__ m2) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nch) return;
+  double s = 0.0, q = 0.0;
+  for (int p = 0; p < nparts; ++p) {
+    s += (double)part[(int64_t)p * 2 * nch + c];
+    q += (double)part[(int64_t)p * 2 * nch + nch + c];
+  }
+  dbeta[c] = (float)s;
+  dgamma[c] = (float)q;
+  m1[c] = training ? (float)(s / count) : 0.f;
+  m2[c] = training ? (float)(q / count) : 0.f;
+}
+
+extern "C" int eav_bn_bwd_finalize(const float* part, int nparts, int nch, double count, int training,
+                                   float* dgamma, float* dbeta, float* m1, float* m2, void* stream) {
+  EAV_REQUIRE(part && nparts > 0 && nch > 0 && count > 0 && dgamma && dbeta && m1 && m2,
+              "eav_bn_bwd_finalize: bad arguments");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(nch, 64)), dim3(64), 0, (hipStream_t)stream, part, nparts,
+                     nch, count, training, dgamma, dbeta, m1, m2);
+  EAV_CHECK_LAUNCH("eav_bn_bwd_finalize");
+  return EAV_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Tensor.renorm_(p=2, dim=0, maxnorm) on a [rows, cols] matrix (EEGNet_tor.py:34,48):
+// rows with ||w||_2 > maxnorm are scaled by maxnorm / (norm + 1e-7).
+__global__ void renorm_rows_kernel(float* __restrict__ w, int rows, int cols, float maxnorm) {
+  __shared__ float red[8];
+  int r = blockIdx.x;
+  float* row = w + (int64_t)r * cols;
+  float v[1] = {0.f};
+  for (int i = threadIdx.x; i < cols; i += 256) v[0] += row[i] * row[i];
+  block_sum_256<1>(v, red);
+  __shared__ float sc;
+  if (threadIdx.x == 0) {
+    float norm = sqrtf(v[0]);
+    sc = norm > maxnorm ? maxnorm / (norm + 1e-7f) : 1.f;
+  }
+  __syncthreads();
+  float s = sc;
+  if (s != 1.f)
+    for (int i = threadIdx.x; i < cols; i += 256) row[i] *= s;
+}
+
+extern "C" int eav_renorm_rows(float* w, int rows, int cols, float maxnorm, void* stream) {
+  EAV_REQUIRE(w && rows > 0 && cols > 0, "eav_renorm_rows: bad arguments");
+  hipLaunchKernelGGL(renorm_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, w, rows, cols, maxnorm);
+  EAV_CHECK_LAUNCH("eav_renorm_rows");
+  return EAV_OK;
+}

@@ -1,0 +1,342 @@
+// EEGNet element-wise / reduction kernels around the three convolutions (HBM-bound, fp32).
+//
+//  dw_fwd   : firstBN -> ELU -> depthwiseConv (30 channels -> D=8 per filter)   EEGNet_tor.py:52-54
+//  pool_fwd : BN -> ELU -> AvgPool(1,P) -> Dropout                               :55-58 / :60-63
+//  pool_bwd : backward of pool_fwd (two passes: BN-backward sums, then apply)
+//  dw_bwd   : backward of dw_fwd: depthwise weight grad, g = dL/d(firstBN out), BN-backward sums
+// All tensors are channels-first, time innermost; lanes run along time, 16 B per lane where the
+// row length allows (row bases are then 16-B aligned), scalar fallback otherwise.
+#include "eav_common.h"
+#include "../../include/eav_hip.h"
+
+namespace {
+
+constexpr int F1 = 8, DD = 8, CHMAX = 32;
+
+__device__ __forceinline__ void ld4(const float* p, int i, int n, bool vec, float (&v)[4]) {
+  if (vec && i + 3 < n) {
+    float4 a = *reinterpret_cast<const float4*>(p + i);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (i + e < n) ? p[i + e] : 0.f;
+  }
+}
+__device__ __forceinline__ void st4(float* p, int i, int n, bool vec, const float (&v)[4]) {
+  if (vec && i + 3 < n) {
+    *reinterpret_cast<float4*>(p + i) = make_float4(v[0], v[1], v[2], v[3]);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (i + e < n) p[i + e] = v[e];
+  }
+}
+
+// ------------------------------------------------------------------------------------- dw_fwd
+// grid (nchunk, F1, B); block 256 threads x 4 samples = 1024 samples of one (b, f).
+// z[b, f*8+d, t] = sum_c w2[f*8+d, c] * ELU(scale1[f]*y1[b,f,c,t] + shift1[f])
+// part[(b*nchunk+chunk)][2*64]: per-channel sum z / sum z^2 (slots of this block's 8 channels).
+__global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ y1, const float* __restrict__ bn1,
+                                                     const float* __restrict__ w2, float* __restrict__ z,
+                                                     float* __restrict__ part, int C, int S) {
+  __shared__ float wsh[DD * CHMAX];
+  __shared__ float red[4 * 16];
+  const int chunk = blockIdx.x, f = blockIdx.y, b = blockIdx.z;
+  for (int i = threadIdx.x; i < DD * C; i += 256) wsh[i] = w2[f * DD * C + i];
+  __syncthreads();
+  const float sc = bn1[16 + f], sh = bn1[24 + f];  // layout: mean, invstd, scale, shift (8 each)
+  const bool vec = (S & 3) == 0;
+  const int t = chunk * 1024 + threadIdx.x * 4;
+  float acc[DD][4];
+#pragma unroll
+  for (int d = 0; d < DD; ++d)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[d][e] = 0.f;
+  if (t < S) {
+    const float* src = y1 + ((int64_t)b * F1 + f) * C * S;
+    for (int c = 0; c < C; ++c) {
+      float v[4];
+      ld4(src + (int64_t)c * S, t, S, vec, v);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = elu_f(sc * v[e] + sh);
+#pragma unroll
+      for (int d = 0; d < DD; ++d) {
+        const float w = wsh[d * C + c];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[d][e] += w * v[e];
+      }
+    }
+  }
+  float st[16];
+#pragma unroll
+  for (int d = 0; d < DD; ++d) {
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v = (t + e < S) ? acc[d][e] : 0.f;
+      s += v;
+      q += v * v;
+    }
+    st[d] = s;
+    st[8 + d] = q;
+    if (t < S) st4(z + ((int64_t)b * F1 * DD + f * DD + d) * S, t, S, vec, acc[d]);
+  }
+  block_sum_256<16>(st, red);
+  if (threadIdx.x < 16) {
+    const int nch = F1 * DD;
+    float* dst = part + ((int64_t)b * gridDim.x + chunk) * 2 * nch;
+    const int d = threadIdx.x & 7;
+    dst[(threadIdx.x < 8 ? 0 : nch) + f * DD + d] = st[0];
+  }
+}
+
+// ------------------------------------------------------------------------------------ pool_fwd
+// one block per (b, ch) row: out[b,ch,to] = drop * mean_{j<P} ELU(scale*in[b,ch,to*P+j] + shift)
+template <int P>
+__global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__ in, const float* __restrict__ bn,
+                                                       float* __restrict__ out, int CH, int T, float drop_p,
+                                                       uint64_t seed, const uint8_t* __restrict__ mask) {
+  const int row = blockIdx.x, ch = row % CH;
+  const float sc = bn[2 * CH + ch], sh = bn[3 * CH + ch];
+  const int To = T / P;
+  const float* src = in + (int64_t)row * T;
+  const bool vec = (T & 3) == 0;
+  for (int to = threadIdx.x; to < To; to += 256) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < P; j += 4) {
+      float v[4];
+      ld4(src, to * P + j, T, vec, v);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s += elu_f(sc * v[e] + sh);
+    }
+    const uint64_t oi = (uint64_t)row * To + to;
+    out[oi] = s * (1.0f / P) * dropout_mult(drop_p, seed, mask, oi);
+  }
+}
+
+// ------------------------------------------------------------------------------------ pool_bwd
+// g[b,ch,t] = dp[b,ch,t/P]/P * drop * ELU'(v),  v = scale*u + shift,  (0 for the dropped tail)
+// pass 1: part[b][ch] = sum_t g, part[b][CH+ch] = sum_t g*uhat
+template <int P>
+__global__ __launch_bounds__(256) void pool_bwd_reduce_kernel(const float* __restrict__ dp,
+                                                              const float* __restrict__ u,
+                                                              const float* __restrict__ bn, float* __restrict__ part,
+                                                              int CH, int T, float drop_p, uint64_t seed,
+                                                              const uint8_t* __restrict__ mask) {
+  __shared__ float red[8];
+  const int row = blockIdx.x, ch = row % CH, b = row / CH;
+  const float mean = bn[ch], invstd = bn[CH + ch], sc = bn[2 * CH + ch], sh = bn[3 * CH + ch];
+  const int To = T / P;
+  const float* src = u + (int64_t)row * T;
+  const bool vec = (T & 3) == 0;
+  float st[2] = {0.f, 0.f};
+  for (int to = threadIdx.x; to < To; to += 256) {
+    const uint64_t oi = (uint64_t)row * To + to;
+    const float go = dp[oi] * (1.0f / P) * dropout_mult(drop_p, seed, mask, oi);
+#pragma unroll
+    for (int j = 0; j < P; j += 4) {
+      float v[4];
+      ld4(src, to * P + j, T, vec, v);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float pre = sc * v[e] + sh;
+        const float g = go * elu_grad_from_out(pre, elu_f(pre));
+        st[0] += g;
+        st[1] += g * ((v[e] - mean) * invstd);
+      }
+    }
+  }
+  block_sum_256<2>(st, red);
+  if (threadIdx.x < 2) part[(int64_t)b * 2 * CH + threadIdx.x * CH + ch] = st[0];
+}
+
+// pass 2: du = scale*(g - m1 - uhat*m2) for every t < T (tail included: g = 0 there)
+template <int P>
+__global__ __launch_bounds__(256) void pool_bwd_apply_kernel(const float* __restrict__ dp,
+                                                             const float* __restrict__ u,
+                                                             const float* __restrict__ bn,
+                                                             const float* __restrict__ m12, float* __restrict__ du,
+                                                             int CH, int T, float drop_p, uint64_t seed,
+                                                             const uint8_t* __restrict__ mask) {
+  const int row = blockIdx.x, ch = row % CH;
+  const float mean = bn[ch], invstd = bn[CH + ch], sc = bn[2 * CH + ch], sh = bn[3 * CH + ch];
+  const float m1 = m12[ch], m2 = m12[CH + ch];
+  const int To = T / P;
+  const float* src = u + (int64_t)row * T;
+  float* dst = du + (int64_t)row * T;
+  const bool vec = (T & 3) == 0;
+  for (int q = threadIdx.x; q < (T + 3) / 4; q += 256) {
+    const int t = 4 * q;
+    const int to = t / P;  // 4 | P: the quad lies inside one pooling window
+    float go = 0.f;
+    if (to < To) {
+      const uint64_t oi = (uint64_t)row * To + to;
+      go = dp[oi] * (1.0f / P) * dropout_mult(drop_p, seed, mask, oi);
+    }
+    float v[4], o[4];
+    ld4(src, t, T, vec, v);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float pre = sc * v[e] + sh;
+      const float g = go * elu_grad_from_out(pre, elu_f(pre));
+      o[e] = sc * (g - m1 - (v[e] - mean) * invstd * m2);
+    }
+    st4(dst, t, T, vec, o);
+  }
+}
+
+// -------------------------------------------------------------------------------------- dw_bwd
+// grid (nchunk, F1, B) as dw_fwd.  For every (c, t):
+//   v = scale1*y1 + shift1, a1 = ELU(v), da1 = sum_d w2[f*8+d,c]*dz[b,f*8+d,t], g = da1*ELU'(v)
+//   g1[b,f,c,t] = g;  stats: sum g, sum g*yhat;  dW2[f*8+d,c] += sum_t dz[d,t]*a1[c,t]
+// part_st[(b*nchunk+chunk)][2*8] (slot f), part_w[(b*nchunk+chunk)][64*C] (this block's 8*C slice)
+__global__ __launch_bounds__(256) void dw_bwd_kernel(const float* __restrict__ y1, const float* __restrict__ dz,
+                                                     const float* __restrict__ bn1, const float* __restrict__ w2,
+                                                     float* __restrict__ g1, float* __restrict__ part_st,
+                                                     float* __restrict__ part_w, int C, int S) {
+  __shared__ float wsh[DD * CHMAX];
+  __shared__ float red[4 * 8];
+  __shared__ float wacc[4 * DD * CHMAX];
+  const int chunk = blockIdx.x, f = blockIdx.y, b = blockIdx.z;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < DD * C; i += 256) wsh[i] = w2[f * DD * C + i];
+  __syncthreads();
+  const float mean = bn1[f], invstd = bn1[8 + f], sc = bn1[16 + f], sh = bn1[24 + f];
+  const bool vec = (S & 3) == 0;
+  const int t = chunk * 1024 + threadIdx.x * 4;
+  float dzv[DD][4];
+#pragma unroll
+  for (int d = 0; d < DD; ++d) ld4(dz + ((int64_t)b * F1 * DD + f * DD + d) * S, t < S ? t : S, S, vec, dzv[d]);
+  float st[2] = {0.f, 0.f};
+  const int64_t base = ((int64_t)b * F1 + f) * C * S;
+  for (int c = 0; c < C; ++c) {
+    float v[4], g[4], a[4];
+    ld4(y1 + base + (int64_t)c * S, t < S ? t : S, S, vec, v);
+    float wd[DD];
+#pragma unroll
+    for (int d = 0; d < DD; ++d) wd[d] = wsh[d * C + c];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float pre = sc * v[e] + sh;
+      a[e] = elu_f(pre);
+      float da = 0.f;
+#pragma unroll
+      for (int d = 0; d < DD; ++d) da += wd[d] * dzv[d][e];
+      g[e] = da * elu_grad_from_out(pre, a[e]);
+      st[0] += g[e];
+      st[1] += g[e] * ((v[e] - mean) * invstd);
+    }
+    if (t < S) st4(g1 + base + (int64_t)c * S, t, S, vec, g);
+    // depthwise weight gradient: 8 values per thread -> transposing butterfly over the wave
+    float r[DD];
+#pragma unroll
+    for (int d = 0; d < DD; ++d)
+      r[d] = (dzv[d][0] * a[0] + dzv[d][1] * a[1]) + (dzv[d][2] * a[2] + dzv[d][3] * a[3]);
+    // step xor 1: keep 4 values; xor 2: keep 2; xor 4: keep 1; then plain reduce over the rest
+    float r4[4], r2[2], r1;
+    {
+      const bool hi = lane & 1;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float mine = hi ? r[4 + k] : r[k], other = hi ? r[k] : r[4 + k];
+        r4[k] = mine + __shfl_xor(other, 1, 64);
+      }
+    }
+    {
+      const bool hi = lane & 2;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        float mine = hi ? r4[2 + k] : r4[k], other = hi ? r4[k] : r4[2 + k];
+        r2[k] = mine + __shfl_xor(other, 2, 64);
+      }
+    }
+    {
+      const bool hi = lane & 4;
+      float mine = hi ? r2[1] : r2[0], other = hi ? r2[0] : r2[1];
+      r1 = mine + __shfl_xor(other, 4, 64);
+    }
+    r1 += __shfl_xor(r1, 8, 64);
+    r1 += __shfl_xor(r1, 16, 64);
+    r1 += __shfl_xor(r1, 32, 64);
+    // lane l (l < 8) now holds the wave total of d = 4*(l&1) + 2*((l>>1)&1) + ((l>>2)&1)
+    if (lane < 8) {
+      const int d = 4 * (lane & 1) + 2 * ((lane >> 1) & 1) + ((lane >> 2) & 1);
+      wacc[wave * DD * CHMAX + d * C + c] = r1;  // one slot per wave: summed in a fixed order below
+    }
+  }
+  block_sum_256<2>(st, red);
+  if (threadIdx.x < 2) part_st[((int64_t)b * gridDim.x + chunk) * 16 + threadIdx.x * 8 + f] = st[0];
+  __syncthreads();
+  float* dst = part_w + ((int64_t)b * gridDim.x + chunk) * (F1 * DD * C) + f * DD * C;
+  for (int i = threadIdx.x; i < DD * C; i += 256)
+    dst[i] = (wacc[i] + wacc[DD * CHMAX + i]) + (wacc[2 * DD * CHMAX + i] + wacc[3 * DD * CHMAX + i]);
+}
+
+}  // namespace
+
+extern "C" int eav_eegnet_dw_fwd(const float* y1, const float* bn1, const float* w2, float* z, float* stat_part,
+                                 int B, int C, int S, void* stream) {
+  EAV_REQUIRE(y1 && bn1 && w2 && z && stat_part && B > 0 && C > 0 && C <= CHMAX && S > 0,
+              "eav_eegnet_dw_fwd: bad arguments (Chans must be <= %d)", CHMAX);
+  dim3 grid(cdiv(S, 1024), F1, B);
+  hipLaunchKernelGGL(dw_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, y1, bn1, w2, z, stat_part, C, S);
+  EAV_CHECK_LAUNCH("eav_eegnet_dw_fwd");
+  return EAV_OK;
+}
+
+extern "C" int eav_eegnet_dw_bwd(const float* y1, const float* dz, const float* bn1, const float* w2, float* g1,
+                                 float* stat_part, float* w_part, int B, int C, int S, void* stream) {
+  EAV_REQUIRE(y1 && dz && bn1 && w2 && g1 && stat_part && w_part && B > 0 && C > 0 && C <= CHMAX && S > 0,
+              "eav_eegnet_dw_bwd: bad arguments (Chans must be <= %d)", CHMAX);
+  dim3 grid(cdiv(S, 1024), F1, B);
+  hipLaunchKernelGGL(dw_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, y1, dz, bn1, w2, g1, stat_part, w_part,
+                     C, S);
+  EAV_CHECK_LAUNCH("eav_eegnet_dw_bwd");
+  return EAV_OK;
+}
+
+extern "C" int eav_bn_elu_pool_fwd(const float* in, const float* bn, float* out, int B, int CH, int T, int P,
+                                   float drop_p, uint64_t seed, const uint8_t* mask, void* stream) {
+  EAV_REQUIRE(in && bn && out && B > 0 && CH > 0 && T >= P, "eav_bn_elu_pool_fwd: bad arguments");
+  EAV_REQUIRE(P == 4 || P == 8, "eav_bn_elu_pool_fwd: pool %d not in {4,8}", P);
+  EAV_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "eav_bn_elu_pool_fwd: dropout %f outside [0,1)", drop_p);
+  if (P == 4)
+    hipLaunchKernelGGL(pool_fwd_kernel<4>, dim3(B * CH), dim3(256), 0, (hipStream_t)stream, in, bn, out, CH, T,
+                       drop_p, seed, mask);
+  else
+    hipLaunchKernelGGL(pool_fwd_kernel<8>, dim3(B * CH), dim3(256), 0, (hipStream_t)stream, in, bn, out, CH, T,
+                       drop_p, seed, mask);
+  EAV_CHECK_LAUNCH("eav_bn_elu_pool_fwd");
+  return EAV_OK;
+}
+
+extern "C" int eav_bn_elu_pool_bwd_reduce(const float* dp, const float* u, const float* bn, float* part, int B,
+                                          int CH, int T, int P, float drop_p, uint64_t seed, const uint8_t* mask,
+                                          void* stream) {
+  EAV_REQUIRE(dp && u && bn && part && B > 0 && CH > 0 && T >= P, "eav_bn_elu_pool_bwd_reduce: bad arguments");
+  EAV_REQUIRE(P == 4 || P == 8, "eav_bn_elu_pool_bwd_reduce: pool %d not in {4,8}", P);
+  if (P == 4)
+    hipLaunchKernelGGL(pool_bwd_reduce_kernel<4>, dim3(B * CH), dim3(256), 0, (hipStream_t)stream, dp, u, bn, part,
+                       CH, T, drop_p, seed, mask);
+  else
+    hipLaunchKernelGGL(pool_bwd_reduce_kernel<8>, dim3(B * CH), dim3(256), 0, (hipStream_t)stream, dp, u, bn, part,
+                       CH, T, drop_p, seed, mask);
+  EAV_CHECK_LAUNCH("eav_bn_elu_pool_bwd_reduce");
+  return EAV_OK;
+}
+
+extern "C" int eav_bn_elu_pool_bwd_apply(const float* dp, const float* u, const float* bn, const float* m12,
+                                         float* du, int B, int CH, int T, int P, float drop_p, uint64_t seed,
+                                         const uint8_t* mask, void* stream) {
+  EAV_REQUIRE(dp && u && bn && m12 && du && B > 0 && CH > 0 && T >= P, "eav_bn_elu_pool_bwd_apply: bad arguments");
+  EAV_REQUIRE(P == 4 || P == 8, "eav_bn_elu_pool_bwd_apply: pool %d not in {4,8}", P);
+  if (P == 4)
+    hipLaunchKernelGGL(pool_bwd_apply_kernel<4>, dim3(B * CH), dim3(256), 0, (hipStream_t)stream, dp, u, bn, m12, du,
+                       CH, T, drop_p, seed, mask);
+  else
+    hipLaunchKernelGGL(pool_bwd_apply_kernel<8>, dim3(B * CH), dim3(256), 0, (hipStream_t)stream, dp, u, bn, m12, du,
+                       CH, T, drop_p, seed, mask);
+  EAV_CHECK_LAUNCH("eav_bn_elu_pool_bwd_apply");
+  return EAV_OK;
+}

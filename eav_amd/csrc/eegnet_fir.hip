@@ -1,0 +1,264 @@
+// EEGNet temporal FIR (firstConv, K<=300 taps, 1 -> 8 filters) on the gfx950 fp32 matrix cores.
+//
+// Reference op: nn.Conv2d(1, F1=8, (1, kernLength=300), padding='same', bias=False)
+// (CNN_torch/EEGNet_tor.py:24,51) and its weight gradient (autograd of the same call, :109).
+// 'same' with an even kernel pads (K-1)/2 = 149 zeros left and 150 right.
+//
+// Forward as a Toeplitz GEMM on v_mfma_f32_32x32x2_f32 (exact f32 fma chain):
+//   C[(f,s), n] = sum_j A[(f,s), j] * B[j, n]
+//   A[(f,s), j] = w[f, j-s]            (8 filters x 4 shifts = 32 rows, j in [0,304))
+//   B[j, n]     = xpad[t0 + 4n + j]    (32 columns, time stride 4)
+//   => C[(f,s), n] = y[f, t0 + 4n + s]: one 32x32 tile = 8 filters x 128 consecutive samples,
+//   152 MFMAs per tile (300/304 = 98.7 % useful).  A stays in registers for the whole kernel;
+//   B is read from a polyphase (u mod 4) LDS image of the padded input row so that the 32 lanes
+//   of a half-wave hit 32 consecutive banks.  The accumulator layout gives every lane four
+//   consecutive samples of four filters -> float4 stores of y1, coalesced 512 B per half-wave.
+//   BatchNorm batch statistics (sum, sum of squares per filter) are taken in the epilogue.
+//
+// Weight gradient as a GEMM on v_mfma_f32_16x16x4_f32:
+//   C[(f,s), n] = sum_u A[(f,s), u] * B[u, n],  A[(f,s),u] = dy[f, u-s], B[u,n] = xpad[u + 2n]
+//   => C[(f,s), n] = dW[f, k = 2n + s]; 8 filters x 2 shifts = 16 rows, 150 of 160 columns used.
+//   dy (gradient w.r.t. the FIR output) is formed on the fly while staging, from the saved FIR
+//   output y1 and g = dL/d(BN1 output): dy = scale*(g - m1 - yhat*m2)  (BatchNorm backward).
+#include "eav_common.h"
+#include "../../include/eav_hip.h"
+
+namespace {
+
+constexpr int F1 = 8;
+constexpr int NSTEP = 152;        // (300 + 3 shifts -> 304) / 2
+constexpr int TILE = 128;         // samples per MFMA tile
+constexpr int TPS = 16;           // tiles per LDS segment
+constexpr int SEG_M4 = TPS * 32 + 76;  // floats per polyphase plane
+
+// ------------------------------------------------------------------------------------------ fwd
+__global__ __launch_bounds__(256, 2) void fir_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w1,
+                                                         float* __restrict__ y1, float* __restrict__ part, int rows,
+                                                         int C, int S, int klen, int padl, int nseg, int ntiles) {
+  __shared__ __attribute__((aligned(16))) float xs[4 * SEG_M4];
+  __shared__ float red[4 * 16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = lane & 31, kk = lane >> 5;
+
+  // A operand, resident for the whole kernel: row i = f*4 + s, column j = 2p + kk
+  float a[NSTEP];
+  {
+    const int f = n >> 2, s = n & 3;
+#pragma unroll
+    for (int p = 0; p < NSTEP; ++p) {
+      int j = 2 * p + kk - s;
+      a[p] = (j >= 0 && j < klen) ? w1[f * klen + j] : 0.f;
+    }
+  }
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool vec = (S & 3) == 0;
+  const int nwork = rows * nseg;
+  for (int work = blockIdx.x; work < nwork; work += gridDim.x) {
+    const int row = work / nseg, seg = work - row * nseg;
+    const int tile0 = seg * TPS;
+    const int nt = min(TPS, ntiles - tile0);
+    const int useg0 = tile0 * TILE;
+    const float* xrow = x + (int64_t)row * S;
+    // stage the padded segment, polyphase: xs[(u&3)][u>>2], u local to the segment
+    const int nload = nt * TILE + 304;
+    for (int idx = threadIdx.x; idx < nload; idx += 256) {
+      int t = useg0 + idx - padl;
+      float v = (t >= 0 && t < S) ? xrow[t] : 0.f;
+      xs[(idx & 3) * SEG_M4 + (idx >> 2)] = v;
+    }
+    __syncthreads();
+    const int b = row / C, c = row - b * C;
+    for (int tile = wave; tile < nt; tile += 4) {
+      const float* pe = xs + kk * SEG_M4 + tile * 32 + n;
+      const float* po = xs + (2 + kk) * SEG_M4 + tile * 32 + n;
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int p = 0; p < NSTEP; ++p) {
+        float bv = (p & 1) ? po[p >> 1] : pe[p >> 1];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[p], bv, acc, 0, 0, 0);
+      }
+      // C layout: col = lane&31 (n), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) = f*4 + s
+      const int t = useg0 + tile * TILE + 4 * n;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int f = 2 * g + kk;
+        float* dst = y1 + (((int64_t)b * F1 + f) * C + c) * S + t;
+        float v0 = acc[4 * g + 0], v1 = acc[4 * g + 1], v2 = acc[4 * g + 2], v3 = acc[4 * g + 3];
+        if (vec && t + 3 < S) {
+          *reinterpret_cast<float4*>(dst) = make_float4(v0, v1, v2, v3);
+        } else {
+          if (t + 0 < S) dst[0] = v0; else v0 = 0.f;
+          if (t + 1 < S) dst[1] = v1; else v1 = 0.f;
+          if (t + 2 < S) dst[2] = v2; else v2 = 0.f;
+          if (t + 3 < S) dst[3] = v3; else v3 = 0.f;
+        }
+        s1[g] += (v0 + v1) + (v2 + v3);
+        s2[g] += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+      }
+    }
+    __syncthreads();
+  }
+  // per-block partial statistics: lanes of one half hold filters f = 2g + kk
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    float a1 = half_sum(s1[g]), a2 = half_sum(s2[g]);
+    if (n == 0) {
+      red[wave * 16 + 2 * g + kk] = a1;
+      red[wave * 16 + 8 + 2 * g + kk] = a2;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 16)
+    part[blockIdx.x * 16 + threadIdx.x] =
+        (red[threadIdx.x] + red[16 + threadIdx.x]) + (red[32 + threadIdx.x] + red[48 + threadIdx.x]);
+}
+
+// ---------------------------------------------------------------------------------------- wgrad
+constexpr int WG_NT = 10;          // 10 column tiles of 16 -> lags k = 2n+s, n < 160
+constexpr int WG_CHMAX = 1024;     // max time chunk per work item
+constexpr int WG_DYSTRIDE = WG_CHMAX + 4;  // == 4 (mod 32): conflict-free A reads, 16-B aligned rows
+constexpr int WG_XLEN = WG_CHMAX + 320 + 4;
+
+__global__ __launch_bounds__(256, 2) void fir_wgrad_kernel(
+    const float* __restrict__ x, const float* __restrict__ y1, const float* __restrict__ g1,
+    const float* __restrict__ bnp /* mean, invstd, scale, shift, m1, m2 (8 each) */, float* __restrict__ part, int rows,
+    int C, int S, int klen, int padl, int nchunk, int CH) {
+  __shared__ __attribute__((aligned(16))) float dyl[F1 * WG_DYSTRIDE];
+  __shared__ __attribute__((aligned(16))) float xl[WG_XLEN];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane & 15, kq = lane >> 4;
+  const int af = col >> 1, as = col & 1;  // A row i = f*2 + s
+  f32x4 acc[WG_NT];
+#pragma unroll
+  for (int i = 0; i < WG_NT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const bool vec = (S & 3) == 0;
+  const int nwork = rows * nchunk;
+  for (int work = blockIdx.x; work < nwork; work += gridDim.x) {
+    const int row = work / nchunk, chunk = work - row * nchunk;
+    const int c0 = chunk * CH;                 // u range [c0, c0 + CH)
+    const int b = row / C, c = row - b * C;
+    // ---- stage dy[f][4 + (u - c0)], u in [c0-4, c0+CH): dy = scale*(g - m1 - yhat*m2)
+    for (int idx = threadIdx.x; idx < F1 * (CH / 4 + 1); idx += 256) {
+      const int f = idx / (CH / 4 + 1), q = idx - f * (CH / 4 + 1);
+      const int t = c0 - 4 + 4 * q;
+      const int64_t base = (((int64_t)b * F1 + f) * C + c) * S;
+      const float mean = bnp[f], invstd = bnp[8 + f], sc = bnp[16 + f], m1 = bnp[32 + f], m2 = bnp[40 + f];
+      float yv[4], gv[4];
+      if (vec && t >= 0 && t + 3 < S) {
+        float4 a = *reinterpret_cast<const float4*>(y1 + base + t);
+        float4 d = *reinterpret_cast<const float4*>(g1 + base + t);
+        yv[0] = a.x; yv[1] = a.y; yv[2] = a.z; yv[3] = a.w;
+        gv[0] = d.x; gv[1] = d.y; gv[2] = d.z; gv[3] = d.w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) yv[e] = sc * (gv[e] - m1 - (yv[e] - mean) * invstd * m2);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          int te = t + e;
+          if (te >= 0 && te < S) {
+            float yy = y1[base + te], gg = g1[base + te];
+            yv[e] = sc * (gg - m1 - (yy - mean) * invstd * m2);
+          } else {
+            yv[e] = 0.f;
+          }
+        }
+      }
+      *reinterpret_cast<float4*>(&dyl[f * WG_DYSTRIDE + 4 * q]) = make_float4(yv[0], yv[1], yv[2], yv[3]);
+    }
+    // ---- stage xpad[u], u in [c0, c0 + CH + 320)
+    {
+      const float* xrow = x + (int64_t)row * S;
+      for (int idx = threadIdx.x; idx < CH + 320; idx += 256) {
+        int t = c0 + idx - padl;
+        xl[idx] = (t >= 0 && t < S) ? xrow[t] : 0.f;
+      }
+    }
+    __syncthreads();
+    // ---- each wave contracts its quarter of the chunk
+    const int ksteps = CH / 16;
+    const float* ap = dyl + af * WG_DYSTRIDE + 4 + wave * (CH / 4) + kq - as;
+    const float* bp = xl + wave * (CH / 4) + kq + 2 * col;
+    for (int ks = 0; ks < ksteps; ++ks) {
+      float av = ap[4 * ks];
+#pragma unroll
+      for (int nt = 0; nt < WG_NT; ++nt) {
+        float bv = bp[4 * ks + 32 * nt];
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[nt], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  // ---- combine the 4 waves' accumulators through LDS (reuse dyl: 4*16*160 floats = 40 KB > dyl) 
+  // C layout 16x16: col = lane&15, row = (lane>>4)*4 + reg = f*2 + s
+  float* red = dyl;  // 8*1028 = 8224 floats; need 16*160 = 2560 per wave -> reduce wave by wave
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int nt = 0; nt < WG_NT; ++nt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = kq * 4 + r;            // row = f*2 + s
+          const int k = 2 * (16 * nt + col) + (i & 1);
+          const int f = i >> 1;
+          float* dst = red + f * 320 + k;
+          if (w == 0) *dst = acc[nt][r]; else *dst += acc[nt][r];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  for (int idx = threadIdx.x; idx < F1 * klen; idx += 256) {
+    const int f = idx / klen, k = idx - f * klen;
+    part[(int64_t)blockIdx.x * (F1 * klen) + idx] = red[f * 320 + k];
+  }
+}
+
+}  // namespace
+
+static int fir_grid(int nwork) { return nwork < 512 ? nwork : 512; }
+
+extern "C" int eav_eegnet_fir_fwd_nparts(int B, int C, int S) {
+  int ntiles = cdiv(S, TILE), nseg = cdiv(ntiles, TPS);
+  return fir_grid(B * C * nseg);
+}
+
+extern "C" int eav_eegnet_fir_fwd(const float* x, const float* w1, float* y1, float* stat_part, int B, int C, int S,
+                                  int klen, void* stream) {
+  EAV_REQUIRE(x && w1 && y1 && stat_part && B > 0 && C > 0 && S > 0, "eav_eegnet_fir_fwd: bad arguments");
+  EAV_REQUIRE(klen >= 1 && klen <= 300, "eav_eegnet_fir_fwd: kernLength %d outside [1,300]", klen);
+  const int ntiles = cdiv(S, TILE), nseg = cdiv(ntiles, TPS);
+  const int nwork = B * C * nseg;
+  hipLaunchKernelGGL(fir_fwd_kernel, dim3(fir_grid(nwork)), dim3(256), 0, (hipStream_t)stream, x, w1, y1, stat_part,
+                     B * C, C, S, klen, (klen - 1) / 2, nseg, ntiles);
+  EAV_CHECK_LAUNCH("eav_eegnet_fir_fwd");
+  return EAV_OK;
+}
+
+static void wgrad_geometry(int S, int* nchunk, int* CH) {
+  int n = cdiv(S + 1, WG_CHMAX);
+  int ch = cdiv(cdiv(S + 1, n), 16) * 16;
+  *nchunk = n;
+  *CH = ch;
+}
+
+extern "C" int eav_eegnet_fir_wgrad_nparts(int B, int C, int S) {
+  int nchunk, CH;
+  wgrad_geometry(S, &nchunk, &CH);
+  return fir_grid(B * C * nchunk);
+}
+
+// part: [nparts][8][klen] floats; sum over parts = dL/d(firstConv.weight)
+extern "C" int eav_eegnet_fir_wgrad(const float* x, const float* y1, const float* g1, const float* bn_params,
+                                    float* part, int B, int C, int S, int klen, void* stream) {
+  EAV_REQUIRE(x && y1 && g1 && bn_params && part && B > 0 && C > 0 && S > 0, "eav_eegnet_fir_wgrad: bad arguments");
+  EAV_REQUIRE(klen >= 1 && klen <= 300, "eav_eegnet_fir_wgrad: kernLength %d outside [1,300]", klen);
+  int nchunk, CH;
+  wgrad_geometry(S, &nchunk, &CH);
+  const int nwork = B * C * nchunk;
+  hipLaunchKernelGGL(fir_wgrad_kernel, dim3(fir_grid(nwork)), dim3(256), 0, (hipStream_t)stream, x, y1, g1,
+                     bn_params, part, B * C, C, S, klen, (klen - 1) / 2, nchunk, CH);
+  EAV_CHECK_LAUNCH("eav_eegnet_fir_wgrad");
+  return EAV_OK;
+}

@@ -1,0 +1,186 @@
+// Classifier head, loss and optimiser kernels shared by the three encoders.
+//   dense + softmax (EEGNet_tor.py:64-66), cross-entropy with mean reduction
+//   (nn.CrossEntropyLoss: EEGNet_tor.py:81,105; Transformer_Audio.py:31,73; HF ViT loss),
+//   Adam / AdamW single-tensor update (EEGNet_tor.py:82; Transformer_Audio.py:30; Transformer_Vision.py:36).
+#include "eav_common.h"
+#include "../../include/eav_hip.h"
+
+namespace {
+
+constexpr int NCMAX = 16;
+
+// one block per sample: logits[j] = bias[j] + sum_i W[j,i]*in[b,i];  probs = softmax(logits)
+__global__ __launch_bounds__(256) void dense_softmax_fwd_kernel(const float* __restrict__ in,
+                                                                const float* __restrict__ w,
+                                                                const float* __restrict__ bias,
+                                                                float* __restrict__ logits, float* __restrict__ probs,
+                                                                int NF, int NC) {
+  __shared__ float red[4 * NCMAX];
+  const int b = blockIdx.x;
+  const float* src = in + (int64_t)b * NF;
+  float acc[NCMAX];
+#pragma unroll
+  for (int j = 0; j < NCMAX; ++j) acc[j] = 0.f;
+  for (int i = threadIdx.x; i < NF; i += 256) {
+    const float v = src[i];
+#pragma unroll
+    for (int j = 0; j < NCMAX; ++j)
+      if (j < NC) acc[j] += w[(int64_t)j * NF + i] * v;
+  }
+  block_sum_256<NCMAX>(acc, red);
+  __shared__ float lg[NCMAX];
+  if (threadIdx.x < NC) lg[threadIdx.x] = acc[0] + bias[threadIdx.x];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float mx = lg[0];
+    for (int j = 1; j < NC; ++j) mx = fmaxf(mx, lg[j]);
+    float e[NCMAX], s = 0.f;
+    for (int j = 0; j < NC; ++j) { e[j] = expf(lg[j] - mx); s += e[j]; }
+    for (int j = 0; j < NC; ++j) {
+      if (logits) logits[b * NC + j] = lg[j];
+      if (probs) probs[b * NC + j] = e[j] / s;
+    }
+  }
+}
+
+// dlogits from dprobs (softmax backward) or passed through; one thread per input feature i:
+//   dW[j,i] = sum_b dl[b,j]*in[b,i];  din[b,i] = sum_j W[j,i]*dl[b,j];  dbias[j] = sum_b dl[b,j]
+__global__ __launch_bounds__(256) void dense_softmax_bwd_kernel(const float* __restrict__ dout,
+                                                                const float* __restrict__ probs,
+                                                                const float* __restrict__ in,
+                                                                const float* __restrict__ w, float* __restrict__ dw,
+                                                                float* __restrict__ dbias, float* __restrict__ din,
+                                                                int B, int NF, int NC) {
+  extern __shared__ float dl[];  // [B][NC]
+  for (int idx = threadIdx.x; idx < B * NC; idx += 256) {
+    const int b = idx / NC;
+    float v = dout[idx];
+    if (probs) {  // dl = p * (dp - sum_j dp_j p_j)
+      float dot = 0.f;
+      for (int j = 0; j < NC; ++j) dot += dout[b * NC + j] * probs[b * NC + j];
+      v = probs[idx] * (v - dot);
+    }
+    dl[idx] = v;
+  }
+  __syncthreads();
+  if (blockIdx.x == 0 && threadIdx.x < NC) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += dl[b * NC + threadIdx.x];
+    dbias[threadIdx.x] = s;
+  }
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= NF) return;
+  float wv[NCMAX], acc[NCMAX];
+#pragma unroll
+  for (int j = 0; j < NCMAX; ++j) {
+    wv[j] = j < NC ? w[(int64_t)j * NF + i] : 0.f;
+    acc[j] = 0.f;
+  }
+  for (int b = 0; b < B; ++b) {
+    const float v = in[(int64_t)b * NF + i];
+    float d = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCMAX; ++j)
+      if (j < NC) {
+        const float g = dl[b * NC + j];
+        acc[j] += g * v;
+        d += wv[j] * g;
+      }
+    if (din) din[(int64_t)b * NF + i] = d;
+  }
+#pragma unroll
+  for (int j = 0; j < NCMAX; ++j)
+    if (j < NC) dw[(int64_t)j * NF + i] = acc[j];
+}
+
+// mean cross-entropy over B rows of `in` (treated as logits) + gradient (softmax - onehot)/B
+__global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ in, const int64_t* __restrict__ y,
+                                                 float* __restrict__ loss, float* __restrict__ din,
+                                                 int* __restrict__ ncorrect, int B, int NC) {
+  __shared__ float red[8];
+  float st[2] = {0.f, 0.f};
+  for (int b = threadIdx.x; b < B; b += 256) {
+    const float* r = in + (int64_t)b * NC;
+    float mx = r[0];
+    int am = 0;
+    for (int j = 1; j < NC; ++j)
+      if (r[j] > mx) { mx = r[j]; am = j; }
+    float s = 0.f;
+    for (int j = 0; j < NC; ++j) s += expf(r[j] - mx);
+    const float lse = mx + logf(s);
+    const int yy = (int)y[b];
+    st[0] += lse - r[yy];
+    st[1] += (am == yy) ? 1.f : 0.f;
+    if (din)
+      for (int j = 0; j < NC; ++j) din[(int64_t)b * NC + j] = (expf(r[j] - lse) - (j == yy ? 1.f : 0.f)) / (float)B;
+  }
+  block_sum_256<2>(st, red);
+  if (threadIdx.x == 0 && loss) *loss = st[0] / (float)B;
+  if (threadIdx.x == 1 && ncorrect) *ncorrect += (int)(st[0] + 0.5f);
+}
+
+// torch.optim.Adam / AdamW (foreach/fused semantics, fp32 state):
+//   adamw: p *= 1 - lr*wd;  adam: g += wd*p
+//   m = b1*m + (1-b1)*g;  v = b2*v + (1-b2)*g*g;  p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
+                                                   float b1, float b2, float eps, float wd, float bc1,
+                                                   float bc2_sqrt, int decoupled) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    float pv = p[i], gv = g[i];
+    if (wd != 0.f) {
+      if (decoupled) pv *= 1.f - lr * wd; else gv += wd * pv;
+    }
+    const float mv = b1 * m[i] + (1.f - b1) * gv;
+    const float vv = b2 * v[i] + (1.f - b2) * gv * gv;
+    m[i] = mv;
+    v[i] = vv;
+    const float denom = sqrtf(vv) / bc2_sqrt + eps;
+    p[i] = pv - (lr / bc1) * (mv / denom);
+  }
+}
+
+}  // namespace
+
+extern "C" int eav_dense_softmax_fwd(const float* in, const float* w, const float* bias, float* logits, float* probs,
+                                     int B, int NF, int NC, void* stream) {
+  EAV_REQUIRE(in && w && bias && (logits || probs) && B > 0 && NF > 0 && NC > 0 && NC <= NCMAX,
+              "eav_dense_softmax_fwd: bad arguments (classes <= %d)", NCMAX);
+  hipLaunchKernelGGL(dense_softmax_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, in, w, bias, logits, probs,
+                     NF, NC);
+  EAV_CHECK_LAUNCH("eav_dense_softmax_fwd");
+  return EAV_OK;
+}
+
+extern "C" int eav_dense_softmax_bwd(const float* dout, const float* probs, const float* in, const float* w,
+                                     float* dw, float* dbias, float* din, int B, int NF, int NC, void* stream) {
+  EAV_REQUIRE(dout && in && w && dw && dbias && B > 0 && NF > 0 && NC > 0 && NC <= NCMAX,
+              "eav_dense_softmax_bwd: bad arguments (classes <= %d)", NCMAX);
+  EAV_REQUIRE((size_t)B * NC * sizeof(float) <= 48 * 1024, "eav_dense_softmax_bwd: batch %d too large", B);
+  hipLaunchKernelGGL(dense_softmax_bwd_kernel, dim3(cdiv(NF, 256)), dim3(256), B * NC * sizeof(float),
+                     (hipStream_t)stream, dout, probs, in, w, dw, dbias, din, B, NF, NC);
+  EAV_CHECK_LAUNCH("eav_dense_softmax_bwd");
+  return EAV_OK;
+}
+
+extern "C" int eav_ce_fwd_bwd(const float* in, const int64_t* y, float* loss, float* din, int* ncorrect, int B,
+                              int NC, void* stream) {
+  EAV_REQUIRE(in && y && B > 0 && NC > 0, "eav_ce_fwd_bwd: bad arguments");
+  hipLaunchKernelGGL(ce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, in, y, loss, din, ncorrect, B, NC);
+  EAV_CHECK_LAUNCH("eav_ce_fwd_bwd");
+  return EAV_OK;
+}
+
+extern "C" int eav_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                             float beta2, float eps, float weight_decay, int64_t step, int decoupled, void* stream) {
+  EAV_REQUIRE(p && g && m && v && n > 0 && step >= 1, "eav_adam_step: bad arguments");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  int64_t blocks = cdiv64(n, 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(adam_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1,
+                     beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), decoupled);
+  EAV_CHECK_LAUNCH("eav_adam_step");
+  return EAV_OK;
+}

@@ -1,0 +1,341 @@
+"""EEGNet_tor + Trainer_uni on MI355X: the reference's class API over libeav_hip.so.
+
+Mirrors CNN_torch/EEGNet_tor.py one-for-one at the Python boundary:
+
+    EEGNet_tor(nb_classes, Chans=30, Samples=500, dropoutRate=0.5, kernLength=300,
+               F1=8, D=8, F2=64, norm_rate=1.0, dropoutType='Dropout')      (:16-17)
+        __call__(x[B,1,Chans,Samples]) -> softmax probabilities [B,nb_classes]   (:50-67)
+    Trainer_uni(model, data, lr=1e-4, batch_size=32, num_epochs=10, device=None) (:70)
+        .train() / .validate()                                                   (:96,:118)
+
+The module owns the same sub-modules, so ``state_dict()`` keys and the default
+initialisation stream (torch RNG) are those of the reference; the arithmetic of
+forward and backward is entirely in hand-written gfx950 kernels (eav_amd/csrc).
+Reference behaviour kept on purpose: max-norm renorm after the
+forward and before the backward (Q1/Q2), softmax output fed to CrossEntropyLoss
+(Q3), ``model.train()`` called once so that epochs >= 2 train in eval mode (Q4).
+
+There is no CPU path: calling the model with a non-device tensor raises.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .optim import CrossEntropyLoss, FusedAdam, flatten_parameters
+
+_PARAM_ORDER = [
+    "firstConv.weight", "firstBN.weight", "firstBN.bias",
+    "depthwiseConv.weight", "depthwiseBN.weight", "depthwiseBN.bias",
+    "separableConv.weight", "separableBN.weight", "separableBN.bias",
+    "dense.weight", "dense.bias",
+]
+
+
+class _Workspace:
+    """Device buffers for one (B, Chans, Samples) problem size (all fp32)."""
+
+    def __init__(self, B, C, S, klen, nb, dev):
+        f = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)  # noqa: E731
+        self.key = (B, C, S)
+        T2, T3 = S // 4, S // 4 // 8
+        self.T2, self.T3, self.NF = T2, T3, 64 * T3
+        nchunk = (S + 1023) // 1024
+        self.nchunk = nchunk
+        self.y1, self.g1 = f(B, 8, C, S), f(B, 8, C, S)
+        self.z, self.dz = f(B, 64, S), f(B, 64, S)
+        self.p2, self.dp2 = f(B, 64, T2), f(B, 64, T2)
+        self.u3, self.du3 = f(B, 64, T2), f(B, 64, T2)
+        self.p3, self.dp3 = f(B, 64 * T3), f(B, 64 * T3)
+        self.probs = f(B, nb)
+        self.bn1, self.bn2, self.bn3 = f(6 * 8), f(6 * 64), f(6 * 64)
+        self.wTf, self.wTb = f(1024, 64), f(1024, 64)
+        self.np_fir = _lib.plain("eav_eegnet_fir_fwd_nparts", B, C, S)
+        self.part_fir = f(self.np_fir, 16)
+        self.part_dw = f(B * nchunk, 128)
+        self.ntile3 = _lib.plain("eav_conv64_ntiles", T2)
+        self.part_c3 = f(B * self.ntile3, 128)
+        self.part_pb = f(B, 128)
+        self.part_dst = f(B * nchunk, 16)
+        self.part_dw2 = f(B * nchunk, 64 * C)
+        self.np_fw = _lib.plain("eav_eegnet_fir_wgrad_nparts", B, C, S)
+        self.part_fw = f(self.np_fw, 8 * klen)
+        self.np_cw = _lib.plain("eav_conv64_wgrad_nparts", B, T2)
+        self.part_cw = f(self.np_cw, 64 * 1024)
+
+
+class _EEGNetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, model, *params):
+        ctx.model = model
+        ctx.token = model._launch_forward(x)
+        return model._ws.probs.clone()
+
+    @staticmethod
+    def backward(ctx, dprobs):
+        grads = ctx.model._launch_backward(dprobs.contiguous(), ctx.token)
+        return (None, None, *grads)
+
+
+class EEGNet_tor(nn.Module):
+    def __init__(self, nb_classes, Chans=30, Samples=500, dropoutRate=0.5, kernLength=300, F1=8, D=8, F2=64,
+                 norm_rate=1.0, dropoutType='Dropout'):
+        super().__init__()
+        if F1 != 8 or D != 8 or F2 != 64:
+            raise NotImplementedError("eav_amd.EEGNet_tor: the gfx950 kernels are built for F1=8, D=8, F2=64 "
+                                      "(the reference configuration, EEGNet_tor.py:159)")
+        if not (1 <= kernLength <= 300) or not (1 <= Chans <= 32) or not (1 <= nb_classes <= 16) or Samples < 32:
+            raise NotImplementedError("eav_amd.EEGNet_tor: need kernLength<=300, Chans<=32, nb_classes<=16, Samples>=32")
+        # same sub-modules in the same construction order as the reference (:21-48): identical
+        # state_dict keys and identical consumption of the torch RNG by the default initialisers
+        self.dropout = nn.Dropout(dropoutRate) if dropoutType == 'Dropout' else nn.Dropout2d(dropoutRate)
+        self.firstConv = nn.Conv2d(1, F1, (1, kernLength), padding='same', bias=False)
+        self.firstBN = nn.BatchNorm2d(F1)
+        self.elu = nn.ELU()
+        self.depthwiseConv = nn.Conv2d(F1, F1 * D, (Chans, 1), groups=F1, padding=0, bias=False)
+        self.depthwiseBN = nn.BatchNorm2d(F1 * D)
+        self.depthwisePool = nn.AvgPool2d((1, 4))
+        self.separableConv = nn.Conv2d(F1 * D, F2, (1, 16), padding='same', bias=False)
+        self.separableBN = nn.BatchNorm2d(F2)
+        self.separablePool = nn.AvgPool2d((1, 8))
+        self.flatten = nn.Flatten()
+        self.dense = nn.Linear(F2 * (Samples // 4 // 8), nb_classes)
+        self.softmax = nn.Softmax(dim=1)
+
+        self.nb_classes, self.Chans, self.Samples, self.kernLength = nb_classes, Chans, Samples, kernLength
+        self.norm_rate, self.dropoutRate = float(norm_rate), float(dropoutRate)
+        if dropoutType != 'Dropout' and dropoutRate > 0:
+            raise NotImplementedError("eav_amd.EEGNet_tor: only element-wise Dropout is implemented")
+        self._ws = None
+        self._flat = None
+        self._token = 0
+        self._saved = None
+        self.dropout_seed = 0x0EA5EED          # base seed of the counter-based dropout generator
+        self._dropout_masks = None             # tests: (mask1 uint8 [B,64,S/4], mask2 uint8 [B,64,S/32])
+        self.apply_max_norm = True
+
+    # ------------------------------------------------------------------ plumbing
+    def _ensure_flat(self):
+        p0 = self.firstConv.weight
+        if self._flat is None or self._flat[0].device != p0.device or getattr(p0, "_eav_flat", None) is None \
+                or p0.data_ptr() != self._flat[0].data_ptr():
+            ordered = dict(self.named_parameters())
+            assert list(ordered) == _PARAM_ORDER, list(ordered)
+            self._flat = flatten_parameters(self)
+
+    def _params(self):
+        n = dict(self.named_parameters())
+        return [n[k] for k in _PARAM_ORDER]
+
+    def set_dropout_masks(self, masks):
+        """Testing hook: explicit uint8 keep-masks instead of the counter-based generator."""
+        self._dropout_masks = masks
+
+    def forward(self, x):
+        if not isinstance(x, torch.Tensor) or not x.is_cuda:
+            raise _lib.EavError("eav_amd.EEGNet_tor runs on an MI355X only: move the model and the input to the "
+                                "ROCm device (there is no CPU fallback)")
+        if x.dim() == 3:
+            x = x.unsqueeze(1)
+        if x.dim() != 4 or x.shape[1] != 1 or x.shape[2] != self.Chans or x.shape[3] != self.Samples:
+            raise ValueError(f"expected input [B,1,{self.Chans},{self.Samples}], got {tuple(x.shape)}")
+        if self.firstConv.weight.device != x.device:
+            raise _lib.EavError("model and input are on different devices")
+        x = x.contiguous().float()
+        self._ensure_flat()
+        return _EEGNetFn.apply(x, self, *self._params())
+
+    # ------------------------------------------------------------------ kernels
+    def _launch_forward(self, x):
+        L, P, st = _lib.call, _lib.ptr, _lib.stream_ptr()
+        B, C, S, K, nb = x.shape[0], self.Chans, self.Samples, self.kernLength, self.nb_classes
+        if self._ws is None or self._ws.key != (B, C, S) or self._ws.y1.device != x.device:
+            self._ws = _Workspace(B, C, S, K, nb, x.device)
+        ws = self._ws
+        training = bool(self.training)
+        w1, g1w, g1b, w2, g2w, g2b, w3, g3w, g3b, wd, bd = [P(p) for p in self._params()]
+        bn1, bn2, bn3 = self.firstBN, self.depthwiseBN, self.separableBN
+        drop = self.dropoutRate if training else 0.0
+        masks = self._dropout_masks if training else None
+        self._token += 1
+        seed1 = (self.dropout_seed + 2 * self._token) & 0xFFFFFFFFFFFFFFFF
+        seed2 = seed1 + 1
+        m1 = P(masks[0]) if masks is not None else None
+        m2 = P(masks[1]) if masks is not None else None
+
+        def bnfin(part, nparts, nch, count, gw, gb, bn, buf):
+            b0 = P(buf)
+            L("eav_bn_finalize", P(part), nparts, nch, float(count), gw, gb, P(bn.running_mean), P(bn.running_var),
+              int(training), float(bn.momentum), float(bn.eps), b0, b0 + 4 * nch, b0 + 8 * nch, b0 + 12 * nch, st)
+            if training:
+                bn.num_batches_tracked += 1
+
+        L("eav_eegnet_fir_fwd", P(x), w1, P(ws.y1), P(ws.part_fir), B, C, S, K, st)
+        bnfin(ws.part_fir, ws.np_fir, 8, B * C * S, g1w, g1b, bn1, ws.bn1)
+        L("eav_eegnet_dw_fwd", P(ws.y1), P(ws.bn1), w2, P(ws.z), P(ws.part_dw), B, C, S, st)
+        bnfin(ws.part_dw, B * ws.nchunk, 64, B * S, g2w, g2b, bn2, ws.bn2)
+        L("eav_bn_elu_pool_fwd", P(ws.z), P(ws.bn2), P(ws.p2), B, 64, S, 4, drop, seed1, m1, st)
+        L("eav_conv64_prep_weights", w3, P(ws.wTf), P(ws.wTb), st)
+        L("eav_conv64_fwd", P(ws.p2), P(ws.wTf), P(ws.u3), P(ws.part_c3), B, ws.T2, 7, st)
+        bnfin(ws.part_c3, B * ws.ntile3, 64, B * ws.T2, g3w, g3b, bn3, ws.bn3)
+        L("eav_bn_elu_pool_fwd", P(ws.u3), P(ws.bn3), P(ws.p3), B, 64, ws.T2, 8, drop, seed2, m2, st)
+        L("eav_dense_softmax_fwd", P(ws.p3), wd, bd, None, P(ws.probs), B, ws.NF, nb, st)
+        if self.apply_max_norm:  # the forward hooks of the reference (:33-34, :47-48), intended meaning
+            L("eav_renorm_rows", w2, 64, C, self.norm_rate, st)
+            L("eav_renorm_rows", wd, nb, ws.NF, self.norm_rate, st)
+        self._saved = (self._token, x, training, drop, seed1, seed2, masks)
+        return self._token
+
+    def _launch_backward(self, dprobs, token):
+        if self._saved is None or self._saved[0] != token:
+            raise _lib.EavError("EEGNet_tor.backward: the activations of this forward were overwritten by a later "
+                                "forward (one outstanding forward per backward)")
+        L, P, st = _lib.call, _lib.ptr, _lib.stream_ptr()
+        _, x, training, drop, seed1, seed2, masks = self._saved
+        ws = self._ws
+        B, C, S, K, nb = x.shape[0], self.Chans, self.Samples, self.kernLength, self.nb_classes
+        T2, NF = ws.T2, ws.NF
+        flat, gflat, offs = self._flat
+        g = {k: gflat[offs[k][0]:offs[k][0] + offs[k][1]] for k in _PARAM_ORDER}
+        w2, wd = P(self.depthwiseConv.weight), P(self.dense.weight)
+        m1 = P(masks[0]) if masks is not None else None
+        m2 = P(masks[1]) if masks is not None else None
+        tr = int(training)
+
+        L("eav_dense_softmax_bwd", P(dprobs), P(ws.probs), P(ws.p3), wd, P(g["dense.weight"]), P(g["dense.bias"]),
+          P(ws.dp3), B, NF, nb, st)
+        # block 2: Dropout <- AvgPool8 <- ELU <- separableBN
+        b3 = P(ws.bn3)
+        L("eav_bn_elu_pool_bwd_reduce", P(ws.dp3), P(ws.u3), b3, P(ws.part_pb), B, 64, T2, 8, drop, seed2, m2, st)
+        L("eav_bn_bwd_finalize", P(ws.part_pb), B, 64, float(B * T2), tr, P(g["separableBN.weight"]),
+          P(g["separableBN.bias"]), b3 + 4 * 256, b3 + 4 * 320, st)
+        L("eav_bn_elu_pool_bwd_apply", P(ws.dp3), P(ws.u3), b3, b3 + 4 * 256, P(ws.du3), B, 64, T2, 8, drop, seed2,
+          m2, st)
+        # separableConv: data gradient (flipped/transposed taps, pad 8) and weight gradient
+        L("eav_conv64_fwd", P(ws.du3), P(ws.wTb), P(ws.dp2), None, B, T2, 8, st)
+        L("eav_conv64_wgrad", P(ws.du3), P(ws.p2), P(ws.part_cw), B, T2, 7, st)
+        L("eav_reduce_partials", P(ws.part_cw), ws.np_cw, 65536, 65536, 1.0, P(g["separableConv.weight"]), st)
+        # block 1 tail: Dropout <- AvgPool4 <- ELU <- depthwiseBN
+        b2 = P(ws.bn2)
+        L("eav_bn_elu_pool_bwd_reduce", P(ws.dp2), P(ws.z), b2, P(ws.part_pb), B, 64, S, 4, drop, seed1, m1, st)
+        L("eav_bn_bwd_finalize", P(ws.part_pb), B, 64, float(B * S), tr, P(g["depthwiseBN.weight"]),
+          P(g["depthwiseBN.bias"]), b2 + 4 * 256, b2 + 4 * 320, st)
+        L("eav_bn_elu_pool_bwd_apply", P(ws.dp2), P(ws.z), b2, b2 + 4 * 256, P(ws.dz), B, 64, S, 4, drop, seed1, m1,
+          st)
+        # depthwiseConv <- ELU <- firstBN (uses the post-renorm depthwise weight, Q2)
+        b1 = P(ws.bn1)
+        L("eav_eegnet_dw_bwd", P(ws.y1), P(ws.dz), b1, w2, P(ws.g1), P(ws.part_dst), P(ws.part_dw2), B, C, S, st)
+        L("eav_reduce_partials", P(ws.part_dw2), B * ws.nchunk, 64 * C, 64 * C, 1.0, P(g["depthwiseConv.weight"]), st)
+        L("eav_bn_bwd_finalize", P(ws.part_dst), B * ws.nchunk, 8, float(B * C * S), tr, P(g["firstBN.weight"]),
+          P(g["firstBN.bias"]), b1 + 4 * 32, b1 + 4 * 40, st)
+        # firstConv weight gradient (BN backward folded into the operand staging)
+        L("eav_eegnet_fir_wgrad", P(x), P(ws.y1), P(ws.g1), b1, P(ws.part_fw), B, C, S, K, st)
+        L("eav_reduce_partials", P(ws.part_fw), ws.np_fw, 8 * K, 8 * K, 1.0, P(g["firstConv.weight"]), st)
+        named = dict(self.named_parameters())
+        return [g[k].view(named[k].shape) if named[k].requires_grad else None for k in _PARAM_ORDER]
+
+
+# ----------------------------------------------------------------------------- data plumbing
+class DeviceLoader:
+    """DataLoader-shaped iterator over a device-resident TensorDataset.
+
+    The reference builds ``DataLoader(TensorDataset(x, y), batch_size, shuffle)`` on
+    the host and copies every batch to the device inside the loop
+    (EEGNet_tor.py:91-94,100-101).  Here the whole split lives in HBM once and a
+    batch is assembled by one gather; the *index order* is produced by the same
+    torch samplers (RandomSampler / SequentialSampler + BatchSampler), consuming
+    the torch RNG exactly as ``iter(DataLoader)`` does, so a seeded run visits
+    the same batches as the reference.
+    """
+
+    def __init__(self, x, y, batch_size, shuffle, device):
+        from torch.utils.data import TensorDataset
+        self.x = torch.as_tensor(x, dtype=torch.float32).to(device).contiguous()
+        self.y = torch.as_tensor(y, dtype=torch.long).to(device).contiguous()
+        self.dataset = TensorDataset(self.x, self.y)
+        self.batch_size, self.shuffle, self.device = batch_size, shuffle, device
+        self.order_override = None  # tests: list of index arrays, one per epoch
+
+    def __len__(self):
+        return (len(self.dataset) + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        from torch.utils.data import BatchSampler, RandomSampler, SequentialSampler
+        n = len(self.dataset)
+        # iter(DataLoader) draws its base seed first (torch/utils/data/dataloader.py, _BaseDataLoaderIter)
+        torch.empty((), dtype=torch.int64).random_()
+        if self.order_override:
+            order = [int(i) for i in self.order_override.pop(0)]
+            batches = [order[i:i + self.batch_size] for i in range(0, n, self.batch_size)]
+        else:
+            sampler = RandomSampler(range(n)) if self.shuffle else SequentialSampler(range(n))
+            batches = BatchSampler(sampler, self.batch_size, drop_last=False)
+        for idx in batches:
+            if not self.shuffle and not self.order_override and idx[-1] - idx[0] == len(idx) - 1:
+                yield self.x[idx[0]:idx[-1] + 1], self.y[idx[0]:idx[-1] + 1]
+            else:
+                it = torch.as_tensor(idx, dtype=torch.long, device=self.device)
+                yield self.x.index_select(0, it), self.y.index_select(0, it)
+
+
+class Trainer_uni:
+    def __init__(self, model, data, lr=1e-4, batch_size=32, num_epochs=10, device=None):
+        self.lr = lr
+        self.batch_size = batch_size
+        self.num_epochs = num_epochs
+        self.device = device if device else torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        self.device = torch.device(self.device)
+        if self.device.type != "cuda":
+            raise _lib.EavError("eav_amd.Trainer_uni needs an MI355X (torch device 'cuda' on ROCm); no CPU fallback")
+        self.tr_x, self.tr_y, self.te_x, self.te_y = data
+        self.train_dataloader = self._prepare_dataloader(self.tr_x, self.tr_y, shuffle=True)
+        self.test_dataloader = self._prepare_dataloader(self.te_x, self.te_y, shuffle=False)
+
+        self.model = model
+        self.criterion = CrossEntropyLoss()                       # EEGNet_tor.py:81
+        self.optimizer = FusedAdam(self.model.parameters(), lr=self.lr)   # :82 (Adam, wd 0)
+        # :86-88 wraps in nn.DataParallel when several GPUs are visible; here multi-GPU is one
+        # process per GPU with an RCCL gradient all-reduce (eav_amd.dist), enabled by the launcher.
+        self.model.to(self.device)
+        self.grad_sync = None  # set by eav_amd.dist.attach(trainer) under torchrun
+
+    def _prepare_dataloader(self, x, y, shuffle=False):
+        return DeviceLoader(x, y, self.batch_size, shuffle, self.device)
+
+    def train(self):
+        self.model.train()  # once, before the epoch loop - as the reference (:97)
+        for epoch in range(self.num_epochs):
+            for batch_idx, (data, targets) in enumerate(self.train_dataloader):
+                scores = self.model(data)
+                loss = self.criterion(scores, targets)
+                self.optimizer.zero_grad()
+                loss.backward()
+                if self.grad_sync is not None:
+                    self.grad_sync()
+                self.optimizer.step()
+                if batch_idx % 100 == 0:
+                    print(f"Epoch [{epoch+1}/{self.num_epochs}], Step [{batch_idx}/{len(self.train_dataloader)}], "
+                          f"Loss: {loss.item():.4f}")
+            if self.test_dataloader:
+                self.validate()
+
+    def validate(self):
+        self.model.eval()
+        total_loss = 0
+        total_correct = 0
+        with torch.no_grad():
+            for data, targets in self.test_dataloader:
+                scores = self.model(data)
+                loss = self.criterion(scores, targets)
+                total_loss += loss.item()
+                predictions = scores.argmax(dim=1)
+                total_correct += (predictions == targets).sum().item()
+        avg_loss = total_loss / len(self.test_dataloader)
+        accuracy = total_correct / len(self.test_dataloader.dataset)
+        print(f"Validation - Loss: {avg_loss:.4f}, Accuracy: {accuracy:.4f}")
+
+
+def _as_numpy(a):
+    return a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)

@@ -1,0 +1,138 @@
+"""Fused Adam / AdamW over flat parameter storage + the cross-entropy criterion.
+
+Host-side mirrors of what the reference trainers construct:
+  * ``optim.Adam(model.parameters(), lr)``            CNN_torch/EEGNet_tor.py:82
+  * ``optim.AdamW(model.parameters(), lr)``           Transformer_Audio.py:30, Transformer_Vision.py:36
+    (weight_decay is torch's default 0.01 - the trainer's ctor argument is ignored)
+  * ``nn.CrossEntropyLoss()``                          EEGNet_tor.py:81, Transformer_Audio.py:31
+
+The arithmetic runs in libeav_hip.so (``eav_adam_step`` / ``eav_ce_fwd_bwd``).
+Parameters that live in one flat buffer (``flatten_parameters``) are updated
+with one launch per run of tensors that share a step count - the frozen and
+unfrozen fine-tuning phases give the head and the backbone different counts
+(SURVEY Q11), and tensors whose ``grad`` is None are skipped like torch does.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+
+def flatten_parameters(module: torch.nn.Module):
+    """Re-home every parameter of ``module`` as a view of one flat fp32 device
+    buffer (and allocate a same-shaped flat gradient buffer).  Parameter objects
+    are preserved, so optimisers created earlier stay valid.  Returns
+    (flat_param, flat_grad, {name: (offset, numel)})."""
+    params = [(n, p) for n, p in module.named_parameters()]
+    if not params:
+        raise ValueError("module has no parameters")
+    dev = params[0][1].device
+    offsets, total = {}, 0
+    for n, p in params:
+        if p.dtype != torch.float32:
+            raise TypeError(f"{n}: only fp32 parameters are supported")
+        offsets[n] = (total, p.numel())
+        total += (p.numel() + 3) // 4 * 4  # keep every tensor 16-byte aligned
+    flat = torch.zeros(total, dtype=torch.float32, device=dev)
+    gflat = torch.zeros(total, dtype=torch.float32, device=dev)
+    for n, p in params:
+        off, num = offsets[n]
+        view = flat[off:off + num].view(p.shape)
+        view.copy_(p.data)
+        p.data = view
+        p._eav_flat = (flat, gflat, off)
+    return flat, gflat, offsets
+
+
+class FusedAdam(torch.optim.Optimizer):
+    """Adam (``decoupled=False``) / AdamW (``decoupled=True``) with torch's
+    hyper-parameter names; one ``eav_adam_step`` launch per contiguous run."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, decoupled=False):
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, decoupled=decoupled)
+        super().__init__(params, defaults)
+        self._flat_state = {}
+
+    @staticmethod
+    def _launch(p_ptr, g_ptr, m_ptr, v_ptr, n, group, step):
+        b1, b2 = group["betas"]
+        _lib.call("eav_adam_step", p_ptr, g_ptr, m_ptr, v_ptr, n, float(group["lr"]), float(b1), float(b2),
+                  float(group["eps"]), float(group["weight_decay"]), int(step), int(bool(group["decoupled"])),
+                  _lib.stream_ptr())
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        for group in self.param_groups:
+            runs = []  # (p_ptr, g_ptr, m_ptr, v_ptr, numel, step) candidates for merging
+            for p in group["params"]:
+                g = p.grad
+                if g is None:
+                    continue
+                if not p.is_cuda:
+                    raise _lib.EavError("FusedAdam needs parameters on a ROCm device (no CPU fallback)")
+                if not g.is_contiguous():
+                    g = g.contiguous()
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    flat = getattr(p, "_eav_flat", None)
+                    if flat is not None and flat[0].data_ptr() + 4 * flat[2] == p.data_ptr():
+                        shared = self._flat_state.setdefault(flat[0].data_ptr(), {})
+                        if not shared:
+                            shared["m"] = torch.zeros_like(flat[0])
+                            shared["v"] = torch.zeros_like(flat[0])
+                        st["exp_avg"] = shared["m"][flat[2]:flat[2] + p.numel()].view(p.shape)
+                        st["exp_avg_sq"] = shared["v"][flat[2]:flat[2] + p.numel()].view(p.shape)
+                    else:
+                        st["exp_avg"] = torch.zeros_like(p)
+                        st["exp_avg_sq"] = torch.zeros_like(p)
+                st["step"] += 1
+                runs.append([p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                             p.numel(), st["step"], g])
+            # merge runs that are adjacent (up to 16-B alignment padding) in all four buffers
+            runs.sort(key=lambda r: r[0])
+            merged = []
+            for r in runs:
+                if merged:
+                    q = merged[-1]
+                    gap = r[0] - (q[0] + 4 * q[4])
+                    if (0 <= gap < 16 and r[5] == q[5] and r[1] - q[1] == r[0] - q[0]
+                            and r[2] - q[2] == r[0] - q[0] and r[3] - q[3] == r[0] - q[0]):
+                        q[4] = (r[0] - q[0]) // 4 + r[4]
+                        continue
+                merged.append(r)
+            for r in merged:
+                self._launch(r[0], r[1], r[2], r[3], r[4], group, r[5])
+        return loss
+
+
+class _CEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, scores, targets):
+        if not scores.is_cuda:
+            raise _lib.EavError("CrossEntropyLoss needs device tensors (no CPU fallback)")
+        scores = scores.contiguous().float()
+        B, NC = scores.shape
+        loss = torch.empty((), dtype=torch.float32, device=scores.device)
+        dsc = torch.empty_like(scores)
+        _lib.call("eav_ce_fwd_bwd", scores.data_ptr(), targets.contiguous().data_ptr(), loss.data_ptr(),
+                  dsc.data_ptr(), None, B, NC, _lib.stream_ptr())
+        ctx.save_for_backward(dsc)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        (dsc,) = ctx.saved_tensors
+        return dsc * gout, None
+
+
+class CrossEntropyLoss:
+    """``nn.CrossEntropyLoss()`` (mean reduction) as one fused HIP kernel that
+    produces the loss and its input gradient together."""
+
+    def __call__(self, scores, targets):
+        if targets.dtype != torch.int64:
+            targets = targets.long()
+        return _CEFn.apply(scores, targets)

@@ -1,0 +1,101 @@
+/* libeav_hip.so - C ABI of the MI355X (gfx950) kernels behind the EAV trainer API.
+ *
+ * The reference (nubcico/EAV) has no native/FFI layer: its hot path is Python calling torch ops.
+ * Each entry point below therefore names the *reference op call site* it replaces
+ * (file:line under /root/reference).  The Python mirror of the reference's trainer classes
+ * (eav_amd/eegnet.py, audio.py, vision.py) binds these with ctypes - see INTEGRATION.md.
+ *
+ * Conventions: every function returns 0 on success or a negative EAV_E* code (message from
+ * eav_last_error(), thread-local).  All pointers are caller-owned DEVICE pointers unless said
+ * otherwise; nothing is allocated inside; `stream` is a hipStream_t (NULL = default stream);
+ * launches are asynchronous.  Tensors are dense, row-major, fp32 unless noted.
+ */
+#ifndef EAV_HIP_H
+#define EAV_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EAV_ABI_VERSION 1
+
+const char* eav_last_error(void);
+int eav_abi_version(void);
+
+/* ---- generic ------------------------------------------------------------------------------ */
+/* out[i] = scale * sum_p part[p*stride + i], fp64 accumulation in fixed order (deterministic). */
+int eav_reduce_partials(const float* part, int nparts, int64_t stride, int n, float scale, float* out, void* stream);
+
+/* nn.BatchNorm2d forward statistics (EEGNet_tor.py:25,29,38).  part[p][0..nch) = sum x,
+ * part[p][nch..2nch) = sum x^2.  Writes bn[0..nch)=mean, invstd, scale=gamma*invstd,
+ * shift=beta-mean*scale as four separate arrays; training!=0 also updates the running stats
+ * (momentum, unbiased variance); training==0 uses the running stats. */
+int eav_bn_finalize(const float* part, int nparts, int nch, double count, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, int training, float momentum, float eps, float* mean,
+                    float* invstd, float* scale, float* shift, void* stream);
+/* BatchNorm backward sums -> dgamma, dbeta and the two means of the input-gradient formula. */
+int eav_bn_bwd_finalize(const float* part, int nparts, int nch, double count, int training, float* dgamma,
+                        float* dbeta, float* m1, float* m2, void* stream);
+/* weight.data.renorm_(p=2, dim=0, maxnorm) - the max-norm hooks, EEGNet_tor.py:33-34,47-48. */
+int eav_renorm_rows(float* w, int rows, int cols, float maxnorm, void* stream);
+
+/* ---- EEGNet block 1 ----------------------------------------------------------------------- */
+/* firstConv forward: nn.Conv2d(1,8,(1,K<=300),padding='same',bias=False), EEGNet_tor.py:24,51.
+ * x [B,C,S] -> y1 [B,8,C,S]; stat_part [eav_eegnet_fir_fwd_nparts()][16] = per-filter sum / sum sq. */
+int eav_eegnet_fir_fwd_nparts(int B, int C, int S);
+int eav_eegnet_fir_fwd(const float* x, const float* w1, float* y1, float* stat_part, int B, int C, int S, int klen,
+                       void* stream);
+/* firstConv weight gradient fused with firstBN backward (autograd of EEGNet_tor.py:51-52):
+ * bn_params = mean, invstd, scale, shift, m1, m2 (8 floats each); part [nparts][8][klen]. */
+int eav_eegnet_fir_wgrad_nparts(int B, int C, int S);
+int eav_eegnet_fir_wgrad(const float* x, const float* y1, const float* g1, const float* bn_params, float* part,
+                         int B, int C, int S, int klen, void* stream);
+/* firstBN -> ELU -> depthwiseConv (EEGNet_tor.py:52-54): y1 -> z [B,64,S];
+ * stat_part [B*ceil(S/1024)][128]. */
+int eav_eegnet_dw_fwd(const float* y1, const float* bn1, const float* w2, float* z, float* stat_part, int B, int C,
+                      int S, void* stream);
+/* backward of the above: g1 [B,8,C,S] = dL/d(firstBN out); stat_part [B*ceil(S/1024)][16];
+ * w_part [B*ceil(S/1024)][64*C]. */
+int eav_eegnet_dw_bwd(const float* y1, const float* dz, const float* bn1, const float* w2, float* g1,
+                      float* stat_part, float* w_part, int B, int C, int S, void* stream);
+
+/* ---- BN -> ELU -> AvgPool(1,P) -> Dropout (EEGNet_tor.py:55-58, 60-63), P in {4,8} -------- */
+/* bn = mean, invstd, scale, shift (CH each).  mask: optional uint8 keep-mask [B,CH,T/P]
+ * (NULL = counter-based generator keyed by seed); drop_p = 0 disables dropout. */
+int eav_bn_elu_pool_fwd(const float* in, const float* bn, float* out, int B, int CH, int T, int P, float drop_p,
+                        uint64_t seed, const uint8_t* mask, void* stream);
+int eav_bn_elu_pool_bwd_reduce(const float* dp, const float* u, const float* bn, float* part /*[B][2*CH]*/, int B,
+                               int CH, int T, int P, float drop_p, uint64_t seed, const uint8_t* mask, void* stream);
+int eav_bn_elu_pool_bwd_apply(const float* dp, const float* u, const float* bn, const float* m12 /*m1[CH],m2[CH]*/,
+                              float* du, int B, int CH, int T, int P, float drop_p, uint64_t seed,
+                              const uint8_t* mask, void* stream);
+
+/* ---- separableConv: dense 64->64, 16 taps, 'same' (EEGNet_tor.py:37,59) ------------------- */
+int eav_conv64_prep_weights(const float* w /*[64,64,16]*/, float* wT_fwd /*[1024,64]*/, float* wT_bwd, void* stream);
+int eav_conv64_ntiles(int T);
+/* out[b,o,t] = sum wT[(i*16+k)][o]*in[b,i,t+k-padl]; stat_part (may be NULL) [B*ntiles][128]. */
+int eav_conv64_fwd(const float* in, const float* wT, float* out, float* stat_part, int B, int T, int padl,
+                   void* stream);
+int eav_conv64_wgrad_nparts(int B, int T);
+/* part [nparts][64*64*16]; sum over parts = dL/dW[o,i,k]. */
+int eav_conv64_wgrad(const float* du, const float* in, float* part, int B, int T, int padl, void* stream);
+
+/* ---- head, loss, optimiser ---------------------------------------------------------------- */
+/* nn.Linear + nn.Softmax(dim=1) (EEGNet_tor.py:65-66); logits or probs may be NULL. */
+int eav_dense_softmax_fwd(const float* in, const float* w, const float* bias, float* logits, float* probs, int B,
+                          int NF, int NC, void* stream);
+/* probs != NULL: dout is dL/dprobs (softmax backward applied first); NULL: dout is dL/dlogits. */
+int eav_dense_softmax_bwd(const float* dout, const float* probs, const float* in, const float* w, float* dw,
+                          float* dbias, float* din, int B, int NF, int NC, void* stream);
+/* nn.CrossEntropyLoss (mean) on [B,NC] rows + gradient; *ncorrect += #argmax hits (may be NULL). */
+int eav_ce_fwd_bwd(const float* in, const int64_t* y, float* loss, float* din, int* ncorrect, int B, int NC,
+                   void* stream);
+/* torch.optim.Adam (decoupled=0) / AdamW (decoupled=1) update of one flat tensor; step >= 1. */
+int eav_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, int64_t step, int decoupled, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EAV_HIP_H */

@@ -162,16 +162,24 @@ def make_eegnet_loop(mod):
     load_eegnet_state(model, eegnet_weights(21, S))
     trainer = mod.Trainer_uni(model=model, data=[tr_x, tr_y, te_x, te_y], lr=1e-3, batch_size=16,
                               num_epochs=2, device=torch.device("cpu"))
-    # record the shuffle order: re-seed, iterate sampler the way the loop will
+    # record the shuffle order the reference loop really uses: wrap RandomSampler.__iter__
+    from torch.utils.data import sampler as _sampler
     orders = []
+    orig_iter = _sampler.RandomSampler.__iter__
+
+    def rec_iter(self):
+        idx = list(orig_iter(self))
+        orders.append(np.array(idx, dtype=np.int64))
+        return iter(idx)
+    _sampler.RandomSampler.__iter__ = rec_iter
     torch.manual_seed(1234)
-    g_state = torch.get_rng_state()
-    for _ in range(2):
-        orders.append(np.array(list(iter(trainer.train_dataloader.sampler)), dtype=np.int64))
-    torch.set_rng_state(g_state)
     buf = io.StringIO()
-    with contextlib.redirect_stdout(buf):
-        trainer.train()
+    try:
+        with contextlib.redirect_stdout(buf):
+            trainer.train()
+    finally:
+        _sampler.RandomSampler.__iter__ = orig_iter
+    assert len(orders) == 2
     out = {"S": S, "ntr": ntr, "nte": nte, "xseed": 777, "wseed": 21, "lr": 1e-3, "batch_size": 16,
            "epochs": 2, "order0": orders[0], "order1": orders[1], "stdout": np.array(buf.getvalue())}
     full = model.state_dict()

@@ -1,0 +1,117 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol declared in
+include/eav_hip.h, the host classes keep the reference's names / signatures /
+state_dict keys, and the product path fails loudly without a device."""
+import inspect
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "eav_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(eav_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from eav_amd import _lib
+    lib = _lib.load()
+    names = _declared_symbols()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/eav_hip.h but not exported"
+    assert sorted(_lib.EXPORTS) == names, set(_lib.EXPORTS) ^ set(names)
+    assert lib.eav_abi_version() == 1
+
+
+def test_argument_validation_without_gpu():
+    """Status/err-string path of the ABI (no kernel is launched for bad arguments)."""
+    from eav_amd import _lib
+    with pytest.raises(_lib.EavError, match="kernLength"):
+        _lib.call("eav_eegnet_fir_fwd", 1, 1, 1, 1, 1, 30, 500, 301, None)
+    with pytest.raises(_lib.EavError, match="pool"):
+        _lib.call("eav_bn_elu_pool_fwd", 1, 1, 1, 1, 64, 100, 3, 0.0, 0, None, None)
+    assert _lib.plain("eav_conv64_ntiles", 2500) == 20
+    assert _lib.plain("eav_eegnet_fir_fwd_nparts", 64, 30, 10000) == 512
+
+
+def test_eegnet_class_surface_matches_reference(golden_dir):
+    from eav_amd.eegnet import EEGNet_tor, Trainer_uni
+    sig = inspect.signature(EEGNet_tor.__init__)
+    assert list(sig.parameters)[1:] == ["nb_classes", "Chans", "Samples", "dropoutRate", "kernLength", "F1", "D",
+                                        "F2", "norm_rate", "dropoutType"]
+    d = {k: v.default for k, v in sig.parameters.items()}
+    assert (d["Chans"], d["Samples"], d["dropoutRate"], d["kernLength"], d["F1"], d["D"], d["F2"], d["norm_rate"]) == \
+        (30, 500, 0.5, 300, 8, 8, 64, 1.0)
+    tsig = inspect.signature(Trainer_uni.__init__)
+    assert list(tsig.parameters)[1:] == ["model", "data", "lr", "batch_size", "num_epochs", "device"]
+    assert tsig.parameters["lr"].default == 1e-4 and tsig.parameters["batch_size"].default == 32
+    m = EEGNet_tor(nb_classes=5, Samples=500)
+    g = np.load(os.path.join(golden_dir, "eegnet_s500_train.npz"))
+    ref_keys = sorted(k[len("post0."):] for k in g.files if k.startswith("post0."))
+    mine = sorted(k for k in m.state_dict() if not k.endswith("num_batches_tracked"))
+    assert mine == ref_keys
+    for k in ref_keys:
+        assert tuple(m.state_dict()[k].shape) == g[f"post0.{k}"].shape
+    assert sum(p.numel() for p in m.parameters()) == 74933          # SURVEY 2.1 (S=500)
+    assert sum(p.numel() for p in EEGNet_tor(5, Samples=10000).parameters()) == 169973
+
+
+def test_default_init_consumes_torch_rng_like_reference():
+    """Same sub-modules in the same order => torch.manual_seed gives the same initial weights as
+    the reference's nn.Module would draw (checked against plain torch layers built in that order)."""
+    from eav_amd.eegnet import EEGNet_tor
+    torch.manual_seed(7)
+    m = EEGNet_tor(nb_classes=5, Samples=500)
+    torch.manual_seed(7)
+    torch.nn.Dropout(0.5)
+    c1 = torch.nn.Conv2d(1, 8, (1, 300), padding='same', bias=False)
+    torch.nn.BatchNorm2d(8)
+    c2 = torch.nn.Conv2d(8, 64, (30, 1), groups=8, bias=False)
+    torch.nn.BatchNorm2d(64)
+    c3 = torch.nn.Conv2d(64, 64, (1, 16), padding='same', bias=False)
+    torch.nn.BatchNorm2d(64)
+    d = torch.nn.Linear(64 * 15, 5)
+    assert torch.equal(m.firstConv.weight, c1.weight) and torch.equal(m.depthwiseConv.weight, c2.weight)
+    assert torch.equal(m.separableConv.weight, c3.weight) and torch.equal(m.dense.weight, d.weight)
+
+
+def test_no_cpu_fallback():
+    from eav_amd import _lib
+    from eav_amd.eegnet import EEGNet_tor, Trainer_uni
+    m = EEGNet_tor(nb_classes=5, Samples=500)
+    with pytest.raises(_lib.EavError):
+        m(torch.zeros(2, 1, 30, 500))
+    if not torch.cuda.is_available():
+        with pytest.raises(_lib.EavError):
+            Trainer_uni(m, [np.zeros((4, 1, 30, 500), np.float32), np.zeros(4, np.int64)] * 2)
+    with pytest.raises(NotImplementedError):
+        EEGNet_tor(nb_classes=5, F1=4)
+
+
+def test_device_loader_visits_batches_like_dataloader():
+    """Index order == torch DataLoader's for the same torch.manual_seed (CPU tensors here)."""
+    from torch.utils.data import DataLoader, TensorDataset
+    from eav_amd.eegnet import DeviceLoader
+    x = torch.arange(23, dtype=torch.float32).view(23, 1)
+    y = torch.arange(23)
+    torch.manual_seed(3)
+    ref = [b[1].tolist() for _ in range(2) for b in DataLoader(TensorDataset(x, y), batch_size=5, shuffle=True)]
+    torch.manual_seed(3)
+    dl = DeviceLoader(x, y, 5, True, torch.device("cpu"))
+    got = [b[1].tolist() for _ in range(2) for b in dl]
+    assert got == ref and len(dl) == 5
+
+
+def test_product_package_never_imports_oracle():
+    pkg = os.path.join(ROOT, "eav_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", text, flags=re.M), f

@@ -1,0 +1,318 @@
+"""Per-kernel parity of the EEGNet HIP kernels (through the C ABI) against the
+fp32 CPU restatement of the same op.  Tolerances are stated per test; the
+reference arithmetic is fp32, so differences are summation-order rounding."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from eav_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L():
+    from eav_amd import _lib
+    _lib.load()
+    return _lib
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def close(got, ref, rtol, atol, what=""):
+    got = got.detach().cpu().double().numpy() if isinstance(got, torch.Tensor) else np.asarray(got, np.float64)
+    ref = ref.detach().cpu().double().numpy() if isinstance(ref, torch.Tensor) else np.asarray(ref, np.float64)
+    err = np.abs(got - ref)
+    tol = atol + rtol * np.abs(ref)
+    assert (err <= tol).all(), f"{what}: max err {err.max():.3e}, ref max {np.abs(ref).max():.3e}"
+
+
+def bn_buf(nch, mean, invstd, scale, shift, m1=None, m2=None):
+    z = np.zeros(nch, np.float32)
+    return dev(np.concatenate([mean, invstd, scale, shift, z if m1 is None else m1, z if m2 is None else m2]).astype(np.float32))
+
+
+@pytest.mark.parametrize("B,C,S,K", [(2, 30, 500, 300), (1, 30, 10000, 300), (2, 5, 333, 300), (1, 3, 2100, 64),
+                                     (3, 32, 130, 7)])
+def test_fir_fwd(L, B, C, S, K):
+    x = synth.normal(1, (B, C, S))
+    w = synth.uniform(2, (8, K), -0.1, 0.1)
+    xd, wd = dev(x), dev(w)
+    y = torch.empty(B, 8, C, S, device="cuda")
+    npart = L.plain("eav_eegnet_fir_fwd_nparts", B, C, S)
+    part = torch.zeros(npart, 16, device="cuda")
+    L.call("eav_eegnet_fir_fwd", xd.data_ptr(), wd.data_ptr(), y.data_ptr(), part.data_ptr(), B, C, S, K, None)
+    torch.cuda.synchronize()
+    xt = torch.from_numpy(x).unsqueeze(1)
+    left = (K - 1) // 2
+    ref = F.conv2d(F.pad(xt, (left, K - 1 - left)), torch.from_numpy(w).view(8, 1, 1, K))
+    close(y, ref, 1e-4, 2e-5, "y1")
+    st = part.sum(0).cpu().double().numpy()
+    close(st[:8], ref.double().sum((0, 2, 3)), 1e-5, 1e-3, "sum")
+    close(st[8:], (ref.double() ** 2).sum((0, 2, 3)), 1e-5, 1e-3, "sumsq")
+
+
+@pytest.mark.parametrize("B,C,S,K", [(2, 30, 500, 300), (1, 30, 10000, 300), (2, 4, 333, 300), (1, 3, 1100, 64)])
+def test_fir_wgrad(L, B, C, S, K):
+    x = synth.normal(3, (B, C, S))
+    y1 = synth.normal(4, (B, 8, C, S))
+    g1 = synth.normal(5, (B, 8, C, S))
+    mean, invstd = synth.uniform(6, (8,), -0.2, 0.2), synth.uniform(7, (8,), 0.5, 2.0)
+    scale, m1, m2 = synth.uniform(8, (8,), 0.5, 1.5), synth.uniform(9, (8,), -0.1, 0.1), synth.uniform(10, (8,), -0.1, 0.1)
+    bn = bn_buf(8, mean, invstd, scale, np.zeros(8, np.float32), m1, m2)
+    npart = L.plain("eav_eegnet_fir_wgrad_nparts", B, C, S)
+    part = torch.zeros(npart, 8 * K, device="cuda")
+    L.call("eav_eegnet_fir_wgrad", dev(x).data_ptr(), dev(y1).data_ptr(), dev(g1).data_ptr(), bn.data_ptr(),
+           part.data_ptr(), B, C, S, K, None)
+    out = torch.empty(8, K, device="cuda")
+    L.call("eav_reduce_partials", part.data_ptr(), npart, 8 * K, 8 * K, 1.0, out.data_ptr(), None)
+    torch.cuda.synchronize()
+    bc = lambda v: torch.from_numpy(v).double()[None, :, None, None]  # noqa: E731
+    dy = bc(scale) * (torch.from_numpy(g1).double() - bc(m1) - (torch.from_numpy(y1).double() - bc(mean)) * bc(invstd) * bc(m2))
+    left = (K - 1) // 2
+    xp = F.pad(torch.from_numpy(x).double(), (left, K - 1 - left))      # [B,C,S+K-1]
+    win = xp.unfold(2, S, 1)                                            # [B,C,K,S]
+    ref = torch.einsum("bfcs,bcks->fk", dy, win)
+    close(out, ref, 2e-4, 2e-4 * float(ref.abs().max()), "dW1")
+
+
+@pytest.mark.parametrize("B,C,S", [(2, 30, 500), (1, 30, 2050), (2, 7, 333)])
+def test_dw_fwd_bwd(L, B, C, S):
+    y1 = synth.normal(11, (B, 8, C, S))
+    w2 = synth.uniform(12, (64, C), -0.3, 0.3)
+    mean, invstd = synth.uniform(13, (8,), -0.2, 0.2), synth.uniform(14, (8,), 0.5, 2.0)
+    gamma, beta = synth.uniform(15, (8,), 0.5, 1.5), synth.uniform(16, (8,), -0.2, 0.2)
+    scale = gamma * invstd
+    shift = beta - mean * scale
+    bn = bn_buf(8, mean, invstd, scale, shift)
+    nchunk = (S + 1023) // 1024
+    z = torch.empty(B, 64, S, device="cuda")
+    part = torch.zeros(B * nchunk, 128, device="cuda")
+    y1d, w2d = dev(y1), dev(w2)
+    L.call("eav_eegnet_dw_fwd", y1d.data_ptr(), bn.data_ptr(), w2d.data_ptr(), z.data_ptr(), part.data_ptr(), B, C, S, None)
+    torch.cuda.synchronize()
+    yt = torch.from_numpy(y1).double().requires_grad_(True)
+    wt = torch.from_numpy(w2).double().requires_grad_(True)
+    a1 = F.elu(yt * torch.from_numpy(scale).double()[None, :, None, None] + torch.from_numpy(shift).double()[None, :, None, None])
+    zr = torch.einsum("bfcs,fdc->bfds", a1, wt.view(8, 8, C)).reshape(B, 64, S)
+    close(z, zr, 1e-4, 1e-5, "z")
+    st = part.sum(0).cpu().double().numpy()
+    close(st[:64], zr.detach().sum((0, 2)), 1e-4, 1e-3, "sum z")
+    close(st[64:], (zr.detach() ** 2).sum((0, 2)), 1e-4, 1e-3, "sum z2")
+    # backward
+    dz = synth.normal(17, (B, 64, S))
+    zr.backward(torch.from_numpy(dz).double())
+    g_ref = yt.grad / torch.from_numpy(scale).double()[None, :, None, None]   # dL/d(BN out) = dL/dy1 / scale
+    g1 = torch.empty(B, 8, C, S, device="cuda")
+    pst = torch.zeros(B * nchunk, 16, device="cuda")
+    pw = torch.zeros(B * nchunk, 64 * C, device="cuda")
+    L.call("eav_eegnet_dw_bwd", y1d.data_ptr(), dev(dz).data_ptr(), bn.data_ptr(), w2d.data_ptr(), g1.data_ptr(),
+           pst.data_ptr(), pw.data_ptr(), B, C, S, None)
+    torch.cuda.synchronize()
+    close(g1, g_ref, 1e-4, 1e-5, "g1")
+    close(pw.sum(0).view(64, C), wt.grad, 1e-4, 1e-4 * float(wt.grad.abs().max()), "dW2")
+    yhat = (torch.from_numpy(y1).double() - torch.from_numpy(mean).double()[None, :, None, None]) * torch.from_numpy(invstd).double()[None, :, None, None]
+    s = pst.sum(0).cpu().double().numpy()
+    close(s[:8], g_ref.sum((0, 2, 3)), 1e-4, 1e-3, "sum g")
+    close(s[8:], (g_ref * yhat).sum((0, 2, 3)), 1e-4, 1e-3, "sum g*yhat")
+
+
+@pytest.mark.parametrize("B,T,P,drop", [(2, 500, 4, 0.0), (2, 125, 8, 0.0), (1, 2500, 8, 0.5), (2, 1000, 4, 0.5), (1, 333, 4, 0.0)])
+def test_pool_fwd_bwd(L, B, T, P, drop):
+    CH = 64
+    u = synth.normal(21, (B, CH, T))
+    mean, invstd = synth.uniform(22, (CH,), -0.2, 0.2), synth.uniform(23, (CH,), 0.5, 2.0)
+    gamma, beta = synth.uniform(24, (CH,), 0.5, 1.5), synth.uniform(25, (CH,), -0.2, 0.2)
+    scale, shift = gamma * invstd, beta - mean * gamma * invstd
+    m1, m2 = synth.uniform(26, (CH,), -0.01, 0.01), synth.uniform(27, (CH,), -0.01, 0.01)
+    bn = bn_buf(CH, mean, invstd, scale, shift, m1, m2)
+    To = T // P
+    mask = (synth.uniform(28, (B, CH, To)) >= 0.5).astype(np.uint8) if drop > 0 else None
+    maskd = dev(mask) if mask is not None else None
+    mp = maskd.data_ptr() if maskd is not None else None
+    out = torch.empty(B, CH, To, device="cuda")
+    ud = dev(u)
+    L.call("eav_bn_elu_pool_fwd", ud.data_ptr(), bn.data_ptr(), out.data_ptr(), B, CH, T, P, drop, 0, mp, None)
+    torch.cuda.synchronize()
+    ut = torch.from_numpy(u).double().requires_grad_(True)
+    bc = lambda v: torch.from_numpy(v).double()[None, :, None]  # noqa: E731
+    act = F.elu(ut * bc(scale) + bc(shift))
+    ref = F.avg_pool1d(act, P)
+    if mask is not None:
+        ref = ref * torch.from_numpy(mask).double() / (1 - drop)
+    close(out, ref, 1e-5, 1e-6, "pool out")
+    dp = synth.normal(29, (B, CH, To))
+    ref.backward(torch.from_numpy(dp).double())
+    g_ref = ut.grad / bc(scale)                      # gradient w.r.t. the BN output
+    part = torch.zeros(B, 2 * CH, device="cuda")
+    dpd = dev(dp)
+    L.call("eav_bn_elu_pool_bwd_reduce", dpd.data_ptr(), ud.data_ptr(), bn.data_ptr(), part.data_ptr(), B, CH, T, P,
+           drop, 0, mp, None)
+    du = torch.empty(B, CH, T, device="cuda")
+    L.call("eav_bn_elu_pool_bwd_apply", dpd.data_ptr(), ud.data_ptr(), bn.data_ptr(), bn.data_ptr() + 4 * 4 * CH,
+           du.data_ptr(), B, CH, T, P, drop, 0, mp, None)
+    torch.cuda.synchronize()
+    uhat = (torch.from_numpy(u).double() - bc(mean)) * bc(invstd)
+    s = part.sum(0).cpu().double().numpy()
+    close(s[:CH], g_ref.sum((0, 2)), 1e-4, 1e-4, "sum g")
+    close(s[CH:], (g_ref * uhat).sum((0, 2)), 1e-4, 1e-4, "sum g uhat")
+    du_ref = bc(scale) * (g_ref - bc(m1) - uhat * bc(m2))
+    close(du, du_ref, 1e-4, 1e-6, "du")
+
+
+def test_dropout_generator_statistics(L):
+    B, CH, T, P = 4, 64, 4000, 4
+    u = np.ones((B, CH, T), np.float32)
+    one, zero = np.ones(CH, np.float32), np.zeros(CH, np.float32)
+    bn = bn_buf(CH, zero, one, one, zero)
+    out = torch.empty(B, CH, T // P, device="cuda")
+    L.call("eav_bn_elu_pool_fwd", dev(u).data_ptr(), bn.data_ptr(), out.data_ptr(), B, CH, T, P, 0.5, 1234, None, None)
+    o = out.cpu().numpy()
+    assert set(np.unique(o)) == {0.0, 2.0}
+    assert abs((o == 0).mean() - 0.5) < 0.01
+    out2 = torch.empty_like(out)
+    L.call("eav_bn_elu_pool_fwd", dev(u).data_ptr(), bn.data_ptr(), out2.data_ptr(), B, CH, T, P, 0.5, 1234, None, None)
+    assert torch.equal(out, out2)            # same seed -> same mask (needed by the backward)
+    L.call("eav_bn_elu_pool_fwd", dev(u).data_ptr(), bn.data_ptr(), out2.data_ptr(), B, CH, T, P, 0.5, 1235, None, None)
+    assert not torch.equal(out, out2)
+
+
+@pytest.mark.parametrize("B,T", [(2, 125), (1, 2500), (3, 300)])
+def test_conv64(L, B, T):
+    x = synth.normal(31, (B, 64, T))
+    w = synth.uniform(32, (64, 64, 16), -0.05, 0.05)
+    wTf, wTb = torch.empty(1024, 64, device="cuda"), torch.empty(1024, 64, device="cuda")
+    wd, xd = dev(w), dev(x)
+    L.call("eav_conv64_prep_weights", wd.data_ptr(), wTf.data_ptr(), wTb.data_ptr(), None)
+    nt = L.plain("eav_conv64_ntiles", T)
+    out = torch.empty(B, 64, T, device="cuda")
+    part = torch.zeros(B * nt, 128, device="cuda")
+    L.call("eav_conv64_fwd", xd.data_ptr(), wTf.data_ptr(), out.data_ptr(), part.data_ptr(), B, T, 7, None)
+    torch.cuda.synchronize()
+    xt = torch.from_numpy(x).double().requires_grad_(True)
+    wt = torch.from_numpy(w).double().requires_grad_(True)
+    ref = F.conv1d(F.pad(xt, (7, 8)), wt)
+    close(out, ref, 1e-4, 1e-5, "conv out")
+    st = part.sum(0).cpu().double().numpy()
+    close(st[:64], ref.detach().sum((0, 2)), 1e-4, 1e-3, "sum")
+    close(st[64:], (ref.detach() ** 2).sum((0, 2)), 1e-4, 1e-3, "sumsq")
+    du = synth.normal(33, (B, 64, T))
+    ref.backward(torch.from_numpy(du).double())
+    dud = dev(du)
+    dx = torch.empty(B, 64, T, device="cuda")
+    L.call("eav_conv64_fwd", dud.data_ptr(), wTb.data_ptr(), dx.data_ptr(), None, B, T, 8, None)
+    npart = L.plain("eav_conv64_wgrad_nparts", B, T)
+    pw = torch.zeros(npart, 65536, device="cuda")
+    L.call("eav_conv64_wgrad", dud.data_ptr(), xd.data_ptr(), pw.data_ptr(), B, T, 7, None)
+    dw = torch.empty(64, 64, 16, device="cuda")
+    L.call("eav_reduce_partials", pw.data_ptr(), npart, 65536, 65536, 1.0, dw.data_ptr(), None)
+    torch.cuda.synchronize()
+    close(dx, xt.grad, 1e-4, 1e-5, "dgrad")
+    close(dw, wt.grad, 1e-4, 1e-4 * float(wt.grad.abs().max()), "wgrad")
+
+
+def test_bn_finalize_and_bwd_finalize(L):
+    nch, nparts, count = 64, 7, 12345.0
+    part = synth.uniform(41, (nparts, 2 * nch), 0.0, 1.0)
+    part[:, :nch] *= 100.0
+    part[:, nch:] = part[:, nch:] * 100.0 + 50000.0
+    gamma, beta = synth.uniform(42, (nch,), 0.5, 1.5), synth.uniform(43, (nch,), -0.2, 0.2)
+    rm, rv = synth.uniform(44, (nch,), -0.1, 0.1), synth.uniform(45, (nch,), 0.5, 1.5)
+    for training in (1, 0):
+        rmd, rvd = dev(rm), dev(rv)
+        buf = torch.zeros(4 * nch, device="cuda")
+        b0 = buf.data_ptr()
+        L.call("eav_bn_finalize", dev(part).data_ptr(), nparts, nch, count, dev(gamma).data_ptr(), dev(beta).data_ptr(),
+               rmd.data_ptr(), rvd.data_ptr(), training, 0.1, 1e-5, b0, b0 + 4 * nch, b0 + 8 * nch, b0 + 12 * nch, None)
+        torch.cuda.synchronize()
+        s, q = part[:, :nch].astype(np.float64).sum(0), part[:, nch:].astype(np.float64).sum(0)
+        if training:
+            mean = s / count
+            var = q / count - mean ** 2
+            close(rmd, 0.9 * rm + 0.1 * mean, 1e-6, 1e-7, "running mean")
+            close(rvd, 0.9 * rv + 0.1 * var * count / (count - 1), 1e-6, 1e-7, "running var")
+        else:
+            mean, var = rm.astype(np.float64), rv.astype(np.float64)
+            assert torch.equal(rmd.cpu(), torch.from_numpy(rm))
+        invstd = 1 / np.sqrt(var + 1e-5)
+        b = buf.cpu().numpy()
+        close(b[:nch], mean, 1e-6, 1e-7, "mean")
+        close(b[nch:2 * nch], invstd, 1e-6, 1e-7, "invstd")
+        close(b[2 * nch:3 * nch], gamma * invstd, 1e-6, 1e-7, "scale")
+        close(b[3 * nch:], beta - mean * gamma * invstd, 1e-5, 1e-6, "shift")
+    out = torch.zeros(4 * nch, device="cuda")
+    o = out.data_ptr()
+    L.call("eav_bn_bwd_finalize", dev(part).data_ptr(), nparts, nch, count, 1, o, o + 4 * nch, o + 8 * nch, o + 12 * nch, None)
+    r = out.cpu().numpy()
+    close(r[:nch], q, 1e-6, 1e-3, "dgamma")
+    close(r[nch:2 * nch], s, 1e-6, 1e-3, "dbeta")
+    close(r[2 * nch:3 * nch], s / count, 1e-6, 1e-7, "m1")
+    close(r[3 * nch:], q / count, 1e-6, 1e-6, "m2")
+
+
+def test_renorm_rows(L):
+    w = synth.uniform(51, (64, 30), -0.5, 0.5)
+    w[::2] *= 0.1
+    wd = dev(w)
+    L.call("eav_renorm_rows", wd.data_ptr(), 64, 30, 1.0, None)
+    ref = torch.from_numpy(w.copy())
+    ref.renorm_(p=2, dim=0, maxnorm=1.0)
+    close(wd, ref, 1e-6, 1e-7, "renorm")
+    assert (np.linalg.norm(w, axis=1) > 1).any() and (np.linalg.norm(w, axis=1) < 1).any()
+
+
+@pytest.mark.parametrize("B,NF,NC", [(4, 960, 5), (64, 19968, 5), (3, 77, 7)])
+def test_dense_softmax_ce(L, B, NF, NC):
+    x = synth.normal(61, (B, NF))
+    w = synth.uniform(62, (NC, NF), -0.02, 0.02)
+    b = synth.uniform(63, (NC,), -0.1, 0.1)
+    y = synth.labels(64, B, NC)
+    xd, wd, bd = dev(x), dev(w), dev(b)
+    probs, logits = torch.empty(B, NC, device="cuda"), torch.empty(B, NC, device="cuda")
+    L.call("eav_dense_softmax_fwd", xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), logits.data_ptr(), probs.data_ptr(), B, NF, NC, None)
+    xt = torch.from_numpy(x).double().requires_grad_(True)
+    wt = torch.from_numpy(w).double().requires_grad_(True)
+    bt = torch.from_numpy(b).double().requires_grad_(True)
+    lg = F.linear(xt, wt, bt)
+    pr = torch.softmax(lg, 1)
+    close(logits, lg, 1e-5, 1e-5, "logits")
+    close(probs, pr, 1e-5, 1e-6, "probs")
+    loss = torch.empty((), device="cuda")
+    dpr = torch.empty(B, NC, device="cuda")
+    nc = torch.zeros((), dtype=torch.int32, device="cuda")
+    L.call("eav_ce_fwd_bwd", probs.data_ptr(), dev(y).data_ptr(), loss.data_ptr(), dpr.data_ptr(), nc.data_ptr(), B, NC, None)
+    pr2 = pr.detach().clone().requires_grad_(True)
+    lref = F.cross_entropy(pr2, torch.from_numpy(y))          # CE on probabilities: the double softmax (Q3)
+    lref.backward()
+    close(loss, lref, 1e-5, 1e-6, "loss")
+    close(dpr, pr2.grad, 1e-4, 1e-7, "dprobs")
+    assert int(nc.item()) == int((pr.argmax(1) == torch.from_numpy(y)).sum())
+    pr.backward(pr2.grad)
+    dw, db, dx = torch.empty(NC, NF, device="cuda"), torch.empty(NC, device="cuda"), torch.empty(B, NF, device="cuda")
+    L.call("eav_dense_softmax_bwd", dpr.data_ptr(), probs.data_ptr(), xd.data_ptr(), wd.data_ptr(), dw.data_ptr(),
+           db.data_ptr(), dx.data_ptr(), B, NF, NC, None)
+    torch.cuda.synchronize()
+    close(dw, wt.grad, 1e-3, 1e-4 * float(wt.grad.abs().max()), "dW")
+    close(db, bt.grad, 1e-3, 1e-4 * float(bt.grad.abs().max()), "db")
+    close(dx, xt.grad, 1e-3, 1e-4 * float(xt.grad.abs().max()), "dx")
+
+
+@pytest.mark.parametrize("decoupled,wd", [(0, 0.0), (1, 0.01), (0, 0.01)])
+def test_adam_step_matches_torch(L, decoupled, wd):
+    n = 10007
+    p0, g = synth.normal(71, (n,)), synth.normal(72, (n,), 0, 1e-3)
+    g[::50] = 1e-9 * g[::50]
+    ref_p = torch.nn.Parameter(torch.from_numpy(p0.copy()))
+    opt = (torch.optim.AdamW if decoupled else torch.optim.Adam)([ref_p], lr=1e-3, weight_decay=wd)
+    pd, m, v = dev(p0), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    for step in range(1, 4):
+        gs = g * np.float32(step)
+        ref_p.grad = torch.from_numpy(gs.copy())
+        opt.step()
+        L.call("eav_adam_step", pd.data_ptr(), dev(gs).data_ptr(), m.data_ptr(), v.data_ptr(), n, 1e-3, 0.9, 0.999,
+               1e-8, wd, step, decoupled, None)
+        torch.cuda.synchronize()
+        close(pd, ref_p.detach(), 1e-6, 2e-7, f"p step {step}")

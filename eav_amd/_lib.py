@@ -72,6 +72,9 @@ def load():
             f"{LIB_PATH} is missing - the HIP extension is not built. Run "
             "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C eav_amd/csrc`). "
             "There is no CPU fallback.")
+    # torch ships its own libamdhip64.so.7; import it first so that this library binds to the SAME
+    # HIP runtime instance (streams and device pointers are shared with torch's allocator).
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)

@@ -18,8 +18,18 @@ def L():
     return _lib
 
 
+_KEEP = []
+
+
 def dev(a):
-    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    """Host array -> device tensor that stays alive until the test module is torn down
+    (a temporary's memory would be recycled by the caching allocator before the kernel ran)."""
+    t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    _KEEP.append(t)
+    if len(_KEEP) > 64:
+        torch.cuda.synchronize()
+        del _KEEP[:32]
+    return t
 
 
 def close(got, ref, rtol, atol, what=""):

@@ -1,0 +1,150 @@
+#!/usr/bin/env python3
+"""Headline benchmark: EEGNet_tor training step on MI355X (BASELINE.json configs[1]).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = gather a batch of 64 trials from the HBM-resident synthetic subject, forward,
+CrossEntropy on the softmax output, backward, (gradient all-reduce over RCCL when N > 1), fused
+Adam - i.e. the body of Trainer_uni.train() (CNN_torch/EEGNet_tor.py:99-110), fp32, nothing skipped.
+Prints ONE JSON line on rank 0 (contract in the task description).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+B_PER_GPU, CHANS, SAMPLES, KLEN, TRIALS = 64, 30, 10000, 300, 200
+PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 MFMA = fp32 vector peak
+FIR_FLOP_PER_LAUNCH = 2.0 * KLEN * 8 * CHANS * SAMPLES * B_PER_GPU   # 92.16 GFLOP (fwd) = wgrad
+
+
+def cpu_baseline(steps=2, batch=16):
+    """The oracle (pure fp32 torch CPU restatement, validated against the imported reference) timed
+    on this box's host cores on a bounded sample of the same workload."""
+    import torch
+    from eav_amd import synth
+    from oracle import eegnet_oracle as orc
+    from tests.golden_util import eegnet_weights
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))   # torch CPU conv kernels stop scaling well before 256 threads
+    sd = eegnet_weights(31, SAMPLES)
+    P = {k: torch.from_numpy(sd[k].copy()) for k in orc.PARAM_NAMES}
+    Bf = {k: torch.from_numpy(sd[k].copy()) for k in orc.BUFFER_NAMES}
+    st = orc.Stepper(P, Bf, lr=1e-5, drop_p=0.0)
+    x, y = synth.eeg_batch(99, batch, CHANS, SAMPLES)
+    xt, yt = torch.from_numpy(x), torch.from_numpy(y)
+    st.step(xt, yt, True, None)                     # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        st.step(xt, yt, True, None)
+    dt = time.perf_counter() - t0
+    return {"value": round(steps * batch / dt, 3), "unit": "samples/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"{steps} train steps (fwd+CE+bwd+Adam) of the oracle on [{batch},1,{CHANS},{SAMPLES}] fp32 "
+                      f"after 1 warm-up, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from eav_amd import dist as eav_dist
+    from eav_amd import synth
+    from eav_amd.eegnet import EEGNet_tor
+    from eav_amd.optim import CrossEntropyLoss, FusedAdam
+
+    rank, world, local = eav_dist.init_from_env("nccl")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    # synthetic subject (one per rank: subject-level sharding of the data), resident in HBM
+    xs, ys = synth.eeg_subject(1 + rank, TRIALS, CHANS, SAMPLES)
+    xs = torch.from_numpy(xs).unsqueeze(1).to(dev)
+    ys = torch.from_numpy(ys).to(dev)
+    torch.manual_seed(0)                                  # identical replicas on every rank
+    model = EEGNet_tor(nb_classes=5, Chans=CHANS, Samples=SAMPLES, kernLength=KLEN, F1=8, D=8, F2=64,
+                       dropoutRate=0.5).to(dev).train()
+    crit = CrossEntropyLoss()
+    opt = FusedAdam(model.parameters(), lr=1e-5)
+    model._ensure_flat()
+    sync = eav_dist.GradSync([model._flat[1]]) if world > 1 else None
+    gen = torch.Generator().manual_seed(1234 + rank)
+    batches = [torch.randperm(TRIALS, generator=gen)[:B_PER_GPU].to(dev) for _ in range(args.steps + args.warmup)]
+
+    def step(i):
+        idx = batches[i]
+        data, targets = xs.index_select(0, idx), ys.index_select(0, idx)
+        scores = model(data)
+        loss = crit(scores, targets)
+        opt.zero_grad()
+        loss.backward()
+        if sync is not None:
+            sync()
+        opt.step()
+        return loss
+
+    for i in range(args.warmup):
+        step(i)
+    timed = ("eav_eegnet_fir_fwd", "eav_eegnet_fir_wgrad")
+    model.kernel_events = {k: [] for k in timed}
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    kern_ms = {k: sum(a.elapsed_time(b) for a, b in v) / max(len(v), 1) for k, v in model.kernel_events.items()}
+    model.kernel_events = None
+    final_loss = float(loss.item())
+
+    if rank == 0:
+        dom = max(kern_ms, key=kern_ms.get)
+        achieved = FIR_FLOP_PER_LAUNCH / (kern_ms[dom] * 1e-3) / 1e12
+        out = {
+            "metric": "EEGNet training samples/sec (fwd+CE+bwd+Adam), whole job",
+            "value": round(args.steps * B_PER_GPU * world / dt, 2),
+            "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "EEGNet_tor(5, Chans=30, Samples=10000, kernLength=300, F1=8, D=8, F2=64) "
+                                   "train step on x[64,1,30,10000] fp32 per GPU (BASELINE.json configs[1])",
+                       "global_batch": B_PER_GPU * world, "per_gpu_batch": B_PER_GPU,
+                       "parallelism": f"dp{world}" + (" (RCCL grad all-reduce)" if world > 1 else ""),
+                       "optimizer": "Adam lr=1e-5", "dropout": 0.5, "final_loss": round(final_loss, 5)},
+            "roofline": {"bound": "mfma", "kernel": dom.replace("eav_eegnet_", "") + "_kernel",
+                         "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "flop_per_launch": FIR_FLOP_PER_LAUNCH,
+                         "avg_kernel_ms": {k.replace("eav_eegnet_", ""): round(v, 4) for k, v in kern_ms.items()}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -21,19 +21,39 @@ extern "C" int eav_abi_version(void) { return EAV_ABI_VERSION; }
 
 // ---------------------------------------------------------------------------------------------
 // out[i] = scale * sum_p part[p*stride + i]   (fp64 accumulation; deterministic order)
-__global__ void reduce_partials_kernel(const float* __restrict__ part, int nparts, int64_t stride, int n,
-                                       float scale, float* __restrict__ out) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+// block = 16 outputs x 16 part-lanes; every lane sums its parts in fp64, the 16 lane sums are
+// added in a fixed order -> bit-reproducible.
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int nparts,
+                                                              int64_t stride, int n, float scale,
+                                                              float* __restrict__ out) {
+  __shared__ double sh[16][17];
+  const int ol = threadIdx.x & 15, pl = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + ol;
   double s = 0.0;
-  for (int p = 0; p < nparts; ++p) s += (double)part[(int64_t)p * stride + i];
-  out[i] = (float)(s * (double)scale);
+  if (i < n) {
+    const float* src = part + i;
+    int p = pl;
+    for (; p + 48 < nparts; p += 64) {
+      float a = src[(int64_t)p * stride], b = src[(int64_t)(p + 16) * stride];
+      float c = src[(int64_t)(p + 32) * stride], d = src[(int64_t)(p + 48) * stride];
+      s += ((double)a + (double)b) + ((double)c + (double)d);
+    }
+    for (; p < nparts; p += 16) s += (double)src[(int64_t)p * stride];
+  }
+  sh[pl][ol] = s;
+  __syncthreads();
+  if (threadIdx.x < 16 && i < n) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += sh[k][threadIdx.x];
+    out[i] = (float)(t * (double)scale);
+  }
 }
 
 extern "C" int eav_reduce_partials(const float* part, int nparts, int64_t stride, int n, float scale, float* out,
                                    void* stream) {
   EAV_REQUIRE(part && out && nparts > 0 && n > 0, "eav_reduce_partials: bad arguments");
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, part, nparts,
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(n, 16)), dim3(256), 0, (hipStream_t)stream, part, nparts,
                      stride, n, scale, out);
   EAV_CHECK_LAUNCH("eav_reduce_partials");
   return EAV_OK;
@@ -49,15 +69,28 @@ __global__ void bn_finalize_kernel(const float* __restrict__ part, int nparts, i
                                    float* __restrict__ rmean, float* __restrict__ rvar, int training, float momentum,
                                    float eps, float* __restrict__ mean_o, float* __restrict__ invstd_o,
                                    float* __restrict__ scale_o, float* __restrict__ shift_o) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= nch) return;
+  const int c = blockIdx.x;
+  __shared__ double shs[256], shq[256];
   float mean, var;
   if (training) {
     double s = 0.0, q = 0.0;
-    for (int p = 0; p < nparts; ++p) {
+    for (int p = threadIdx.x; p < nparts; p += 256) {
       s += (double)part[(int64_t)p * 2 * nch + c];
       q += (double)part[(int64_t)p * 2 * nch + nch + c];
     }
+    shs[threadIdx.x] = s;
+    shq[threadIdx.x] = q;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (threadIdx.x < o) {
+        shs[threadIdx.x] += shs[threadIdx.x + o];
+        shq[threadIdx.x] += shq[threadIdx.x + o];
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    s = shs[0];
+    q = shq[0];
     double m = s / count;
     double v = q / count - m * m;
     if (v < 0.0) v = 0.0;
@@ -67,6 +100,7 @@ __global__ void bn_finalize_kernel(const float* __restrict__ part, int nparts, i
     rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
     rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
   } else {
+    if (threadIdx.x != 0) return;
     mean = rmean[c];
     var = rvar[c];
   }
@@ -85,7 +119,7 @@ extern "C" int eav_bn_finalize(const float* part, int nparts, int nch, double co
   EAV_REQUIRE(nch > 0 && gamma && beta && running_mean && running_var && mean && invstd && scale && shift,
               "eav_bn_finalize: bad arguments");
   EAV_REQUIRE(!training || (part && nparts > 0 && count > 0), "eav_bn_finalize: training needs partials");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(nch, 64)), dim3(64), 0, (hipStream_t)stream, part, nparts, nch,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(nch), dim3(256), 0, (hipStream_t)stream, part, nparts, nch,
                      count, gamma, beta, running_mean, running_var, training, momentum, eps, mean, invstd, scale,
                      shift);
   EAV_CHECK_LAUNCH("eav_bn_finalize");
@@ -99,13 +133,26 @@ extern "C" int eav_bn_finalize(const float* part, int nparts, int nch, double co
 __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nparts, int nch, double count,
                                        int training, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                        float* __restrict__ m1, float* __restrict__ m2) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= nch) return;
+  const int c = blockIdx.x;
+  __shared__ double shs[256], shq[256];
   double s = 0.0, q = 0.0;
-  for (int p = 0; p < nparts; ++p) {
+  for (int p = threadIdx.x; p < nparts; p += 256) {
     s += (double)part[(int64_t)p * 2 * nch + c];
     q += (double)part[(int64_t)p * 2 * nch + nch + c];
   }
+  shs[threadIdx.x] = s;
+  shq[threadIdx.x] = q;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      shs[threadIdx.x] += shs[threadIdx.x + o];
+      shq[threadIdx.x] += shq[threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
+  s = shs[0];
+  q = shq[0];
   dbeta[c] = (float)s;
   dgamma[c] = (float)q;
   m1[c] = training ? (float)(s / count) : 0.f;
@@ -116,7 +163,7 @@ extern "C" int eav_bn_bwd_finalize(const float* part, int nparts, int nch, doubl
                                    float* dgamma, float* dbeta, float* m1, float* m2, void* stream) {
   EAV_REQUIRE(part && nparts > 0 && nch > 0 && count > 0 && dgamma && dbeta && m1 && m2,
               "eav_bn_bwd_finalize: bad arguments");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(nch, 64)), dim3(64), 0, (hipStream_t)stream, part, nparts,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(nch), dim3(256), 0, (hipStream_t)stream, part, nparts,
                      nch, count, training, dgamma, dbeta, m1, m2);
   EAV_CHECK_LAUNCH("eav_bn_bwd_finalize");
   return EAV_OK;

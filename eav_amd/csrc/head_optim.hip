@@ -9,27 +9,39 @@ namespace {
 
 constexpr int NCMAX = 16;
 
-// one block per sample: logits[j] = bias[j] + sum_i W[j,i]*in[b,i];  probs = softmax(logits)
-__global__ __launch_bounds__(256) void dense_softmax_fwd_kernel(const float* __restrict__ in,
-                                                                const float* __restrict__ w,
-                                                                const float* __restrict__ bias,
-                                                                float* __restrict__ logits, float* __restrict__ probs,
-                                                                int NF, int NC) {
-  __shared__ float red[4 * NCMAX];
+// one block (1024 threads) per sample: logits[j] = bias[j] + sum_i W[j,i]*in[b,i];  probs = softmax
+__global__ __launch_bounds__(1024) void dense_softmax_fwd_kernel(const float* __restrict__ in,
+                                                                 const float* __restrict__ w,
+                                                                 const float* __restrict__ bias,
+                                                                 float* __restrict__ logits, float* __restrict__ probs,
+                                                                 int NF, int NC) {
+  __shared__ float red[16 * NCMAX];
   const int b = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float* src = in + (int64_t)b * NF;
   float acc[NCMAX];
 #pragma unroll
   for (int j = 0; j < NCMAX; ++j) acc[j] = 0.f;
-  for (int i = threadIdx.x; i < NF; i += 256) {
+  for (int i = threadIdx.x; i < NF; i += 1024) {
     const float v = src[i];
 #pragma unroll
     for (int j = 0; j < NCMAX; ++j)
       if (j < NC) acc[j] += w[(int64_t)j * NF + i] * v;
   }
-  block_sum_256<NCMAX>(acc, red);
+#pragma unroll
+  for (int j = 0; j < NCMAX; ++j)
+    if (j < NC) {
+      float s = wave_sum(acc[j]);
+      if (lane == 0) red[wave * NCMAX + j] = s;
+    }
+  __syncthreads();
   __shared__ float lg[NCMAX];
-  if (threadIdx.x < NC) lg[threadIdx.x] = acc[0] + bias[threadIdx.x];
+  if (threadIdx.x < NC) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += red[k * NCMAX + threadIdx.x];
+    lg[threadIdx.x] = s + bias[threadIdx.x];
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
     float mx = lg[0];
@@ -147,7 +159,7 @@ extern "C" int eav_dense_softmax_fwd(const float* in, const float* w, const floa
                                      int B, int NF, int NC, void* stream) {
   EAV_REQUIRE(in && w && bias && (logits || probs) && B > 0 && NF > 0 && NC > 0 && NC <= NCMAX,
               "eav_dense_softmax_fwd: bad arguments (classes <= %d)", NCMAX);
-  hipLaunchKernelGGL(dense_softmax_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, in, w, bias, logits, probs,
+  hipLaunchKernelGGL(dense_softmax_fwd_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, in, w, bias, logits, probs,
                      NF, NC);
   EAV_CHECK_LAUNCH("eav_dense_softmax_fwd");
   return EAV_OK;

@@ -115,6 +115,7 @@ class EEGNet_tor(nn.Module):
         self.dropout_seed = 0x0EA5EED          # base seed of the counter-based dropout generator
         self._dropout_masks = None             # tests: (mask1 uint8 [B,64,S/4], mask2 uint8 [B,64,S/32])
         self.apply_max_norm = True
+        self.kernel_events = None              # bench: {kernel name: [(start_event, end_event), ...]}
 
     # ------------------------------------------------------------------ plumbing
     def _ensure_flat(self):
@@ -148,8 +149,21 @@ class EEGNet_tor(nn.Module):
         return _EEGNetFn.apply(x, self, *self._params())
 
     # ------------------------------------------------------------------ kernels
+    def _call(self, name, *args):
+        """_lib.call, optionally bracketed by HIP events on the launch stream (bench.py's live
+        per-kernel timing of the dominant kernels)."""
+        ev = self.kernel_events
+        if ev is not None and name in ev:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            _lib.call(name, *args)
+            b.record()
+            ev[name].append((a, b))
+        else:
+            _lib.call(name, *args)
+
     def _launch_forward(self, x):
-        L, P, st = _lib.call, _lib.ptr, _lib.stream_ptr()
+        L, P, st = self._call, _lib.ptr, _lib.stream_ptr()
         B, C, S, K, nb = x.shape[0], self.Chans, self.Samples, self.kernLength, self.nb_classes
         if self._ws is None or self._ws.key != (B, C, S) or self._ws.y1.device != x.device:
             self._ws = _Workspace(B, C, S, K, nb, x.device)
@@ -192,7 +206,7 @@ class EEGNet_tor(nn.Module):
         if self._saved is None or self._saved[0] != token:
             raise _lib.EavError("EEGNet_tor.backward: the activations of this forward were overwritten by a later "
                                 "forward (one outstanding forward per backward)")
-        L, P, st = _lib.call, _lib.ptr, _lib.stream_ptr()
+        L, P, st = self._call, _lib.ptr, _lib.stream_ptr()
         _, x, training, drop, seed1, seed2, masks = self._saved
         ws = self._ws
         B, C, S, K, nb = x.shape[0], self.Chans, self.Samples, self.kernLength, self.nb_classes

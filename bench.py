@@ -119,6 +119,14 @@ def main():
 
     if rank == 0:
         dom = max(kern_ms, key=kern_ms.get)
+        traffic, traffic_src = None, None
+        try:  # HBM bytes per launch from the separate --pmc passes (tools/pmc_summary.py), if committed
+            import glob
+            f = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_eegnet_hbm_traffic.json")))[-1]
+            traffic = json.load(open(f))["kernels"][dom.replace("eav_eegnet_", "") + "_kernel"]["total_bytes"]
+            traffic_src = os.path.relpath(f, ROOT)
+        except Exception:
+            pass
         achieved = FIR_FLOP_PER_LAUNCH / (kern_ms[dom] * 1e-3) / 1e12
         out = {
             "metric": "EEGNet training samples/sec (fwd+CE+bwd+Adam), whole job",
@@ -135,7 +143,9 @@ def main():
                        "optimizer": "Adam lr=1e-5", "dropout": 0.5, "final_loss": round(final_loss, 5)},
             "roofline": {"bound": "mfma", "kernel": dom.replace("eav_eegnet_", "") + "_kernel",
                          "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                         "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc, gfx950-corrected)",
+                         "traffic_source": traffic_src,
                          "flop_per_launch": FIR_FLOP_PER_LAUNCH,
                          "avg_kernel_ms": {k.replace("eav_eegnet_", ""): round(v, 4) for k, v in kern_ms.items()}},
         }

@@ -32,3 +32,21 @@ def eegnet_weights(seed, samples, chans=30, klen=300, F1=8, D=8, F2=64, nb=5, sc
         "separableBN.running_mean": u(seed + 16, (F2,), -0.05, 0.05),
         "separableBN.running_var": u(seed + 17, (F2,), 0.5, 1.5),
     }
+
+
+def tf_weights(seed, shapes, std=0.02):
+    """Deterministic transformer weights keyed by HF names: matrices ~ N(0, std^2) (HF
+    initializer_range 0.02), biases / tokens / position embeddings small non-zero, LayerNorm
+    gains around 1 - so that no term of the forward or backward is trivially zero."""
+    out = {}
+    for i, (k, shp) in enumerate(shapes.items()):
+        s = seed * 1000 + i
+        if k.endswith("layernorm.weight") or "layernorm_before.weight" in k or "layernorm_after.weight" in k:
+            out[k] = synth.uniform(s, shp, 0.8, 1.2)
+        elif k.endswith(".bias"):
+            out[k] = synth.normal(s, shp, 0.0, 0.02)
+        elif "token" in k or "position_embeddings" in k:
+            out[k] = synth.normal(s, shp, 0.0, 0.02)
+        else:
+            out[k] = synth.normal(s, shp, 0.0, std)
+    return out

@@ -46,6 +46,19 @@ SIGNATURES = {
     "eav_dense_softmax_bwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     "eav_ce_fwd_bwd": [_p, _p, _p, _p, _p, _i, _i, _p],
     "eav_adam_step": [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _i64, _i, _p],
+    "eav_gemm_f32": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64, _f, _p,
+                     _i, _p, _p, _i, _i, _p],
+    "eav_layernorm_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _f, _p],
+    "eav_layernorm_bwd": [_p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _p],
+    "eav_softmax_fwd": [_p, _i64, _i, _i, _p],
+    "eav_softmax_bwd": [_p, _p, _i64, _i, _i, _p],
+    "eav_gelu_bwd": [_p, _p, _i64, _p],
+    "eav_colsum": [_p, _p, _i, _i, _i, _p],
+    "eav_im2col": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "eav_embed_finish": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "eav_embed_bwd": [_p, _p, _p, _i, _i, _i, _i, _p],
+    "eav_token_rows": [_p, _p, _i, _i, _i, _i, _i, _p],
+    "eav_pair_mean": [_p, _p, _i, _i, _i, _p],
 }
 # helpers that return a plain value (no status)
 PLAIN = {
@@ -55,6 +68,8 @@ PLAIN = {
     "eav_eegnet_fir_wgrad_nparts": ([_i, _i, _i], _i),
     "eav_conv64_ntiles": ([_i], _i),
     "eav_conv64_wgrad_nparts": ([_i, _i], _i),
+    "eav_layernorm_bwd_nparts": ([_i], _i),
+    "eav_colsum_nparts": ([_i], _i),
 }
 
 EXPORTS = sorted(list(SIGNATURES) + list(PLAIN))

@@ -19,12 +19,16 @@ import torch
 from . import _lib
 
 
-def flatten_parameters(module: torch.nn.Module):
+def flatten_parameters(module: torch.nn.Module, order=None):
     """Re-home every parameter of ``module`` as a view of one flat fp32 device
     buffer (and allocate a same-shaped flat gradient buffer).  Parameter objects
     are preserved, so optimisers created earlier stay valid.  Returns
     (flat_param, flat_grad, {name: (offset, numel)})."""
     params = [(n, p) for n, p in module.named_parameters()]
+    if order is not None:  # explicit flat layout (e.g. q/k/v weights adjacent for one fused GEMM)
+        named = dict(params)
+        assert sorted(named) == sorted(order), "order must name every parameter exactly once"
+        params = [(n, named[n]) for n in order]
     if not params:
         raise ValueError("module has no parameters")
     dev = params[0][1].device

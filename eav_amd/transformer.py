@@ -1,0 +1,484 @@
+"""AST / ViT classification encoders on MI355X: forward, backward and weight hand-off.
+
+The reference never defines these models - it instantiates Hugging Face classes
+(`AutoModelForAudioClassification.from_pretrained`, Transformer_Audio.py:22;
+`AutoModelForImageClassification.from_pretrained`, Transformer_Vision.py:29) and trains them
+with `loss.backward()`.  This module restates that arithmetic as an explicit schedule of
+libeav_hip.so kernels (fp32 MFMA GEMMs + row kernels), keeps the HF 5.x parameter names so
+`state_dict()` / safetensors checkpoints interchange (HF 4.x names are accepted on load), and
+exposes the pieces the reference trainers touch: `model(x).logits`, `model.classifier`,
+`model.parameters()`, `train()/eval()`, `.to(device)`.
+
+Everything is kept resident (288 GB HBM): all activations a backward needs are saved, nothing is
+recomputed; attention probabilities are materialised per layer ([B*H, N, N] fp32).
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .optim import flatten_parameters
+
+
+# ----------------------------------------------------------------------------- configuration
+def make_config(kind, hidden=768, layers=12, heads=12, ff=3072, eps=1e-12, num_labels=5, patch=16, mel=128,
+                frames=1024, fstride=10, tstride=10, image=224, channels=3):
+    if kind == "ast":
+        ny, nx = (mel - patch) // fstride + 1, (frames - patch) // tstride + 1
+        geo = dict(C=1, H=mel, W=frames, sy=fstride, sx=tstride, transposed=1)
+        nextra, prefix = 2, "audio_spectrogram_transformer"
+    elif kind == "vit":
+        ny = nx = image // patch
+        geo = dict(C=channels, H=image, W=image, sy=patch, sx=patch, transposed=0)
+        nextra, prefix = 1, "vit"
+    else:
+        raise ValueError(kind)
+    return SimpleNamespace(kind=kind, hidden=hidden, layers=layers, heads=heads, ff=ff, eps=eps,
+                           num_labels=num_labels, patch=patch, ny=ny, nx=nx, npatch=ny * nx, nextra=nextra,
+                           ntok=ny * nx + nextra, prefix=prefix, kp=geo["C"] * patch * patch, **geo)
+
+
+def config_from_hf(cfg_json: dict):
+    mt = cfg_json.get("model_type", "")
+    common = dict(hidden=cfg_json.get("hidden_size", 768), layers=cfg_json.get("num_hidden_layers", 12),
+                  heads=cfg_json.get("num_attention_heads", 12), ff=cfg_json.get("intermediate_size", 3072),
+                  eps=cfg_json.get("layer_norm_eps", 1e-12), patch=cfg_json.get("patch_size", 16),
+                  num_labels=len(cfg_json["id2label"]) if "id2label" in cfg_json else cfg_json.get("num_labels", 2))
+    if cfg_json.get("hidden_act", "gelu") != "gelu":
+        raise NotImplementedError("only the exact erf GELU is implemented")
+    if mt == "audio-spectrogram-transformer":
+        return make_config("ast", mel=cfg_json.get("num_mel_bins", 128), frames=cfg_json.get("max_length", 1024),
+                           fstride=cfg_json.get("frequency_stride", 10), tstride=cfg_json.get("time_stride", 10),
+                           **common)
+    if mt == "vit":
+        return make_config("vit", image=cfg_json.get("image_size", 224), channels=cfg_json.get("num_channels", 3),
+                           **common)
+    raise NotImplementedError(f"model_type {mt!r}")
+
+
+def param_shapes(cfg):
+    """Ordered {HF 5.x key: shape}.  Order = flat-buffer order: q,k,v weights (and biases) adjacent so the
+    three projections run as one [3D, D] GEMM."""
+    d, ff, p = cfg.hidden, cfg.ff, cfg.prefix
+    s = {f"{p}.embeddings.cls_token": (1, 1, d)}
+    if cfg.kind == "ast":
+        s[f"{p}.embeddings.distillation_token"] = (1, 1, d)
+    s[f"{p}.embeddings.position_embeddings"] = (1, cfg.ntok, d)
+    s[f"{p}.embeddings.patch_embeddings.projection.weight"] = (d, cfg.C, cfg.patch, cfg.patch)
+    s[f"{p}.embeddings.patch_embeddings.projection.bias"] = (d,)
+    for i in range(cfg.layers):
+        L = f"{p}.layers.{i}"
+        for n in ("q", "k", "v"):
+            s[f"{L}.attention.{n}_proj.weight"] = (d, d)
+        for n in ("q", "k", "v"):
+            s[f"{L}.attention.{n}_proj.bias"] = (d,)
+        s[f"{L}.attention.o_proj.weight"] = (d, d)
+        s[f"{L}.attention.o_proj.bias"] = (d,)
+        for n in ("layernorm_before", "layernorm_after"):
+            s[f"{L}.{n}.weight"] = (d,)
+            s[f"{L}.{n}.bias"] = (d,)
+        s[f"{L}.mlp.fc1.weight"] = (ff, d)
+        s[f"{L}.mlp.fc1.bias"] = (ff,)
+        s[f"{L}.mlp.fc2.weight"] = (d, ff)
+        s[f"{L}.mlp.fc2.bias"] = (d,)
+    s[f"{p}.layernorm.weight"] = (d,)
+    s[f"{p}.layernorm.bias"] = (d,)
+    if cfg.kind == "ast":
+        s["classifier.layernorm.weight"] = (d,)
+        s["classifier.layernorm.bias"] = (d,)
+        s["classifier.dense.weight"] = (cfg.num_labels, d)
+        s["classifier.dense.bias"] = (cfg.num_labels,)
+    else:
+        s["classifier.weight"] = (cfg.num_labels, d)
+        s["classifier.bias"] = (cfg.num_labels,)
+    return s
+
+
+_HF4 = [  # (HF 4.x fragment, HF 5.x fragment)
+    (".encoder.layer.", ".layers."), (".attention.attention.query.", ".attention.q_proj."),
+    (".attention.attention.key.", ".attention.k_proj."), (".attention.attention.value.", ".attention.v_proj."),
+    (".attention.output.dense.", ".attention.o_proj."), (".intermediate.dense.", ".mlp.fc1."),
+    (".output.dense.", ".mlp.fc2."),
+]
+
+
+def normalise_key(k):
+    for a, b in _HF4:
+        k = k.replace(a, b)
+    return k
+
+
+class _Node(nn.Module):
+    """Anonymous container so that dotted HF names become real sub-modules (model.classifier.dense ...)."""
+
+
+def _set_param(root, dotted, value):
+    parts = dotted.split(".")
+    m = root
+    for p in parts[:-1]:
+        if not hasattr(m, p):
+            m.add_module(p, _Node())
+        m = getattr(m, p)
+    m.register_parameter(parts[-1], nn.Parameter(value))
+
+
+class _Out:
+    def __init__(self, logits, loss=None):
+        self.logits, self.loss = logits, loss
+
+
+class _EncFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, model, *params):
+        ctx.model = model
+        ctx.token = model._launch_forward(x)
+        return model._ws.logits.clone()
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        return (None, None, *ctx.model._launch_backward(dlogits.contiguous(), ctx.token))
+
+
+class Encoder(nn.Module):
+    """ASTForAudioClassification / ViTForImageClassification (5-class head) on the HIP kernels."""
+
+    def __init__(self, cfg, weights=None):
+        super().__init__()
+        self.cfg = cfg
+        shapes = param_shapes(cfg)
+        for k, shp in shapes.items():
+            if weights is not None and k in weights:
+                v = torch.as_tensor(np.asarray(weights[k]), dtype=torch.float32).reshape(shp).clone()
+            elif k.endswith("layernorm.weight") or k.endswith("layernorm_before.weight") or k.endswith("layernorm_after.weight"):
+                v = torch.ones(shp)
+            elif k.endswith(".bias") or "token" in k or "position_embeddings" in k:
+                v = torch.zeros(shp)
+            else:
+                v = torch.randn(shp) * 0.02          # HF initializer_range
+            _set_param(self, k, v)
+        self._names = list(shapes)
+        self._ws = None
+        self._flat = None
+        self._token = 0
+        self._saved = None
+        self.kernel_events = None
+        if cfg.hidden % cfg.heads or (cfg.hidden // cfg.heads) % 4 or cfg.hidden % 4 or cfg.hidden > 1024:
+            raise NotImplementedError("hidden size must be <= 1024, a multiple of 4, head_dim a multiple of 4")
+        if cfg.ntok > 2048 or cfg.num_labels > 16:
+            raise NotImplementedError("at most 2048 tokens and 16 classes")
+
+    # ------------------------------------------------------------------ loading
+    @classmethod
+    def from_pretrained(cls, model_path):
+        """HF directory: config.json + model.safetensors (pytorch_model.bin accepted)."""
+        cfg = config_from_hf(json.load(open(os.path.join(model_path, "config.json"))))
+        st = os.path.join(model_path, "model.safetensors")
+        if os.path.exists(st):
+            from safetensors.numpy import load_file
+            raw = load_file(st)
+        elif os.path.exists(os.path.join(model_path, "pytorch_model.bin")):
+            raw = {k: v.numpy() for k, v in torch.load(os.path.join(model_path, "pytorch_model.bin"), map_location="cpu").items()}
+        else:
+            raise OSError(f"no model.safetensors / pytorch_model.bin under {model_path}")
+        w = {normalise_key(k): v for k, v in raw.items()}
+        shapes = param_shapes(cfg)
+        missing = [k for k in shapes if k not in w]
+        if missing:
+            raise KeyError(f"checkpoint lacks {missing[:4]} ...")
+        return cls(cfg, w)
+
+    def reset_head(self, weight, bias):
+        """Replace the classification Linear (the reference does `classifier.dense = nn.Linear(768, n)`,
+        Transformer_Audio.py:24 / `classifier = nn.Linear(...)`, Transformer_Vision.py:30)."""
+        head = self.classifier.dense if self.cfg.kind == "ast" else self.classifier
+        dev = head.weight.device
+        head.weight = nn.Parameter(torch.as_tensor(weight, dtype=torch.float32).clone().to(dev))
+        head.bias = nn.Parameter(torch.as_tensor(bias, dtype=torch.float32).clone().to(dev))
+        self.cfg.num_labels = head.weight.shape[0]
+        self._flat = None
+        self._ws = None
+
+    def head_parameters(self):
+        return list(self.classifier.parameters())
+
+    # ------------------------------------------------------------------ plumbing
+    def _ensure_flat(self):
+        p0 = next(self.parameters())
+        ok = (self._flat is not None and getattr(p0, "_eav_flat", None) is not None
+              and p0._eav_flat[0] is self._flat[0] and p0.data_ptr() == self._flat[0].data_ptr()
+              and all(getattr(p, "_eav_flat", (None,))[0] is self._flat[0] for p in self.parameters()))
+        if not ok:
+            self._flat = flatten_parameters(self, order=self._names)
+            self._pmap = dict(self.named_parameters())
+
+    def forward(self, x=None, labels=None, pixel_values=None, input_values=None):
+        x = x if x is not None else (pixel_values if pixel_values is not None else input_values)
+        if not isinstance(x, torch.Tensor) or not x.is_cuda:
+            raise _lib.EavError("eav_amd encoders run on an MI355X only (no CPU fallback): move model and input to "
+                                "the ROCm device")
+        c = self.cfg
+        want = (c.W, c.H) if c.kind == "ast" else (c.C, c.H, c.W)
+        if tuple(x.shape[1:]) != want:
+            raise ValueError(f"expected input [B,{','.join(map(str, want))}], got {tuple(x.shape)}")
+        x = x.contiguous().float()
+        self._ensure_flat()
+        self._want_full = torch.is_grad_enabled() and any(
+            p.requires_grad for k, p in self._pmap.items() if not k.startswith("classifier."))
+        logits = _EncFn.apply(x, self, *[self._pmap[k] for k in self._names])
+        loss = None
+        if labels is not None:
+            from .optim import CrossEntropyLoss
+            loss = CrossEntropyLoss()(logits, labels)
+        return _Out(logits, loss)
+
+    # ------------------------------------------------------------------ kernel schedule
+    def _call(self, name, *args):
+        ev = self.kernel_events
+        if ev is not None and name in ev:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            _lib.call(name, *args)
+            b.record()
+            ev[name].append((a, b))
+        else:
+            _lib.call(name, *args)
+
+    def _gemm(self, A, B, C, M, N, K, lda, ldb, ldc, tA=0, tB=0, batch=1, heads=1, sA=(0, 0), sB=(0, 0), sC=(0, 0),
+              alpha=1.0, bias=None, gelu=0, pre=None, resid=None, ldr=0, acc=0):
+        self._call("eav_gemm_f32", A, B, C, M, N, K, lda, ldb, ldc, tA, tB, batch, heads, sA[0], sA[1], sB[0], sB[1],
+                   sC[0], sC[1], float(alpha), bias, gelu, pre, resid, ldr, acc, self._st)
+
+    def _alloc(self, B, dev, full_backward):
+        c = self.cfg
+        D, FF, N, H, Lr = c.hidden, c.ff, c.ntok, c.heads, c.layers
+        M = B * N
+        ldn = (N + 3) // 4 * 4
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
+        ws = SimpleNamespace(B=B, M=M, ldn=ldn, full=full_backward)
+        nsave = Lr if full_backward else 1
+        ws.col = f(B * c.npatch, c.kp)
+        ws.hs = [f(M, D) for _ in range(Lr + 1)] if full_backward else [f(M, D), f(M, D)]
+        ws.y1 = [f(M, D) for _ in range(nsave)]
+        ws.qkv = [f(M, 3 * D) for _ in range(nsave)]
+        ws.P = [torch.zeros(B * H, N, ldn, dtype=torch.float32, device=dev) for _ in range(nsave)]
+        ws.ao = [f(M, D) for _ in range(nsave)]
+        ws.hmid = [f(M, D) for _ in range(nsave)]
+        ws.y2 = [f(M, D) for _ in range(nsave)]
+        ws.pre = [f(M, FF) for _ in range(nsave)]
+        ws.act = [f(M, FF) for _ in range(nsave)]
+        ws.st = [f(4, M) for _ in range(nsave)]           # mean1, rstd1, mean2, rstd2
+        R = B * c.nextra
+        ws.rows, ws.seqr, ws.stf = f(R, D), f(R, D), f(2, R)
+        ws.pooled, ws.hl, ws.sth = f(B, D), f(B, D), f(2, B)
+        ws.logits = f(B, c.num_labels)
+        if full_backward:
+            ws.dh, ws.dy, ws.dao = f(M, D), f(M, D), f(M, D)
+            ws.dact, ws.dqkv = f(M, FF), f(M, 3 * D)
+            ws.dP = torch.zeros(B * H, N, ldn, dtype=torch.float32, device=dev)
+            ws.demb = f(B * c.npatch, D)
+            ws.np_ln = _lib.plain("eav_layernorm_bwd_nparts", M)
+            ws.part_ln = f(ws.np_ln, 2 * D)
+            ws.np_cs = _lib.plain("eav_colsum_nparts", M)
+            ws.part_cs = f(ws.np_cs, max(FF, 3 * D))
+        ws.drows, ws.dseqr = f(R, D), f(R, D)
+        ws.dpooled, ws.dhl = f(B, D), f(B, D)
+        ws.np_lnr = _lib.plain("eav_layernorm_bwd_nparts", R)
+        ws.part_lnr = f(ws.np_lnr, 2 * D)
+        return ws
+
+    def _launch_forward(self, x):
+        c = self.cfg
+        P, L = _lib.ptr, self._call
+        self._st = st = _lib.stream_ptr()
+        B = x.shape[0]
+        D, FF, N, H = c.hidden, c.ff, c.ntok, c.heads
+        hd = D // H
+        pm = self._pmap
+        full = self._want_full
+        ws = self._ws
+        if ws is None or ws.B != B or ws.hs[0].device != x.device or (full and not ws.full):
+            ws = self._ws = self._alloc(B, x.device, full)
+        M, ldn = ws.M, ws.ldn
+        pre = c.prefix
+        w = lambda k: P(pm[k])  # noqa: E731
+        # patch embedding: im2col rows x projection weight -> token rows [nextra:], then cls/dist + positions
+        L("eav_im2col", P(x), P(ws.col), B, c.C, c.H, c.W, c.patch, c.sy, c.sx, c.transposed, st)
+        h0 = ws.hs[0]
+        self._gemm(P(ws.col), w(f"{pre}.embeddings.patch_embeddings.projection.weight"), P(h0) + 4 * c.nextra * D,
+                   c.npatch, D, c.kp, c.kp, c.kp, D, batch=B, sA=(c.npatch * c.kp, 0), sC=(N * D, 0),
+                   bias=w(f"{pre}.embeddings.patch_embeddings.projection.bias"))
+        L("eav_embed_finish", P(h0), w(f"{pre}.embeddings.cls_token"),
+          w(f"{pre}.embeddings.distillation_token") if c.kind == "ast" else None,
+          w(f"{pre}.embeddings.position_embeddings"), B, N, D, c.nextra, st)
+        scale = hd ** -0.5
+        for i in range(c.layers):
+            j = i if ws.full else 0
+            hin = ws.hs[i] if ws.full else ws.hs[i & 1]
+            hout = ws.hs[i + 1] if ws.full else ws.hs[(i + 1) & 1]
+            Lk = f"{pre}.layers.{i}"
+            stp = P(ws.st[j])
+            L("eav_layernorm_fwd", P(hin), w(f"{Lk}.layernorm_before.weight"), w(f"{Lk}.layernorm_before.bias"),
+              P(ws.y1[j]), stp, stp + 4 * M, M, D, c.eps, st)
+            qkv = P(ws.qkv[j])
+            self._gemm(P(ws.y1[j]), w(f"{Lk}.attention.q_proj.weight"), qkv, M, 3 * D, D, D, D, 3 * D,
+                       bias=w(f"{Lk}.attention.q_proj.bias"))
+            Pm = P(ws.P[j])
+            self._gemm(qkv, qkv + 4 * D, Pm, N, N, hd, 3 * D, 3 * D, ldn, batch=B * H, heads=H,
+                       sA=(N * 3 * D, hd), sB=(N * 3 * D, hd), sC=(H * N * ldn, N * ldn), alpha=scale)
+            L("eav_softmax_fwd", Pm, B * H * N, N, ldn, st)
+            self._gemm(Pm, qkv + 8 * D, P(ws.ao[j]), N, hd, N, ldn, 3 * D, D, tB=1, batch=B * H, heads=H,
+                       sA=(H * N * ldn, N * ldn), sB=(N * 3 * D, hd), sC=(N * D, hd))
+            self._gemm(P(ws.ao[j]), w(f"{Lk}.attention.o_proj.weight"), P(ws.hmid[j]), M, D, D, D, D, D,
+                       bias=w(f"{Lk}.attention.o_proj.bias"), resid=P(hin), ldr=D)
+            L("eav_layernorm_fwd", P(ws.hmid[j]), w(f"{Lk}.layernorm_after.weight"), w(f"{Lk}.layernorm_after.bias"),
+              P(ws.y2[j]), stp + 8 * M, stp + 12 * M, M, D, c.eps, st)
+            self._gemm(P(ws.y2[j]), w(f"{Lk}.mlp.fc1.weight"), P(ws.act[j]), M, FF, D, D, D, FF,
+                       bias=w(f"{Lk}.mlp.fc1.bias"), gelu=1, pre=P(ws.pre[j]))
+            self._gemm(P(ws.act[j]), w(f"{Lk}.mlp.fc2.weight"), P(hout), M, D, FF, FF, FF, D,
+                       bias=w(f"{Lk}.mlp.fc2.bias"), resid=P(ws.hmid[j]), ldr=D)
+        hlast = ws.hs[c.layers] if ws.full else ws.hs[c.layers & 1]
+        R = B * c.nextra
+        L("eav_token_rows", P(hlast), P(ws.rows), B, N, D, c.nextra, 0, st)
+        sf = P(ws.stf)
+        L("eav_layernorm_fwd", P(ws.rows), w(f"{pre}.layernorm.weight"), w(f"{pre}.layernorm.bias"), P(ws.seqr), sf,
+          sf + 4 * R, R, D, c.eps, st)
+        if c.kind == "ast":
+            L("eav_pair_mean", P(ws.seqr), P(ws.pooled), B, D, 0, st)
+            sh = P(ws.sth)
+            L("eav_layernorm_fwd", P(ws.pooled), w("classifier.layernorm.weight"), w("classifier.layernorm.bias"),
+              P(ws.hl), sh, sh + 4 * B, B, D, c.eps, st)
+            L("eav_dense_softmax_fwd", P(ws.hl), w("classifier.dense.weight"), w("classifier.dense.bias"),
+              P(ws.logits), None, B, D, c.num_labels, st)
+        else:
+            L("eav_dense_softmax_fwd", P(ws.seqr), w("classifier.weight"), w("classifier.bias"), P(ws.logits), None,
+              B, D, c.num_labels, st)
+        self._token += 1
+        self._saved = (self._token, x, full, None)
+        return self._token
+
+    def _reduce(self, part, nparts, stride, n, out):
+        self._call("eav_reduce_partials", _lib.ptr(part), nparts, stride, n, 1.0, out, self._st)
+
+    def _bias_grad(self, dy_ptr, M, N, ld, out):
+        ws = self._ws
+        self._call("eav_colsum", dy_ptr, _lib.ptr(ws.part_cs), M, N, ld, self._st)
+        self._call("eav_reduce_partials", _lib.ptr(ws.part_cs), ws.np_cs, N, N, 1.0, out, self._st)
+
+    def _launch_backward(self, dlogits, token):
+        if self._saved is None or self._saved[0] != token:
+            raise _lib.EavError("Encoder.backward: activations were overwritten by a later forward")
+        c = self.cfg
+        P, L = _lib.ptr, self._call
+        st = self._st = _lib.stream_ptr()
+        _, x, full, _ = self._saved
+        ws = self._ws
+        B, M, ldn = ws.B, ws.M, ws.ldn
+        D, FF, N, H = c.hidden, c.ff, c.ntok, c.heads
+        hd = D // H
+        pm = self._pmap
+        flat, gflat, offs = self._flat
+        gp = lambda k: gflat.data_ptr() + 4 * offs[k][0]  # noqa: E731
+        w = lambda k: P(pm[k])  # noqa: E731
+        pre = c.prefix
+        R = B * c.nextra
+        # ---- head
+        if c.kind == "ast":
+            L("eav_dense_softmax_bwd", P(dlogits), None, P(ws.hl), w("classifier.dense.weight"),
+              gp("classifier.dense.weight"), gp("classifier.dense.bias"), P(ws.dhl), B, D, c.num_labels, st)
+            sh = P(ws.sth)
+            L("eav_layernorm_bwd", P(ws.dhl), P(ws.pooled), w("classifier.layernorm.weight"), sh, sh + 4 * B,
+              P(ws.dpooled), 0, P(ws.part_lnr), B, D, st)
+            npb = _lib.plain("eav_layernorm_bwd_nparts", B)
+            self._reduce(ws.part_lnr, npb, 2 * D, D, gp("classifier.layernorm.weight"))
+            L("eav_reduce_partials", P(ws.part_lnr) + 4 * D, npb, 2 * D, D, 1.0, gp("classifier.layernorm.bias"), st)
+            if full:
+                L("eav_pair_mean", P(ws.dseqr), P(ws.dpooled), B, D, 1, st)
+        else:
+            L("eav_dense_softmax_bwd", P(dlogits), None, P(ws.seqr), w("classifier.weight"), gp("classifier.weight"),
+              gp("classifier.bias"), P(ws.dseqr), B, D, c.num_labels, st)
+        if full:
+            sf = P(ws.stf)
+            L("eav_layernorm_bwd", P(ws.dseqr), P(ws.rows), w(f"{pre}.layernorm.weight"), sf, sf + 4 * R,
+              P(ws.drows), 0, P(ws.part_lnr), R, D, st)
+            self._reduce(ws.part_lnr, ws.np_lnr, 2 * D, D, gp(f"{pre}.layernorm.weight"))
+            L("eav_reduce_partials", P(ws.part_lnr) + 4 * D, ws.np_lnr, 2 * D, D, 1.0, gp(f"{pre}.layernorm.bias"), st)
+            ws.dh.zero_()
+            L("eav_token_rows", P(ws.dh), P(ws.drows), B, N, D, c.nextra, 1, st)
+            scale = hd ** -0.5
+            dh, dy, dao, dact, dqkv, dP = P(ws.dh), P(ws.dy), P(ws.dao), P(ws.dact), P(ws.dqkv), P(ws.dP)
+            for i in reversed(range(c.layers)):
+                Lk = f"{pre}.layers.{i}"
+                stp = P(ws.st[i])
+                # fc2: h_out = h_mid + act.W2^T + b2
+                self._gemm(dh, P(ws.act[i]), gp(f"{Lk}.mlp.fc2.weight"), D, FF, M, D, FF, FF, tA=1, tB=1)
+                self._bias_grad(dh, M, D, D, gp(f"{Lk}.mlp.fc2.bias"))
+                self._gemm(dh, w(f"{Lk}.mlp.fc2.weight"), dact, M, FF, D, D, FF, FF, tB=1)
+                L("eav_gelu_bwd", dact, P(ws.pre[i]), M * FF, st)
+                # fc1
+                self._gemm(dact, P(ws.y2[i]), gp(f"{Lk}.mlp.fc1.weight"), FF, D, M, FF, D, D, tA=1, tB=1)
+                self._bias_grad(dact, M, FF, FF, gp(f"{Lk}.mlp.fc1.bias"))
+                self._gemm(dact, w(f"{Lk}.mlp.fc1.weight"), dy, M, D, FF, FF, D, D, tB=1)
+                # layernorm_after: dh (now gradient w.r.t. h_mid) += LN backward
+                L("eav_layernorm_bwd", dy, P(ws.hmid[i]), w(f"{Lk}.layernorm_after.weight"), stp + 8 * M,
+                  stp + 12 * M, dh, 1, P(ws.part_ln), M, D, st)
+                self._reduce(ws.part_ln, ws.np_ln, 2 * D, D, gp(f"{Lk}.layernorm_after.weight"))
+                L("eav_reduce_partials", P(ws.part_ln) + 4 * D, ws.np_ln, 2 * D, D, 1.0,
+                  gp(f"{Lk}.layernorm_after.bias"), st)
+                # o_proj
+                self._gemm(dh, P(ws.ao[i]), gp(f"{Lk}.attention.o_proj.weight"), D, D, M, D, D, D, tA=1, tB=1)
+                self._bias_grad(dh, M, D, D, gp(f"{Lk}.attention.o_proj.bias"))
+                self._gemm(dh, w(f"{Lk}.attention.o_proj.weight"), dao, M, D, D, D, D, D, tB=1)
+                # attention core, batched over (image, head)
+                qkv, Pm = P(ws.qkv[i]), P(ws.P[i])
+                sP, sQ, sO = (H * N * ldn, N * ldn), (N * 3 * D, hd), (N * D, hd)
+                self._gemm(Pm, dao, dqkv + 8 * D, N, hd, N, ldn, D, 3 * D, tA=1, tB=1, batch=B * H, heads=H,
+                           sA=sP, sB=sO, sC=sQ)                                            # dV = P^T dO
+                self._gemm(dao, qkv + 8 * D, dP, N, N, hd, D, 3 * D, ldn, batch=B * H, heads=H,
+                           sA=sO, sB=sQ, sC=sP)                                            # dP = dO V^T
+                L("eav_softmax_bwd", Pm, dP, B * H * N, N, ldn, st)
+                self._gemm(dP, qkv + 4 * D, dqkv, N, hd, N, ldn, 3 * D, 3 * D, tB=1, batch=B * H, heads=H,
+                           sA=sP, sB=sQ, sC=sQ, alpha=scale)                               # dQ = s dS K
+                self._gemm(dP, qkv, dqkv + 4 * D, N, hd, N, ldn, 3 * D, 3 * D, tA=1, tB=1, batch=B * H, heads=H,
+                           sA=sP, sB=sQ, sC=sQ, alpha=scale)                               # dK = s dS^T Q
+                # fused q/k/v projection
+                self._gemm(dqkv, P(ws.y1[i]), gp(f"{Lk}.attention.q_proj.weight"), 3 * D, D, M, 3 * D, D, D, tA=1, tB=1)
+                self._bias_grad(dqkv, M, 3 * D, 3 * D, gp(f"{Lk}.attention.q_proj.bias"))
+                self._gemm(dqkv, w(f"{Lk}.attention.q_proj.weight"), dy, M, D, 3 * D, 3 * D, D, D, tB=1)
+                L("eav_layernorm_bwd", dy, P(ws.hs[i]), w(f"{Lk}.layernorm_before.weight"), stp, stp + 4 * M, dh, 1,
+                  P(ws.part_ln), M, D, st)
+                self._reduce(ws.part_ln, ws.np_ln, 2 * D, D, gp(f"{Lk}.layernorm_before.weight"))
+                L("eav_reduce_partials", P(ws.part_ln) + 4 * D, ws.np_ln, 2 * D, D, 1.0,
+                  gp(f"{Lk}.layernorm_before.bias"), st)
+            # embeddings
+            L("eav_embed_bwd", dh, gp(f"{pre}.embeddings.position_embeddings"), P(ws.demb), B, N, D, c.nextra, st)
+            gpos = gflat[offs[f"{pre}.embeddings.position_embeddings"][0]:]
+            gflat[offs[f"{pre}.embeddings.cls_token"][0]:][:D].copy_(gpos[:D])
+            if c.kind == "ast":
+                gflat[offs[f"{pre}.embeddings.distillation_token"][0]:][:D].copy_(gpos[D:2 * D])
+            MP = B * c.npatch
+            self._gemm(P(ws.demb), P(ws.col), gp(f"{pre}.embeddings.patch_embeddings.projection.weight"), D, c.kp, MP,
+                       D, c.kp, c.kp, tA=1, tB=1)
+            self._call("eav_colsum", P(ws.demb), P(ws.part_cs), MP, D, D, st)
+            self._call("eav_reduce_partials", P(ws.part_cs), _lib.plain("eav_colsum_nparts", MP), D, D, 1.0,
+                       gp(f"{pre}.embeddings.patch_embeddings.projection.bias"), st)
+        out = []
+        for k in self._names:
+            p = pm[k]
+            trained = p.requires_grad and (full or k.startswith("classifier."))
+            out.append(gflat[offs[k][0]:offs[k][0] + offs[k][1]].view(p.shape) if trained else None)
+        return out
+
+
+def ASTForAudioClassification(cfg=None, weights=None):
+    return Encoder(cfg or make_config("ast"), weights)
+
+
+def ViTForImageClassification(cfg=None, weights=None):
+    return Encoder(cfg or make_config("vit"), weights)

@@ -95,6 +95,45 @@ int eav_ce_fwd_bwd(const float* in, const int64_t* y, float* loss, float* din, i
 int eav_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                   float eps, float weight_decay, int64_t step, int decoupled, void* stream);
 
+/* ---- AST / ViT encoders (HF ASTForAudioClassification / ViTForImageClassification as called at
+ *      Transformer_Audio.py:22,72 and Transformer_Vision.py:29,92) ------------------------------ */
+/* Batched fp32 GEMM on the fp32 matrix cores: C[z] = epilogue(alpha * opA(A[z]) . opB(B[z])).
+ * transA=0: A is [M,K]; 1: A is [K,M].  transB=0: B is [N,K] (nn.Linear weight layout); 1: B is [K,N].
+ * z = zb*heads + zh, operand z at base + zb*s?b + zh*s?h (element strides, multiples of 4).
+ * Epilogue: +bias[n]; pre (optional) receives the value before GELU; gelu=1 applies erf-GELU; +resid;
+ * accumulate=1 adds into C.  Replaces nn.Linear fwd/bwd, the patch-embedding conv (with eav_im2col),
+ * Q.K^T, P.V and the attention backward products. */
+int eav_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                 int transA, int transB, int batch, int heads, int64_t sAb, int64_t sAh, int64_t sBb, int64_t sBh,
+                 int64_t sCb, int64_t sCh, float alpha, const float* bias, int gelu, float* pre, const float* resid,
+                 int ldr, int accumulate, void* stream);
+/* nn.LayerNorm(D, eps) forward over M rows; mean/rstd [M] saved for the backward (may be NULL). */
+int eav_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                      int M, int D, float eps, void* stream);
+int eav_layernorm_bwd_nparts(int M);
+/* dx (accumulate=1: dx += ...) and per-block partials part[nparts][2*D] = (dgamma, dbeta); part may be NULL. */
+int eav_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                      float* dx, int accumulate, float* part, int M, int D, void* stream);
+/* softmax over rows of length N (leading dimension ld), in place; backward dS = P o (dP - sum dP*P) in place on dP. */
+int eav_softmax_fwd(float* s, int64_t rows, int N, int ld, void* stream);
+int eav_softmax_bwd(const float* P, float* dP, int64_t rows, int N, int ld, void* stream);
+/* dact *= GELU'(pre) (exact erf form, HF GELUActivation), in place. */
+int eav_gelu_bwd(float* dact, const float* pre, int64_t n, void* stream);
+/* bias gradient: part[eav_colsum_nparts(M)][N] partial column sums of dy [M,N]. */
+int eav_colsum_nparts(int M);
+int eav_colsum(const float* dy, float* part, int M, int N, int ld, void* stream);
+/* patch extraction for the Conv2d patch embedding (HF AST :53-61 with transposed=1, HF ViT :60-69). */
+int eav_im2col(const float* x, float* col, int B, int C, int H, int W, int P, int sy, int sx, int transposed,
+               void* stream);
+/* h[b,t] = (t<nextra ? token_t : h[b,t]) + pos[t]  (HF AST :93-97, ViT :146-157) and its backward. */
+int eav_embed_finish(float* h, const float* cls, const float* dist, const float* pos, int B, int ntok, int D,
+                     int nextra, void* stream);
+int eav_embed_bwd(const float* dh, float* dpos, float* demb, int B, int ntok, int D, int nextra, void* stream);
+/* gather (scatter=0) / scatter (1) the first nextra token rows of every image: rows[b*nextra+e] <-> h[b,e]. */
+int eav_token_rows(float* h, float* rows, int B, int ntok, int D, int nextra, int scatter, void* stream);
+/* AST pooled = (cls + dist)/2 (HF AST :304); backward=1 writes dseq from dpooled. */
+int eav_pair_mean(float* seq, float* pooled, int B, int D, int backward, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

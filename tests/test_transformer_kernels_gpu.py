@@ -1,0 +1,206 @@
+"""Kernel-level parity of the AST/ViT building blocks (through the C ABI) against fp64 torch on the
+host.  The GEMM is an exact-fp32 MFMA fma chain, so tolerances are fp32 summation-order level."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from eav_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L():
+    from eav_amd import _lib
+    _lib.load()
+    return _lib
+
+
+_KEEP = []
+
+
+def dev(a):
+    """Host array -> device tensor kept alive for the module (temporaries would be recycled by the
+    caching allocator before the asynchronous kernel ran)."""
+    t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    _KEEP.append(t)
+    if len(_KEEP) > 64:
+        torch.cuda.synchronize()
+        del _KEEP[:32]
+    return t
+
+
+def close(got, ref, rtol, atol, what=""):
+    got = got.detach().cpu().double().numpy() if isinstance(got, torch.Tensor) else np.asarray(got, np.float64)
+    ref = ref.detach().cpu().double().numpy() if isinstance(ref, torch.Tensor) else np.asarray(ref, np.float64)
+    err = np.abs(got - ref)
+    assert (err <= atol + rtol * np.abs(ref)).all(), f"{what}: max err {err.max():.3e}, ref max {np.abs(ref).max():.3e}"
+
+
+def gemm(L, A, B, C, M, N, K, lda, ldb, ldc, tA=0, tB=0, batch=1, heads=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), alpha=1.0,
+         bias=None, gelu=0, pre=None, resid=None, ldr=0, acc=0):
+    p = lambda t: None if t is None else (t if isinstance(t, int) else t.data_ptr())  # noqa: E731
+    L.call("eav_gemm_f32", p(A), p(B), p(C), M, N, K, lda, ldb, ldc, tA, tB, batch, heads, sA[0], sA[1], sB[0], sB[1],
+           sC[0], sC[1], alpha, p(bias), gelu, p(pre), p(resid), ldr, acc, None)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (300, 200, 100), (77, 64, 48), (1214, 1214, 64), (257, 40, 1214),
+                                   (9, 5, 12), (130, 3072, 768)])
+@pytest.mark.parametrize("tA,tB", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_gemm_all_layouts(L, M, N, K, tA, tB):
+    pad = lambda v: (v + 3) // 4 * 4  # noqa: E731
+    a = synth.normal(1, (K, M) if tA else (M, K))
+    b = synth.normal(2, (K, N) if tB else (N, K))
+    lda, ldb = pad(a.shape[1]), pad(b.shape[1])
+    ap, bp = np.zeros((a.shape[0], lda), np.float32), np.zeros((b.shape[0], ldb), np.float32)
+    ap[:, :a.shape[1]], bp[:, :b.shape[1]] = a, b
+    A, B = dev(ap), dev(bp)
+    C = torch.full((M, N + 3), 7.0, device="cuda")
+    gemm(L, A, B, C, M, N, K, lda, ldb, N + 3, tA, tB, alpha=0.5)
+    ad = torch.from_numpy(a).double()
+    bd = torch.from_numpy(b).double()
+    ref = 0.5 * (ad.t() if tA else ad) @ (bd if tB else bd.t())
+    close(C[:, :N], ref, 1e-5, 2e-5 * float(ref.abs().max()), "C")
+    assert torch.all(C[:, N:] == 7.0)                    # never writes outside [M,N]
+
+
+def test_gemm_epilogues(L):
+    M, N, K = 200, 136, 72
+    a, b = synth.normal(3, (M, K)), synth.normal(4, (N, K), 0, 0.2)
+    bias, resid = synth.normal(5, (N,)), synth.normal(6, (M, N))
+    A, B, bi, rs = dev(a), dev(b), dev(bias), dev(resid)
+    C, pre = torch.zeros(M, N, device="cuda"), torch.zeros(M, N, device="cuda")
+    gemm(L, A, B, C, M, N, K, K, K, N, bias=bi, gelu=1, pre=pre, resid=rs, ldr=N)
+    z = torch.from_numpy(a).double() @ torch.from_numpy(b).double().t() + torch.from_numpy(bias).double()
+    close(pre, z, 1e-5, 1e-5, "pre")
+    ref = z * 0.5 * (1 + torch.erf(z / np.sqrt(2))) + torch.from_numpy(resid).double()
+    close(C, ref, 1e-5, 2e-5, "gelu+resid")
+    C2 = C.clone()
+    gemm(L, A, B, C2, M, N, K, K, K, N, acc=1)
+    close(C2, ref + (z - torch.from_numpy(bias).double()), 1e-5, 4e-5, "accumulate")
+
+
+def test_gemm_batched_head_strides(L):
+    """The attention products exactly as the encoder issues them: Q.K^T, P.V, dV, dK over (image, head)."""
+    Bn, H, N, hd = 2, 3, 197, 16
+    D = H * hd
+    ldn = 200
+    qkv = synth.normal(7, (Bn * N, 3 * D))
+    Q = dev(qkv)
+    S = torch.zeros(Bn * H, N, ldn, device="cuda")
+    sQ, sP, sO = (N * 3 * D, hd), (H * N * ldn, N * ldn), (N * D, hd)
+    gemm(L, Q.data_ptr(), Q.data_ptr() + 4 * D, S, N, N, hd, 3 * D, 3 * D, ldn, batch=Bn * H, heads=H, sA=sQ, sB=sQ,
+         sC=sP, alpha=0.25)
+    t = torch.from_numpy(qkv).double().view(Bn, N, 3, H, hd)
+    q, k, v = (t[:, :, i].permute(0, 2, 1, 3) for i in range(3))       # [B,H,N,hd]
+    sref = 0.25 * q @ k.transpose(2, 3)
+    close(S.view(Bn, H, N, ldn)[..., :N], sref, 1e-5, 1e-5, "scores")
+    assert torch.all(S.view(Bn, H, N, ldn)[..., N:] == 0)
+    L.call("eav_softmax_fwd", S.data_ptr(), Bn * H * N, N, ldn, None)
+    pref = torch.softmax(sref, -1)
+    close(S.view(Bn, H, N, ldn)[..., :N], pref, 1e-5, 1e-7, "softmax")
+    O = torch.zeros(Bn * N, D, device="cuda")
+    gemm(L, S, Q.data_ptr() + 8 * D, O, N, hd, N, ldn, 3 * D, D, tB=1, batch=Bn * H, heads=H, sA=sP, sB=sQ, sC=sO)
+    oref = (pref @ v).permute(0, 2, 1, 3).reshape(Bn * N, D)
+    close(O, oref, 1e-5, 1e-6, "P.V")
+    do = synth.normal(8, (Bn * N, D))
+    dO = dev(do)
+    dqkv = torch.zeros(Bn * N, 3 * D, device="cuda")
+    gemm(L, S, dO, dqkv.data_ptr() + 8 * D, N, hd, N, ldn, D, 3 * D, tA=1, tB=1, batch=Bn * H, heads=H, sA=sP, sB=sO, sC=sQ)
+    dot = torch.from_numpy(do).double().view(Bn, N, H, hd).permute(0, 2, 1, 3)
+    dv = (pref.transpose(2, 3) @ dot).permute(0, 2, 1, 3).reshape(Bn * N, D)
+    close(dqkv[:, 2 * D:], dv, 1e-5, 1e-6, "dV")
+    dP = torch.zeros(Bn * H, N, ldn, device="cuda")
+    gemm(L, dO, Q.data_ptr() + 8 * D, dP, N, N, hd, D, 3 * D, ldn, batch=Bn * H, heads=H, sA=sO, sB=sQ, sC=sP)
+    dpref = dot @ v.transpose(2, 3)
+    close(dP.view(Bn, H, N, ldn)[..., :N], dpref, 1e-5, 1e-5, "dP")
+    L.call("eav_softmax_bwd", S.data_ptr(), dP.data_ptr(), Bn * H * N, N, ldn, None)
+    dsref = pref * (dpref - (dpref * pref).sum(-1, keepdim=True))
+    close(dP.view(Bn, H, N, ldn)[..., :N], dsref, 1e-4, 1e-7, "dS")
+    gemm(L, dP, Q, dqkv.data_ptr() + 4 * D, N, hd, N, ldn, 3 * D, 3 * D, tA=1, tB=1, batch=Bn * H, heads=H, sA=sP,
+         sB=sQ, sC=sQ, alpha=0.25)
+    dk = 0.25 * (dsref.transpose(2, 3) @ q).permute(0, 2, 1, 3).reshape(Bn * N, D)
+    close(dqkv[:, D:2 * D], dk, 1e-4, 1e-7, "dK")
+
+
+@pytest.mark.parametrize("M,D", [(9, 64), (1000, 768), (33, 1024)])
+def test_layernorm_fwd_bwd(L, M, D):
+    x = synth.normal(11, (M, D), 0.3, 2.0)
+    x[1] = 0.467                                           # constant row (AST padding value): var = 0, eps = 1e-12
+    g, b = synth.uniform(12, (D,), 0.5, 1.5), synth.normal(13, (D,), 0, 0.1)
+    X, G, Bt = dev(x), dev(g), dev(b)
+    y, st = torch.empty(M, D, device="cuda"), torch.empty(2, M, device="cuda")
+    L.call("eav_layernorm_fwd", X.data_ptr(), G.data_ptr(), Bt.data_ptr(), y.data_ptr(), st.data_ptr(),
+           st.data_ptr() + 4 * M, M, D, 1e-12, None)
+    xt = torch.from_numpy(x).double().requires_grad_(True)
+    gt = torch.from_numpy(g).double().requires_grad_(True)
+    bt = torch.from_numpy(b).double().requires_grad_(True)
+    ref = F.layer_norm(xt, (D,), gt, bt, 1e-12)
+    keep = np.ones(M, bool)
+    keep[1] = False                                        # the degenerate row is checked for finiteness only
+    close(y[torch.from_numpy(keep).cuda()], ref[torch.from_numpy(keep)], 1e-4, 2e-5, "ln fwd")
+    assert torch.isfinite(y).all()
+    dy = synth.normal(14, (M, D))
+    dy[1] = 0
+    ref.backward(torch.from_numpy(dy).double())
+    dx = torch.full((M, D), 1.0, device="cuda")
+    npart = L.plain("eav_layernorm_bwd_nparts", M)
+    part = torch.zeros(npart, 2 * D, device="cuda")
+    L.call("eav_layernorm_bwd", dev(dy).data_ptr(), X.data_ptr(), G.data_ptr(), st.data_ptr(), st.data_ptr() + 4 * M,
+           dx.data_ptr(), 1, part.data_ptr(), M, D, None)
+    torch.cuda.synchronize()
+    close((dx - 1.0)[torch.from_numpy(keep).cuda()], xt.grad[torch.from_numpy(keep)], 1e-3, 1e-4, "ln dx (accumulated)")
+    ps = part.sum(0).cpu().double()
+    # the constant row contributes xhat = 0 * 1e6-ish garbage-free terms only through dy = 0
+    close(ps[:D], gt.grad, 1e-3, 1e-3, "dgamma")
+    close(ps[D:], bt.grad, 1e-4, 1e-4, "dbeta")
+
+
+def test_gelu_bwd_colsum_im2col_embed(L):
+    n = 4096
+    pre, d = synth.normal(21, (n,), 0, 2.0), synth.normal(22, (n,))
+    D_ = dev(d)
+    L.call("eav_gelu_bwd", D_.data_ptr(), dev(pre).data_ptr(), n, None)
+    pt = torch.from_numpy(pre).double().requires_grad_(True)
+    (pt * 0.5 * (1 + torch.erf(pt / np.sqrt(2)))).backward(torch.from_numpy(d).double())
+    close(D_, pt.grad, 1e-5, 1e-6, "gelu bwd")
+    M, N = 1000, 200
+    dy = synth.normal(23, (M, N))
+    npart = L.plain("eav_colsum_nparts", M)
+    part = torch.zeros(npart, N, device="cuda")
+    L.call("eav_colsum", dev(dy).data_ptr(), part.data_ptr(), M, N, N, None)
+    close(part.sum(0), dy.astype(np.float64).sum(0), 1e-5, 1e-4, "colsum")
+    # im2col: AST view (transposed input, stride 10) and ViT view
+    x = synth.normal(24, (2, 40, 36))                     # [B, frames=40, mel=36]
+    col = torch.zeros(2 * 3 * 3, 256, device="cuda")      # ny = (36-16)/10+1 = 3, nx = (40-16)/10+1 = 3
+    L.call("eav_im2col", dev(x).data_ptr(), col.data_ptr(), 2, 1, 36, 40, 16, 10, 10, 1, None)
+    img = torch.from_numpy(x).unsqueeze(1).transpose(2, 3)
+    ref = F.unfold(img, 16, stride=10).transpose(1, 2).reshape(-1, 256)
+    assert torch.equal(col.cpu(), ref)
+    xv = synth.normal(25, (2, 3, 32, 32))
+    colv = torch.zeros(2 * 4, 768, device="cuda")
+    L.call("eav_im2col", dev(xv).data_ptr(), colv.data_ptr(), 2, 3, 32, 32, 16, 16, 16, 0, None)
+    refv = F.unfold(torch.from_numpy(xv), 16, stride=16).transpose(1, 2).reshape(-1, 768)
+    assert torch.equal(colv.cpu(), refv)
+    # embedding finish / backward / token rows / pair mean
+    B, ntok, D, nx = 3, 7, 8, 2
+    h = synth.normal(26, (B, ntok, D))
+    cls, dist, pos = synth.normal(27, (D,)), synth.normal(28, (D,)), synth.normal(29, (ntok, D))
+    H_ = dev(h)
+    L.call("eav_embed_finish", H_.data_ptr(), dev(cls).data_ptr(), dev(dist).data_ptr(), dev(pos).data_ptr(), B, ntok,
+           D, nx, None)
+    ref = h.copy()
+    ref[:, 0], ref[:, 1] = cls, dist
+    ref += pos
+    assert np.allclose(H_.cpu().numpy(), ref, atol=1e-7)
+    dpos, demb = torch.zeros(ntok, D, device="cuda"), torch.zeros(B * (ntok - nx), D, device="cuda")
+    L.call("eav_embed_bwd", H_.data_ptr(), dpos.data_ptr(), demb.data_ptr(), B, ntok, D, nx, None)
+    assert np.allclose(dpos.cpu().numpy(), ref.sum(0), atol=1e-6)
+    assert np.allclose(demb.cpu().numpy(), ref[:, nx:].reshape(-1, D))
+    rows = torch.zeros(B * nx, D, device="cuda")
+    L.call("eav_token_rows", H_.data_ptr(), rows.data_ptr(), B, ntok, D, nx, 0, None)
+    assert np.allclose(rows.cpu().numpy(), ref[:, :nx].reshape(-1, D))
+    pooled = torch.zeros(B, D, device="cuda")
+    L.call("eav_pair_mean", rows.data_ptr(), pooled.data_ptr(), B, D, 0, None)
+    assert np.allclose(pooled.cpu().numpy(), ref[:, :2].mean(1), atol=1e-7)

@@ -1,0 +1,96 @@
+"""AudioModelTrainer / ImageClassifierTrainer against the UNMODIFIED reference trainers
+(tests/golden/{ast,vit}_trainer.npz): frozen epoch then unfrozen epoch on 6 train / 4 test items;
+the parity surface is outputs_test within 1e-3, plus the printed accuracy lines."""
+import io
+import json
+import os
+from contextlib import redirect_stdout
+
+import numpy as np
+import pytest
+import torch
+
+from eav_amd import synth
+from tests.golden_util import tf_weights
+
+pytestmark = pytest.mark.gpu
+
+
+def _save_model_dir(tmp_path, kind, seed):
+    """HF-format directory (config.json + model.safetensors [+ preprocessor_config.json]) with the
+    same generator-seeded weights the golden run used."""
+    from safetensors.numpy import save_file
+    from oracle import vit_oracle as vo
+    ocfg = vo.cfg_ast(hidden=64, layers=2, heads=4, ff=128) if kind == "ast" else vo.cfg_vit(hidden=64, layers=2, heads=4, ff=128)
+    W = tf_weights(seed, vo.param_shapes(ocfg), std=0.08)
+    save_file({k: np.ascontiguousarray(v) for k, v in W.items()}, str(tmp_path / "model.safetensors"))
+    common = {"hidden_size": 64, "num_hidden_layers": 2, "num_attention_heads": 4, "intermediate_size": 128,
+              "patch_size": 16, "layer_norm_eps": 1e-12, "hidden_act": "gelu",
+              "id2label": {str(i): f"LABEL_{i}" for i in range(5)}}
+    if kind == "ast":
+        cfg = dict(common, model_type="audio-spectrogram-transformer", num_mel_bins=128, max_length=1024,
+                   frequency_stride=10, time_stride=10)
+    else:
+        cfg = dict(common, model_type="vit", image_size=224, num_channels=3)
+        json.dump({"do_normalize": True, "do_rescale": True, "do_resize": True, "image_mean": [0.5, 0.5, 0.5],
+                   "image_std": [0.5, 0.5, 0.5], "image_processor_type": "ViTImageProcessor", "resample": 2,
+                   "rescale_factor": 1 / 255, "size": {"height": 224, "width": 224}},
+                  open(tmp_path / "preprocessor_config.json", "w"))
+    json.dump(cfg, open(tmp_path / "config.json", "w"))
+    return str(tmp_path)
+
+
+def _compare_lines(got, ref):
+    g = [l for l in got.strip().splitlines() if l.startswith("Epoch")]
+    r = [l for l in ref.strip().splitlines() if l.startswith("Epoch")]
+    assert g == r, (g, r)
+
+
+def test_audio_trainer_matches_reference(golden_dir, tmp_path, monkeypatch):
+    from eav_amd.audio import AudioModelTrainer
+    g = np.load(os.path.join(golden_dir, "ast_trainer.npz"))
+    path = _save_model_dir(tmp_path, "ast", int(g["wseed"]))
+    monkeypatch.chdir(tmp_path)
+    wav = synth.normal(90, (10, 80000), 0.0, 0.1)
+    y = synth.labels(91, 10)
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        tr = AudioModelTrainer([wav[:6], y[:6], wav[6:], y[6:]], path, sub="s", num_classes=5, batch_size=4)
+        # the reference's own ASTFeatureExtractor call is kept: same input_values
+        assert np.allclose(tr.tr_x.numpy(), g["tr_x"], atol=1e-5) and np.allclose(tr.te_x.numpy(), g["te_x"], atol=1e-5)
+        tr.model.reset_head(g["head.weight"], g["head.bias"])       # the head the reference drew from its RNG
+        tr.optimizer = type(tr.optimizer)(tr.model.parameters(), lr=tr.initial_lr, weight_decay=0.01, decoupled=True)
+        tr.train_dataloader.order_override = [g["order0"], g["order1"]]
+        tr.train(epochs=1, lr=5e-4, freeze=True)
+        assert not hasattr(tr, "outputs_test")                      # Q15: only after the unfrozen phase
+        tr.train(epochs=1, lr=5e-6, freeze=False)
+    err = np.abs(tr.outputs_test - g["outputs_test"]).max()
+    assert tr.outputs_test.shape == g["outputs_test"].shape and tr.outputs_test.dtype == np.float32
+    assert err < 1e-3, err
+    _compare_lines(buf.getvalue(), str(g["stdout"]))
+    assert open("training_performance_audio.txt").read().count("Epoch") == 2      # Q17
+
+
+def test_vision_trainer_matches_reference(golden_dir, tmp_path, monkeypatch):
+    from eav_amd.vision import ImageClassifierTrainer, trial_vote
+    g = np.load(os.path.join(golden_dir, "vit_trainer.npz"))
+    path = _save_model_dir(tmp_path, "vit", int(g["wseed"]))
+    monkeypatch.chdir(tmp_path)
+    frames = (synth.uniform(92, (10, 2, 56, 56, 3)) * 255).astype(np.uint8)
+    y = synth.labels(93, 10)
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        tr = ImageClassifierTrainer([frames[:6], y[:6], frames[6:], y[6:]], path, sub="s", num_labels=5, batch_size=4)
+        assert np.allclose(tr.train_dataloader.x.cpu().numpy(), g["tr_x"], atol=1e-6)
+        tr.model.reset_head(g["head.weight"], g["head.bias"])
+        tr.optimizer = type(tr.optimizer)(tr.model.parameters(), lr=tr.initial_lr, weight_decay=0.01, decoupled=True)
+        tr.train_dataloader.order_override = [g["order0"], g["order1"]]
+        tr.train(epochs=1, lr=5e-4, freeze=True)
+        tr.train(epochs=1, lr=5e-6, freeze=False)
+    err = np.abs(tr.outputs_test - g["outputs_test"]).max()
+    assert tr.outputs_test.shape == g["outputs_test"].shape
+    assert err < 1e-3, err
+    _compare_lines(buf.getvalue(), str(g["stdout"]))
+    pred, acc, f1 = trial_vote(tr.outputs_test, g["te_y"], frames_per_trial=2)
+    ref_pred = np.argmax(g["outputs_test"].reshape(-1, 2, 5).mean(1), 1)
+    assert np.array_equal(pred, ref_pred) and 0.0 <= acc <= 1.0 and 0.0 <= f1 <= 1.0

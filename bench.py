@@ -48,12 +48,66 @@ def cpu_baseline(steps=2, batch=16):
                       f"after 1 warm-up, {dt:.1f} s"}
 
 
+# fwd GFLOP per sample: AST 261.03, ViT-B/16 35.13; an unfrozen step = 3x
+ENC = {"ast": dict(B=8, gflop_fwd=261.03, cpu=(0.50, 1.87)), "vit": dict(B=128, gflop_fwd=35.13, cpu=(3.78, 21.1))}
+
+
+def bench_encoder(kind, dev, world, sync_factory, steps=4, warmup=2):
+    """Frozen (classifier only) and unfrozen AdamW train steps of the 12-layer AST / ViT-B/16 on synthetic
+    input (BASELINE.json configs[2], configs[3]); batch sizes are the reference drivers' (8 / 128)."""
+    import torch
+    from eav_amd import synth, transformer as T
+    from eav_amd.optim import CrossEntropyLoss, FusedAdam
+    cfg = T.make_config(kind)
+    torch.manual_seed(0)
+    model = T.Encoder(cfg).to(dev).train()
+    B = ENC[kind]["B"]
+    x, y = (synth.mel_batch(5, B) if kind == "ast" else synth.frame_batch(5, B))
+    x, y = torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
+    opt = FusedAdam(model.parameters(), lr=5e-6, weight_decay=0.01, decoupled=True)
+    crit = CrossEntropyLoss()
+    model._ensure_flat()
+    sync = sync_factory(model._flat[1])
+    res = {}
+    for phase, freeze in (("frozen", True), ("unfrozen", False)):
+        for k, p in model.named_parameters():
+            p.requires_grad = (not freeze) or k.startswith("classifier.")
+
+        def step():
+            opt.zero_grad()
+            loss = crit(model(x).logits, y)
+            loss.backward()
+            if sync is not None and not freeze:
+                sync()
+            opt.step()
+        for _ in range(warmup):
+            step()
+        model.kernel_events = {"eav_gemm_f32": []}
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        gemm_ms = sum(a.elapsed_time(b) for a, b in model.kernel_events["eav_gemm_f32"]) / steps
+        model.kernel_events = None
+        gflop = ENC[kind]["gflop_fwd"] * (1 if freeze else 3) * B
+        res[phase] = {"samples_per_s": round(B * world / dt, 2), "ms_per_step": round(dt * 1e3, 3), "batch_per_gpu": B,
+                      "gemm_ms_per_step": round(gemm_ms, 3),
+                      "achieved_tflops_f32": round(gflop / dt / 1e3, 2),
+                      "frac_of_f32_mfma_peak": round(gflop / dt / 1e3 / PEAK_F32_MFMA_TFLOPS, 4)}
+    del model, opt
+    torch.cuda.empty_cache()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-encoders", action="store_true", help="skip the AST / ViT sections of the report")
     args = ap.parse_args()
 
     import torch
@@ -116,6 +170,12 @@ def main():
     kern_ms = {k: sum(a.elapsed_time(b) for a, b in v) / max(len(v), 1) for k, v in model.kernel_events.items()}
     model.kernel_events = None
     final_loss = float(loss.item())
+    encoders = None
+    if not args.no_encoders:
+        del xs, model, opt
+        torch.cuda.empty_cache()
+        mk = (lambda g: eav_dist.GradSync([g])) if world > 1 else (lambda g: None)
+        encoders = {k: bench_encoder(k, dev, world, mk) for k in ("ast", "vit")}
 
     if rank == 0:
         dom = max(kern_ms, key=kern_ms.get)
@@ -149,6 +209,10 @@ def main():
                          "flop_per_launch": FIR_FLOP_PER_LAUNCH,
                          "avg_kernel_ms": {k.replace("eav_eegnet_", ""): round(v, 4) for k, v in kern_ms.items()}},
         }
+        if encoders is not None:
+            out["encoders"] = {"note": "12-layer AST / ViT-B/16, synthetic input, fp32 MFMA GEMMs (exact fp32: bf16 "
+                                       "operands miss the 1e-3 logit bound, DESIGN.md section 8); whole-job samples/s",
+                               **encoders}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

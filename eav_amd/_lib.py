@@ -48,6 +48,7 @@ SIGNATURES = {
     "eav_adam_step": [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _i64, _i, _p],
     "eav_gemm_f32": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64, _f, _p,
                      _i, _p, _p, _i, _i, _p],
+    "eav_gemm_f32_splitk": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "eav_layernorm_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _f, _p],
     "eav_layernorm_bwd": [_p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _p],
     "eav_softmax_fwd": [_p, _i64, _i, _i, _p],
@@ -69,6 +70,7 @@ PLAIN = {
     "eav_conv64_ntiles": ([_i], _i),
     "eav_conv64_wgrad_nparts": ([_i, _i], _i),
     "eav_layernorm_bwd_nparts": ([_i], _i),
+    "eav_gemm_f32_splitk_plan": ([_i, _i, _i], _i),
     "eav_colsum_nparts": ([_i], _i),
 }
 

@@ -36,6 +36,7 @@ struct GemmArgs {
   float alpha;
   int gelu;             // 1: erf-GELU after bias
   int accumulate;       // 1: C += result
+  int ksplit;           // > 0: split-K mode - slice z covers k in [z*ksplit, min(K, (z+1)*ksplit)), C[z] = partial
 };
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
@@ -70,10 +71,35 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int n = lane & 31, kk = lane >> 5;
-  const int M = g.M, N = g.N, K = g.K;
+  const int M = g.M, N = g.N;
+  int K = g.K;
+  if (g.ksplit > 0) {   // split-K: this z owns a K slice and its own partial-C slab
+    const int kbase = z * g.ksplit;
+    K = min(g.ksplit, g.K - kbase);
+    A = g.A + (TA ? (int64_t)kbase * g.lda : (int64_t)kbase);
+    B = g.B + (TB ? (int64_t)kbase * g.ldb : (int64_t)kbase);
+    C = g.C + (int64_t)z * g.M * g.ldc;
+  }
+  // interior tiles take the unguarded path (no per-element bounds logic in the hot loop)
+  const bool interior = (m0 + BM <= M) && (n0 + BN <= N) && (K % BK == 0);
 
   float4 ra[4], rb[NB4];
   auto load_tiles = [&](int k0) {
+    if (interior) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int f = t + 256 * i;
+        if (!TA) ra[i] = *reinterpret_cast<const float4*>(A + (int64_t)(m0 + (f >> 3)) * g.lda + k0 + 4 * (f & 7));
+        else ra[i] = *reinterpret_cast<const float4*>(A + (int64_t)(k0 + (f >> 5)) * g.lda + m0 + 4 * (f & 31));
+      }
+#pragma unroll
+      for (int i = 0; i < NB4; ++i) {
+        const int f = t + 256 * i;
+        if (!TB) rb[i] = *reinterpret_cast<const float4*>(B + (int64_t)(n0 + (f >> 3)) * g.ldb + k0 + 4 * (f & 7));
+        else rb[i] = *reinterpret_cast<const float4*>(B + (int64_t)(k0 + f / (BN / 4)) * g.ldb + n0 + 4 * (f % (BN / 4)));
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int f = t + 256 * i;
@@ -147,17 +173,31 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
     if (kt + 1 < nk) load_tiles((kt + 1) * BK);
     const float* as = As + buf * BK * SA + wm * 64 + n;
     const float* bs = Bs + buf * BK * SB + wn * WN + n;
+    // operands of k-step ks+1 are read while the MFMAs of step ks execute
+    float a0 = as[kk * SA], a1 = as[kk * SA + 32];
+    float bv[NT];
+#pragma unroll
+    for (int b = 0; b < NT; ++b) bv[b] = bs[kk * SB + 32 * b];
 #pragma unroll
     for (int ks = 0; ks < BK / 2; ++ks) {
-      const int k = 2 * ks + kk;
-      const float a0 = as[k * SA], a1 = as[k * SA + 32];
-      float bv[NT];
+      float a0n = 0.f, a1n = 0.f, bn[NT];
+      if (ks + 1 < BK / 2) {
+        const int k = 2 * (ks + 1) + kk;
+        a0n = as[k * SA];
+        a1n = as[k * SA + 32];
 #pragma unroll
-      for (int b = 0; b < NT; ++b) bv[b] = bs[k * SB + 32 * b];
+        for (int b = 0; b < NT; ++b) bn[b] = bs[k * SB + 32 * b];
+      }
 #pragma unroll
       for (int b = 0; b < NT; ++b) {
         acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv[b], acc[0][b], 0, 0, 0);
         acc[1][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv[b], acc[1][b], 0, 0, 0);
+      }
+      if (ks + 1 < BK / 2) {
+        a0 = a0n;
+        a1 = a1n;
+#pragma unroll
+        for (int b = 0; b < NT; ++b) bv[b] = bn[b];
       }
     }
     if (kt + 1 < nk) store_tiles(buf ^ 1);
@@ -194,8 +234,8 @@ int launch(const GemmArgs& g, int batch, hipStream_t st) {
   const size_t lds = (size_t)2 * BK * (SA + SB) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<BN, TA, TB>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<BN, TA, TB>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM), batch);
@@ -219,7 +259,7 @@ extern "C" int eav_gemm_f32(const float* A, const float* B, float* C, int M, int
   g.A = A; g.B = B; g.C = C; g.bias = bias; g.resid = resid; g.pre = pre;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr; g.H = heads;
   g.sAb = sAb; g.sAh = sAh; g.sBb = sBb; g.sBh = sBh; g.sCb = sCb; g.sCh = sCh;
-  g.alpha = alpha; g.gelu = gelu; g.accumulate = accumulate;
+  g.alpha = alpha; g.gelu = gelu; g.accumulate = accumulate; g.ksplit = 0;
   hipStream_t st = (hipStream_t)stream;
   const bool narrow = N <= 64;
   const int v = (narrow ? 4 : 0) | (transA ? 2 : 0) | (transB ? 1 : 0);
@@ -234,5 +274,62 @@ extern "C" int eav_gemm_f32(const float* A, const float* B, float* C, int M, int
     default: launch<64, true, true>(g, batch, st); break;
   }
   EAV_CHECK_LAUNCH("eav_gemm_f32");
+  return EAV_OK;
+}
+
+// Split-K form for the weight gradients (few output tiles, very long contraction over tokens):
+// nsplit K-slices write partial products to `ws` ([nsplit][M][N] floats), which are then summed in a
+// fixed order (fp64) into C - deterministic, no atomics.  eav_gemm_f32_splitk_plan returns nsplit.
+extern "C" int eav_gemm_f32_splitk_plan(int M, int N, int K) {
+  const int tiles = cdiv(M, BM) * cdiv(N, N <= 64 ? 64 : 128);
+  int ns = cdiv(1024, tiles);
+  const int maxs = cdiv(K, 256);
+  if (ns > maxs) ns = maxs;
+  if (ns > 64) ns = 64;
+  return ns < 1 ? 1 : ns;
+}
+
+__global__ void splitk_reduce_kernel(const float* __restrict__ ws, int nsplit, int64_t n, float* __restrict__ out) {
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n) return;
+  double a = 0, b = 0, c = 0, d = 0;
+  for (int s = 0; s < nsplit; ++s) {
+    const float4 v = *reinterpret_cast<const float4*>(ws + (int64_t)s * n + i);
+    a += v.x; b += v.y; c += v.z; d += v.w;
+  }
+  *reinterpret_cast<float4*>(out + i) = make_float4((float)a, (float)b, (float)c, (float)d);
+}
+
+extern "C" int eav_gemm_f32_splitk(const float* A, const float* B, float* C, float* ws, int M, int N, int K, int lda,
+                                   int ldb, int transA, int transB, void* stream) {
+  EAV_REQUIRE(A && B && C && ws && M > 0 && N > 0 && K > 0, "eav_gemm_f32_splitk: bad arguments");
+  EAV_REQUIRE((lda & 3) == 0 && (ldb & 3) == 0 && (N & 3) == 0 && (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)ws) & 15) == 0,
+              "eav_gemm_f32_splitk: operands must be 16-byte aligned, leading dimensions and N multiples of 4");
+  const int nsplit = eav_gemm_f32_splitk_plan(M, N, K);
+  GemmArgs g;
+  g.A = A; g.B = B; g.C = nsplit > 1 ? ws : C; g.bias = nullptr; g.resid = nullptr; g.pre = nullptr;
+  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = N; g.ldr = 0; g.H = 1;
+  g.sAb = g.sAh = g.sBb = g.sBh = g.sCb = g.sCh = 0;
+  g.alpha = 1.f; g.gelu = 0; g.accumulate = 0;
+  g.ksplit = nsplit > 1 ? cdiv(cdiv(K, nsplit), BK) * BK : 0;
+  const int nz = nsplit > 1 ? cdiv(K, g.ksplit) : 1;
+  hipStream_t st = (hipStream_t)stream;
+  const int v = (N <= 64 ? 4 : 0) | (transA ? 2 : 0) | (transB ? 1 : 0);
+  switch (v) {
+    case 0: launch<128, false, false>(g, nz, st); break;
+    case 1: launch<128, false, true>(g, nz, st); break;
+    case 2: launch<128, true, false>(g, nz, st); break;
+    case 3: launch<128, true, true>(g, nz, st); break;
+    case 4: launch<64, false, false>(g, nz, st); break;
+    case 5: launch<64, false, true>(g, nz, st); break;
+    case 6: launch<64, true, false>(g, nz, st); break;
+    default: launch<64, true, true>(g, nz, st); break;
+  }
+  EAV_CHECK_LAUNCH("eav_gemm_f32_splitk");
+  if (nsplit > 1) {
+    const int64_t n = (int64_t)M * N;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv64(n, 1024)), dim3(256), 0, st, ws, nz, n, C);
+    EAV_CHECK_LAUNCH("eav_gemm_f32_splitk(reduce)");
+  }
   return EAV_OK;
 }

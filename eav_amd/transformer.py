@@ -287,6 +287,8 @@ class Encoder(nn.Module):
             ws.part_ln = f(ws.np_ln, 2 * D)
             ws.np_cs = _lib.plain("eav_colsum_nparts", M)
             ws.part_cs = f(ws.np_cs, max(FF, 3 * D))
+            shapes = [(D, FF, M), (FF, D, M), (3 * D, D, M), (D, D, M), (D, c.kp, B * c.npatch)]
+            ws.splitk = f(max(_lib.plain("eav_gemm_f32_splitk_plan", m, n, k) * m * n for m, n, k in shapes))
         ws.drows, ws.dseqr = f(R, D), f(R, D)
         ws.dpooled, ws.dhl = f(B, D), f(B, D)
         ws.np_lnr = _lib.plain("eav_layernorm_bwd_nparts", R)
@@ -363,6 +365,10 @@ class Encoder(nn.Module):
         self._saved = (self._token, x, full, None)
         return self._token
 
+    def _wgrad(self, A, B, C, M, N, K, lda, ldb):
+        """C[M,N] = A^T.B for A stored [K,M], B stored [K,N] (weight gradient: contraction over tokens)."""
+        self._call("eav_gemm_f32_splitk", A, B, C, _lib.ptr(self._ws.splitk), M, N, K, lda, ldb, 1, 1, self._st)
+
     def _reduce(self, part, nparts, stride, n, out):
         self._call("eav_reduce_partials", _lib.ptr(part), nparts, stride, n, 1.0, out, self._st)
 
@@ -417,12 +423,12 @@ class Encoder(nn.Module):
                 Lk = f"{pre}.layers.{i}"
                 stp = P(ws.st[i])
                 # fc2: h_out = h_mid + act.W2^T + b2
-                self._gemm(dh, P(ws.act[i]), gp(f"{Lk}.mlp.fc2.weight"), D, FF, M, D, FF, FF, tA=1, tB=1)
+                self._wgrad(dh, P(ws.act[i]), gp(f"{Lk}.mlp.fc2.weight"), D, FF, M, D, FF)
                 self._bias_grad(dh, M, D, D, gp(f"{Lk}.mlp.fc2.bias"))
                 self._gemm(dh, w(f"{Lk}.mlp.fc2.weight"), dact, M, FF, D, D, FF, FF, tB=1)
                 L("eav_gelu_bwd", dact, P(ws.pre[i]), M * FF, st)
                 # fc1
-                self._gemm(dact, P(ws.y2[i]), gp(f"{Lk}.mlp.fc1.weight"), FF, D, M, FF, D, D, tA=1, tB=1)
+                self._wgrad(dact, P(ws.y2[i]), gp(f"{Lk}.mlp.fc1.weight"), FF, D, M, FF, D)
                 self._bias_grad(dact, M, FF, FF, gp(f"{Lk}.mlp.fc1.bias"))
                 self._gemm(dact, w(f"{Lk}.mlp.fc1.weight"), dy, M, D, FF, FF, D, D, tB=1)
                 # layernorm_after: dh (now gradient w.r.t. h_mid) += LN backward
@@ -432,7 +438,7 @@ class Encoder(nn.Module):
                 L("eav_reduce_partials", P(ws.part_ln) + 4 * D, ws.np_ln, 2 * D, D, 1.0,
                   gp(f"{Lk}.layernorm_after.bias"), st)
                 # o_proj
-                self._gemm(dh, P(ws.ao[i]), gp(f"{Lk}.attention.o_proj.weight"), D, D, M, D, D, D, tA=1, tB=1)
+                self._wgrad(dh, P(ws.ao[i]), gp(f"{Lk}.attention.o_proj.weight"), D, D, M, D, D)
                 self._bias_grad(dh, M, D, D, gp(f"{Lk}.attention.o_proj.bias"))
                 self._gemm(dh, w(f"{Lk}.attention.o_proj.weight"), dao, M, D, D, D, D, D, tB=1)
                 # attention core, batched over (image, head)
@@ -448,7 +454,7 @@ class Encoder(nn.Module):
                 self._gemm(dP, qkv, dqkv + 4 * D, N, hd, N, ldn, 3 * D, 3 * D, tA=1, tB=1, batch=B * H, heads=H,
                            sA=sP, sB=sQ, sC=sQ, alpha=scale)                               # dK = s dS^T Q
                 # fused q/k/v projection
-                self._gemm(dqkv, P(ws.y1[i]), gp(f"{Lk}.attention.q_proj.weight"), 3 * D, D, M, 3 * D, D, D, tA=1, tB=1)
+                self._wgrad(dqkv, P(ws.y1[i]), gp(f"{Lk}.attention.q_proj.weight"), 3 * D, D, M, 3 * D, D)
                 self._bias_grad(dqkv, M, 3 * D, 3 * D, gp(f"{Lk}.attention.q_proj.bias"))
                 self._gemm(dqkv, w(f"{Lk}.attention.q_proj.weight"), dy, M, D, 3 * D, 3 * D, D, D, tB=1)
                 L("eav_layernorm_bwd", dy, P(ws.hs[i]), w(f"{Lk}.layernorm_before.weight"), stp, stp + 4 * M, dh, 1,
@@ -463,8 +469,8 @@ class Encoder(nn.Module):
             if c.kind == "ast":
                 gflat[offs[f"{pre}.embeddings.distillation_token"][0]:][:D].copy_(gpos[D:2 * D])
             MP = B * c.npatch
-            self._gemm(P(ws.demb), P(ws.col), gp(f"{pre}.embeddings.patch_embeddings.projection.weight"), D, c.kp, MP,
-                       D, c.kp, c.kp, tA=1, tB=1)
+            self._wgrad(P(ws.demb), P(ws.col), gp(f"{pre}.embeddings.patch_embeddings.projection.weight"), D, c.kp, MP,
+                        D, c.kp)
             self._call("eav_colsum", P(ws.demb), P(ws.part_cs), MP, D, D, st)
             self._call("eav_reduce_partials", P(ws.part_cs), _lib.plain("eav_colsum_nparts", MP), D, D, 1.0,
                        gp(f"{pre}.embeddings.patch_embeddings.projection.bias"), st)

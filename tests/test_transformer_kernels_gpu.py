@@ -65,6 +65,21 @@ def test_gemm_all_layouts(L, M, N, K, tA, tB):
     assert torch.all(C[:, N:] == 7.0)                    # never writes outside [M,N]
 
 
+@pytest.mark.parametrize("M,N,K", [(768, 768, 9712), (3072, 768, 2500), (64, 256, 2424), (200, 40, 700), (8, 8, 64)])
+def test_gemm_splitk_weight_gradient(L, M, N, K):
+    a, b = synth.normal(31, (K, M)), synth.normal(32, (K, N))
+    A, B = dev(a), dev(b)
+    ns = L.plain("eav_gemm_f32_splitk_plan", M, N, K)
+    ws = torch.empty(max(ns, 1) * M * N, device="cuda")
+    C = torch.empty(M, N, device="cuda")
+    L.call("eav_gemm_f32_splitk", A.data_ptr(), B.data_ptr(), C.data_ptr(), ws.data_ptr(), M, N, K, M, N, 1, 1, None)
+    ref = torch.from_numpy(a).double().t() @ torch.from_numpy(b).double()
+    close(C, ref, 1e-5, 2e-5 * float(ref.abs().max()), f"split-K x{ns}")
+    C2 = torch.empty_like(C)
+    L.call("eav_gemm_f32_splitk", A.data_ptr(), B.data_ptr(), C2.data_ptr(), ws.data_ptr(), M, N, K, M, N, 1, 1, None)
+    assert torch.equal(C, C2)                               # fixed-order reduction: bit-reproducible
+
+
 def test_gemm_epilogues(L):
     M, N, K = 200, 136, 72
     a, b = synth.normal(3, (M, K)), synth.normal(4, (N, K), 0, 0.2)

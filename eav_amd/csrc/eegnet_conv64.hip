@@ -41,14 +41,17 @@ __global__ __launch_bounds__(256, 2) void conv64_fwd_kernel(const float* __restr
     for (int idx = threadIdx.x; idx < WCH * NCH / 4; idx += 256)
       reinterpret_cast<float4*>(ws)[idx] = reinterpret_cast<const float4*>(wT + (int64_t)ic * WCH * NCH)[idx];
     __syncthreads();
+    // software pipeline: operands of step ks+1 are read while the two MFMAs of step ks run
+    auto ldb = [&](int ks) { return ins[(ic * 8 + (ks >> 3)) * INS + wave * 32 + n + 2 * (ks & 7) + kk]; };
+    float bv = ldb(0), a0 = ws[kk * NCH + n], a1 = ws[kk * NCH + 32 + n];
 #pragma unroll 8
     for (int ks = 0; ks < WCH / 2; ++ks) {
-      const int kd = 2 * ks + kk;                       // contraction row within the chunk
-      const int il = ic * 8 + (ks >> 3), k = 2 * (ks & 7) + kk;
-      const float bv = ins[il * INS + wave * 32 + n + k];
-      const float a0 = ws[kd * NCH + n], a1 = ws[kd * NCH + 32 + n];
+      const int kn = (ks + 1 < WCH / 2) ? ks + 1 : ks;
+      const float bn = ldb(kn);
+      const float a0n = ws[(2 * kn + kk) * NCH + n], a1n = ws[(2 * kn + kk) * NCH + 32 + n];
       acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc1, 0, 0, 0);
+      bv = bn; a0 = a0n; a1 = a1n;
     }
   }
   // C layout: col = n (sample), row = (reg&3) + 8*(reg>>2) + 4*kk (output channel within the 32-tile)
@@ -126,14 +129,16 @@ __global__ __launch_bounds__(256, 2) void conv64_wgrad_kernel(const float* __res
     const float* bp1 = bp0 + 2 * P2S;
     const float* ap0 = dus + n * DUS + kk;
     const float* ap1 = ap0 + 32 * DUS;
+    float a0 = ap0[0], a1 = ap1[0], b0 = bp0[0], b1 = bp1[0];
 #pragma unroll 8
     for (int ks = 0; ks < TT / 2; ++ks) {
-      const float a0 = ap0[2 * ks], a1 = ap1[2 * ks];
-      const float b0 = bp0[2 * ks], b1 = bp1[2 * ks];
+      const int kn = (ks + 1 < TT / 2) ? ks + 1 : ks;     // prefetch the next step's operands
+      const float a0n = ap0[2 * kn], a1n = ap1[2 * kn], b0n = bp0[2 * kn], b1n = bp1[2 * kn];
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
       acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      a0 = a0n; a1 = a1n; b0 = b0n; b1 = b1n;
     }
   }
   // part[slice][o][i][k]; C layout: col = n -> (channel n>>4, tap n&15), row -> o

@@ -53,20 +53,38 @@ __global__ __launch_bounds__(256, 2) void fir_fwd_kernel(const float* __restrict
   float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
   const bool vec = (S & 3) == 0;
   const int nwork = rows * nseg;
-  for (int work = blockIdx.x; work < nwork; work += gridDim.x) {
+  // the padded input segment of the NEXT work item is fetched into registers before the MFMA phase of
+  // the current one, so its HBM latency is hidden behind ~39k cycles of matrix work
+  constexpr int NLD = (TPS * TILE + 304 + 255) / 256;
+  float xr[NLD];
+  auto fetch = [&](int work) {
     const int row = work / nseg, seg = work - row * nseg;
     const int tile0 = seg * TPS;
     const int nt = min(TPS, ntiles - tile0);
     const int useg0 = tile0 * TILE;
     const float* xrow = x + (int64_t)row * S;
-    // stage the padded segment, polyphase: xs[(u&3)][u>>2], u local to the segment
     const int nload = nt * TILE + 304;
-    for (int idx = threadIdx.x; idx < nload; idx += 256) {
-      int t = useg0 + idx - padl;
-      float v = (t >= 0 && t < S) ? xrow[t] : 0.f;
-      xs[(idx & 3) * SEG_M4 + (idx >> 2)] = v;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int idx = threadIdx.x + 256 * i;
+      const int t = useg0 + idx - padl;
+      xr[i] = (idx < nload && t >= 0 && t < S) ? xrow[t] : 0.f;
+    }
+  };
+  if ((int)blockIdx.x < nwork) fetch(blockIdx.x);
+  for (int work = blockIdx.x; work < nwork; work += gridDim.x) {
+    const int row = work / nseg, seg = work - row * nseg;
+    const int tile0 = seg * TPS;
+    const int nt = min(TPS, ntiles - tile0);
+    const int useg0 = tile0 * TILE;
+    // polyphase image: xs[(u&3)][u>>2], u local to the segment
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int idx = threadIdx.x + 256 * i;
+      if (idx < TPS * TILE + 304) xs[(idx & 3) * SEG_M4 + (idx >> 2)] = xr[i];
     }
     __syncthreads();
+    if (work + (int)gridDim.x < nwork) fetch(work + gridDim.x);
     const int b = row / C, c = row - b * C;
     for (int tile = wave; tile < nt; tile += 4) {
       const float* pe = xs + kk * SEG_M4 + tile * 32 + n;
@@ -135,58 +153,110 @@ __global__ __launch_bounds__(256, 2) void fir_wgrad_kernel(
   for (int i = 0; i < WG_NT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const bool vec = (S & 3) == 0;
   const int nwork = rows * nchunk;
-  for (int work = blockIdx.x; work < nwork; work += gridDim.x) {
+  // staging is split: fetch(item) issues every global load of an item into registers, commit(item)
+  // forms dy = scale*(g - m1 - yhat*m2) and writes the LDS images.  The next item is fetched before
+  // the MFMA phase of the current one (HBM latency hidden behind ~20k cycles of matrix work).
+  constexpr int NQ = 8;                 // ceil(F1*(WG_CHMAX/4+1)/256)
+  constexpr int NX = (WG_CHMAX + 320 + 255) / 256;
+  float4 ry[NQ], rg[NQ];
+  float rx[NX];
+  const int nq1 = CH / 4 + 1;
+  auto fetch = [&](int work) {
     const int row = work / nchunk, chunk = work - row * nchunk;
-    const int c0 = chunk * CH;                 // u range [c0, c0 + CH)
+    const int c0 = chunk * CH;
     const int b = row / C, c = row - b * C;
-    // ---- stage dy[f][4 + (u - c0)], u in [c0-4, c0+CH): dy = scale*(g - m1 - yhat*m2)
-    for (int idx = threadIdx.x; idx < F1 * (CH / 4 + 1); idx += 256) {
-      const int f = idx / (CH / 4 + 1), q = idx - f * (CH / 4 + 1);
-      const int t = c0 - 4 + 4 * q;
-      const int64_t base = (((int64_t)b * F1 + f) * C + c) * S;
-      const float mean = bnp[f], invstd = bnp[8 + f], sc = bnp[16 + f], m1 = bnp[32 + f], m2 = bnp[40 + f];
-      float yv[4], gv[4];
-      if (vec && t >= 0 && t + 3 < S) {
-        float4 a = *reinterpret_cast<const float4*>(y1 + base + t);
-        float4 d = *reinterpret_cast<const float4*>(g1 + base + t);
-        yv[0] = a.x; yv[1] = a.y; yv[2] = a.z; yv[3] = a.w;
-        gv[0] = d.x; gv[1] = d.y; gv[2] = d.z; gv[3] = d.w;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) yv[e] = sc * (gv[e] - m1 - (yv[e] - mean) * invstd * m2);
-      } else {
+    for (int i = 0; i < NQ; ++i) {
+      const int idx = threadIdx.x + 256 * i;
+      ry[i] = rg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < F1 * nq1) {
+        const int f = idx / nq1, q = idx - f * nq1;
+        const int t = c0 - 4 + 4 * q;
+        const int64_t base = (((int64_t)b * F1 + f) * C + c) * S;
+        if (vec && t >= 0 && t + 3 < S) {
+          ry[i] = *reinterpret_cast<const float4*>(y1 + base + t);
+          rg[i] = *reinterpret_cast<const float4*>(g1 + base + t);
+        } else {
+          float yv[4], gv[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          int te = t + e;
-          if (te >= 0 && te < S) {
-            float yy = y1[base + te], gg = g1[base + te];
-            yv[e] = sc * (gg - m1 - (yy - mean) * invstd * m2);
-          } else {
-            yv[e] = 0.f;
+          for (int e = 0; e < 4; ++e) {
+            const int te = t + e;
+            const bool ok = te >= 0 && te < S;
+            yv[e] = ok ? y1[base + te] : 0.f;
+            gv[e] = ok ? g1[base + te] : 0.f;
           }
+          ry[i] = make_float4(yv[0], yv[1], yv[2], yv[3]);
+          rg[i] = make_float4(gv[0], gv[1], gv[2], gv[3]);
         }
       }
-      *reinterpret_cast<float4*>(&dyl[f * WG_DYSTRIDE + 4 * q]) = make_float4(yv[0], yv[1], yv[2], yv[3]);
     }
-    // ---- stage xpad[u], u in [c0, c0 + CH + 320)
-    {
-      const float* xrow = x + (int64_t)row * S;
-      for (int idx = threadIdx.x; idx < CH + 320; idx += 256) {
-        int t = c0 + idx - padl;
-        xl[idx] = (t >= 0 && t < S) ? xrow[t] : 0.f;
+    const float* xrow = x + (int64_t)row * S;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int idx = threadIdx.x + 256 * i;
+      const int t = c0 + idx - padl;
+      rx[i] = (idx < CH + 320 && t >= 0 && t < S) ? xrow[t] : 0.f;
+    }
+  };
+  auto commit = [&](int work) {
+    const int chunk = work % nchunk;
+    const int c0 = chunk * CH;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const int idx = threadIdx.x + 256 * i;
+      if (idx < F1 * nq1) {
+        const int f = idx / nq1, q = idx - f * nq1;
+        const int t = c0 - 4 + 4 * q;
+        const float mean = bnp[f], invstd = bnp[8 + f], sc = bnp[16 + f], m1 = bnp[32 + f], m2 = bnp[40 + f];
+        const float yv[4] = {ry[i].x, ry[i].y, ry[i].z, ry[i].w};
+        const float gv[4] = {rg[i].x, rg[i].y, rg[i].z, rg[i].w};
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int te = t + e;
+          o[e] = (te >= 0 && te < S) ? sc * (gv[e] - m1 - (yv[e] - mean) * invstd * m2) : 0.f;
+        }
+        *reinterpret_cast<float4*>(&dyl[f * WG_DYSTRIDE + 4 * q]) = make_float4(o[0], o[1], o[2], o[3]);
       }
     }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int idx = threadIdx.x + 256 * i;
+      if (idx < CH + 320) xl[idx] = rx[i];
+    }
+  };
+  if ((int)blockIdx.x < nwork) fetch(blockIdx.x);
+  for (int work = blockIdx.x; work < nwork; work += gridDim.x) {
+    commit(work);
     __syncthreads();
+    if (work + (int)gridDim.x < nwork) fetch(work + gridDim.x);
     // ---- each wave contracts its quarter of the chunk
     const int ksteps = CH / 16;
     const float* ap = dyl + af * WG_DYSTRIDE + 4 + wave * (CH / 4) + kq - as;
     const float* bp = xl + wave * (CH / 4) + kq + 2 * col;
-    for (int ks = 0; ks < ksteps; ++ks) {
-      float av = ap[4 * ks];
+    // software pipeline, two register sets (no copies): the 11 operands of the next K-step are read
+    // while the 10 MFMAs of the current one run; sched_barrier pins loads-before-MFMAs.
+    float av0 = ap[0], bv0[WG_NT], av1, bv1[WG_NT];
 #pragma unroll
-      for (int nt = 0; nt < WG_NT; ++nt) {
-        float bv = bp[4 * ks + 32 * nt];
-        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[nt], 0, 0, 0);
-      }
+    for (int nt = 0; nt < WG_NT; ++nt) bv0[nt] = bp[32 * nt];
+    for (int ks = 0; ks < ksteps; ks += 2) {        // ksteps = CH/16 is even only if CH % 32 == 0: guard below
+      const int k1 = (ks + 1 < ksteps) ? ks + 1 : ks;
+      av1 = ap[4 * k1];
+#pragma unroll
+      for (int nt = 0; nt < WG_NT; ++nt) bv1[nt] = bp[4 * k1 + 32 * nt];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int nt = 0; nt < WG_NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0, bv0[nt], acc[nt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ks + 1 >= ksteps) break;
+      const int k2 = (ks + 2 < ksteps) ? ks + 2 : ks + 1;
+      av0 = ap[4 * k2];
+#pragma unroll
+      for (int nt = 0; nt < WG_NT; ++nt) bv0[nt] = bp[4 * k2 + 32 * nt];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int nt = 0; nt < WG_NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1, bv1[nt], acc[nt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
   }
@@ -218,6 +288,7 @@ __global__ __launch_bounds__(256, 2) void fir_wgrad_kernel(
 }  // namespace
 
 static int fir_grid(int nwork) { return nwork < 512 ? nwork : 512; }
+static int wgrad_grid(int nwork) { return nwork < 512 ? nwork : 512; }
 
 extern "C" int eav_eegnet_fir_fwd_nparts(int B, int C, int S) {
   int ntiles = cdiv(S, TILE), nseg = cdiv(ntiles, TPS);
@@ -246,7 +317,7 @@ static void wgrad_geometry(int S, int* nchunk, int* CH) {
 extern "C" int eav_eegnet_fir_wgrad_nparts(int B, int C, int S) {
   int nchunk, CH;
   wgrad_geometry(S, &nchunk, &CH);
-  return fir_grid(B * C * nchunk);
+  return wgrad_grid(B * C * nchunk);
 }
 
 // part: [nparts][8][klen] floats; sum over parts = dL/d(firstConv.weight)
@@ -257,7 +328,7 @@ extern "C" int eav_eegnet_fir_wgrad(const float* x, const float* y1, const float
   int nchunk, CH;
   wgrad_geometry(S, &nchunk, &CH);
   const int nwork = B * C * nchunk;
-  hipLaunchKernelGGL(fir_wgrad_kernel, dim3(fir_grid(nwork)), dim3(256), 0, (hipStream_t)stream, x, y1, g1,
+  hipLaunchKernelGGL(fir_wgrad_kernel, dim3(wgrad_grid(nwork)), dim3(256), 0, (hipStream_t)stream, x, y1, g1,
                      bn_params, part, B * C, C, S, klen, (klen - 1) / 2, nchunk, CH);
   EAV_CHECK_LAUNCH("eav_eegnet_fir_wgrad");
   return EAV_OK;

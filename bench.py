@@ -117,7 +117,11 @@ def main():
     from eav_amd.eegnet import EEGNet_tor
     from eav_amd.optim import CrossEntropyLoss, FusedAdam
 
-    rank, world, local = eav_dist.init_from_env("nccl")
+    # EAV_DIST_BACKEND=gloo + EAV_FORCE_DEVICE=0 let two ranks share one GPU (logic test on a 1-GPU box)
+    backend = os.environ.get("EAV_DIST_BACKEND", "nccl")
+    if "EAV_FORCE_DEVICE" in os.environ:
+        os.environ["LOCAL_RANK"] = os.environ["EAV_FORCE_DEVICE"]
+    rank, world, local = eav_dist.init_from_env(backend)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     torch.cuda.set_device(local)

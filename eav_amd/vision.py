@@ -83,6 +83,20 @@ class ImageClassifierTrainer:
         return loader, processed_x, y_repeated
 
     def preprocess_images(self, image_list):
+        """Reference: a Python loop calling the HF processor per frame, then one stack().to(device)
+        (:52-59).  Uniform uint8 HWC frames with the standard resize/rescale/normalize recipe go through
+        one HIP kernel (bit-identical result); anything else takes the reference's host route."""
+        p = self.processor
+        arr = np.asarray(image_list) if not isinstance(image_list, np.ndarray) else image_list
+        std_recipe = (getattr(p, "do_resize", False) and getattr(p, "do_rescale", False)
+                      and getattr(p, "do_normalize", False) and not getattr(p, "do_center_crop", False)
+                      and int(getattr(p, "resample", 2)) == 2 and getattr(p, "size", None) is not None)
+        if std_recipe and arr.dtype == np.uint8 and arr.ndim == 5 and arr.shape[-1] == 3:
+            from .preprocess import frames_to_pixel_values
+            sz = p.size
+            hw = (int(sz["height"]), int(sz["width"])) if isinstance(sz, dict) else (int(sz.height), int(sz.width))
+            return frames_to_pixel_values(arr.reshape(-1, *arr.shape[2:]), hw, p.image_mean, p.image_std,
+                                          p.rescale_factor, self.device)
         pixel_values_list = []
         for img_set in image_list:
             for img in img_set:

@@ -139,6 +139,15 @@ int eav_token_rows(float* h, float* rows, int B, int ntok, int D, int nextra, in
 /* AST pooled = (cls + dist)/2 (HF AST :304); backward=1 writes dseq from dpooled. */
 int eav_pair_mean(float* seq, float* pooled, int B, int D, int backward, void* stream);
 
+/* ---- pre-processing (SURVEY section 8f "next" rows) ------------------------------------------------ */
+/* HF image processor on a batch of uint8 HWC frames (Transformer_Vision.py:52-59): Pillow-exact 8-bit
+ * bilinear resize (coefficient tables kx/ky [out][ksize] int32 and bounds [out][2] = (first, count), built
+ * on the host like Pillow's precompute_coeffs), * rescale (float64), (x - mean) / std -> out [n,C,OH,OW] fp32.
+ * mean3 / std3 are HOST pointers. */
+int eav_resize_normalize_u8(const uint8_t* frames, const int* kx, const int* boundsx, const int* ky,
+                            const int* boundsy, float* out, int n, int H, int W, int C, int OH, int OW, int ksize_x,
+                            int ksize_y, double rescale, const float* mean3, const float* std3, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,84 @@
+"""Oracle: the host pre-processing either side of the encoders, restated in numpy.
+
+TEST INFRASTRUCTURE - see oracle/__init__.py.
+
+resize_bilinear_u8 restates Pillow's 8-bit resampler (third-party dependency of the reference via the
+HF image processor, Transformer_Vision.py:56; Pillow's published algorithm in src/libImaging/Resample.c:
+precompute_coeffs, normalize_coeffs_8bpc, ImagingResampleHorizontal_8bpc / Vertical_8bpc): triangle filter,
+support scaled by max(in/out, 1), coefficients normalised in float64 and rounded to 22-bit fixed point,
+horizontal pass rounded to uint8 before the vertical pass.  vit_preprocess adds the HF steps
+(image * (1/255) in float64 -> float32, then (x - mean) / std in float32).  Pinned against the processed
+frames the reference trainer itself produced (tests/golden/vit_trainer.npz: tr_x / te_x).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+PRECISION_BITS = 32 - 8 - 2
+
+
+def precompute_coeffs(in_size, out_size):
+    """-> (bounds int32 [out,2] = (first, count), coeffs int32 [out, ksize]) - Pillow precompute_coeffs +
+    normalize_coeffs_8bpc for the bilinear (triangle, support 1.0) filter over the whole input range."""
+    scale = in_size / out_size
+    filterscale = max(scale, 1.0)
+    support = 1.0 * filterscale
+    ksize = int(np.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), np.int32)
+    kk = np.zeros((out_size, ksize), np.float64)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = max(int(center - support + 0.5), 0)
+        xmax = min(int(center + support + 0.5), in_size) - xmin
+        w = np.array([max(0.0, 1.0 - abs((x + xmin - center + 0.5) * ss)) for x in range(xmax)], np.float64)
+        ww = w.sum()
+        if ww != 0.0:
+            w = w / ww
+        kk[xx, :xmax] = w
+        bounds[xx] = (xmin, xmax)
+    fixed = np.where(kk < 0, (-0.5 + kk * (1 << PRECISION_BITS)).astype(np.int64),
+                     (0.5 + kk * (1 << PRECISION_BITS)).astype(np.int64)).astype(np.int32)
+    return bounds, fixed
+
+
+def _clip8(v):
+    return np.clip(v >> PRECISION_BITS, 0, 255).astype(np.uint8)
+
+
+def resize_bilinear_u8(img, out_h, out_w):
+    """img uint8 [H,W,C] -> uint8 [out_h,out_w,C] exactly as PIL.Image.resize(..., BILINEAR) does."""
+    H, W, C = img.shape
+    bx, kx = precompute_coeffs(W, out_w)
+    by, ky = precompute_coeffs(H, out_h)
+    src = img.astype(np.int64)
+    tmp = np.zeros((H, out_w, C), np.uint8)
+    for xx in range(out_w):
+        x0, n = bx[xx]
+        acc = (1 << (PRECISION_BITS - 1)) + (src[:, x0:x0 + n, :] * kx[xx, :n].astype(np.int64)[None, :, None]).sum(1)
+        tmp[:, xx, :] = _clip8(acc)
+    t64 = tmp.astype(np.int64)
+    out = np.zeros((out_h, out_w, C), np.uint8)
+    for yy in range(out_h):
+        y0, n = by[yy]
+        acc = (1 << (PRECISION_BITS - 1)) + (t64[y0:y0 + n] * ky[yy, :n].astype(np.int64)[:, None, None]).sum(0)
+        out[yy] = _clip8(acc)
+    return out
+
+
+def vit_preprocess(frames, size=224, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5), rescale=1 / 255):
+    """frames uint8 [n,H,W,3] -> float32 [n,3,size,size] (HF ViTImageProcessor defaults, Transformer_Vision.py:52-59)."""
+    out = np.zeros((len(frames), 3, size, size), np.float32)
+    m = np.asarray(mean, np.float32)[:, None, None]
+    s = np.asarray(std, np.float32)[:, None, None]
+    for i, f in enumerate(frames):
+        r = resize_bilinear_u8(f, size, size).transpose(2, 0, 1)
+        x = (r.astype(np.float64) * rescale).astype(np.float32)
+        out[i] = (x - m) / s
+    return out
+
+
+def trial_vote(outputs_test, frames_per_trial=25):
+    """reshape(n_trials, frames, classes).mean(1).argmax(1) - Transformer_Vision.py:177-180."""
+    a = np.reshape(outputs_test, (-1, frames_per_trial, outputs_test.shape[-1]), 'C')
+    return np.argmax(np.mean(a, 1), axis=1)

@@ -1,0 +1,32 @@
+"""Pin oracle/preprocess_oracle.py: Pillow-exact resize vs PIL itself and vs the frames the reference
+trainer's own HF processor produced (tests/golden/vit_trainer.npz)."""
+import os
+
+import numpy as np
+
+from eav_amd import synth
+from oracle import preprocess_oracle as po
+
+
+def test_resize_matches_pillow_bit_exact():
+    from PIL import Image
+    for seed, (h, w, oh, ow) in enumerate([(56, 56, 224, 224), (56, 56, 100, 75), (64, 48, 32, 24), (7, 9, 20, 31)]):
+        img = (synth.uniform(500 + seed, (h, w, 3)) * 256).astype(np.uint8)
+        ref = np.asarray(Image.fromarray(img).resize((ow, oh), resample=Image.BILINEAR))
+        got = po.resize_bilinear_u8(img, oh, ow)
+        assert np.array_equal(got, ref), (h, w, oh, ow, np.abs(got.astype(int) - ref.astype(int)).max())
+
+
+def test_vit_preprocess_matches_reference_trainer_frames(golden_dir):
+    g = np.load(os.path.join(golden_dir, "vit_trainer.npz"))
+    frames = (synth.uniform(92, (10, 2, 56, 56, 3)) * 255).astype(np.uint8)
+    got = po.vit_preprocess(frames[:6].reshape(-1, 56, 56, 3))
+    assert got.shape == g["tr_x"].shape
+    assert np.array_equal(got, g["tr_x"])                    # bit-exact, float32
+    got_te = po.vit_preprocess(frames[6:].reshape(-1, 56, 56, 3))
+    assert np.array_equal(got_te, g["te_x"])
+
+
+def test_trial_vote():
+    o = synth.normal(7, (50, 5))
+    assert np.array_equal(po.trial_vote(o, 25), o.reshape(2, 25, 5).mean(1).argmax(1))

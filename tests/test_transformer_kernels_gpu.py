@@ -219,3 +219,26 @@ def test_gelu_bwd_colsum_im2col_embed(L):
     pooled = torch.zeros(B, D, device="cuda")
     L.call("eav_pair_mean", rows.data_ptr(), pooled.data_ptr(), B, D, 0, None)
     assert np.allclose(pooled.cpu().numpy(), ref[:, :2].mean(1), atol=1e-7)
+
+
+def test_frame_preprocessing_bit_exact(golden_dir):
+    """GPU frames -> pixel_values == the oracle (Pillow-exact) == what the reference trainer's HF processor made."""
+    import os
+    from eav_amd.preprocess import frames_to_pixel_values, pillow_bilinear_tables
+    from oracle import preprocess_oracle as po
+    for a, b in ((56, 224), (48, 100), (224, 56), (7, 31)):
+        rb, rk = po.precompute_coeffs(a, b)
+        gb, gk = pillow_bilinear_tables(a, b)
+        assert np.array_equal(rb, gb) and np.array_equal(rk, gk), (a, b)
+    frames = (synth.uniform(92, (10, 2, 56, 56, 3)) * 255).astype(np.uint8).reshape(-1, 56, 56, 3)
+    got = frames_to_pixel_values(frames).cpu().numpy()
+    assert np.array_equal(got, po.vit_preprocess(frames))
+    g = np.load(os.path.join(golden_dir, "vit_trainer.npz"))
+    assert np.array_equal(got[:12], g["tr_x"]) and np.array_equal(got[12:], g["te_x"])
+    odd = (synth.uniform(93, (3, 40, 64, 3)) * 256).astype(np.uint8)          # non-square, down- and up-scaling
+    got = frames_to_pixel_values(odd, size=(96, 48), mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)).cpu().numpy()
+    ref = po.vit_preprocess
+    exp = np.stack([((po.resize_bilinear_u8(f, 96, 48).transpose(2, 0, 1).astype(np.float64) / 255).astype(np.float32)
+                     - np.float32([0.485, 0.456, 0.406])[:, None, None]) / np.float32([0.229, 0.224, 0.225])[:, None, None]
+                    for f in odd])
+    assert np.allclose(got, exp, atol=1e-6)

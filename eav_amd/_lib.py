@@ -60,6 +60,7 @@ SIGNATURES = {
     "eav_embed_bwd": [_p, _p, _p, _i, _i, _i, _i, _p],
     "eav_token_rows": [_p, _p, _i, _i, _i, _i, _i, _p],
     "eav_pair_mean": [_p, _p, _i, _i, _i, _p],
+    "eav_ast_fbank": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _d, _d, _f, _f, _p],
     "eav_resize_normalize_u8": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _d, _p, _p, _p],
 }
 # helpers that return a plain value (no status)

@@ -51,9 +51,15 @@ class AudioModelTrainer:
         return DeviceLoader(x, y, self.batch_size, shuffle, self.device)
 
     def _feature_extract(self, x):
+        """Reference (:38-42): ASTFeatureExtractor()(x, sampling_rate=16000, padding='max_length') on the host.
+        Equal-length clips go through the HIP log-mel kernel (same recipe, float64 up to the log)."""
         if isinstance(x, torch.Tensor) and x.dim() == 3:
             return x                                    # already [N,1024,128] input_values
-        from transformers import ASTFeatureExtractor   # host front-end, exactly the reference's call (:39-42)
+        arr = np.asarray(x)
+        if arr.ndim == 2 and arr.dtype != object and arr.shape[1] >= 400:
+            from .preprocess import waveforms_to_input_values
+            return waveforms_to_input_values(arr, device=self.device).cpu()
+        from transformers import ASTFeatureExtractor   # ragged input: the reference's own host call
         feature_extractor = ASTFeatureExtractor()
         ft = feature_extractor(x, sampling_rate=16000, padding='max_length', return_tensors='pt')
         return ft['input_values']

@@ -46,6 +46,74 @@ __global__ __launch_bounds__(256) void resize_norm_kernel(const uint8_t* __restr
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// AST log-mel front-end: what AudioModelTrainer._feature_extract does per clip on
+// the host (Transformer_Audio.py:38-42 -> HF ASTFeatureExtractor, numpy path): frames of 400 samples every
+// 160, remove DC, pre-emphasis 0.97, Hann (symmetric) window, 512-point real FFT, power, 128 kaldi-mel
+// filters (triangular in mel space, 20 Hz - 8 kHz), floor 1.19e-7, log, pad/truncate to max_len frames,
+// (x - mean) / (2 std).  Everything up to the log is float64 like the numpy reference (incl. its rounding
+// of the spectrum to complex64).  One block per (clip, frame).
+__global__ __launch_bounds__(256) void ast_fbank_kernel(const float* __restrict__ wav, const double* __restrict__ window,
+                                                        const double* __restrict__ tw /*[256][2] cos,-sin*/,
+                                                        const double* __restrict__ melT /*[nmel][257]*/,
+                                                        float* __restrict__ out, int L, int nframes, int max_len,
+                                                        int nmel, double preemph, double mel_floor, float mean,
+                                                        float std2) {
+  __shared__ double re[512], im[512], pw[257], red[4];
+  const int clip = blockIdx.y, frame = blockIdx.x;
+  float* dst = out + ((int64_t)clip * max_len + frame) * nmel;
+  if (frame >= nframes) {  // zero padding of the feature matrix, then normalised like every other value
+    if ((int)threadIdx.x < nmel) dst[threadIdx.x] = (0.0f - mean) / std2;
+    return;
+  }
+  const float* src = wav + (int64_t)clip * L + (int64_t)frame * 160;
+  const int t = threadIdx.x;
+  double a = (double)src[t], b = (t + 256 < 400) ? (double)src[t + 256] : 0.0;
+  // mean over the 400 samples (fixed-order tree)
+  double s = a + b;
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((t & 63) == 0) red[t >> 6] = s;
+  __syncthreads();
+  const double mu = ((red[0] + red[1]) + (red[2] + red[3])) / 400.0;
+  re[t] = a - mu;
+  re[t + 256] = (t + 256 < 400) ? b - mu : 0.0;
+  __syncthreads();
+  // pre-emphasis (on the DC-removed frame) and window, written in bit-reversed order for the DIT FFT
+  auto emph = [&](int i) { return i == 0 ? re[0] * (1.0 - preemph) : re[i] - preemph * re[i - 1]; };
+  const double v0 = emph(t) * window[t];
+  const double v1 = (t + 256 < 400) ? emph(t + 256) * window[t + 256] : 0.0;
+  __syncthreads();
+  auto brev9 = [](int i) { return (int)(__brev((unsigned)i) >> 23); };
+  re[brev9(t)] = v0; im[brev9(t)] = 0.0;
+  re[brev9(t + 256)] = v1; im[brev9(t + 256)] = 0.0;
+  __syncthreads();
+  for (int half = 1; half < 512; half <<= 1) {      // 9 radix-2 stages, one butterfly per thread
+    const int j = t & (half - 1), base = ((t - j) << 1) + j;
+    const int k = j * (256 / half);                  // twiddle index: W_512^(j * 512/(2*half))
+    const double wr = tw[2 * k], wi = tw[2 * k + 1];
+    const double xr = re[base + half], xi = im[base + half];
+    const double tr = wr * xr - wi * xi, ti = wr * xi + wi * xr;
+    const double ur = re[base], ui = im[base];
+    re[base] = ur + tr; im[base] = ui + ti;
+    re[base + half] = ur - tr; im[base + half] = ui - ti;
+    __syncthreads();
+  }
+  for (int f = t; f < 257; f += 256) {              // complex64 rounding of the spectrum, |.| in float64, ^2
+    const double r = (double)(float)re[f], i = (double)(float)im[f];
+    const double mag = hypot(r, i);
+    pw[f] = mag * mag;
+  }
+  __syncthreads();
+  if (t < nmel) {
+    const double* m = melT + (int64_t)t * 257;
+    double acc = 0.0;
+    for (int f = 0; f < 257; ++f) acc += m[f] * pw[f];
+    const float v = (float)log(fmax(mel_floor, acc));
+    dst[t] = (v - mean) / std2;
+  }
+}
+
 }  // namespace
 
 extern "C" int eav_resize_normalize_u8(const uint8_t* frames, const int* kx, const int* boundsx, const int* ky,
@@ -61,5 +129,18 @@ extern "C" int eav_resize_normalize_u8(const uint8_t* frames, const int* kx, con
                      boundsy, out, H, W, C, OH, OW, ksize_x, ksize_y, rescale, mean3[0], mean3[C > 1 ? 1 : 0],
                      mean3[C > 2 ? 2 : 0], std3[0], std3[C > 1 ? 1 : 0], std3[C > 2 ? 2 : 0]);
   EAV_CHECK_LAUNCH("eav_resize_normalize_u8");
+  return EAV_OK;
+}
+
+extern "C" int eav_ast_fbank(const float* wav, const double* window400, const double* twiddle256,
+                             const double* melT, float* out, int n, int L, int max_len, int nmel, double preemph,
+                             double mel_floor, float mean, float std2, void* stream) {
+  EAV_REQUIRE(wav && window400 && twiddle256 && melT && out && n > 0 && L >= 400 && max_len > 0 && nmel > 0 &&
+                  nmel <= 256, "eav_ast_fbank: bad arguments (clips must hold at least one 400-sample frame)");
+  const int nframes = 1 + (L - 400) / 160;
+  dim3 grid(max_len, n);
+  hipLaunchKernelGGL(ast_fbank_kernel, grid, dim3(256), 0, (hipStream_t)stream, wav, window400, twiddle256, melT, out,
+                     L, nframes < max_len ? nframes : max_len, max_len, nmel, preemph, mel_floor, mean, std2);
+  EAV_CHECK_LAUNCH("eav_ast_fbank");
   return EAV_OK;
 }

@@ -61,3 +61,44 @@ def frames_to_pixel_values(frames, size=(224, 224), mean=(0.5, 0.5, 0.5), std=(0
               s.ctypes.data, _lib.stream_ptr())
     torch.cuda.current_stream().synchronize()      # tables / host constants must outlive the launch
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+def kaldi_mel_filters(nbins=257, nmel=128, fmin=20.0, fmax=8000.0, sr=16000):
+    """[nbins, nmel] float64 kaldi-mel triangular filters (HF mel_filter_bank(..., mel_scale='kaldi',
+    triangularize_in_mel_space=True, norm=None), as ASTFeatureExtractor builds them)."""
+    mel = lambda f: 1127.0 * np.log(1.0 + f / 700.0)  # noqa: E731
+    mel_freqs = np.linspace(mel(fmin), mel(fmax), nmel + 2)
+    fft_freqs = mel(sr / ((nbins - 1) * 2) * np.arange(nbins))
+    diff = np.diff(mel_freqs)
+    slopes = mel_freqs[None, :] - fft_freqs[:, None]
+    return np.maximum(0.0, np.minimum(-slopes[:, :-2] / diff[:-1], slopes[:, 2:] / diff[1:]))
+
+
+_FBANK_TABLES = {}
+
+
+def waveforms_to_input_values(wav, max_length=1024, nmel=128, mean=-4.2677393, std=4.5689974, device="cuda"):
+    """AudioModelTrainer._feature_extract on the GPU: wav [n,L] float (16 kHz mono) ->
+    input_values float32 [n,max_length,nmel] (device tensor), the HF ASTFeatureExtractor recipe."""
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise _lib.EavError("waveforms_to_input_values runs on the MI355X only (no CPU fallback)")
+    w = torch.as_tensor(np.asarray(wav, dtype=np.float32) if not isinstance(wav, torch.Tensor) else wav).float()
+    if w.dim() == 1:
+        w = w[None]
+    w = w.to(dev).contiguous()
+    n, L = w.shape
+    key = (str(dev), nmel)
+    if key not in _FBANK_TABLES:
+        k = np.arange(256)
+        tw = np.stack([np.cos(2 * np.pi * k / 512), -np.sin(2 * np.pi * k / 512)], 1)
+        melT = np.ascontiguousarray(kaldi_mel_filters(257, nmel).T)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)  # noqa: E731
+        _FBANK_TABLES[key] = (t(np.hanning(400)), t(tw), t(melT))
+    win, tw, melT = _FBANK_TABLES[key]
+    out = torch.empty(n, max_length, nmel, dtype=torch.float32, device=dev)
+    _lib.call("eav_ast_fbank", w.data_ptr(), win.data_ptr(), tw.data_ptr(), melT.data_ptr(), out.data_ptr(), n, L,
+              max_length, nmel, 0.97, 1.192092955078125e-07, float(np.float32(mean)), float(np.float32(std * 2)),
+              _lib.stream_ptr())
+    return out

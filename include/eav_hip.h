@@ -148,6 +148,14 @@ int eav_resize_normalize_u8(const uint8_t* frames, const int* kx, const int* bou
                             const int* boundsy, float* out, int n, int H, int W, int C, int OH, int OW, int ksize_x,
                             int ksize_y, double rescale, const float* mean3, const float* std3, void* stream);
 
+/* AST log-mel front-end, HF ASTFeatureExtractor numpy path (Transformer_Audio.py:38-42): wav [n,L] fp32 (16 kHz)
+ * -> out [n,max_len,nmel] fp32 = (log-mel - mean) / std2 with frames beyond the clip zero-padded before the
+ * normalisation.  window400 (Hann, symmetric), twiddle256 ([k] = cos, -sin of 2 pi k/512) and melT [nmel][257]
+ * are float64 DEVICE tables built by the host (eav_amd/preprocess.py). */
+int eav_ast_fbank(const float* wav, const double* window400, const double* twiddle256, const double* melT, float* out,
+                  int n, int L, int max_len, int nmel, double preemph, double mel_floor, float mean, float std2,
+                  void* stream);
+
 #ifdef __cplusplus
 }
 #endif

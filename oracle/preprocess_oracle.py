@@ -82,3 +82,49 @@ def trial_vote(outputs_test, frames_per_trial=25):
     """reshape(n_trials, frames, classes).mean(1).argmax(1) - Transformer_Vision.py:177-180."""
     a = np.reshape(outputs_test, (-1, frames_per_trial, outputs_test.shape[-1]), 'C')
     return np.argmax(np.mean(a, 1), axis=1)
+
+
+# ---------------------------------------------------------------------------------------------------
+# AST log-mel front-end: HF ASTFeatureExtractor numpy path (transformers 5.15.0,
+# models/audio_spectrogram_transformer/feature_extraction_audio_spectrogram_transformer.py:91-158 and
+# audio_utils.spectrogram / mel_filter_bank), called by the reference at Transformer_Audio.py:38-42.
+# Pinned against tests/golden/ast_trainer.npz (tr_x / te_x produced by the reference trainer itself).
+def kaldi_mel_filters(nbins=257, nmel=128, fmin=20.0, fmax=8000.0, sr=16000):
+    """[nbins, nmel] float64: triangles in kaldi-mel space (1127 ln(1 + f/700)), no normalisation."""
+    mel = lambda f: 1127.0 * np.log(1.0 + f / 700.0)  # noqa: E731
+    mel_freqs = np.linspace(mel(fmin), mel(fmax), nmel + 2)
+    fft_freqs = mel(sr / ((nbins - 1) * 2) * np.arange(nbins))
+    diff = np.diff(mel_freqs)
+    slopes = mel_freqs[None, :] - fft_freqs[:, None]
+    down = -slopes[:, :-2] / diff[:-1]
+    up = slopes[:, 2:] / diff[1:]
+    return np.maximum(0.0, np.minimum(down, up))
+
+
+def ast_fbank(wav, max_length=1024, nmel=128, mean=-4.2677393, std=4.5689974):
+    """wav float32 [n,L] @16 kHz -> input_values float32 [n,max_length,nmel]."""
+    wav = np.asarray(wav, np.float32)
+    window = np.hanning(400).astype(np.float64)
+    filt = kaldi_mel_filters(257, nmel)
+    out = []
+    for w in wav:
+        x = w.astype(np.float64)
+        nfr = 1 + (x.size - 400) // 160
+        idx = np.arange(400)[None, :] + 160 * np.arange(nfr)[:, None]
+        fr = x[idx]
+        fr = fr - fr.mean(1, keepdims=True)                                  # remove_dc_offset
+        pe = np.empty_like(fr)
+        pe[:, 1:] = fr[:, 1:] - 0.97 * fr[:, :-1]                            # preemphasis
+        pe[:, 0] = fr[:, 0] * (1 - 0.97)
+        buf = np.zeros((nfr, 512))
+        buf[:, :400] = pe * window
+        spec = np.fft.rfft(buf, axis=1).astype(np.complex64)                 # the reference stores complex64
+        power = np.abs(spec, dtype=np.float64) ** 2.0
+        melspec = np.maximum(1.192092955078125e-07, filt.T @ power.T)        # [nmel, nfr]
+        fb = np.log(melspec).astype(np.float32).T                            # [nfr, nmel]
+        if nfr < max_length:
+            fb = np.concatenate([fb, np.zeros((max_length - nfr, nmel), np.float32)], 0)
+        else:
+            fb = fb[:max_length]
+        out.append((fb - mean) / (std * 2))
+    return np.stack(out).astype(np.float32)

@@ -30,3 +30,13 @@ def test_vit_preprocess_matches_reference_trainer_frames(golden_dir):
 def test_trial_vote():
     o = synth.normal(7, (50, 5))
     assert np.array_equal(po.trial_vote(o, 25), o.reshape(2, 25, 5).mean(1).argmax(1))
+
+
+def test_ast_fbank_matches_reference_trainer_features(golden_dir):
+    g = np.load(os.path.join(golden_dir, "ast_trainer.npz"))
+    wav = synth.normal(90, (10, 80000), 0.0, 0.1)
+    got = po.ast_fbank(wav[:6])
+    assert got.shape == g["tr_x"].shape == (6, 1024, 128) and got.dtype == np.float32
+    assert np.abs(got - g["tr_x"]).max() < 2e-6
+    assert np.abs(po.ast_fbank(wav[6:]) - g["te_x"]).max() < 2e-6
+    assert abs(float(got[0, 600, 0]) - 0.4670) < 1e-4          # padded frames carry the pad value

@@ -242,3 +242,21 @@ def test_frame_preprocessing_bit_exact(golden_dir):
                      - np.float32([0.485, 0.456, 0.406])[:, None, None]) / np.float32([0.229, 0.224, 0.225])[:, None, None]
                     for f in odd])
     assert np.allclose(got, exp, atol=1e-6)
+
+
+def test_ast_logmel_frontend(golden_dir):
+    """GPU log-mel == oracle (numpy restatement of the HF recipe) == the reference trainer's features."""
+    import os
+    from eav_amd.preprocess import waveforms_to_input_values
+    from oracle import preprocess_oracle as po
+    g = np.load(os.path.join(golden_dir, "ast_trainer.npz"))
+    wav = synth.normal(90, (10, 80000), 0.0, 0.1)
+    got = waveforms_to_input_values(wav).cpu().numpy()
+    assert got.shape == (10, 1024, 128) and got.dtype == np.float32
+    assert np.abs(got[:6] - g["tr_x"]).max() < 5e-6 and np.abs(got[6:] - g["te_x"]).max() < 5e-6
+    short = synth.normal(94, (2, 3000), 0.0, 0.3)                # 17 frames, 1007 padded
+    long_ = synth.normal(95, (1, 170000), 0.0, 0.3)              # 1060 frames -> truncated to 1024
+    for w in (short, long_):
+        assert np.abs(waveforms_to_input_values(w).cpu().numpy() - po.ast_fbank(w)).max() < 5e-6
+    silent = np.zeros((1, 16000), np.float32)                    # log of the floor, no NaN/inf
+    assert np.isfinite(waveforms_to_input_values(silent).cpu().numpy()).all()

@@ -134,48 +134,49 @@ __global__ __launch_bounds__(256, 2) void fir_fwd_kernel(const float* __restrict
 }
 
 // ---------------------------------------------------------------------------------------- wgrad
-constexpr int WG_NT = 10;          // 10 column tiles of 16 -> lags k = 2n+s, n < 160
-constexpr int WG_CHMAX = 1024;     // max time chunk per work item
-constexpr int WG_DYSTRIDE = WG_CHMAX + 4;  // == 4 (mod 32): conflict-free A reads, 16-B aligned rows
-constexpr int WG_XLEN = WG_CHMAX + 320 + 4;
+// Wave-independent schedule: a work item = (row, 252-sample chunk) belongs to ONE wave, which stages its
+// own LDS images (wave-private region, no block barrier in the loop), prefetches the next item's y1/g1/x
+// into registers before its MFMA phase, and keeps its 16x160 accumulator tile in registers for its whole
+// work list.  Waves of a CU drift apart, so one wave's staging overlaps the others' matrix work.
+constexpr int WG_NT = 10;                 // 10 column tiles of 16 -> lags k = 2n+s, n < 160
+constexpr int WG_CW = 252;                // max u-samples per wave item (63 K-steps of 4)
+constexpr int WG_QS = WG_CW + 8;          // dy row stride: 260 == 4 (mod 32), rows 16-B aligned
+constexpr int WG_XW = WG_CW + 4 + 320;    // x window per item
+constexpr int WG_WAVE_LDS = F1 * WG_QS + WG_XW;   // floats per wave
 
-__global__ __launch_bounds__(256, 2) void fir_wgrad_kernel(
+__global__ __launch_bounds__(256, 3) void fir_wgrad_kernel(
     const float* __restrict__ x, const float* __restrict__ y1, const float* __restrict__ g1,
     const float* __restrict__ bnp /* mean, invstd, scale, shift, m1, m2 (8 each) */, float* __restrict__ part, int rows,
     int C, int S, int klen, int padl, int nchunk, int CH) {
-  __shared__ __attribute__((aligned(16))) float dyl[F1 * WG_DYSTRIDE];
-  __shared__ __attribute__((aligned(16))) float xl[WG_XLEN];
+  __shared__ __attribute__((aligned(16))) float lds[4 * WG_WAVE_LDS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* dyl = lds + wave * WG_WAVE_LDS;
+  float* xl = dyl + F1 * WG_QS;
   const int col = lane & 15, kq = lane >> 4;
   const int af = col >> 1, as = col & 1;  // A row i = f*2 + s
   f32x4 acc[WG_NT];
 #pragma unroll
   for (int i = 0; i < WG_NT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const bool vec = (S & 3) == 0;
+  const int nq1 = CH / 4 + 1;               // quads per filter row incl. the one-quad left halo (<= 64)
   const int nwork = rows * nchunk;
-  // staging is split: fetch(item) issues every global load of an item into registers, commit(item)
-  // forms dy = scale*(g - m1 - yhat*m2) and writes the LDS images.  The next item is fetched before
-  // the MFMA phase of the current one (HBM latency hidden behind ~20k cycles of matrix work).
-  constexpr int NQ = 8;                 // ceil(F1*(WG_CHMAX/4+1)/256)
-  constexpr int NX = (WG_CHMAX + 320 + 255) / 256;
-  float4 ry[NQ], rg[NQ];
+  const int nwaves = gridDim.x * 4, gw = blockIdx.x * 4 + wave;
+  constexpr int NX = (WG_XW + 63) / 64;
+  float4 ry[F1], rg[F1];
   float rx[NX];
-  const int nq1 = CH / 4 + 1;
   auto fetch = [&](int work) {
     const int row = work / nchunk, chunk = work - row * nchunk;
     const int c0 = chunk * CH;
     const int b = row / C, c = row - b * C;
+    const int t = c0 - 4 + 4 * lane;        // lane = quad index q; register i = filter f
 #pragma unroll
-    for (int i = 0; i < NQ; ++i) {
-      const int idx = threadIdx.x + 256 * i;
-      ry[i] = rg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (idx < F1 * nq1) {
-        const int f = idx / nq1, q = idx - f * nq1;
-        const int t = c0 - 4 + 4 * q;
+    for (int f = 0; f < F1; ++f) {
+      ry[f] = rg[f] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (lane < nq1) {
         const int64_t base = (((int64_t)b * F1 + f) * C + c) * S;
         if (vec && t >= 0 && t + 3 < S) {
-          ry[i] = *reinterpret_cast<const float4*>(y1 + base + t);
-          rg[i] = *reinterpret_cast<const float4*>(g1 + base + t);
+          ry[f] = *reinterpret_cast<const float4*>(y1 + base + t);
+          rg[f] = *reinterpret_cast<const float4*>(g1 + base + t);
         } else {
           float yv[4], gv[4];
 #pragma unroll
@@ -185,61 +186,58 @@ __global__ __launch_bounds__(256, 2) void fir_wgrad_kernel(
             yv[e] = ok ? y1[base + te] : 0.f;
             gv[e] = ok ? g1[base + te] : 0.f;
           }
-          ry[i] = make_float4(yv[0], yv[1], yv[2], yv[3]);
-          rg[i] = make_float4(gv[0], gv[1], gv[2], gv[3]);
+          ry[f] = make_float4(yv[0], yv[1], yv[2], yv[3]);
+          rg[f] = make_float4(gv[0], gv[1], gv[2], gv[3]);
         }
       }
     }
     const float* xrow = x + (int64_t)row * S;
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
-      const int idx = threadIdx.x + 256 * i;
-      const int t = c0 + idx - padl;
-      rx[i] = (idx < CH + 320 && t >= 0 && t < S) ? xrow[t] : 0.f;
+      const int idx = lane + 64 * i;
+      const int tx = c0 + idx - padl;
+      rx[i] = (idx < CH + 320 && tx >= 0 && tx < S) ? xrow[tx] : 0.f;
     }
   };
   auto commit = [&](int work) {
     const int chunk = work % nchunk;
-    const int c0 = chunk * CH;
+    const int t = chunk * CH - 4 + 4 * lane;
+    if (lane < nq1) {
 #pragma unroll
-    for (int i = 0; i < NQ; ++i) {
-      const int idx = threadIdx.x + 256 * i;
-      if (idx < F1 * nq1) {
-        const int f = idx / nq1, q = idx - f * nq1;
-        const int t = c0 - 4 + 4 * q;
+      for (int f = 0; f < F1; ++f) {
         const float mean = bnp[f], invstd = bnp[8 + f], sc = bnp[16 + f], m1 = bnp[32 + f], m2 = bnp[40 + f];
-        const float yv[4] = {ry[i].x, ry[i].y, ry[i].z, ry[i].w};
-        const float gv[4] = {rg[i].x, rg[i].y, rg[i].z, rg[i].w};
+        const float yv[4] = {ry[f].x, ry[f].y, ry[f].z, ry[f].w};
+        const float gv[4] = {rg[f].x, rg[f].y, rg[f].z, rg[f].w};
         float o[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int te = t + e;
           o[e] = (te >= 0 && te < S) ? sc * (gv[e] - m1 - (yv[e] - mean) * invstd * m2) : 0.f;
         }
-        *reinterpret_cast<float4*>(&dyl[f * WG_DYSTRIDE + 4 * q]) = make_float4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<float4*>(&dyl[f * WG_QS + 4 * lane]) = make_float4(o[0], o[1], o[2], o[3]);
       }
     }
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
-      const int idx = threadIdx.x + 256 * i;
+      const int idx = lane + 64 * i;
       if (idx < CH + 320) xl[idx] = rx[i];
     }
   };
-  if ((int)blockIdx.x < nwork) fetch(blockIdx.x);
-  for (int work = blockIdx.x; work < nwork; work += gridDim.x) {
+  if (gw < nwork) fetch(gw);
+  const int ksteps = CH / 4;
+  const float* ap = dyl + af * WG_QS + 4 + kq - as;
+  const float* bp = xl + kq + 2 * col;
+  for (int work = gw; work < nwork; work += nwaves) {
     commit(work);
-    __syncthreads();
-    if (work + (int)gridDim.x < nwork) fetch(work + gridDim.x);
-    // ---- each wave contracts its quarter of the chunk
-    const int ksteps = CH / 16;
-    const float* ap = dyl + af * WG_DYSTRIDE + 4 + wave * (CH / 4) + kq - as;
-    const float* bp = xl + wave * (CH / 4) + kq + 2 * col;
-    // software pipeline, two register sets (no copies): the 11 operands of the next K-step are read
-    // while the 10 MFMAs of the current one run; sched_barrier pins loads-before-MFMAs.
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's LDS image is complete (wave-private)
+    __builtin_amdgcn_wave_barrier();
+    if (work + nwaves < nwork) fetch(work + nwaves);
+    // software pipeline, two register sets: the 11 operands of the next K-step are read while the
+    // 10 MFMAs of the current one run; sched_barrier pins loads-before-MFMAs.
     float av0 = ap[0], bv0[WG_NT], av1, bv1[WG_NT];
 #pragma unroll
     for (int nt = 0; nt < WG_NT; ++nt) bv0[nt] = bp[32 * nt];
-    for (int ks = 0; ks < ksteps; ks += 2) {        // ksteps = CH/16 is even only if CH % 32 == 0: guard below
+    for (int ks = 0; ks < ksteps; ks += 2) {
       const int k1 = (ks + 1 < ksteps) ? ks + 1 : ks;
       av1 = ap[4 * k1];
 #pragma unroll
@@ -258,11 +256,13 @@ __global__ __launch_bounds__(256, 2) void fir_wgrad_kernel(
       for (int nt = 0; nt < WG_NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1, bv1[nt], acc[nt], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // all reads of this image retired before it is overwritten
+    __builtin_amdgcn_wave_barrier();
   }
-  // ---- combine the 4 waves' accumulators through LDS (reuse dyl: 4*16*160 floats = 40 KB > dyl) 
+  // ---- combine the 4 waves' accumulators through LDS (fixed order), then one partial per block
   // C layout 16x16: col = lane&15, row = (lane>>4)*4 + reg = f*2 + s
-  float* red = dyl;  // 8*1028 = 8224 floats; need 16*160 = 2560 per wave -> reduce wave by wave
+  __syncthreads();
+  float* red = lds;  // needs 8*320 floats
   for (int w = 0; w < 4; ++w) {
     if (wave == w) {
 #pragma unroll
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256, 2) void fir_wgrad_kernel(
 }  // namespace
 
 static int fir_grid(int nwork) { return nwork < 512 ? nwork : 512; }
-static int wgrad_grid(int nwork) { return nwork < 512 ? nwork : 512; }
+static int wgrad_grid(int nwork) { return nwork < 768 ? nwork : 768; }
 
 extern "C" int eav_eegnet_fir_fwd_nparts(int B, int C, int S) {
   int ntiles = cdiv(S, TILE), nseg = cdiv(ntiles, TPS);
@@ -308,8 +308,8 @@ extern "C" int eav_eegnet_fir_fwd(const float* x, const float* w1, float* y1, fl
 }
 
 static void wgrad_geometry(int S, int* nchunk, int* CH) {
-  int n = cdiv(S + 1, WG_CHMAX);
-  int ch = cdiv(cdiv(S + 1, n), 16) * 16;
+  int n = cdiv(S + 1, WG_CW);
+  int ch = cdiv(cdiv(S + 1, n), 4) * 4;      // <= 252, multiple of 4
   *nchunk = n;
   *CH = ch;
 }

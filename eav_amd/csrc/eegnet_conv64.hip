@@ -13,7 +13,7 @@ namespace {
 constexpr int NCH = 64, KT = 16, KD = NCH * KT;  // 1024 = contraction length of the forward GEMM
 constexpr int TT = 128;                          // output samples per block
 constexpr int INS = TT + 16;                     // LDS row stride of the input tile (144)
-constexpr int WCH = 128;                         // contraction rows per weight chunk (8 input channels)
+constexpr int WCH = 64;                          // contraction rows per weight chunk (4 input channels)
 
 // ------------------------------------------------------------------------------------------ fwd
 // grid (ntile, B); 4 waves: wave w owns samples [32w, 32w+32) of the tile and all 64 outputs.
@@ -21,28 +21,43 @@ __global__ __launch_bounds__(256, 2) void conv64_fwd_kernel(const float* __restr
                                                             const float* __restrict__ wT, float* __restrict__ out,
                                                             float* __restrict__ part, int T, int padl) {
   __shared__ __attribute__((aligned(16))) float ins[NCH * INS];
-  __shared__ __attribute__((aligned(16))) float ws[WCH * NCH];
+  __shared__ __attribute__((aligned(16))) float wsb[2][WCH * NCH];
   __shared__ float red[4 * 128];
   const int tile = blockIdx.x, b = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = lane & 31, kk = lane >> 5;
   const int t0 = tile * TT;
   const float* src = in + (int64_t)b * NCH * T;
+  // weight-chunk prefetch registers (explicit scalars: keeps them out of scratch)
+  float4 rw0, rw1, rw2, rw3;
+  static_assert(WCH * NCH / 4 / 256 == 4, "4 float4 per thread per weight chunk");
+#define FETCH_W(ic)                                                                         \
+  {                                                                                         \
+    const float4* wp = reinterpret_cast<const float4*>(wT + (int64_t)(ic) * WCH * NCH) + threadIdx.x; \
+    rw0 = wp[0]; rw1 = wp[256]; rw2 = wp[512]; rw3 = wp[768];                               \
+  }
+#define COMMIT_W(buf)                                                                       \
+  {                                                                                         \
+    float4* wq = reinterpret_cast<float4*>(wsb[buf]) + threadIdx.x;                         \
+    wq[0] = rw0; wq[256] = rw1; wq[512] = rw2; wq[768] = rw3;                               \
+  }
+  FETCH_W(0);
   for (int idx = threadIdx.x; idx < NCH * INS; idx += 256) {
     const int i = idx / INS, u = idx - i * INS;
     const int t = t0 + u - padl;
     ins[idx] = (t >= 0 && t < T) ? src[(int64_t)i * T + t] : 0.f;
   }
+  COMMIT_W(0);
+  __syncthreads();
   f32x16 acc0, acc1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-  for (int ic = 0; ic < KD / WCH; ++ic) {
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < WCH * NCH / 4; idx += 256)
-      reinterpret_cast<float4*>(ws)[idx] = reinterpret_cast<const float4*>(wT + (int64_t)ic * WCH * NCH)[idx];
-    __syncthreads();
+  constexpr int NCHUNK = KD / WCH;                     // 16
+  for (int ic = 0; ic < NCHUNK; ++ic) {
+    const float* ws = wsb[ic & 1];
+    if (ic + 1 < NCHUNK) FETCH_W(ic + 1);             // next chunk's weights in flight during the MFMAs
     // software pipeline: operands of step ks+1 are read while the two MFMAs of step ks run
-    auto ldb = [&](int ks) { return ins[(ic * 8 + (ks >> 3)) * INS + wave * 32 + n + 2 * (ks & 7) + kk]; };
+    auto ldb = [&](int ks) { return ins[(ic * (WCH / KT) + (ks >> 3)) * INS + wave * 32 + n + 2 * (ks & 7) + kk]; };
     float bv = ldb(0), a0 = ws[kk * NCH + n], a1 = ws[kk * NCH + 32 + n];
 #pragma unroll 8
     for (int ks = 0; ks < WCH / 2; ++ks) {
@@ -53,6 +68,8 @@ __global__ __launch_bounds__(256, 2) void conv64_fwd_kernel(const float* __restr
       acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc1, 0, 0, 0);
       bv = bn; a0 = a0n; a1 = a1n;
     }
+    if (ic + 1 < NCHUNK) COMMIT_W((ic + 1) & 1);      // the other buffer was last read in iteration ic-1
+    __syncthreads();
   }
   // C layout: col = n (sample), row = (reg&3) + 8*(reg>>2) + 4*kk (output channel within the 32-tile)
   const int t = t0 + wave * 32 + n;
@@ -90,7 +107,7 @@ __global__ __launch_bounds__(256, 2) void conv64_fwd_kernel(const float* __restr
 constexpr int DUS = TT + 1;   // 129: odd stride -> 32 rows hit 32 banks
 constexpr int P2S = 144;      // == 16 (mod 32): the two channels of a column tile use disjoint banks
 
-__global__ __launch_bounds__(256, 2) void conv64_wgrad_kernel(const float* __restrict__ du,
+__global__ __launch_bounds__(256, 3) void conv64_wgrad_kernel(const float* __restrict__ du,
                                                               const float* __restrict__ in,
                                                               float* __restrict__ part, int B, int T, int padl,
                                                               int ntile) {
@@ -107,23 +124,47 @@ __global__ __launch_bounds__(256, 2) void conv64_wgrad_kernel(const float* __res
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
   const int nitems = B * ntile;
-  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+  const bool vec = (T & 3) == 0;
+  // next item's tiles are fetched into registers before the MFMA phase of the current one
+  float4 rdu[8];
+  float rp[9];
+  auto fetch = [&](int item) {
     const int b = item / ntile, tile = item - b * ntile;
     const int t0 = tile * TT;
-    __syncthreads();
     const float* dsrc = du + (int64_t)b * NCH * T;
-    for (int idx = threadIdx.x; idx < NCH * TT; idx += 256) {
-      const int o = idx >> 7, tl = idx & 127;
-      const int t = t0 + tl;
-      dus[o * DUS + tl] = t < T ? dsrc[(int64_t)o * T + t] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int f = threadIdx.x + 256 * i;
+      const int o = f >> 5, t = t0 + 4 * (f & 31);
+      const float* p = dsrc + (int64_t)o * T + t;
+      if (vec && t + 3 < T) rdu[i] = *reinterpret_cast<const float4*>(p);
+      else rdu[i] = make_float4(t < T ? p[0] : 0.f, t + 1 < T ? p[1] : 0.f, t + 2 < T ? p[2] : 0.f, t + 3 < T ? p[3] : 0.f);
     }
     const float* isrc = in + ((int64_t)b * NCH + ig * 16) * T;
-    for (int idx = threadIdx.x; idx < 16 * P2S; idx += 256) {
-      const int i = idx / P2S, u = idx - i * P2S;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const int idx = threadIdx.x + 256 * i;
+      const int ch = idx / P2S, u = idx - ch * P2S;
       const int t = t0 + u - padl;
-      p2s[idx] = (t >= 0 && t < T) ? isrc[(int64_t)i * T + t] : 0.f;
+      rp[i] = (idx < 16 * P2S && t >= 0 && t < T) ? isrc[(int64_t)ch * T + t] : 0.f;
+    }
+  };
+  if ((int)blockIdx.x < nitems) fetch(blockIdx.x);
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int f = threadIdx.x + 256 * i;
+      float* d = dus + (f >> 5) * DUS + 4 * (f & 31);
+      d[0] = rdu[i].x; d[1] = rdu[i].y; d[2] = rdu[i].z; d[3] = rdu[i].w;
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const int idx = threadIdx.x + 256 * i;
+      if (idx < 16 * P2S) p2s[idx] = rp[i];
     }
     __syncthreads();
+    if (item + (int)gridDim.x < nitems) fetch(item + gridDim.x);
     // wave w owns input channels [4w, 4w+4) of the group: two column tiles of (2 channels x 16 taps)
     const float* bp0 = p2s + (4 * wave + (n >> 4)) * P2S + (n & 15) + kk;
     const float* bp1 = bp0 + 2 * P2S;
@@ -188,7 +229,7 @@ extern "C" int eav_conv64_fwd(const float* in, const float* wT, float* out, floa
 
 extern "C" int eav_conv64_wgrad_nparts(int B, int T) {
   int nitems = B * cdiv(T, TT);
-  return nitems < 128 ? nitems : 128;
+  return nitems < 192 ? nitems : 192;
 }
 
 extern "C" int eav_conv64_wgrad(const float* du, const float* in, float* part, int B, int T, int padl,

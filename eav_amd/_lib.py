@@ -48,6 +48,9 @@ SIGNATURES = {
     "eav_adam_step": [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _i64, _i, _p],
     "eav_gemm_f32": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64, _f, _p,
                      _i, _p, _p, _i, _i, _p],
+    "eav_gemm_bf16": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64, _f, _p,
+                      _i, _p, _p, _i, _i, _p],
+    "eav_gemm_bf16_splitk": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "eav_gemm_f32_splitk": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "eav_layernorm_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _f, _p],
     "eav_layernorm_bwd": [_p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _p],

@@ -169,6 +169,11 @@ class Encoder(nn.Module):
         self._token = 0
         self._saved = None
         self.kernel_events = None
+        # GEMM operand precision: "fp32" (default; exact-fp32 MFMA, meets the 1e-3 logit bound), "bf16"
+        # (bf16 MFMA operands everywhere, fp32 accumulate: ~5e-3 logit drift) or "bf16_bwd" (fp32 forward
+        # - logits unchanged - and bf16 operands for the backward products only).
+        self.precision = "fp32"
+        self._phase = "fwd"
         if cfg.hidden % cfg.heads or (cfg.hidden // cfg.heads) % 4 or cfg.hidden % 4 or cfg.hidden > 1024:
             raise NotImplementedError("hidden size must be <= 1024, a multiple of 4, head_dim a multiple of 4")
         if cfg.ntok > 2048 or cfg.num_labels > 16:
@@ -252,8 +257,15 @@ class Encoder(nn.Module):
 
     def _gemm(self, A, B, C, M, N, K, lda, ldb, ldc, tA=0, tB=0, batch=1, heads=1, sA=(0, 0), sB=(0, 0), sC=(0, 0),
               alpha=1.0, bias=None, gelu=0, pre=None, resid=None, ldr=0, acc=0):
-        self._call("eav_gemm_f32", A, B, C, M, N, K, lda, ldb, ldc, tA, tB, batch, heads, sA[0], sA[1], sB[0], sB[1],
-                   sC[0], sC[1], float(alpha), bias, gelu, pre, resid, ldr, acc, self._st)
+        self._call(self._gemm_name(), A, B, C, M, N, K, lda, ldb, ldc, tA, tB, batch, heads, sA[0], sA[1], sB[0],
+                   sB[1], sC[0], sC[1], float(alpha), bias, gelu, pre, resid, ldr, acc, self._st)
+
+    def _gemm_name(self):
+        p = self.precision
+        if p not in ("fp32", "bf16", "bf16_bwd"):
+            raise ValueError(f"unknown precision {p!r}")
+        low = p == "bf16" or (p == "bf16_bwd" and self._phase == "bwd")
+        return "eav_gemm_bf16" if low else "eav_gemm_f32"
 
     def _alloc(self, B, dev, full_backward):
         c = self.cfg
@@ -299,6 +311,7 @@ class Encoder(nn.Module):
         c = self.cfg
         P, L = _lib.ptr, self._call
         self._st = st = _lib.stream_ptr()
+        self._phase = "fwd"
         B = x.shape[0]
         D, FF, N, H = c.hidden, c.ff, c.ntok, c.heads
         hd = D // H
@@ -367,7 +380,7 @@ class Encoder(nn.Module):
 
     def _wgrad(self, A, B, C, M, N, K, lda, ldb):
         """C[M,N] = A^T.B for A stored [K,M], B stored [K,N] (weight gradient: contraction over tokens)."""
-        self._call("eav_gemm_f32_splitk", A, B, C, _lib.ptr(self._ws.splitk), M, N, K, lda, ldb, 1, 1, self._st)
+        self._call(self._gemm_name() + "_splitk", A, B, C, _lib.ptr(self._ws.splitk), M, N, K, lda, ldb, 1, 1, self._st)
 
     def _reduce(self, part, nparts, stride, n, out):
         self._call("eav_reduce_partials", _lib.ptr(part), nparts, stride, n, 1.0, out, self._st)
@@ -383,6 +396,7 @@ class Encoder(nn.Module):
         c = self.cfg
         P, L = _lib.ptr, self._call
         st = self._st = _lib.stream_ptr()
+        self._phase = "bwd"
         _, x, full, _ = self._saved
         ws = self._ws
         B, M, ldn = ws.B, ws.M, ws.ldn

@@ -112,6 +112,14 @@ int eav_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, 
 int eav_gemm_f32_splitk_plan(int M, int N, int K);
 int eav_gemm_f32_splitk(const float* A, const float* B, float* C, float* ws, int M, int N, int K, int lda, int ldb,
                         int transA, int transB, void* stream);
+/* Same contracts with bf16 MFMA operands (fp32 in memory, rounded to bf16 while staging; fp32 accumulate and
+ * output).  Opt-in fast mode: outside north_star's 1e-3 logit bound. */
+int eav_gemm_bf16(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                  int transA, int transB, int batch, int heads, int64_t sAb, int64_t sAh, int64_t sBb, int64_t sBh,
+                  int64_t sCb, int64_t sCh, float alpha, const float* bias, int gelu, float* pre, const float* resid,
+                  int ldr, int accumulate, void* stream);
+int eav_gemm_bf16_splitk(const float* A, const float* B, float* C, float* ws, int M, int N, int K, int lda, int ldb,
+                         int transA, int transB, void* stream);
 /* nn.LayerNorm(D, eps) forward over M rows; mean/rstd [M] saved for the backward (may be NULL). */
 int eav_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                       int M, int D, float eps, void* stream);

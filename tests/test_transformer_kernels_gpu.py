@@ -80,6 +80,36 @@ def test_gemm_splitk_weight_gradient(L, M, N, K):
     assert torch.equal(C, C2)                               # fixed-order reduction: bit-reproducible
 
 
+def _bf16_round(a):
+    return torch.from_numpy(a).to(torch.bfloat16).double()
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 200, 100), (1214, 64, 1214), (130, 3072, 768), (9, 5, 12)])
+@pytest.mark.parametrize("tA,tB", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_gemm_bf16_operands(L, M, N, K, tA, tB):
+    """bf16-MFMA variant == the fp64 product of the bf16-rounded (RNE) operands, up to fp32 accumulation."""
+    pad = lambda v: (v + 3) // 4 * 4  # noqa: E731
+    a = synth.normal(41, (K, M) if tA else (M, K))
+    b = synth.normal(42, (K, N) if tB else (N, K))
+    lda, ldb = pad(a.shape[1]), pad(b.shape[1])
+    ap, bp = np.zeros((a.shape[0], lda), np.float32), np.zeros((b.shape[0], ldb), np.float32)
+    ap[:, :a.shape[1]], bp[:, :b.shape[1]] = a, b
+    A, B = dev(ap), dev(bp)
+    C = torch.full((M, N + 3), 7.0, device="cuda")
+    p = lambda t: t.data_ptr()  # noqa: E731
+    L.call("eav_gemm_bf16", p(A), p(B), p(C), M, N, K, lda, ldb, N + 3, tA, tB, 1, 1, 0, 0, 0, 0, 0, 0, 0.5, None, 0,
+           None, None, 0, 0, None)
+    ad, bd = _bf16_round(a), _bf16_round(b)
+    ref = 0.5 * (ad.t() if tA else ad) @ (bd if tB else bd.t())
+    close(C[:, :N], ref, 1e-5, 2e-5 * float(ref.abs().max()), "C (bf16 operands)")
+    assert torch.all(C[:, N:] == 7.0)
+    if tA and tB and (N & 3) == 0:
+        ns = L.plain("eav_gemm_f32_splitk_plan", M, N, K)
+        ws, C2 = torch.empty(max(ns, 1) * M * N, device="cuda"), torch.empty(M, N, device="cuda")
+        L.call("eav_gemm_bf16_splitk", p(A), p(B), p(C2), p(ws), M, N, K, lda, ldb, 1, 1, None)
+        close(C2, 2.0 * ref, 1e-5, 4e-5 * float(ref.abs().max()), "split-K (bf16 operands)")
+
+
 def test_gemm_epilogues(L):
     M, N, K = 200, 136, 72
     a, b = synth.normal(3, (M, K)), synth.normal(4, (N, K), 0, 0.2)

@@ -9,6 +9,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from eav_amd import _lib  # noqa: E402
 
 
+KERNEL = "eav_gemm_f32"
+
+
 def run(name, M, N, K, tA, tB, batch=1, heads=1, strides=None, reps=10):
     lda = (M if tA else K)
     ldb = (N if tB else K)
@@ -21,7 +24,7 @@ def run(name, M, N, K, tA, tB, batch=1, heads=1, strides=None, reps=10):
     sC = (C.stride(0) * heads, C.stride(0)) if batch > 1 else (0, 0)
 
     def call():
-        _lib.call("eav_gemm_f32", A.data_ptr(), B.data_ptr(), C.data_ptr(), M, N, K, lda, ldb, N, tA, tB, batch, heads,
+        _lib.call(KERNEL, A.data_ptr(), B.data_ptr(), C.data_ptr(), M, N, K, lda, ldb, N, tA, tB, batch, heads,
                   sA[0], sA[1], sB[0], sB[1], sC[0], sC[1], 1.0, None, 0, None, None, 0, 0, None)
     for _ in range(3):
         call()
@@ -45,7 +48,7 @@ def run_splitk(name, M, N, K, reps=10):
     ws = torch.empty(ns * M * N, device="cuda")
 
     def call():
-        _lib.call("eav_gemm_f32_splitk", A.data_ptr(), B.data_ptr(), C.data_ptr(), ws.data_ptr(), M, N, K, M, N, 1, 1, None)
+        _lib.call(KERNEL + "_splitk", A.data_ptr(), B.data_ptr(), C.data_ptr(), ws.data_ptr(), M, N, K, M, N, 1, 1, None)
     for _ in range(3):
         call()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -60,6 +63,9 @@ def run_splitk(name, M, N, K, reps=10):
 
 if __name__ == "__main__":
     _lib.load()
+    if len(sys.argv) > 1 and sys.argv[1] == "bf16":
+        KERNEL = "eav_gemm_bf16"
+    print("kernel:", KERNEL)
     for tag, M in (("ast B=8", 9712), ("vit B=128", 25216)):
         print("==", tag)
         run("qkv fwd (NT)", M, 2304, 768, 0, 0)

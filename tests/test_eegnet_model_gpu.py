@@ -180,3 +180,33 @@ def test_cpu_input_raises():
     m = EEGNet_tor(nb_classes=5, Samples=500)
     with pytest.raises(_lib.EavError):
         m(torch.zeros(2, 1, 30, 500))
+
+
+@pytest.mark.parametrize("B,C,S,K,train_mode", [(3, 7, 333, 64, True), (1, 30, 500, 300, True), (5, 32, 1000, 299, True),
+                                                (2, 30, 2049, 300, False), (7, 1, 64, 5, True)])
+def test_ragged_shapes_against_oracle(B, C, S, K, train_mode):
+    """Odd sample counts (scalar/unaligned paths), one electrode, batch 1, odd kernel lengths, eval-mode BN."""
+    from eav_amd.eegnet import EEGNet_tor
+    from eav_amd.optim import CrossEntropyLoss
+    from oracle import eegnet_oracle as orc
+    sd = eegnet_weights(40 + B, S, chans=C, klen=K)
+    m = EEGNet_tor(nb_classes=5, Chans=C, Samples=S, kernLength=K, dropoutRate=0.0)
+    full = m.state_dict()
+    for k, v in sd.items():
+        full[k] = torch.from_numpy(np.ascontiguousarray(v))
+    m.load_state_dict(full)
+    m = m.cuda().train(train_mode)
+    x, y = synth.eeg_batch(400 + S, B, C, S)
+    scores = m(torch.from_numpy(x).cuda())
+    CrossEntropyLoss()(scores, torch.from_numpy(y).cuda()).backward()
+    P = {k: torch.from_numpy(sd[k].copy()) for k in orc.PARAM_NAMES}
+    Bf = {k: torch.from_numpy(sd[k].copy()) for k in orc.BUFFER_NAMES}
+    st = orc.Stepper(P, Bf, lr=1e-3, drop_p=0.0)
+    probs, _, grads = st.step(torch.from_numpy(x), torch.from_numpy(y), train_mode, None)
+    close(scores, probs.numpy(), 1e-4, 2e-5, "probs")
+    named = dict(m.named_parameters())
+    for k in PN:
+        ref = grads[k].numpy()
+        close(named[k].grad, ref, 2e-3, max(2e-3 * np.abs(ref).max(), 1e-9), f"grad.{k}")
+    for k in BN:
+        close(m.state_dict()[k], st.Bf[k].numpy(), 1e-4, 1e-5, k)

@@ -36,16 +36,17 @@ SIGNATURES = {
     "eav_eegnet_fir_wgrad": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "eav_eegnet_dw_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _p],
     "eav_eegnet_dw_bwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
-    "eav_bn_elu_pool_fwd": [_p, _p, _p, _i, _i, _i, _i, _f, _u64, _p, _p],
-    "eav_bn_elu_pool_bwd_reduce": [_p, _p, _p, _p, _i, _i, _i, _i, _f, _u64, _p, _p],
-    "eav_bn_elu_pool_bwd_apply": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _u64, _p, _p],
+    "eav_bn_elu_pool_fwd": [_p, _p, _p, _i, _i, _i, _i, _f, _u64, _p, _p, _p],
+    "eav_bn_elu_pool_bwd_reduce": [_p, _p, _p, _p, _i, _i, _i, _i, _f, _u64, _p, _p, _p],
+    "eav_bn_elu_pool_bwd_apply": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _u64, _p, _p, _p],
     "eav_conv64_prep_weights": [_p, _p, _p, _p],
     "eav_conv64_fwd": [_p, _p, _p, _p, _i, _i, _i, _p],
     "eav_conv64_wgrad": [_p, _p, _p, _i, _i, _i, _p],
     "eav_dense_softmax_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _p],
     "eav_dense_softmax_bwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     "eav_ce_fwd_bwd": [_p, _p, _p, _p, _p, _i, _i, _p],
-    "eav_adam_step": [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _i64, _i, _p],
+    "eav_adam_step": [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _i64, _i, _p, _p],
+    "eav_counter_inc": [_p, _p],
     "eav_gemm_f32": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64, _f, _p,
                      _i, _p, _p, _i, _i, _p],
     "eav_gemm_bf16": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64, _f, _p,

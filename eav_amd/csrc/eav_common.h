@@ -70,6 +70,11 @@ __device__ __forceinline__ uint32_t eav_hash32(uint64_t seed, uint64_t idx) {
   return (uint32_t)(z >> 40);  // 24 random bits
 }
 // returns the multiplier applied to the pooled value: 0 or 1/(1-p); 1 when dropout is off
+// seed_dev (optional): device-resident step counter folded into the seed, so that a captured hipGraph
+// draws a fresh mask on every replay without any host-side argument changing.
+__device__ __forceinline__ uint64_t dropout_seed(uint64_t seed, const uint64_t* seed_dev) {
+  return seed_dev ? seed + 2ull * (*seed_dev) : seed;
+}
 __device__ __forceinline__ float dropout_mult(float drop_p, uint64_t seed, const uint8_t* mask, uint64_t idx) {
   if (drop_p <= 0.f) return 1.f;
   bool keep = mask ? (mask[idx] != 0) : ((float)eav_hash32(seed, idx) * (1.0f / 16777216.0f) >= drop_p);

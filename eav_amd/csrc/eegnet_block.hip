@@ -95,7 +95,9 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ y
 template <int P>
 __global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__ in, const float* __restrict__ bn,
                                                        float* __restrict__ out, int CH, int T, float drop_p,
-                                                       uint64_t seed, const uint8_t* __restrict__ mask) {
+                                                       uint64_t seed_in,
+    const uint8_t* __restrict__ mask, const uint64_t* __restrict__ seed_dev) {
+  const uint64_t seed = dropout_seed(seed_in, seed_dev);
   const int row = blockIdx.x, ch = row % CH;
   const float sc = bn[2 * CH + ch], sh = bn[3 * CH + ch];
   const int To = T / P;
@@ -122,8 +124,9 @@ template <int P>
 __global__ __launch_bounds__(256) void pool_bwd_reduce_kernel(const float* __restrict__ dp,
                                                               const float* __restrict__ u,
                                                               const float* __restrict__ bn, float* __restrict__ part,
-                                                              int CH, int T, float drop_p, uint64_t seed,
-                                                              const uint8_t* __restrict__ mask) {
+                                                              int CH, int T, float drop_p, uint64_t seed_in,
+    const uint8_t* __restrict__ mask, const uint64_t* __restrict__ seed_dev) {
+  const uint64_t seed = dropout_seed(seed_in, seed_dev);
   __shared__ float red[8];
   const int row = blockIdx.x, ch = row % CH, b = row / CH;
   const float mean = bn[ch], invstd = bn[CH + ch], sc = bn[2 * CH + ch], sh = bn[3 * CH + ch];
@@ -157,8 +160,9 @@ __global__ __launch_bounds__(256) void pool_bwd_apply_kernel(const float* __rest
                                                              const float* __restrict__ u,
                                                              const float* __restrict__ bn,
                                                              const float* __restrict__ m12, float* __restrict__ du,
-                                                             int CH, int T, float drop_p, uint64_t seed,
-                                                             const uint8_t* __restrict__ mask) {
+                                                             int CH, int T, float drop_p, uint64_t seed_in,
+    const uint8_t* __restrict__ mask, const uint64_t* __restrict__ seed_dev) {
+  const uint64_t seed = dropout_seed(seed_in, seed_dev);
   const int row = blockIdx.x, ch = row % CH;
   const float mean = bn[ch], invstd = bn[CH + ch], sc = bn[2 * CH + ch], sh = bn[3 * CH + ch];
   const float m1 = m12[ch], m2 = m12[CH + ch];
@@ -297,46 +301,46 @@ extern "C" int eav_eegnet_dw_bwd(const float* y1, const float* dz, const float* 
 }
 
 extern "C" int eav_bn_elu_pool_fwd(const float* in, const float* bn, float* out, int B, int CH, int T, int P,
-                                   float drop_p, uint64_t seed, const uint8_t* mask, void* stream) {
+                                   float drop_p, uint64_t seed, const uint8_t* mask, const uint64_t* seed_dev, void* stream) {
   EAV_REQUIRE(in && bn && out && B > 0 && CH > 0 && T >= P, "eav_bn_elu_pool_fwd: bad arguments");
   EAV_REQUIRE(P == 4 || P == 8, "eav_bn_elu_pool_fwd: pool %d not in {4,8}", P);
   EAV_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "eav_bn_elu_pool_fwd: dropout %f outside [0,1)", drop_p);
   if (P == 4)
     hipLaunchKernelGGL(pool_fwd_kernel<4>, dim3(B * CH), dim3(256), 0, (hipStream_t)stream, in, bn, out, CH, T,
-                       drop_p, seed, mask);
+                       drop_p, seed, mask, seed_dev);
   else
     hipLaunchKernelGGL(pool_fwd_kernel<8>, dim3(B * CH), dim3(256), 0, (hipStream_t)stream, in, bn, out, CH, T,
-                       drop_p, seed, mask);
+                       drop_p, seed, mask, seed_dev);
   EAV_CHECK_LAUNCH("eav_bn_elu_pool_fwd");
   return EAV_OK;
 }
 
 extern "C" int eav_bn_elu_pool_bwd_reduce(const float* dp, const float* u, const float* bn, float* part, int B,
                                           int CH, int T, int P, float drop_p, uint64_t seed, const uint8_t* mask,
-                                          void* stream) {
+                                          const uint64_t* seed_dev, void* stream) {
   EAV_REQUIRE(dp && u && bn && part && B > 0 && CH > 0 && T >= P, "eav_bn_elu_pool_bwd_reduce: bad arguments");
   EAV_REQUIRE(P == 4 || P == 8, "eav_bn_elu_pool_bwd_reduce: pool %d not in {4,8}", P);
   if (P == 4)
     hipLaunchKernelGGL(pool_bwd_reduce_kernel<4>, dim3(B * CH), dim3(256), 0, (hipStream_t)stream, dp, u, bn, part,
-                       CH, T, drop_p, seed, mask);
+                       CH, T, drop_p, seed, mask, seed_dev);
   else
     hipLaunchKernelGGL(pool_bwd_reduce_kernel<8>, dim3(B * CH), dim3(256), 0, (hipStream_t)stream, dp, u, bn, part,
-                       CH, T, drop_p, seed, mask);
+                       CH, T, drop_p, seed, mask, seed_dev);
   EAV_CHECK_LAUNCH("eav_bn_elu_pool_bwd_reduce");
   return EAV_OK;
 }
 
 extern "C" int eav_bn_elu_pool_bwd_apply(const float* dp, const float* u, const float* bn, const float* m12,
                                          float* du, int B, int CH, int T, int P, float drop_p, uint64_t seed,
-                                         const uint8_t* mask, void* stream) {
+                                         const uint8_t* mask, const uint64_t* seed_dev, void* stream) {
   EAV_REQUIRE(dp && u && bn && m12 && du && B > 0 && CH > 0 && T >= P, "eav_bn_elu_pool_bwd_apply: bad arguments");
   EAV_REQUIRE(P == 4 || P == 8, "eav_bn_elu_pool_bwd_apply: pool %d not in {4,8}", P);
   if (P == 4)
     hipLaunchKernelGGL(pool_bwd_apply_kernel<4>, dim3(B * CH), dim3(256), 0, (hipStream_t)stream, dp, u, bn, m12, du,
-                       CH, T, drop_p, seed, mask);
+                       CH, T, drop_p, seed, mask, seed_dev);
   else
     hipLaunchKernelGGL(pool_bwd_apply_kernel<8>, dim3(B * CH), dim3(256), 0, (hipStream_t)stream, dp, u, bn, m12, du,
-                       CH, T, drop_p, seed, mask);
+                       CH, T, drop_p, seed, mask, seed_dev);
   EAV_CHECK_LAUNCH("eav_bn_elu_pool_bwd_apply");
   return EAV_OK;
 }

@@ -137,7 +137,13 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ in, c
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
                                                    float b1, float b2, float eps, float wd, float bc1,
-                                                   float bc2_sqrt, int decoupled) {
+                                                   float bc2_sqrt, int decoupled,
+                                                   const int64_t* __restrict__ step_dev) {
+  if (step_dev) {  // capturable: bias corrections from a device-resident step count
+    const double st = (double)*step_dev;
+    bc1 = (float)(1.0 - pow((double)b1, st));
+    bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, st));
+  }
   const int64_t stride = (int64_t)gridDim.x * 256;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
     float pv = p[i], gv = g[i];
@@ -185,14 +191,25 @@ extern "C" int eav_ce_fwd_bwd(const float* in, const int64_t* y, float* loss, fl
 }
 
 extern "C" int eav_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
-                             float beta2, float eps, float weight_decay, int64_t step, int decoupled, void* stream) {
-  EAV_REQUIRE(p && g && m && v && n > 0 && step >= 1, "eav_adam_step: bad arguments");
+                             float beta2, float eps, float weight_decay, int64_t step, int decoupled,
+                             const int64_t* step_dev, void* stream) {
+  EAV_REQUIRE(p && g && m && v && n > 0 && (step >= 1 || step_dev), "eav_adam_step: bad arguments");
+  if (step < 1) step = 1;
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   int64_t blocks = cdiv64(n, 256);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(adam_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1,
-                     beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), decoupled);
+                     beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), decoupled, step_dev);
   EAV_CHECK_LAUNCH("eav_adam_step");
+  return EAV_OK;
+}
+
+__global__ void counter_inc_kernel(int64_t* p) { *p += 1; }
+
+extern "C" int eav_counter_inc(int64_t* counter, void* stream) {
+  EAV_REQUIRE(counter, "eav_counter_inc: null counter");
+  hipLaunchKernelGGL(counter_inc_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, counter);
+  EAV_CHECK_LAUNCH("eav_counter_inc");
   return EAV_OK;
 }

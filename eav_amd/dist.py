@@ -68,6 +68,8 @@ def attach(trainer):
     model = trainer.model
     model._ensure_flat()
     trainer.grad_sync = GradSync([model._flat[1]])
+    if hasattr(trainer, "use_graph"):
+        trainer.use_graph = False     # the RCCL all-reduce stays outside hipGraph capture
     return trainer
 
 

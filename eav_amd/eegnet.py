@@ -116,6 +116,7 @@ class EEGNet_tor(nn.Module):
         self._dropout_masks = None             # tests: (mask1 uint8 [B,64,S/4], mask2 uint8 [B,64,S/32])
         self.apply_max_norm = True
         self.kernel_events = None              # bench: {kernel name: [(start_event, end_event), ...]}
+        self._fwd_counter = None               # device uint64: number of training forwards (dropout stream)
 
     # ------------------------------------------------------------------ plumbing
     def _ensure_flat(self):
@@ -174,8 +175,15 @@ class EEGNet_tor(nn.Module):
         drop = self.dropoutRate if training else 0.0
         masks = self._dropout_masks if training else None
         self._token += 1
-        seed1 = (self.dropout_seed + 2 * self._token) & 0xFFFFFFFFFFFFFFFF
-        seed2 = seed1 + 1
+        # dropout stream: effective seed = base + 2 * (device-resident count of training forwards) - no host
+        # argument changes from step to step, so the whole step can be replayed from a hipGraph
+        seed1, seed2 = self.dropout_seed, self.dropout_seed + 1
+        cnt = None
+        if drop > 0.0 and masks is None:
+            if self._fwd_counter is None or self._fwd_counter.device != x.device:
+                self._fwd_counter = torch.zeros((), dtype=torch.int64, device=x.device)
+            L("eav_counter_inc", P(self._fwd_counter), st)
+            cnt = P(self._fwd_counter)
         m1 = P(masks[0]) if masks is not None else None
         m2 = P(masks[1]) if masks is not None else None
 
@@ -190,16 +198,16 @@ class EEGNet_tor(nn.Module):
         bnfin(ws.part_fir, ws.np_fir, 8, B * C * S, g1w, g1b, bn1, ws.bn1)
         L("eav_eegnet_dw_fwd", P(ws.y1), P(ws.bn1), w2, P(ws.z), P(ws.part_dw), B, C, S, st)
         bnfin(ws.part_dw, B * ws.nchunk, 64, B * S, g2w, g2b, bn2, ws.bn2)
-        L("eav_bn_elu_pool_fwd", P(ws.z), P(ws.bn2), P(ws.p2), B, 64, S, 4, drop, seed1, m1, st)
+        L("eav_bn_elu_pool_fwd", P(ws.z), P(ws.bn2), P(ws.p2), B, 64, S, 4, drop, seed1, m1, cnt, st)
         L("eav_conv64_prep_weights", w3, P(ws.wTf), P(ws.wTb), st)
         L("eav_conv64_fwd", P(ws.p2), P(ws.wTf), P(ws.u3), P(ws.part_c3), B, ws.T2, 7, st)
         bnfin(ws.part_c3, B * ws.ntile3, 64, B * ws.T2, g3w, g3b, bn3, ws.bn3)
-        L("eav_bn_elu_pool_fwd", P(ws.u3), P(ws.bn3), P(ws.p3), B, 64, ws.T2, 8, drop, seed2, m2, st)
+        L("eav_bn_elu_pool_fwd", P(ws.u3), P(ws.bn3), P(ws.p3), B, 64, ws.T2, 8, drop, seed2, m2, cnt, st)
         L("eav_dense_softmax_fwd", P(ws.p3), wd, bd, None, P(ws.probs), B, ws.NF, nb, st)
         if self.apply_max_norm:  # the forward hooks of the reference (:33-34, :47-48), intended meaning
             L("eav_renorm_rows", w2, 64, C, self.norm_rate, st)
             L("eav_renorm_rows", wd, nb, ws.NF, self.norm_rate, st)
-        self._saved = (self._token, x, training, drop, seed1, seed2, masks)
+        self._saved = (self._token, x, training, drop, seed1, seed2, masks, cnt)
         return self._token
 
     def _launch_backward(self, dprobs, token):
@@ -207,7 +215,7 @@ class EEGNet_tor(nn.Module):
             raise _lib.EavError("EEGNet_tor.backward: the activations of this forward were overwritten by a later "
                                 "forward (one outstanding forward per backward)")
         L, P, st = self._call, _lib.ptr, _lib.stream_ptr()
-        _, x, training, drop, seed1, seed2, masks = self._saved
+        _, x, training, drop, seed1, seed2, masks, cnt = self._saved
         ws = self._ws
         B, C, S, K, nb = x.shape[0], self.Chans, self.Samples, self.kernLength, self.nb_classes
         T2, NF = ws.T2, ws.NF
@@ -222,22 +230,22 @@ class EEGNet_tor(nn.Module):
           P(ws.dp3), B, NF, nb, st)
         # block 2: Dropout <- AvgPool8 <- ELU <- separableBN
         b3 = P(ws.bn3)
-        L("eav_bn_elu_pool_bwd_reduce", P(ws.dp3), P(ws.u3), b3, P(ws.part_pb), B, 64, T2, 8, drop, seed2, m2, st)
+        L("eav_bn_elu_pool_bwd_reduce", P(ws.dp3), P(ws.u3), b3, P(ws.part_pb), B, 64, T2, 8, drop, seed2, m2, cnt, st)
         L("eav_bn_bwd_finalize", P(ws.part_pb), B, 64, float(B * T2), tr, P(g["separableBN.weight"]),
           P(g["separableBN.bias"]), b3 + 4 * 256, b3 + 4 * 320, st)
         L("eav_bn_elu_pool_bwd_apply", P(ws.dp3), P(ws.u3), b3, b3 + 4 * 256, P(ws.du3), B, 64, T2, 8, drop, seed2,
-          m2, st)
+          m2, cnt, st)
         # separableConv: data gradient (flipped/transposed taps, pad 8) and weight gradient
         L("eav_conv64_fwd", P(ws.du3), P(ws.wTb), P(ws.dp2), None, B, T2, 8, st)
         L("eav_conv64_wgrad", P(ws.du3), P(ws.p2), P(ws.part_cw), B, T2, 7, st)
         L("eav_reduce_partials", P(ws.part_cw), ws.np_cw, 65536, 65536, 1.0, P(g["separableConv.weight"]), st)
         # block 1 tail: Dropout <- AvgPool4 <- ELU <- depthwiseBN
         b2 = P(ws.bn2)
-        L("eav_bn_elu_pool_bwd_reduce", P(ws.dp2), P(ws.z), b2, P(ws.part_pb), B, 64, S, 4, drop, seed1, m1, st)
+        L("eav_bn_elu_pool_bwd_reduce", P(ws.dp2), P(ws.z), b2, P(ws.part_pb), B, 64, S, 4, drop, seed1, m1, cnt, st)
         L("eav_bn_bwd_finalize", P(ws.part_pb), B, 64, float(B * S), tr, P(g["depthwiseBN.weight"]),
           P(g["depthwiseBN.bias"]), b2 + 4 * 256, b2 + 4 * 320, st)
         L("eav_bn_elu_pool_bwd_apply", P(ws.dp2), P(ws.z), b2, b2 + 4 * 256, P(ws.dz), B, 64, S, 4, drop, seed1, m1,
-          st)
+          cnt, st)
         # depthwiseConv <- ELU <- firstBN (uses the post-renorm depthwise weight, Q2)
         b1 = P(ws.bn1)
         L("eav_eegnet_dw_bwd", P(ws.y1), P(ws.dz), b1, w2, P(ws.g1), P(ws.part_dst), P(ws.part_dw2), B, C, S, st)
@@ -249,6 +257,56 @@ class EEGNet_tor(nn.Module):
         L("eav_reduce_partials", P(ws.part_fw), ws.np_fw, 8 * K, 8 * K, 1.0, P(g["firstConv.weight"]), st)
         named = dict(self.named_parameters())
         return [g[k].view(named[k].shape) if named[k].requires_grad else None for k in _PARAM_ORDER]
+
+
+class GraphStep:
+    """One EEGNet training step (batch gather, forward, CE, backward, [grad sync], fused Adam) captured in a
+    hipGraph and replayed: at the reference's own shape ([32,1,30,500]) the step is ~35 tiny kernels and is
+    bound by launch overhead, not by the GPU.  Everything that varies between steps lives in device memory
+    (batch indices, dropout counter, Adam step count), so a replay needs no host-side argument updates."""
+
+    def __init__(self, model, optimizer, criterion, xs, ys, batch, grad_sync=None):
+        if not getattr(optimizer, "capturable", False):
+            raise _lib.EavError("GraphStep needs FusedAdam(capturable=True)")
+        self.model, self.batch = model, batch
+        dev = xs.device
+        self.idx = torch.zeros(batch, dtype=torch.long, device=dev)
+
+        def body():
+            data, targets = xs.index_select(0, self.idx), ys.index_select(0, self.idx)
+            scores = model(data)
+            loss = criterion(scores, targets)
+            optimizer.zero_grad(set_to_none=True)
+            loss.backward()
+            if grad_sync is not None:
+                grad_sync()
+            optimizer.step()
+            return scores, loss
+
+        self.warm_steps = 0
+        self.graph = None
+        self._body = body
+
+    def run(self, idx):
+        """idx: sequence of `batch` dataset indices.  The first two calls run eagerly (they are real training
+        steps), the third is captured, later ones are replays."""
+        self.idx.copy_(torch.as_tensor(idx, dtype=torch.long))     # pageable source: staged, no host race
+        if self.graph is None:
+            if self.warm_steps < 2:
+                self.warm_steps += 1
+                scores, loss = self._body()
+                return scores.detach(), loss.detach()     # keep no reference to the autograd graph
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                scores, loss = self._body()
+                self.scores, self.loss = scores.detach(), loss.detach()
+            del scores, loss
+            # capture does not execute: replay once so that this call is a real step too
+            self.graph.replay()
+            return self.scores, self.loss
+        self.graph.replay()
+        return self.scores, self.loss
 
 
 # ----------------------------------------------------------------------------- data plumbing
@@ -275,23 +333,27 @@ class DeviceLoader:
     def __len__(self):
         return (len(self.dataset) + self.batch_size - 1) // self.batch_size
 
-    def __iter__(self):
+    def index_batches(self):
+        """The index lists iter(DataLoader) would visit (same samplers, same torch RNG consumption)."""
         from torch.utils.data import BatchSampler, RandomSampler, SequentialSampler
         n = len(self.dataset)
         # iter(DataLoader) draws its base seed first (torch/utils/data/dataloader.py, _BaseDataLoaderIter)
         torch.empty((), dtype=torch.int64).random_()
         if self.order_override:
             order = [int(i) for i in self.order_override.pop(0)]
-            batches = [order[i:i + self.batch_size] for i in range(0, n, self.batch_size)]
-        else:
-            sampler = RandomSampler(range(n)) if self.shuffle else SequentialSampler(range(n))
-            batches = BatchSampler(sampler, self.batch_size, drop_last=False)
-        for idx in batches:
-            if not self.shuffle and not self.order_override and idx[-1] - idx[0] == len(idx) - 1:
-                yield self.x[idx[0]:idx[-1] + 1], self.y[idx[0]:idx[-1] + 1]
-            else:
-                it = torch.as_tensor(idx, dtype=torch.long, device=self.device)
-                yield self.x.index_select(0, it), self.y.index_select(0, it)
+            return [order[i:i + self.batch_size] for i in range(0, n, self.batch_size)]
+        sampler = RandomSampler(range(n)) if self.shuffle else SequentialSampler(range(n))
+        return list(BatchSampler(sampler, self.batch_size, drop_last=False))
+
+    def gather(self, idx):
+        if idx[-1] - idx[0] == len(idx) - 1 and all(b - a == 1 for a, b in zip(idx, idx[1:])):
+            return self.x[idx[0]:idx[-1] + 1], self.y[idx[0]:idx[-1] + 1]
+        it = torch.as_tensor(idx, dtype=torch.long, device=self.device)
+        return self.x.index_select(0, it), self.y.index_select(0, it)
+
+    def __iter__(self):
+        for idx in self.index_batches():
+            yield self.gather(idx)
 
 
 class Trainer_uni:
@@ -309,26 +371,38 @@ class Trainer_uni:
 
         self.model = model
         self.criterion = CrossEntropyLoss()                       # EEGNet_tor.py:81
-        self.optimizer = FusedAdam(self.model.parameters(), lr=self.lr)   # :82 (Adam, wd 0)
+        self.optimizer = FusedAdam(self.model.parameters(), lr=self.lr, capturable=True)   # :82 (Adam, wd 0)
         # :86-88 wraps in nn.DataParallel when several GPUs are visible; here multi-GPU is one
         # process per GPU with an RCCL gradient all-reduce (eav_amd.dist), enabled by the launcher.
         self.model.to(self.device)
         self.grad_sync = None  # set by eav_amd.dist.attach(trainer) under torchrun
+        self.use_graph = True  # replay full-size batches from a hipGraph (partial batches run eagerly)
+        self._graphs = {}
 
     def _prepare_dataloader(self, x, y, shuffle=False):
         return DeviceLoader(x, y, self.batch_size, shuffle, self.device)
 
     def train(self):
         self.model.train()  # once, before the epoch loop - as the reference (:97)
+        dl = self.train_dataloader
         for epoch in range(self.num_epochs):
-            for batch_idx, (data, targets) in enumerate(self.train_dataloader):
-                scores = self.model(data)
-                loss = self.criterion(scores, targets)
-                self.optimizer.zero_grad()
-                loss.backward()
-                if self.grad_sync is not None:
-                    self.grad_sync()
-                self.optimizer.step()
+            for batch_idx, idx in enumerate(dl.index_batches()):
+                if self.use_graph and len(idx) == self.batch_size:
+                    # one captured graph per (batch size, BN mode): epochs >= 2 train in eval mode (Q4)
+                    key = (len(idx), bool(self.model.training))
+                    if key not in self._graphs:
+                        self._graphs[key] = GraphStep(self.model, self.optimizer, self.criterion, dl.x, dl.y,
+                                                      len(idx), self.grad_sync)
+                    scores, loss = self._graphs[key].run(idx)
+                else:
+                    data, targets = dl.gather(idx)
+                    scores = self.model(data)
+                    loss = self.criterion(scores, targets)
+                    self.optimizer.zero_grad()
+                    loss.backward()
+                    if self.grad_sync is not None:
+                        self.grad_sync()
+                    self.optimizer.step()
                 if batch_idx % 100 == 0:
                     print(f"Epoch [{epoch+1}/{self.num_epochs}], Step [{batch_idx}/{len(self.train_dataloader)}], "
                           f"Loss: {loss.item():.4f}")

@@ -53,26 +53,38 @@ class FusedAdam(torch.optim.Optimizer):
     """Adam (``decoupled=False``) / AdamW (``decoupled=True``) with torch's
     hyper-parameter names; one ``eav_adam_step`` launch per contiguous run."""
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, decoupled=False):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, decoupled=False,
+                 capturable=False):
+        """capturable=True keeps ONE step count in device memory (incremented by a kernel), so that step()
+        can be captured in a hipGraph and replayed; it requires every parameter to receive a gradient on
+        every step (true for EEGNet; the two-phase AST/ViT fine-tune uses the default host-side counts)."""
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, decoupled=decoupled)
         super().__init__(params, defaults)
         self._flat_state = {}
+        self.capturable = capturable
+        self._dev_step = None
 
-    @staticmethod
-    def _launch(p_ptr, g_ptr, m_ptr, v_ptr, n, group, step):
+    def _launch(self, p_ptr, g_ptr, m_ptr, v_ptr, n, group, step):
         b1, b2 = group["betas"]
         _lib.call("eav_adam_step", p_ptr, g_ptr, m_ptr, v_ptr, n, float(group["lr"]), float(b1), float(b2),
                   float(group["eps"]), float(group["weight_decay"]), int(step), int(bool(group["decoupled"])),
-                  _lib.stream_ptr())
+                  None if self._dev_step is None else self._dev_step.data_ptr(), _lib.stream_ptr())
 
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
+        if self.capturable:
+            if self._dev_step is None:
+                dev = next(p for g in self.param_groups for p in g["params"]).device
+                self._dev_step = torch.zeros((), dtype=torch.int64, device=dev)
+            _lib.call("eav_counter_inc", self._dev_step.data_ptr(), _lib.stream_ptr())
         for group in self.param_groups:
             runs = []  # (p_ptr, g_ptr, m_ptr, v_ptr, numel, step) candidates for merging
             for p in group["params"]:
                 g = p.grad
                 if g is None:
+                    if self.capturable:
+                        raise _lib.EavError("FusedAdam(capturable=True): every parameter must have a gradient")
                     continue
                 if not p.is_cuda:
                     raise _lib.EavError("FusedAdam needs parameters on a ROCm device (no CPU fallback)")

@@ -63,13 +63,16 @@ int eav_eegnet_dw_bwd(const float* y1, const float* dz, const float* bn1, const 
 /* ---- BN -> ELU -> AvgPool(1,P) -> Dropout (EEGNet_tor.py:55-58, 60-63), P in {4,8} -------- */
 /* bn = mean, invstd, scale, shift (CH each).  mask: optional uint8 keep-mask [B,CH,T/P]
  * (NULL = counter-based generator keyed by seed); drop_p = 0 disables dropout. */
+/* seed_dev (optional, device uint64): effective seed = seed + 2 * (*seed_dev) - a device-resident step counter,
+ * so that a captured hipGraph draws a fresh mask on every replay. */
 int eav_bn_elu_pool_fwd(const float* in, const float* bn, float* out, int B, int CH, int T, int P, float drop_p,
-                        uint64_t seed, const uint8_t* mask, void* stream);
+                        uint64_t seed, const uint8_t* mask, const uint64_t* seed_dev, void* stream);
 int eav_bn_elu_pool_bwd_reduce(const float* dp, const float* u, const float* bn, float* part /*[B][2*CH]*/, int B,
-                               int CH, int T, int P, float drop_p, uint64_t seed, const uint8_t* mask, void* stream);
+                               int CH, int T, int P, float drop_p, uint64_t seed, const uint8_t* mask,
+                               const uint64_t* seed_dev, void* stream);
 int eav_bn_elu_pool_bwd_apply(const float* dp, const float* u, const float* bn, const float* m12 /*m1[CH],m2[CH]*/,
                               float* du, int B, int CH, int T, int P, float drop_p, uint64_t seed,
-                              const uint8_t* mask, void* stream);
+                              const uint8_t* mask, const uint64_t* seed_dev, void* stream);
 
 /* ---- separableConv: dense 64->64, 16 taps, 'same' (EEGNet_tor.py:37,59) ------------------- */
 int eav_conv64_prep_weights(const float* w /*[64,64,16]*/, float* wT_fwd /*[1024,64]*/, float* wT_bwd, void* stream);
@@ -91,9 +94,12 @@ int eav_dense_softmax_bwd(const float* dout, const float* probs, const float* in
 /* nn.CrossEntropyLoss (mean) on [B,NC] rows + gradient; *ncorrect += #argmax hits (may be NULL). */
 int eav_ce_fwd_bwd(const float* in, const int64_t* y, float* loss, float* din, int* ncorrect, int B, int NC,
                    void* stream);
-/* torch.optim.Adam (decoupled=0) / AdamW (decoupled=1) update of one flat tensor; step >= 1. */
+/* torch.optim.Adam (decoupled=0) / AdamW (decoupled=1) update of one flat tensor; step >= 1.
+ * step_dev (optional, device int64): take the step count from device memory instead (graph-capturable). */
 int eav_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-                  float eps, float weight_decay, int64_t step, int decoupled, void* stream);
+                  float eps, float weight_decay, int64_t step, int decoupled, const int64_t* step_dev, void* stream);
+/* *counter += 1 on the stream (device-resident step counters for hipGraph replay). */
+int eav_counter_inc(int64_t* counter, void* stream);
 
 /* ---- AST / ViT encoders (HF ASTForAudioClassification / ViTForImageClassification as called at
  *      Transformer_Audio.py:22,72 and Transformer_Vision.py:29,92) ------------------------------ */

@@ -35,7 +35,7 @@ def test_argument_validation_without_gpu():
     with pytest.raises(_lib.EavError, match="kernLength"):
         _lib.call("eav_eegnet_fir_fwd", 1, 1, 1, 1, 1, 30, 500, 301, None)
     with pytest.raises(_lib.EavError, match="pool"):
-        _lib.call("eav_bn_elu_pool_fwd", 1, 1, 1, 1, 64, 100, 3, 0.0, 0, None, None)
+        _lib.call("eav_bn_elu_pool_fwd", 1, 1, 1, 1, 64, 100, 3, 0.0, 0, None, None, None)
     assert _lib.plain("eav_conv64_ntiles", 2500) == 20
     assert _lib.plain("eav_eegnet_fir_fwd_nparts", 64, 30, 10000) == 512
 

@@ -145,7 +145,7 @@ def test_pool_fwd_bwd(L, B, T, P, drop):
     mp = maskd.data_ptr() if maskd is not None else None
     out = torch.empty(B, CH, To, device="cuda")
     ud = dev(u)
-    L.call("eav_bn_elu_pool_fwd", ud.data_ptr(), bn.data_ptr(), out.data_ptr(), B, CH, T, P, drop, 0, mp, None)
+    L.call("eav_bn_elu_pool_fwd", ud.data_ptr(), bn.data_ptr(), out.data_ptr(), B, CH, T, P, drop, 0, mp, None, None)
     torch.cuda.synchronize()
     ut = torch.from_numpy(u).double().requires_grad_(True)
     bc = lambda v: torch.from_numpy(v).double()[None, :, None]  # noqa: E731
@@ -160,10 +160,10 @@ def test_pool_fwd_bwd(L, B, T, P, drop):
     part = torch.zeros(B, 2 * CH, device="cuda")
     dpd = dev(dp)
     L.call("eav_bn_elu_pool_bwd_reduce", dpd.data_ptr(), ud.data_ptr(), bn.data_ptr(), part.data_ptr(), B, CH, T, P,
-           drop, 0, mp, None)
+           drop, 0, mp, None, None)
     du = torch.empty(B, CH, T, device="cuda")
     L.call("eav_bn_elu_pool_bwd_apply", dpd.data_ptr(), ud.data_ptr(), bn.data_ptr(), bn.data_ptr() + 4 * 4 * CH,
-           du.data_ptr(), B, CH, T, P, drop, 0, mp, None)
+           du.data_ptr(), B, CH, T, P, drop, 0, mp, None, None)
     torch.cuda.synchronize()
     uhat = (torch.from_numpy(u).double() - bc(mean)) * bc(invstd)
     s = part.sum(0).cpu().double().numpy()
@@ -179,14 +179,14 @@ def test_dropout_generator_statistics(L):
     one, zero = np.ones(CH, np.float32), np.zeros(CH, np.float32)
     bn = bn_buf(CH, zero, one, one, zero)
     out = torch.empty(B, CH, T // P, device="cuda")
-    L.call("eav_bn_elu_pool_fwd", dev(u).data_ptr(), bn.data_ptr(), out.data_ptr(), B, CH, T, P, 0.5, 1234, None, None)
+    L.call("eav_bn_elu_pool_fwd", dev(u).data_ptr(), bn.data_ptr(), out.data_ptr(), B, CH, T, P, 0.5, 1234, None, None, None)
     o = out.cpu().numpy()
     assert set(np.unique(o)) == {0.0, 2.0}
     assert abs((o == 0).mean() - 0.5) < 0.01
     out2 = torch.empty_like(out)
-    L.call("eav_bn_elu_pool_fwd", dev(u).data_ptr(), bn.data_ptr(), out2.data_ptr(), B, CH, T, P, 0.5, 1234, None, None)
+    L.call("eav_bn_elu_pool_fwd", dev(u).data_ptr(), bn.data_ptr(), out2.data_ptr(), B, CH, T, P, 0.5, 1234, None, None, None)
     assert torch.equal(out, out2)            # same seed -> same mask (needed by the backward)
-    L.call("eav_bn_elu_pool_fwd", dev(u).data_ptr(), bn.data_ptr(), out2.data_ptr(), B, CH, T, P, 0.5, 1235, None, None)
+    L.call("eav_bn_elu_pool_fwd", dev(u).data_ptr(), bn.data_ptr(), out2.data_ptr(), B, CH, T, P, 0.5, 1235, None, None, None)
     assert not torch.equal(out, out2)
 
 
@@ -323,6 +323,6 @@ def test_adam_step_matches_torch(L, decoupled, wd):
         ref_p.grad = torch.from_numpy(gs.copy())
         opt.step()
         L.call("eav_adam_step", pd.data_ptr(), dev(gs).data_ptr(), m.data_ptr(), v.data_ptr(), n, 1e-3, 0.9, 0.999,
-               1e-8, wd, step, decoupled, None)
+               1e-8, wd, step, decoupled, None, None)
         torch.cuda.synchronize()
         close(pd, ref_p.detach(), 1e-6, 2e-7, f"p step {step}")

@@ -210,3 +210,40 @@ def test_ragged_shapes_against_oracle(B, C, S, K, train_mode):
         close(named[k].grad, ref, 2e-3, max(2e-3 * np.abs(ref).max(), 1e-9), f"grad.{k}")
     for k in BN:
         close(m.state_dict()[k], st.Bf[k].numpy(), 1e-4, 1e-5, k)
+
+
+@pytest.mark.parametrize("drop", [0.0, 0.5])
+def test_graph_replay_equals_eager(drop):
+    """hipGraph replay of the whole training step == the eager schedule, bit for bit: parameters, BN running
+    statistics and the dropout stream (device-resident counters) after 6 steps on changing batches."""
+    from eav_amd.eegnet import EEGNet_tor, GraphStep
+    from eav_amd.optim import CrossEntropyLoss, FusedAdam
+    S, B, n = 500, 8, 40
+    sd = eegnet_weights(55, S)
+    x, y = synth.eeg_batch(550, n, 30, S)
+    xs, ys = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    batches = [[(7 * s + 3 * j) % n for j in range(B)] for s in range(6)]
+    finals = []
+    for use_graph in (False, True):
+        m = build(S, sd, drop).train()
+        opt, crit = FusedAdam(m.parameters(), lr=1e-3, capturable=True), CrossEntropyLoss()
+        losses = []
+        if use_graph:
+            gs = GraphStep(m, opt, crit, xs, ys, B)
+            for idx in batches:
+                losses.append(float(gs.run(idx)[1].item()))
+            assert gs.graph is not None                       # steps 3..6 were captured / replayed
+        else:
+            for idx in batches:
+                it = torch.as_tensor(idx, device="cuda")
+                loss = crit(m(xs.index_select(0, it)), ys.index_select(0, it))
+                opt.zero_grad()
+                loss.backward()
+                opt.step()
+                losses.append(float(loss.item()))
+        torch.cuda.synchronize()
+        finals.append((losses, {k: v.clone() for k, v in m.state_dict().items()}))
+    assert finals[0][0] == finals[1][0], (finals[0][0], finals[1][0])
+    for k in finals[0][1]:
+        assert torch.equal(finals[0][1][k], finals[1][1][k]), k
+    assert len(set(finals[0][0])) == len(finals[0][0])       # the batches (and masks) really changed

@@ -124,7 +124,7 @@ def main():
     import torch.distributed as dist
     from eav_amd import dist as eav_dist
     from eav_amd import synth
-    from eav_amd.eegnet import EEGNet_tor
+    from eav_amd.eegnet import EEGNet_tor, gather_batch
     from eav_amd.optim import CrossEntropyLoss, FusedAdam
 
     # EAV_DIST_BACKEND=gloo + EAV_FORCE_DEVICE=0 let two ranks share one GPU (logic test on a 1-GPU box)
@@ -152,8 +152,7 @@ def main():
     batches = [torch.randperm(TRIALS, generator=gen)[:B_PER_GPU].to(dev) for _ in range(args.steps + args.warmup)]
 
     def step(i):
-        idx = batches[i]
-        data, targets = xs.index_select(0, idx), ys.index_select(0, idx)
+        data, targets = gather_batch(xs, ys, batches[i])
         scores = model(data)
         loss = crit(scores, targets)
         opt.zero_grad()

@@ -47,6 +47,8 @@ SIGNATURES = {
     "eav_ce_fwd_bwd": [_p, _p, _p, _p, _p, _i, _i, _p],
     "eav_adam_step": [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _i64, _i, _p, _p],
     "eav_counter_inc": [_p, _p],
+    "eav_gather_rows": [_p, _p, _p, _i, _i64, _p],
+    "eav_gather_i64": [_p, _p, _p, _i, _p],
     "eav_gemm_f32": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64, _f, _p,
                      _i, _p, _p, _i, _i, _p],
     "eav_gemm_bf16": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64, _f, _p,
@@ -65,6 +67,8 @@ SIGNATURES = {
     "eav_token_rows": [_p, _p, _i, _i, _i, _i, _i, _p],
     "eav_pair_mean": [_p, _p, _i, _i, _i, _p],
     "eav_ast_fbank": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _d, _d, _f, _f, _p],
+    "eav_decimate_fir_f64": [_p, _p, _p, _i, _i64, _i64, _i, _i, _i, _p],
+    "eav_sosfilt_f64": [_p, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _i, _p],
     "eav_resize_normalize_u8": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _d, _p, _p, _p],
 }
 # helpers that return a plain value (no status)

@@ -213,3 +213,44 @@ extern "C" int eav_counter_inc(int64_t* counter, void* stream) {
   EAV_CHECK_LAUNCH("eav_counter_inc");
   return EAV_OK;
 }
+
+// Batch assembly: out[i, :] = src[idx[i], :] for rows of `row_elems` floats (16-B vectors when possible).
+// Replaces the per-batch host copy of the reference loops (EEGNet_tor.py:100-101, Transformer_Audio.py:70):
+// the split lives in HBM and a batch is one gather.
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, const int64_t* __restrict__ idx,
+                                                          float* __restrict__ out, int64_t row_elems, int vec) {
+  const int64_t r = idx[blockIdx.y];
+  if (vec) {
+    const float4* s = reinterpret_cast<const float4*>(src + r * row_elems);
+    float4* d = reinterpret_cast<float4*>(out + (int64_t)blockIdx.y * row_elems);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < row_elems / 4; i += (int64_t)gridDim.x * 256) d[i] = s[i];
+  } else {
+    const float* s = src + r * row_elems;
+    float* d = out + (int64_t)blockIdx.y * row_elems;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < row_elems; i += (int64_t)gridDim.x * 256) d[i] = s[i];
+  }
+}
+
+__global__ void gather_i64_kernel(const int64_t* __restrict__ src, const int64_t* __restrict__ idx,
+                                  int64_t* __restrict__ out, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = src[idx[i]];
+}
+
+extern "C" int eav_gather_rows(const float* src, const int64_t* idx, float* out, int nrows, int64_t row_elems,
+                               void* stream) {
+  EAV_REQUIRE(src && idx && out && nrows > 0 && row_elems > 0, "eav_gather_rows: bad arguments");
+  const int vec = (row_elems % 4 == 0) && ((((uintptr_t)src | (uintptr_t)out) & 15) == 0);
+  int64_t per = vec ? row_elems / 4 : row_elems;
+  int gx = (int)(cdiv64(per, 256) > 64 ? 64 : cdiv64(per, 256));
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(gx, nrows), dim3(256), 0, (hipStream_t)stream, src, idx, out, row_elems, vec);
+  EAV_CHECK_LAUNCH("eav_gather_rows");
+  return EAV_OK;
+}
+
+extern "C" int eav_gather_i64(const int64_t* src, const int64_t* idx, int64_t* out, int n, void* stream) {
+  EAV_REQUIRE(src && idx && out && n > 0, "eav_gather_i64: bad arguments");
+  hipLaunchKernelGGL(gather_i64_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, src, idx, out, n);
+  EAV_CHECK_LAUNCH("eav_gather_i64");
+  return EAV_OK;
+}

@@ -144,3 +144,133 @@ extern "C" int eav_ast_fbank(const float* wav, const double* window400, const do
   EAV_CHECK_LAUNCH("eav_ast_fbank");
   return EAV_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// EEG pre-processing (Dataload_eeg.py:85-121), float64 like scipy:
+//  * downsampling(): scipy.signal.resample_poly(x, 1, down) = a zero-phase decimating FIR
+//        y[c][m] = sum_j h[j] * x[c][m*down + center - j]           (zeros outside the record)
+//  * bandpass_filter(): scipy.signal.sosfilt(sos, x) per channel - a cascade of biquads in direct form II
+//    transposed, i.e. a linear recurrence over ~2e6 samples.  Parallelised exactly (no truncation):
+//    (1) every chunk of Lc samples runs the cascade from a ZERO state (one thread per chunk) and records its
+//        final state, (2) one thread per channel chains the true chunk-start states
+//        z[c+1] = A^Lc z[c] + zend[c], (3) every sample adds the homogeneous response H[k] . z[chunk].
+//    A^Lc and H come from the host (the same cascade run on unit initial states).
+namespace {
+
+__global__ __launch_bounds__(256) void decimate_fir_kernel(const double* __restrict__ x, const double* __restrict__ h,
+                                                           double* __restrict__ y, int64_t n_in, int64_t n_out,
+                                                           int down, int ntaps, int center) {
+  const int c = blockIdx.y;
+  const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (m >= n_out) return;
+  const double* xr = x + (int64_t)c * n_in;
+  const int64_t base = m * down + center;
+  double acc = 0.0;
+  for (int j = 0; j < ntaps; ++j) {
+    const int64_t i = base - j;
+    if (i >= 0 && i < n_in) acc += h[j] * xr[i];
+  }
+  y[(int64_t)c * n_out + m] = acc;
+}
+
+constexpr int MAXSEC = 8;
+
+// (1) zero-state cascade over one chunk; thread = (channel, chunk)
+__global__ __launch_bounds__(64) void sos_chunk_kernel(const double* __restrict__ x, double* __restrict__ y,
+                                                       const double* __restrict__ sos, double* __restrict__ zend,
+                                                       int nch, int64_t n, int nsec, int Lc, int nchunk) {
+  const int id = blockIdx.x * 64 + threadIdx.x;
+  if (id >= nch * nchunk) return;
+  const int c = id / nchunk, q = id - c * nchunk;
+  double b0[MAXSEC], b1[MAXSEC], b2[MAXSEC], a1[MAXSEC], a2[MAXSEC], z0[MAXSEC], z1[MAXSEC];
+#pragma unroll
+  for (int s = 0; s < MAXSEC; ++s) {
+    if (s < nsec) {
+      b0[s] = sos[s * 6 + 0]; b1[s] = sos[s * 6 + 1]; b2[s] = sos[s * 6 + 2];
+      a1[s] = sos[s * 6 + 4]; a2[s] = sos[s * 6 + 5];
+    }
+    z0[s] = z1[s] = 0.0;
+  }
+  const int64_t n0 = (int64_t)q * Lc, n1 = min(n, n0 + Lc);
+  const double* xr = x + (int64_t)c * n;
+  double* yr = y + (int64_t)c * n;
+  for (int64_t i = n0; i < n1; ++i) {
+    double v = xr[i];
+#pragma unroll
+    for (int s = 0; s < MAXSEC; ++s)
+      if (s < nsec) {   // scipy _sosfilt: direct form II transposed
+        const double o = b0[s] * v + z0[s];
+        z0[s] = b1[s] * v - a1[s] * o + z1[s];
+        z1[s] = b2[s] * v - a2[s] * o;
+        v = o;
+      }
+    yr[i] = v;
+  }
+  double* ze = zend + (int64_t)id * 2 * nsec;
+  for (int s = 0; s < nsec; ++s) { ze[2 * s] = z0[s]; ze[2 * s + 1] = z1[s]; }
+}
+
+// (2) chain the chunk-start states of one channel: zs[q+1] = AL . zs[q] + zend[q]  (chunks are full here)
+__global__ void sos_scan_kernel(const double* __restrict__ zend, const double* __restrict__ AL,
+                                double* __restrict__ zstart, int nch, int nsec, int nchunk) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nch) return;
+  const int ns = 2 * nsec;
+  double z[2 * MAXSEC], t[2 * MAXSEC];
+  for (int j = 0; j < ns; ++j) z[j] = 0.0;
+  for (int q = 0; q < nchunk; ++q) {
+    double* dst = zstart + ((int64_t)c * nchunk + q) * ns;
+    for (int j = 0; j < ns; ++j) dst[j] = z[j];
+    const double* ze = zend + ((int64_t)c * nchunk + q) * ns;
+    for (int i = 0; i < ns; ++i) {
+      double a = ze[i];
+      for (int j = 0; j < ns; ++j) a += AL[i * ns + j] * z[j];
+      t[i] = a;
+    }
+    for (int j = 0; j < ns; ++j) z[j] = t[j];
+  }
+}
+
+// (3) y[n] += H[n - n0] . zstart[chunk]
+__global__ __launch_bounds__(256) void sos_fixup_kernel(double* __restrict__ y, const double* __restrict__ H,
+                                                        const double* __restrict__ zstart, int64_t n, int nsec,
+                                                        int Lc, int nchunk) {
+  const int c = blockIdx.y;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int q = (int)(i / Lc), k = (int)(i - (int64_t)q * Lc);
+  if (q == 0) return;                                   // the first chunk starts from the true zero state
+  const int ns = 2 * nsec;
+  const double* z = zstart + ((int64_t)c * nchunk + q) * ns;
+  const double* hk = H + (int64_t)k * ns;
+  double a = 0.0;
+  for (int j = 0; j < ns; ++j) a += hk[j] * z[j];
+  y[(int64_t)c * n + i] += a;
+}
+
+}  // namespace
+
+extern "C" int eav_decimate_fir_f64(const double* x, const double* h, double* y, int nch, int64_t n_in, int64_t n_out,
+                                    int down, int ntaps, int center, void* stream) {
+  EAV_REQUIRE(x && h && y && nch > 0 && n_in > 0 && n_out > 0 && down > 0 && ntaps > 0, "eav_decimate_fir_f64: bad arguments");
+  dim3 grid((unsigned)cdiv64(n_out, 256), nch);
+  hipLaunchKernelGGL(decimate_fir_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, h, y, n_in, n_out, down, ntaps, center);
+  EAV_CHECK_LAUNCH("eav_decimate_fir_f64");
+  return EAV_OK;
+}
+
+extern "C" int eav_sosfilt_f64(const double* x, double* y, const double* sos, const double* H, const double* AL,
+                               double* zend, double* zstart, int nch, int64_t n, int nsec, int Lc, void* stream) {
+  EAV_REQUIRE(x && y && sos && H && AL && zend && zstart && nch > 0 && n > 0 && nsec > 0 && nsec <= MAXSEC && Lc > 0,
+              "eav_sosfilt_f64: bad arguments (at most %d sections)", MAXSEC);
+  const int nchunk = (int)cdiv64(n, Lc);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(sos_chunk_kernel, dim3(cdiv(nch * nchunk, 64)), dim3(64), 0, st, x, y, sos, zend, nch, n, nsec, Lc, nchunk);
+  EAV_CHECK_LAUNCH("eav_sosfilt_f64(chunks)");
+  hipLaunchKernelGGL(sos_scan_kernel, dim3(cdiv(nch, 64)), dim3(64), 0, st, zend, AL, zstart, nch, nsec, nchunk);
+  EAV_CHECK_LAUNCH("eav_sosfilt_f64(scan)");
+  dim3 grid((unsigned)cdiv64(n, 256), nch);
+  hipLaunchKernelGGL(sos_fixup_kernel, grid, dim3(256), 0, st, y, H, zstart, n, nsec, Lc, nchunk);
+  EAV_CHECK_LAUNCH("eav_sosfilt_f64(fixup)");
+  return EAV_OK;
+}

@@ -259,6 +259,19 @@ class EEGNet_tor(nn.Module):
         return [g[k].view(named[k].shape) if named[k].requires_grad else None for k in _PARAM_ORDER]
 
 
+def gather_batch(xs, ys, idx_dev):
+    """(xs[idx], ys[idx]) assembled in HBM by the library's gather kernels (eav_gather_rows / eav_gather_i64)."""
+    n = idx_dev.numel()
+    if not xs.is_cuda:   # host tensors (CPU-side unit tests of the loader only)
+        return xs.index_select(0, idx_dev), ys.index_select(0, idx_dev)
+    data = torch.empty((n,) + tuple(xs.shape[1:]), dtype=torch.float32, device=xs.device)
+    targets = torch.empty(n, dtype=torch.long, device=xs.device)
+    st = _lib.stream_ptr()
+    _lib.call("eav_gather_rows", xs.data_ptr(), idx_dev.data_ptr(), data.data_ptr(), n, xs[0].numel(), st)
+    _lib.call("eav_gather_i64", ys.data_ptr(), idx_dev.data_ptr(), targets.data_ptr(), n, st)
+    return data, targets
+
+
 class GraphStep:
     """One EEGNet training step (batch gather, forward, CE, backward, [grad sync], fused Adam) captured in a
     hipGraph and replayed: at the reference's own shape ([32,1,30,500]) the step is ~35 tiny kernels and is
@@ -273,7 +286,7 @@ class GraphStep:
         self.idx = torch.zeros(batch, dtype=torch.long, device=dev)
 
         def body():
-            data, targets = xs.index_select(0, self.idx), ys.index_select(0, self.idx)
+            data, targets = gather_batch(xs, ys, self.idx)
             scores = model(data)
             loss = criterion(scores, targets)
             optimizer.zero_grad(set_to_none=True)
@@ -348,8 +361,7 @@ class DeviceLoader:
     def gather(self, idx):
         if idx[-1] - idx[0] == len(idx) - 1 and all(b - a == 1 for a, b in zip(idx, idx[1:])):
             return self.x[idx[0]:idx[-1] + 1], self.y[idx[0]:idx[-1] + 1]
-        it = torch.as_tensor(idx, dtype=torch.long, device=self.device)
-        return self.x.index_select(0, it), self.y.index_select(0, it)
+        return gather_batch(self.x, self.y, torch.as_tensor(idx, dtype=torch.long, device=self.device))
 
     def __iter__(self):
         for idx in self.index_batches():

@@ -98,6 +98,10 @@ int eav_ce_fwd_bwd(const float* in, const int64_t* y, float* loss, float* din, i
  * step_dev (optional, device int64): take the step count from device memory instead (graph-capturable). */
 int eav_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                   float eps, float weight_decay, int64_t step, int decoupled, const int64_t* step_dev, void* stream);
+/* Batch assembly in HBM: out[i,:] = src[idx[i],:] (rows of row_elems floats) / out[i] = src[idx[i]] (labels).
+ * Replaces the per-batch host->device copies of the reference loops (EEGNet_tor.py:100-101). */
+int eav_gather_rows(const float* src, const int64_t* idx, float* out, int nrows, int64_t row_elems, void* stream);
+int eav_gather_i64(const int64_t* src, const int64_t* idx, int64_t* out, int n, void* stream);
 /* *counter += 1 on the stream (device-resident step counters for hipGraph replay). */
 int eav_counter_inc(int64_t* counter, void* stream);
 
@@ -169,6 +173,16 @@ int eav_resize_normalize_u8(const uint8_t* frames, const int* kx, const int* bou
 int eav_ast_fbank(const float* wav, const double* window400, const double* twiddle256, const double* melT, float* out,
                   int n, int L, int max_len, int nmel, double preemph, double mel_floor, float mean, float std2,
                   void* stream);
+
+/* EEG pre-processing, float64 like scipy (Dataload_eeg.py:85-121).
+ * scipy.signal.resample_poly(x, 1, down): y[c][m] = sum_j h[j] x[c][m*down + center - j], x [nch][n_in]. */
+int eav_decimate_fir_f64(const double* x, const double* h, double* y, int nch, int64_t n_in, int64_t n_out, int down,
+                         int ntaps, int center, void* stream);
+/* scipy.signal.sosfilt(sos, x) along the last axis of x [nch][n] (zero initial state), exact chunk-parallel form:
+ * sos [nsec][6]; H [Lc][2 nsec] = cascade output at step k from unit initial state j; AL [2 nsec][2 nsec] = state
+ * after Lc zero-input steps; zend / zstart: scratch [nch][ceil(n/Lc)][2 nsec]. */
+int eav_sosfilt_f64(const double* x, double* y, const double* sos, const double* H, const double* AL, double* zend,
+                    double* zstart, int nch, int64_t n, int nsec, int Lc, void* stream);
 
 #ifdef __cplusplus
 }

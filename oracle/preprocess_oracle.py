@@ -128,3 +128,50 @@ def ast_fbank(wav, max_length=1024, nmel=128, mean=-4.2677393, std=4.5689974):
             fb = fb[:max_length]
         out.append((fb - mean) / (std * 2))
     return np.stack(out).astype(np.float32)
+
+
+# ---------------------------------------------------------------------------------------------------
+# EEG pre-processing (Dataload_eeg.py:85-152).  The arithmetic is scipy's (third-party; installed here: see
+# tests/golden/make_goldens_eeg.py for the version stamp): resample_poly = zero-phase decimating FIR with a
+# Kaiser(5.0)-windowed sinc of 2*10*down+1 taps; sosfilt = cascade of direct-form-II-transposed biquads.
+def resample_poly_down(x, down):
+    """scipy.signal.resample_poly(x, 1, down, axis=-1) for a float64 array [..., n]."""
+    half = 10 * down
+    m = np.arange(-half, half + 1, dtype=np.float64)
+    h = (1.0 / down) * np.sinc(m / down) * np.kaiser(2 * half + 1, 5.0)
+    h /= h.sum()
+    n = x.shape[-1]
+    n_out = n // down + bool(n % down)
+    flat = x.reshape(-1, n)
+    out = np.empty((flat.shape[0], n_out))
+    for i, row in enumerate(flat):
+        full = np.convolve(row, h)                     # full[i] = sum_j h[j] row[i-j]
+        out[i] = full[half::down][:n_out]              # y[m] = full[m*down + half]
+    return out.reshape(x.shape[:-1] + (n_out,))
+
+
+def sosfilt_loop(sos, x):
+    """scipy.signal.sosfilt(sos, x) for 1-D float64 x - plain Python recurrence (small cases only)."""
+    sos = np.asarray(sos, np.float64)
+    z = np.zeros((sos.shape[0], 2))
+    y = np.empty_like(x, dtype=np.float64)
+    for n, v in enumerate(np.asarray(x, np.float64)):
+        for s in range(sos.shape[0]):
+            b0, b1, b2, _, a1, a2 = sos[s]
+            o = b0 * v + z[s, 0]
+            z[s, 0] = b1 * v - a1 * o + z[s, 1]
+            z[s, 1] = b2 * v - a2 * o
+            v = o
+        y[n] = v
+    return y
+
+
+def eeg_segment(seg_f, label, selected=(1, 3, 5, 7, 9), win=500):
+    """segment_and_select_classes (Dataload_eeg.py:123-152) for seg_f [ch, t, trials], one-hot label [10, trials]."""
+    ch, t, tri = seg_f.shape
+    nwin = t // win
+    tm1 = seg_f.reshape((ch, win, nwin, tri), order='F')
+    div = tm1.reshape((ch, win, nwin * tri), order='F')
+    lab = np.repeat(label, repeats=nwin, axis=1)
+    mask = np.isin(np.argmax(lab, axis=0), list(selected))
+    return np.transpose(div[:, :, mask], (2, 0, 1)), np.argmax(lab[:, mask], axis=0)

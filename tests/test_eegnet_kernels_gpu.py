@@ -326,3 +326,14 @@ def test_adam_step_matches_torch(L, decoupled, wd):
                1e-8, wd, step, decoupled, None, None)
         torch.cuda.synchronize()
         close(pd, ref_p.detach(), 1e-6, 2e-7, f"p step {step}")
+
+
+def test_gather_rows(L):
+    from eav_amd.eegnet import gather_batch
+    x = synth.normal(81, (20, 1, 3, 37))          # 111 floats per row: scalar path
+    x4 = synth.normal(82, (20, 1, 30, 500))       # vector path
+    y = synth.labels(83, 20)
+    idx = torch.tensor([5, 0, 19, 5, 7], device="cuda")
+    for arr in (x, x4):
+        d, t = gather_batch(dev(arr), dev(y), idx)
+        assert torch.equal(d.cpu(), torch.from_numpy(arr)[idx.cpu()]) and torch.equal(t.cpu(), torch.from_numpy(y)[idx.cpu()])

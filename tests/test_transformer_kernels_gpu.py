@@ -290,3 +290,46 @@ def test_ast_logmel_frontend(golden_dir):
         assert np.abs(waveforms_to_input_values(w).cpu().numpy() - po.ast_fbank(w)).max() < 5e-6
     silent = np.zeros((1, 16000), np.float32)                    # log of the floor, no NaN/inf
     assert np.isfinite(waveforms_to_input_values(silent).cpu().numpy()).all()
+
+
+def test_eeg_decimate_and_sosfilt():
+    """GPU resample_poly / sosfilt (float64) vs scipy on ragged sizes; the chunk-parallel IIR is exact for any chunk
+    length (incl. chunks longer than the record and a near-unit-circle 0.3 Hz band)."""
+    from scipy import signal
+    from eav_amd import eeg_data as ed
+    x = synth.normal(71, (5, 20011)).astype(np.float64) + 2.0
+    xd = torch.from_numpy(x).cuda()
+    for down in (5, 4):
+        got = ed.decimate(xd, down).cpu().numpy()
+        assert np.abs(got - signal.resample_poly(x, 1, down, axis=1)).max() < 1e-11
+    for band in ([5, 30], [0.3, 45]):
+        sos = signal.butter(5, band, btype='bandpass', fs=100, output='sos')
+        ref = signal.sosfilt(sos, x, axis=1)
+        for chunk in (257, 2048, 50000):
+            got = ed.sosfilt(sos, xd, chunk=chunk).cpu().numpy()
+            assert np.abs(got - ref).max() < 1e-9 * max(1.0, np.abs(ref).max()), (band, chunk)
+
+
+def test_eeg_dataload_pipeline_matches_reference(golden_dir):
+    """eav_amd.DataLoadEEG.downsampling/bandpass_filter/segment_and_select_classes == the reference class on the
+    same synthetic recording [30,10000,200] (sample + checksum fixture)."""
+    import os
+    from eav_amd.eeg_data import DataLoadEEG
+    from tests.golden.make_goldens_eeg import synthetic_recording
+    g = np.load(os.path.join(golden_dir, "eeg_preprocess.npz"))
+    x, lab = synthetic_recording(int(g["seed"]))
+    d = DataLoadEEG(subject=1, band=[5, 30], fs_orig=500, fs_target=100)
+    d.seg, d.label = x, lab
+    d.downsampling()
+    assert np.abs(d.seg.cpu().numpy()[::3, ::41, ::17] - g["down_sample"]).max() < 1e-10
+    d.bandpass_filter()
+    assert np.abs(d.seg_f.cpu().numpy()[::3, ::41, ::17] - g["filt_sample"]).max() < 1e-9
+    d.segment_and_select_classes()
+    assert d.seg_f_div.shape == tuple(g["shape"]) and d.seg_f_div.dtype == np.float64
+    assert np.array_equal(d.label_div, g["labels"])
+    assert np.abs(d.seg_f_div[::7, ::3, ::11] - g["out_sample"]).max() < 1e-9
+    assert abs(np.abs(d.seg_f_div).sum() - float(g["out_abssum"])) < 1e-9 * float(g["out_abssum"])
+    d2 = DataLoadEEG(band=[5, 30], remap_labels=True)
+    d2.seg_f, d2.label = d.seg_f, lab
+    d2.segment_and_select_classes()
+    assert set(np.unique(d2.label_div)) <= {0, 1, 2, 3, 4} and np.array_equal(d2.label_div, (g["labels"] - 1) // 2)

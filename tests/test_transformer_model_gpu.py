@@ -166,3 +166,26 @@ def test_reduced_precision_modes(golden_dir, kind):
         rel = float((grads[mode] - ref).norm() / ref.norm())
         print(f"{kind} {mode}: relative gradient error (fc1.weight, layer 0) = {rel:.2e}")
         assert 1e-5 < rel < 5e-2
+
+
+def test_batch_size_changes_and_eval_mode():
+    """Ragged last batch (workspace re-allocation), batch 1, eval forward after a training step."""
+    from eav_amd import transformer as T
+    from oracle import vit_oracle as vo
+    cfg = T.make_config("vit", hidden=64, layers=2, heads=4, ff=128, image=64)
+    ocfg = vo.cfg_vit(hidden=64, layers=2, heads=4, ff=128, image=64)
+    W = tf_weights(21, vo.param_shapes(ocfg), std=0.08)
+    model = T.Encoder(cfg, W).cuda().train()
+    P = {k: torch.from_numpy(v) for k, v in W.items()}
+    for B in (3, 1, 2, 3):
+        x, y = synth.frame_batch(80 + B, B, 64)
+        out = model(torch.from_numpy(x).cuda(), labels=torch.from_numpy(y).cuda())
+        out.loss.backward()
+        with torch.no_grad():
+            ref = vo.forward(P, torch.from_numpy(x), ocfg)
+        close(out.logits, ref.numpy(), 1e-4, 1e-4, f"logits B={B}")
+        assert abs(float(out.loss) - float(torch.nn.functional.cross_entropy(ref, torch.from_numpy(y)))) < 1e-4
+    model.eval()
+    with torch.no_grad():
+        x, _ = synth.frame_batch(99, 5, 64)
+        close(model(torch.from_numpy(x).cuda()).logits, vo.forward(P, torch.from_numpy(x), ocfg).numpy(), 1e-4, 1e-4, "eval")

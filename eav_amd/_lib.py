@@ -55,6 +55,8 @@ SIGNATURES = {
                       _i, _p, _p, _i, _i, _p],
     "eav_gemm_bf16_splitk": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "eav_gemm_f32_splitk": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "eav_attn_fwd": [_p, _p, _p, _i, _i, _i, _i, _f, _p],
+    "eav_attn_bwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
     "eav_layernorm_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _f, _p],
     "eav_layernorm_bwd": [_p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _p],
     "eav_softmax_fwd": [_p, _i64, _i, _i, _p],

@@ -260,6 +260,11 @@ class Encoder(nn.Module):
         self._call(self._gemm_name(), A, B, C, M, N, K, lda, ldb, ldc, tA, tB, batch, heads, sA[0], sA[1], sB[0],
                    sB[1], sC[0], sC[1], float(alpha), bias, gelu, pre, resid, ldr, acc, self._st)
 
+    def _fused_attention(self):
+        """Flash-style fused attention kernels exist for head_dim 64 (AST, ViT-B); other head sizes take the
+        materialised-score path (GEMM + softmax kernels).  `use_fused_attention = False` forces the latter."""
+        return getattr(self, "use_fused_attention", True) and self.cfg.hidden // self.cfg.heads == 64
+
     def _gemm_name(self):
         p = self.precision
         if p not in ("fp32", "bf16", "bf16_bwd"):
@@ -279,7 +284,12 @@ class Encoder(nn.Module):
         ws.hs = [f(M, D) for _ in range(Lr + 1)] if full_backward else [f(M, D), f(M, D)]
         ws.y1 = [f(M, D) for _ in range(nsave)]
         ws.qkv = [f(M, 3 * D) for _ in range(nsave)]
-        ws.P = [torch.zeros(B * H, N, ldn, dtype=torch.float32, device=dev) for _ in range(nsave)]
+        ws.fused = self._fused_attention()
+        if ws.fused:      # flash-style kernels: only the log-sum-exp per (image, head, query) is kept
+            ws.lse = [f(B * H, N) for _ in range(nsave)]
+            ws.delta = f(B * H, N)
+        else:
+            ws.P = [torch.zeros(B * H, N, ldn, dtype=torch.float32, device=dev) for _ in range(nsave)]
         ws.ao = [f(M, D) for _ in range(nsave)]
         ws.hmid = [f(M, D) for _ in range(nsave)]
         ws.y2 = [f(M, D) for _ in range(nsave)]
@@ -293,7 +303,8 @@ class Encoder(nn.Module):
         if full_backward:
             ws.dh, ws.dy, ws.dao = f(M, D), f(M, D), f(M, D)
             ws.dact, ws.dqkv = f(M, FF), f(M, 3 * D)
-            ws.dP = torch.zeros(B * H, N, ldn, dtype=torch.float32, device=dev)
+            if not ws.fused:
+                ws.dP = torch.zeros(B * H, N, ldn, dtype=torch.float32, device=dev)
             ws.demb = f(B * c.npatch, D)
             ws.np_ln = _lib.plain("eav_layernorm_bwd_nparts", M)
             ws.part_ln = f(ws.np_ln, 2 * D)
@@ -318,7 +329,8 @@ class Encoder(nn.Module):
         pm = self._pmap
         full = self._want_full
         ws = self._ws
-        if ws is None or ws.B != B or ws.hs[0].device != x.device or (full and not ws.full):
+        if ws is None or ws.B != B or ws.hs[0].device != x.device or (full and not ws.full) \
+                or ws.fused != self._fused_attention():
             ws = self._ws = self._alloc(B, x.device, full)
         M, ldn = ws.M, ws.ldn
         pre = c.prefix
@@ -344,12 +356,15 @@ class Encoder(nn.Module):
             qkv = P(ws.qkv[j])
             self._gemm(P(ws.y1[j]), w(f"{Lk}.attention.q_proj.weight"), qkv, M, 3 * D, D, D, D, 3 * D,
                        bias=w(f"{Lk}.attention.q_proj.bias"))
-            Pm = P(ws.P[j])
-            self._gemm(qkv, qkv + 4 * D, Pm, N, N, hd, 3 * D, 3 * D, ldn, batch=B * H, heads=H,
-                       sA=(N * 3 * D, hd), sB=(N * 3 * D, hd), sC=(H * N * ldn, N * ldn), alpha=scale)
-            L("eav_softmax_fwd", Pm, B * H * N, N, ldn, st)
-            self._gemm(Pm, qkv + 8 * D, P(ws.ao[j]), N, hd, N, ldn, 3 * D, D, tB=1, batch=B * H, heads=H,
-                       sA=(H * N * ldn, N * ldn), sB=(N * 3 * D, hd), sC=(N * D, hd))
+            if ws.fused:
+                L("eav_attn_fwd", qkv, P(ws.ao[j]), P(ws.lse[j]), B, H, N, hd, scale, st)
+            else:
+                Pm = P(ws.P[j])
+                self._gemm(qkv, qkv + 4 * D, Pm, N, N, hd, 3 * D, 3 * D, ldn, batch=B * H, heads=H,
+                           sA=(N * 3 * D, hd), sB=(N * 3 * D, hd), sC=(H * N * ldn, N * ldn), alpha=scale)
+                L("eav_softmax_fwd", Pm, B * H * N, N, ldn, st)
+                self._gemm(Pm, qkv + 8 * D, P(ws.ao[j]), N, hd, N, ldn, 3 * D, D, tB=1, batch=B * H, heads=H,
+                           sA=(H * N * ldn, N * ldn), sB=(N * 3 * D, hd), sC=(N * D, hd))
             self._gemm(P(ws.ao[j]), w(f"{Lk}.attention.o_proj.weight"), P(ws.hmid[j]), M, D, D, D, D, D,
                        bias=w(f"{Lk}.attention.o_proj.bias"), resid=P(hin), ldr=D)
             L("eav_layernorm_fwd", P(ws.hmid[j]), w(f"{Lk}.layernorm_after.weight"), w(f"{Lk}.layernorm_after.bias"),
@@ -432,7 +447,7 @@ class Encoder(nn.Module):
             ws.dh.zero_()
             L("eav_token_rows", P(ws.dh), P(ws.drows), B, N, D, c.nextra, 1, st)
             scale = hd ** -0.5
-            dh, dy, dao, dact, dqkv, dP = P(ws.dh), P(ws.dy), P(ws.dao), P(ws.dact), P(ws.dqkv), P(ws.dP)
+            dh, dy, dao, dact, dqkv = P(ws.dh), P(ws.dy), P(ws.dao), P(ws.dact), P(ws.dqkv)
             for i in reversed(range(c.layers)):
                 Lk = f"{pre}.layers.{i}"
                 stp = P(ws.st[i])
@@ -455,18 +470,22 @@ class Encoder(nn.Module):
                 self._wgrad(dh, P(ws.ao[i]), gp(f"{Lk}.attention.o_proj.weight"), D, D, M, D, D)
                 self._bias_grad(dh, M, D, D, gp(f"{Lk}.attention.o_proj.bias"))
                 self._gemm(dh, w(f"{Lk}.attention.o_proj.weight"), dao, M, D, D, D, D, D, tB=1)
-                # attention core, batched over (image, head)
-                qkv, Pm = P(ws.qkv[i]), P(ws.P[i])
-                sP, sQ, sO = (H * N * ldn, N * ldn), (N * 3 * D, hd), (N * D, hd)
-                self._gemm(Pm, dao, dqkv + 8 * D, N, hd, N, ldn, D, 3 * D, tA=1, tB=1, batch=B * H, heads=H,
-                           sA=sP, sB=sO, sC=sQ)                                            # dV = P^T dO
-                self._gemm(dao, qkv + 8 * D, dP, N, N, hd, D, 3 * D, ldn, batch=B * H, heads=H,
-                           sA=sO, sB=sQ, sC=sP)                                            # dP = dO V^T
-                L("eav_softmax_bwd", Pm, dP, B * H * N, N, ldn, st)
-                self._gemm(dP, qkv + 4 * D, dqkv, N, hd, N, ldn, 3 * D, 3 * D, tB=1, batch=B * H, heads=H,
-                           sA=sP, sB=sQ, sC=sQ, alpha=scale)                               # dQ = s dS K
-                self._gemm(dP, qkv, dqkv + 4 * D, N, hd, N, ldn, 3 * D, 3 * D, tA=1, tB=1, batch=B * H, heads=H,
-                           sA=sP, sB=sQ, sC=sQ, alpha=scale)                               # dK = s dS^T Q
+                # attention core
+                qkv = P(ws.qkv[i])
+                if ws.fused:
+                    L("eav_attn_bwd", qkv, P(ws.ao[i]), dao, P(ws.lse[i]), P(ws.delta), dqkv, B, H, N, hd, scale, st)
+                else:     # materialised scores, batched over (image, head)
+                    Pm, dP = P(ws.P[i]), P(ws.dP)
+                    sP, sQ, sO = (H * N * ldn, N * ldn), (N * 3 * D, hd), (N * D, hd)
+                    self._gemm(Pm, dao, dqkv + 8 * D, N, hd, N, ldn, D, 3 * D, tA=1, tB=1, batch=B * H, heads=H,
+                               sA=sP, sB=sO, sC=sQ)                                            # dV = P^T dO
+                    self._gemm(dao, qkv + 8 * D, dP, N, N, hd, D, 3 * D, ldn, batch=B * H, heads=H,
+                               sA=sO, sB=sQ, sC=sP)                                            # dP = dO V^T
+                    L("eav_softmax_bwd", Pm, dP, B * H * N, N, ldn, st)
+                    self._gemm(dP, qkv + 4 * D, dqkv, N, hd, N, ldn, 3 * D, 3 * D, tB=1, batch=B * H, heads=H,
+                               sA=sP, sB=sQ, sC=sQ, alpha=scale)                               # dQ = s dS K
+                    self._gemm(dP, qkv, dqkv + 4 * D, N, hd, N, ldn, 3 * D, 3 * D, tA=1, tB=1, batch=B * H, heads=H,
+                               sA=sP, sB=sQ, sC=sQ, alpha=scale)                               # dK = s dS^T Q
                 # fused q/k/v projection
                 self._wgrad(dqkv, P(ws.y1[i]), gp(f"{Lk}.attention.q_proj.weight"), 3 * D, D, M, 3 * D, D)
                 self._bias_grad(dqkv, M, 3 * D, 3 * D, gp(f"{Lk}.attention.q_proj.bias"))

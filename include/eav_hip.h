@@ -130,6 +130,15 @@ int eav_gemm_bf16(const float* A, const float* B, float* C, int M, int N, int K,
                   int ldr, int accumulate, void* stream);
 int eav_gemm_bf16_splitk(const float* A, const float* B, float* C, float* ws, int M, int N, int K, int lda, int ldb,
                          int transA, int transB, void* stream);
+/* Fused multi-head self-attention (head_dim 64), exact fp32 MFMA, flash-style: softmax(Q K^T scale) V per
+ * (image, head) of qkv [B*N, 3*H*64] (HF eager_attention_forward).  ao [B*N, H*64]; lse [B*H, N] saved for
+ * the backward. */
+int eav_attn_fwd(const float* qkv, float* ao, float* lse, int B, int H, int N, int head_dim, float scale,
+                 void* stream);
+/* Backward of eav_attn_fwd: dqkv [B*N, 3*H*64] <- (dQ | dK | dV) from dout [B*N, H*64]; ao / lse as produced by
+ * the forward; delta: scratch [B*H, N]. */
+int eav_attn_bwd(const float* qkv, const float* ao, const float* dout, const float* lse, float* delta, float* dqkv,
+                 int B, int H, int N, int head_dim, float scale, void* stream);
 /* nn.LayerNorm(D, eps) forward over M rows; mean/rstd [M] saved for the backward (may be NULL). */
 int eav_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                       int M, int D, float eps, void* stream);

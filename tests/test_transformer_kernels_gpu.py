@@ -333,3 +333,44 @@ def test_eeg_dataload_pipeline_matches_reference(golden_dir):
     d2.seg_f, d2.label = d.seg_f, lab
     d2.segment_and_select_classes()
     assert set(np.unique(d2.label_div)) <= {0, 1, 2, 3, 4} and np.array_equal(d2.label_div, (g["labels"] - 1) // 2)
+
+
+def _attn_ref(qkv, B, H, N, hd):
+    t = torch.from_numpy(qkv).double().view(B, N, 3, H, hd)
+    q, k, v = (t[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    s = (q @ k.transpose(2, 3)) * hd ** -0.5
+    return q, k, v, s
+
+
+@pytest.mark.parametrize("B,H,N", [(2, 3, 197), (1, 2, 1214), (2, 2, 70), (1, 1, 33), (1, 1, 128)])
+def test_fused_attention_forward(L, B, H, N):
+    hd, D = 64, H * 64
+    qkv = synth.normal(101, (B * N, 3 * D), 0.0, 1.5)
+    Q = dev(qkv)
+    ao = torch.full((B * N, D), 9.0, device="cuda")
+    lse = torch.zeros(B * H, N, device="cuda")
+    L.call("eav_attn_fwd", Q.data_ptr(), ao.data_ptr(), lse.data_ptr(), B, H, N, hd, hd ** -0.5, None)
+    q, k, v, s = _attn_ref(qkv, B, H, N, hd)
+    ref = (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(B * N, D)
+    close(ao, ref, 1e-4, 2e-6, "attention output")
+    close(lse.view(B, H, N), torch.logsumexp(s, -1), 1e-5, 1e-5, "lse")
+
+
+@pytest.mark.parametrize("B,H,N", [(2, 3, 197), (1, 2, 1214), (2, 2, 70), (1, 1, 33)])
+def test_fused_attention_backward(L, B, H, N):
+    hd, D = 64, H * 64
+    qkv = synth.normal(111, (B * N, 3 * D), 0.0, 1.2)
+    do = synth.normal(112, (B * N, D))
+    Q, dO = dev(qkv), dev(do)
+    ao, lse = torch.empty(B * N, D, device="cuda"), torch.empty(B * H, N, device="cuda")
+    L.call("eav_attn_fwd", Q.data_ptr(), ao.data_ptr(), lse.data_ptr(), B, H, N, hd, hd ** -0.5, None)
+    delta = torch.empty(B * H, N, device="cuda")
+    dqkv = torch.full((B * N, 3 * D), 5.0, device="cuda")
+    L.call("eav_attn_bwd", Q.data_ptr(), ao.data_ptr(), dO.data_ptr(), lse.data_ptr(), delta.data_ptr(), dqkv.data_ptr(),
+           B, H, N, hd, hd ** -0.5, None)
+    t = torch.from_numpy(qkv).double().requires_grad_(True)
+    tv = t.view(B, N, 3, H, hd)
+    q, k, v = (tv[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    o = (torch.softmax((q @ k.transpose(2, 3)) * hd ** -0.5, -1) @ v).permute(0, 2, 1, 3).reshape(B * N, D)
+    o.backward(torch.from_numpy(do).double())
+    close(dqkv, t.grad, 2e-4, 2e-5 * float(t.grad.abs().max()), "dqkv")

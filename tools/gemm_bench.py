@@ -86,3 +86,32 @@ if __name__ == "__main__":
     run("QK^T", 197, 197, 64, 0, 0, batch=1536, heads=12)
     run("PV", 197, 64, 197, 0, 1, batch=1536, heads=12)
     run("dV = P^T dO", 197, 64, 197, 1, 1, batch=1536, heads=12)
+
+    print("== fused attention forward (fp32 MFMA)")
+    for tag, Bn, N in (("ast B=8", 8, 1214), ("vit B=128", 128, 197)):
+        H, D = 12, 768
+        qkv = torch.randn(Bn * N, 3 * D, device="cuda")
+        ao = torch.empty(Bn * N, D, device="cuda")
+        lse = torch.empty(Bn * H, N, device="cuda")
+        f = lambda: _lib.call("eav_attn_fwd", qkv.data_ptr(), ao.data_ptr(), lse.data_ptr(), Bn, H, N, 64, 0.125, None)  # noqa: E731
+        for _ in range(3):
+            f()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(10):
+            f()
+        b.record()
+        torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / 10
+        print(f"{tag:12s} fwd {ms:8.3f} ms  {4.0 * Bn * H * N * N * 64 / ms / 1e9:7.1f} TFLOP/s")
+        dO, dq, delta = torch.randn(Bn * N, D, device="cuda"), torch.empty(Bn * N, 3 * D, device="cuda"), torch.empty(Bn * H, N, device="cuda")
+        g = lambda: _lib.call("eav_attn_bwd", qkv.data_ptr(), ao.data_ptr(), dO.data_ptr(), lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), Bn, H, N, 64, 0.125, None)  # noqa: E731
+        for _ in range(3):
+            g()
+        a.record()
+        for _ in range(10):
+            g()
+        b.record()
+        torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / 10
+        print(f"{tag:12s} bwd {ms:8.3f} ms  {10.0 * Bn * H * N * N * 64 / ms / 1e9:7.1f} TFLOP/s (5 algorithmic products)")

@@ -68,6 +68,8 @@ def bench_encoder(kind, dev, world, sync_factory, steps=4, warmup=2):
     crit = CrossEntropyLoss()
     model._ensure_flat()
     sync = sync_factory(model._flat[1])
+    if sync is not None:
+        model.grad_ready_hook = sync.bucket          # all-reduce buckets overlap the backward
     res = {}
     runs = (("frozen", True, "fp32"), ("unfrozen", False, "fp32"), ("unfrozen_bf16_bwd", False, "bf16_bwd"),
             ("unfrozen_bf16", False, "bf16"))
@@ -75,12 +77,14 @@ def bench_encoder(kind, dev, world, sync_factory, steps=4, warmup=2):
         model.precision = prec
         for k, p in model.named_parameters():
             p.requires_grad = (not freeze) or k.startswith("classifier.")
+        if sync is not None:
+            sync.set_active(model.head_grad_ranges() if freeze else None)
 
         def step():
             opt.zero_grad()
             loss = crit(model(x).logits, y)
             loss.backward()
-            if sync is not None and not freeze:
+            if sync is not None:
                 sync()
             opt.step()
         for _ in range(warmup):

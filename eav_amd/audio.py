@@ -73,6 +73,8 @@ class AudioModelTrainer:
             param.requires_grad = not freeze
         for param in self.model.classifier.parameters():
             param.requires_grad = True
+        if self.grad_sync is not None:     # frozen phase: only the head's gradients cross the xGMI links
+            self.grad_sync.set_active(self.model.head_grad_ranges() if freeze else None)
 
         for epoch in range(epochs):
             self.model.train()

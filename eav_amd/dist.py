@@ -45,19 +45,59 @@ def subjects_for_rank(rank, world, n_subjects=42, first=1):
 
 
 class GradSync:
-    """All-reduce (mean) of flat gradient buffers; call between backward and optimizer.step()."""
+    """All-reduce (mean) of flat gradient buffers; call between backward and optimizer.step().
+
+    Two ways to use it.  (1) `sync()` after the backward: one all-reduce per flat buffer (EEGNet: 0.68 MB,
+    pure latency).  (2) Overlapped: hand `sync.bucket` to a model as its `grad_ready_hook`; the encoders call
+    it from inside the backward as soon as a layer's contiguous slice of the flat gradient buffer is final
+    (last layer first), so the RCCL transfers of ~28 MB buckets run on the communicator's stream under the
+    remaining backward kernels; `sync()` then only waits for the outstanding work and reduces what is left."""
 
     def __init__(self, flat_grads, group=None):
         self.flat_grads = list(flat_grads)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._pending = []
+        self._done = []          # (buffer index, lo, hi) ranges already submitted during this backward
+        self.active = None       # optional {buffer index: [(lo, hi), ...]}: the only slices that carry gradients
+                                 # (frozen fine-tuning phase: the classifier head), default = whole buffers
+
+    def bucket(self, lo, hi, buffer=0):
+        """Asynchronously all-reduce flat_grads[buffer][lo:hi] (elements)."""
+        if self.world == 1 or hi <= lo:
+            return
+        view = self.flat_grads[buffer][lo:hi]
+        self._pending.append((dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True), view))
+        self._done.append((buffer, lo, hi))
 
     def __call__(self):
         if self.world == 1:
             return
-        for g in self.flat_grads:
-            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
-            g.mul_(1.0 / self.world)
+        inv = 1.0 / self.world
+        for work, view in self._pending:
+            work.wait()
+            view.mul_(inv)
+        for i, g in enumerate(self.flat_grads):
+            covered = sorted((lo, hi) for b, lo, hi in self._done if b == i)
+            wanted = sorted(self.active[i]) if self.active is not None and i in self.active else [(0, g.numel())]
+            for wlo, whi in wanted:
+                pos = wlo
+                for lo, hi in covered + [(whi, whi)]:
+                    lo, hi = max(lo, wlo), min(hi, whi)
+                    if lo > pos:                  # a gap no bucket covered
+                        dist.all_reduce(g[pos:lo], op=dist.ReduceOp.SUM, group=self.group)
+                        g[pos:lo].mul_(inv)
+                    pos = max(pos, hi)
+        self._pending, self._done = [], []
+
+    def set_active(self, ranges, buffer=0):
+        """Restrict the synchronised part of a buffer to `ranges` (None = everything)."""
+        if ranges is None:
+            if self.active is not None:
+                self.active.pop(buffer, None)
+        else:
+            self.active = self.active or {}
+            self.active[buffer] = [(int(a), int(b)) for a, b in ranges]
 
 
 def attach(trainer):
@@ -68,6 +108,8 @@ def attach(trainer):
     model = trainer.model
     model._ensure_flat()
     trainer.grad_sync = GradSync([model._flat[1]])
+    if hasattr(model, "grad_ready_hook"):
+        model.grad_ready_hook = trainer.grad_sync.bucket     # overlap the all-reduce with the backward
     if hasattr(trainer, "use_graph"):
         trainer.use_graph = False     # the RCCL all-reduce stays outside hipGraph capture
     return trainer

@@ -174,6 +174,8 @@ class Encoder(nn.Module):
         # - logits unchanged - and bf16 operands for the backward products only).
         self.precision = "fp32"
         self._phase = "fwd"
+        # multi-GPU: called as hook(lo, hi) from inside the backward whenever flat_grad[lo:hi] is final
+        self.grad_ready_hook = None
         if cfg.hidden % cfg.heads or (cfg.hidden // cfg.heads) % 4 or cfg.hidden % 4 or cfg.hidden > 1024:
             raise NotImplementedError("hidden size must be <= 1024, a multiple of 4, head_dim a multiple of 4")
         if cfg.ntok > 2048 or cfg.num_labels > 16:
@@ -212,6 +214,12 @@ class Encoder(nn.Module):
 
     def head_parameters(self):
         return list(self.classifier.parameters())
+
+    def head_grad_ranges(self):
+        """[(lo, hi)] element ranges of the classifier's gradients in the flat gradient buffer."""
+        self._ensure_flat()
+        offs = self._flat[2]
+        return [(offs[k][0], offs[k][0] + offs[k][1]) for k in self._names if k.startswith("classifier.")]
 
     # ------------------------------------------------------------------ plumbing
     def _ensure_flat(self):
@@ -495,6 +503,10 @@ class Encoder(nn.Module):
                 self._reduce(ws.part_ln, ws.np_ln, 2 * D, D, gp(f"{Lk}.layernorm_before.weight"))
                 L("eav_reduce_partials", P(ws.part_ln) + 4 * D, ws.np_ln, 2 * D, D, 1.0,
                   gp(f"{Lk}.layernorm_before.bias"), st)
+                if self.grad_ready_hook is not None:   # layer i's parameters are one contiguous slice
+                    lo = offs[f"{Lk}.attention.q_proj.weight"][0]
+                    hi = offs[f"{Lk}.mlp.fc2.bias"][0] + offs[f"{Lk}.mlp.fc2.bias"][1]
+                    self.grad_ready_hook(lo, hi)
             # embeddings
             L("eav_embed_bwd", dh, gp(f"{pre}.embeddings.position_embeddings"), P(ws.demb), B, N, D, c.nextra, st)
             gpos = gflat[offs[f"{pre}.embeddings.position_embeddings"][0]:]

@@ -112,6 +112,8 @@ class ImageClassifierTrainer:
             param.requires_grad = not freeze
         for param in self.model.classifier.parameters():
             param.requires_grad = True
+        if self.grad_sync is not None:     # frozen phase: only the head's gradients cross the xGMI links
+            self.grad_sync.set_active(self.model.head_grad_ranges() if freeze else None)
 
         print(f"Training with {'frozen' if freeze else 'unfrozen'} feature layers at lr={lr}")
 

@@ -36,6 +36,22 @@ def test_grad_allreduce_gloo_world2(tmp_path):
         ed.GradSync([g, h])()
         assert torch.allclose(g, torch.full((1000,), 1.5)), g[:4]
         assert torch.allclose(h, torch.arange(10, dtype=torch.float32) * 1.5)
+        # overlapped form: buckets submitted out of order during the "backward", the rest at sync time
+        g2 = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+        s = ed.GradSync([g2])
+        s.bucket(600, 900)
+        s.bucket(100, 350)
+        s()
+        assert torch.allclose(g2, torch.arange(1000, dtype=torch.float32) * 1.5), g2[:5]
+        s.bucket(0, 1000)
+        s()
+        g3 = torch.full((100,), float(rank + 1))
+        s3 = ed.GradSync([g3])
+        s3.set_active([(10, 20), (50, 60)])
+        s3()                                        # frozen phase: only the head slices are synchronised
+        exp = torch.full((100,), float(rank + 1)); exp[10:20] = 1.5; exp[50:60] = 1.5
+        assert torch.equal(g3, exp), g3
+        assert torch.allclose(g2, torch.arange(1000, dtype=torch.float32) * 1.5)   # mean of identical replicas
         assert ed.subjects_for_rank(rank, world)[0] == 1 + rank
         dist.barrier()
         dist.destroy_process_group()

@@ -80,6 +80,7 @@ PLAIN = {
     "eav_eegnet_fir_fwd_nparts": ([_i, _i, _i], _i),
     "eav_eegnet_fir_wgrad_nparts": ([_i, _i, _i], _i),
     "eav_conv64_ntiles": ([_i], _i),
+    "eav_conv64_fwd_nparts": ([_i, _i], _i),
     "eav_conv64_wgrad_nparts": ([_i, _i], _i),
     "eav_layernorm_bwd_nparts": ([_i], _i),
     "eav_gemm_f32_splitk_plan": ([_i, _i, _i], _i),

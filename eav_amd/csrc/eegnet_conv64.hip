@@ -13,91 +13,95 @@ namespace {
 constexpr int NCH = 64, KT = 16, KD = NCH * KT;  // 1024 = contraction length of the forward GEMM
 constexpr int TT = 128;                          // output samples per block
 constexpr int INS = TT + 16;                     // LDS row stride of the input tile (144)
-constexpr int WCH = 64;                          // contraction rows per weight chunk (4 input channels)
 
 // ------------------------------------------------------------------------------------------ fwd
-// grid (ntile, B); 4 waves: wave w owns samples [32w, 32w+32) of the tile and all 64 outputs.
-__global__ __launch_bounds__(256, 2) void conv64_fwd_kernel(const float* __restrict__ in,
-                                                            const float* __restrict__ wT, float* __restrict__ out,
-                                                            float* __restrict__ part, int T, int padl) {
+// Weight-stationary schedule: 8 waves per block, wave (ot, ic) keeps the weights of output tile ot (32 channels)
+// x input-channel chunk ic (16 channels = 256 contraction rows) in 128 VGPRs for the whole kernel - no weight
+// staging, no per-chunk barriers.  Per 32-sample sub-tile a wave issues 128 MFMAs whose B operands come from the
+// LDS input tile; the 4 partial tiles of an output tile (one per input chunk) are summed through LDS in a fixed
+// order.  Blocks are persistent over (image, 128-sample tile) items with the next input tile prefetched into
+// registers; BatchNorm statistics accumulate in registers and are written once per block.
+constexpr int V2_THREADS = 512;
+constexpr int V2_NLD = (NCH * INS + V2_THREADS - 1) / V2_THREADS;   // 18 floats per thread per input tile
+
+__global__ __launch_bounds__(V2_THREADS, 1) void conv64_fwd_kernel(const float* __restrict__ in,
+                                                                      const float* __restrict__ wT,
+                                                                      float* __restrict__ out, float* __restrict__ part,
+                                                                      int B, int T, int padl, int ntile) {
   __shared__ __attribute__((aligned(16))) float ins[NCH * INS];
-  __shared__ __attribute__((aligned(16))) float wsb[2][WCH * NCH];
-  __shared__ float red[4 * 128];
-  const int tile = blockIdx.x, b = blockIdx.y;
+  __shared__ float red[2][8][16 * 64];                               // [buffer][wave][reg*64 + lane]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = lane & 31, kk = lane >> 5;
-  const int t0 = tile * TT;
-  const float* src = in + (int64_t)b * NCH * T;
-  // weight-chunk prefetch registers (explicit scalars: keeps them out of scratch)
-  float4 rw0, rw1, rw2, rw3;
-  static_assert(WCH * NCH / 4 / 256 == 4, "4 float4 per thread per weight chunk");
-#define FETCH_W(ic)                                                                         \
-  {                                                                                         \
-    const float4* wp = reinterpret_cast<const float4*>(wT + (int64_t)(ic) * WCH * NCH) + threadIdx.x; \
-    rw0 = wp[0]; rw1 = wp[256]; rw2 = wp[512]; rw3 = wp[768];                               \
-  }
-#define COMMIT_W(buf)                                                                       \
-  {                                                                                         \
-    float4* wq = reinterpret_cast<float4*>(wsb[buf]) + threadIdx.x;                         \
-    wq[0] = rw0; wq[256] = rw1; wq[512] = rw2; wq[768] = rw3;                               \
-  }
-  FETCH_W(0);
-  for (int idx = threadIdx.x; idx < NCH * INS; idx += 256) {
-    const int i = idx / INS, u = idx - i * INS;
-    const int t = t0 + u - padl;
-    ins[idx] = (t >= 0 && t < T) ? src[(int64_t)i * T + t] : 0.f;
-  }
-  COMMIT_W(0);
-  __syncthreads();
-  f32x16 acc0, acc1;
+  const int ot = wave & 1, ic = wave >> 1;
+  float areg[128];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-  constexpr int NCHUNK = KD / WCH;                     // 16
-  for (int ic = 0; ic < NCHUNK; ++ic) {
-    const float* ws = wsb[ic & 1];
-    if (ic + 1 < NCHUNK) FETCH_W(ic + 1);             // next chunk's weights in flight during the MFMAs
-    // software pipeline: operands of step ks+1 are read while the two MFMAs of step ks run
-    auto ldb = [&](int ks) { return ins[(ic * (WCH / KT) + (ks >> 3)) * INS + wave * 32 + n + 2 * (ks & 7) + kk]; };
-    float bv = ldb(0), a0 = ws[kk * NCH + n], a1 = ws[kk * NCH + 32 + n];
-#pragma unroll 8
-    for (int ks = 0; ks < WCH / 2; ++ks) {
-      const int kn = (ks + 1 < WCH / 2) ? ks + 1 : ks;
-      const float bn = ldb(kn);
-      const float a0n = ws[(2 * kn + kk) * NCH + n], a1n = ws[(2 * kn + kk) * NCH + 32 + n];
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc1, 0, 0, 0);
-      bv = bn; a0 = a0n; a1 = a1n;
+  for (int p = 0; p < 128; ++p) areg[p] = wT[(int64_t)(ic * 256 + 2 * p + kk) * NCH + 32 * ot + n];
+  float st_s[4] = {0.f, 0.f, 0.f, 0.f}, st_q[4] = {0.f, 0.f, 0.f, 0.f};
+  float rin[V2_NLD];
+  const int nitems = B * ntile;
+  auto fetch = [&](int item) {
+    const int b = item / ntile, tile = item - b * ntile;
+    const int t0 = tile * TT;
+    const float* src = in + (int64_t)b * NCH * T;
+#pragma unroll
+    for (int i = 0; i < V2_NLD; ++i) {
+      const int idx = threadIdx.x + V2_THREADS * i;
+      const int ch = idx / INS, u = idx - ch * INS;
+      const int t = t0 + u - padl;
+      rin[i] = (idx < NCH * INS && t >= 0 && t < T) ? src[(int64_t)ch * T + t] : 0.f;
     }
-    if (ic + 1 < NCHUNK) COMMIT_W((ic + 1) & 1);      // the other buffer was last read in iteration ic-1
+  };
+  if ((int)blockIdx.x < nitems) fetch(blockIdx.x);
+  int rb = 0;
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const int b = item / ntile, tile = item - b * ntile;
+    const int t0 = tile * TT;
+    __syncthreads();                       // every wave is done with the previous input tile
+#pragma unroll
+    for (int i = 0; i < V2_NLD; ++i) {
+      const int idx = threadIdx.x + V2_THREADS * i;
+      if (idx < NCH * INS) ins[idx] = rin[i];
+    }
     __syncthreads();
-  }
-  // C layout: col = n (sample), row = (reg&3) + 8*(reg>>2) + 4*kk (output channel within the 32-tile)
-  const int t = t0 + wave * 32 + n;
-  const bool ok = t < T;
-  float* dst = out + (int64_t)b * NCH * T + t;
+    if (item + (int)gridDim.x < nitems) fetch(item + gridDim.x);
+    for (int sub = 0; sub < TT / 32; ++sub) {
+      f32x16 acc;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int o = (r & 3) + 8 * (r >> 2) + 4 * kk;
-    float v0 = ok ? acc0[r] : 0.f, v1 = ok ? acc1[r] : 0.f;
-    if (ok) {
-      dst[(int64_t)o * T] = v0;
-      dst[(int64_t)(o + 32) * T] = v1;
-    }
-    if (part) {
-      float s0 = half_sum(v0), q0 = half_sum(v0 * v0), s1 = half_sum(v1), q1 = half_sum(v1 * v1);
-      if (n == 0) {
-        red[wave * 128 + o] = s0;
-        red[wave * 128 + 32 + o] = s1;
-        red[wave * 128 + 64 + o] = q0;
-        red[wave * 128 + 96 + o] = q1;
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const float* bp = ins + (16 * ic) * INS + 32 * sub + n + kk;
+#pragma unroll
+      for (int p = 0; p < 128; ++p)        // contraction row 2p+kk of the chunk: channel p>>3, tap 2(p&7)+kk
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[p], bp[(p >> 3) * INS + 2 * (p & 7)], acc, 0, 0, 0);
+      float* rw = red[rb][wave];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) rw[r * 64 + lane] = acc[r];
+      __syncthreads();
+      // wave (ot, ic) finalises registers r in [4 ic, 4 ic + 4) of output tile ot: sum of the 4 chunk partials
+      const int t = t0 + 32 * sub + n;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = 4 * ic + q;
+        float v = (red[rb][ot][r * 64 + lane] + red[rb][ot + 2][r * 64 + lane]) +
+                  (red[rb][ot + 4][r * 64 + lane] + red[rb][ot + 6][r * 64 + lane]);
+        const int o = 32 * ot + (r & 3) + 8 * (r >> 2) + 4 * kk;
+        if (t < T) out[((int64_t)b * NCH + o) * T + t] = v; else v = 0.f;
+        st_s[q] += v;
+        st_q[q] += v * v;
       }
+      rb ^= 1;                             // the other buffer was last read two barriers ago
     }
   }
   if (part) {
-    __syncthreads();
-    if (threadIdx.x < 128)
-      part[((int64_t)b * gridDim.x + tile) * 128 + threadIdx.x] =
-          (red[threadIdx.x] + red[128 + threadIdx.x]) + (red[256 + threadIdx.x] + red[384 + threadIdx.x]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float s1 = half_sum(st_s[q]), s2 = half_sum(st_q[q]);
+      if (n == 0) {
+        const int r = 4 * ic + q;
+        const int o = 32 * ot + (r & 3) + 8 * (r >> 2) + 4 * kk;
+        part[(int64_t)blockIdx.x * 128 + o] = s1;
+        part[(int64_t)blockIdx.x * 128 + 64 + o] = s2;
+      }
+    }
   }
 }
 
@@ -218,11 +222,17 @@ extern "C" int eav_conv64_prep_weights(const float* w, float* wT_fwd, float* wT_
 
 extern "C" int eav_conv64_ntiles(int T) { return cdiv(T, TT); }
 
+// number of statistics partials eav_conv64_fwd writes ([nparts][128])
+extern "C" int eav_conv64_fwd_nparts(int B, int T) {
+  const int nitems = B * cdiv(T, TT);
+  return nitems < 256 ? nitems : 256;
+}
+
 extern "C" int eav_conv64_fwd(const float* in, const float* wT, float* out, float* stat_part, int B, int T, int padl,
                               void* stream) {
   EAV_REQUIRE(in && wT && out && B > 0 && T > 0 && padl >= 0 && padl <= 15, "eav_conv64_fwd: bad arguments");
-  dim3 grid(cdiv(T, TT), B);
-  hipLaunchKernelGGL(conv64_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, wT, out, stat_part, T, padl);
+  hipLaunchKernelGGL(conv64_fwd_kernel, dim3(eav_conv64_fwd_nparts(B, T)), dim3(V2_THREADS), 0, (hipStream_t)stream,
+                     in, wT, out, stat_part, B, T, padl, cdiv(T, TT));
   EAV_CHECK_LAUNCH("eav_conv64_fwd");
   return EAV_OK;
 }

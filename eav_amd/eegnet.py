@@ -55,8 +55,8 @@ class _Workspace:
         self.np_fir = _lib.plain("eav_eegnet_fir_fwd_nparts", B, C, S)
         self.part_fir = f(self.np_fir, 16)
         self.part_dw = f(B * nchunk, 128)
-        self.ntile3 = _lib.plain("eav_conv64_ntiles", T2)
-        self.part_c3 = f(B * self.ntile3, 128)
+        self.np_c3 = _lib.plain("eav_conv64_fwd_nparts", B, T2)
+        self.part_c3 = f(self.np_c3, 128)
         self.part_pb = f(B, 128)
         self.part_dst = f(B * nchunk, 16)
         self.part_dw2 = f(B * nchunk, 64 * C)
@@ -201,7 +201,7 @@ class EEGNet_tor(nn.Module):
         L("eav_bn_elu_pool_fwd", P(ws.z), P(ws.bn2), P(ws.p2), B, 64, S, 4, drop, seed1, m1, cnt, st)
         L("eav_conv64_prep_weights", w3, P(ws.wTf), P(ws.wTb), st)
         L("eav_conv64_fwd", P(ws.p2), P(ws.wTf), P(ws.u3), P(ws.part_c3), B, ws.T2, 7, st)
-        bnfin(ws.part_c3, B * ws.ntile3, 64, B * ws.T2, g3w, g3b, bn3, ws.bn3)
+        bnfin(ws.part_c3, ws.np_c3, 64, B * ws.T2, g3w, g3b, bn3, ws.bn3)
         L("eav_bn_elu_pool_fwd", P(ws.u3), P(ws.bn3), P(ws.p3), B, 64, ws.T2, 8, drop, seed2, m2, cnt, st)
         L("eav_dense_softmax_fwd", P(ws.p3), wd, bd, None, P(ws.probs), B, ws.NF, nb, st)
         if self.apply_max_norm:  # the forward hooks of the reference (:33-34, :47-48), intended meaning

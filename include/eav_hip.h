@@ -77,7 +77,8 @@ int eav_bn_elu_pool_bwd_apply(const float* dp, const float* u, const float* bn, 
 /* ---- separableConv: dense 64->64, 16 taps, 'same' (EEGNet_tor.py:37,59) ------------------- */
 int eav_conv64_prep_weights(const float* w /*[64,64,16]*/, float* wT_fwd /*[1024,64]*/, float* wT_bwd, void* stream);
 int eav_conv64_ntiles(int T);
-/* out[b,o,t] = sum wT[(i*16+k)][o]*in[b,i,t+k-padl]; stat_part (may be NULL) [B*ntiles][128]. */
+/* out[b,o,t] = sum wT[(i*16+k)][o]*in[b,i,t+k-padl]; stat_part (may be NULL) [eav_conv64_fwd_nparts()][128]. */
+int eav_conv64_fwd_nparts(int B, int T);
 int eav_conv64_fwd(const float* in, const float* wT, float* out, float* stat_part, int B, int T, int padl,
                    void* stream);
 int eav_conv64_wgrad_nparts(int B, int T);

@@ -197,9 +197,9 @@ def test_conv64(L, B, T):
     wTf, wTb = torch.empty(1024, 64, device="cuda"), torch.empty(1024, 64, device="cuda")
     wd, xd = dev(w), dev(x)
     L.call("eav_conv64_prep_weights", wd.data_ptr(), wTf.data_ptr(), wTb.data_ptr(), None)
-    nt = L.plain("eav_conv64_ntiles", T)
+    nt = L.plain("eav_conv64_fwd_nparts", B, T)
     out = torch.empty(B, 64, T, device="cuda")
-    part = torch.zeros(B * nt, 128, device="cuda")
+    part = torch.zeros(nt, 128, device="cuda")
     L.call("eav_conv64_fwd", xd.data_ptr(), wTf.data_ptr(), out.data_ptr(), part.data_ptr(), B, T, 7, None)
     torch.cuda.synchronize()
     xt = torch.from_numpy(x).double().requires_grad_(True)

@@ -23,7 +23,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: dense f
 FIR_FLOP_PER_LAUNCH = 2.0 * KLEN * 8 * CHANS * SAMPLES * B_PER_GPU   # 92.16 GFLOP (fwd) = wgrad
 
 
-def cpu_baseline(steps=2, batch=16):
+def cpu_baseline(steps=3, batch=32):
     """The oracle (pure fp32 torch CPU restatement, validated against the imported reference) timed
     on this box's host cores on a bounded sample of the same workload."""
     import torch

@@ -141,3 +141,14 @@ def test_encoder_reads_real_hf_directories(tmp_path):
         assert enc.cfg.num_labels == 5 and len(enc.head_parameters()) == (4 if kind == "ast" else 2)
         with pytest.raises(Exception):
             enc(torch.zeros(1, 1024, 128) if kind == "ast" else torch.zeros(1, 3, 32, 32))   # no CPU fallback
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    """No silent fallback: if libeav_hip.so is absent every entry into the product path raises EavError."""
+    from eav_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libeav_hip.so"))
+    with pytest.raises(_lib.EavError, match="not built"):
+        _lib.load()
+    with pytest.raises(_lib.EavError):
+        _lib.call("eav_renorm_rows", 1, 1, 1, 1.0, None)

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Step time of the AST / ViT encoders at chosen batch sizes and precision modes (run on the GPU box).
+usage: encoder_step_bench.py ast|vit B [precision]"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from eav_amd import synth, transformer as T  # noqa: E402
+from eav_amd.optim import CrossEntropyLoss, FusedAdam  # noqa: E402
+
+kind, B = sys.argv[1], int(sys.argv[2])
+prec = sys.argv[3] if len(sys.argv) > 3 else "fp32"
+model = T.Encoder(T.make_config(kind)).cuda().train()
+model.precision = prec
+x, y = (synth.mel_batch(5, B) if kind == "ast" else synth.frame_batch(5, B))
+x, y = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+opt, crit = FusedAdam(model.parameters(), lr=5e-6, weight_decay=0.01, decoupled=True), CrossEntropyLoss()
+
+
+def step():
+    opt.zero_grad()
+    crit(model(x).logits, y).backward()
+    opt.step()
+
+
+for _ in range(2):
+    step()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+n = 4
+for _ in range(n):
+    step()
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / n
+gf = {"ast": 783.1, "vit": 105.4}[kind] * B
+print(f"{kind} B={B} {prec}: {dt * 1e3:.1f} ms/step, {B / dt:.1f} samples/s, {gf / dt / 1e3:.1f} TFLOP/s; "
+      f"peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")

@@ -12,7 +12,7 @@
 // reference (measured), 5x the 1e-3 parity bound; the f32 MFMA is bit-exact
 // fp32 at 157 TFLOP/s peak.
 //
-// Tile: 128 x BN x 32 (BN = 128 or 64), 256 threads = 2x2 waves, each wave 64 x BN/2 as 32x32 MFMA
+// Tile: 128 x BN x 16 (BN = 128 or 64; BK = 16 keeps the double-buffered LDS at 33 KB -> 3 blocks per CU), 256 threads = 2x2 waves, each wave 64 x BN/2 as 32x32 MFMA
 // tiles.  Both operands are staged K-major in LDS (As[k][m], Bs[k][n]) so that the 32 lanes of a
 // half-wave read 32 consecutive floats (conflict-free ds_read_b32); the transposing store of a
 // K-contiguous operand uses an odd row stride (129) and is conflict-free as well.  Global loads are
@@ -23,7 +23,11 @@
 
 namespace {
 
-constexpr int BM = 128, BK = 32;
+constexpr int BM = 128;
+#ifndef EAV_GEMM_BK
+#define EAV_GEMM_BK 16
+#endif
+constexpr int BK = EAV_GEMM_BK;
 
 struct GemmArgs {
   const float* A; const float* B; float* C;
@@ -53,10 +57,12 @@ __device__ __forceinline__ float4 ld_guard(const float* p, int64_t off, int i, i
 }
 
 template <int BN, bool TA, bool TB>
-__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmArgs g) {
   constexpr int SA = TA ? (BM + 4) : (BM + 1);   // LDS row strides (floats) of the K-major images
   constexpr int SB = TB ? (BN + 4) : (BN + 1);
-  constexpr int NB4 = BN * BK / 4 / 256;         // float4 loads per thread for B: 4 (BN=128) or 2
+  constexpr int NA4 = BM * BK / 4 / 256;         // float4 loads per thread for A
+  constexpr int NB4 = BN * BK / 4 / 256;         // float4 loads per thread for B
+  constexpr int KQ = BK / 4;                     // float4 per K-contiguous row
   constexpr int WN = BN / 2;                     // wave tile width
   constexpr int NT = WN / 32;                    // 32-wide MFMA column tiles per wave: 2 or 1
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -83,28 +89,28 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
   // interior tiles take the unguarded path (no per-element bounds logic in the hot loop)
   const bool interior = (m0 + BM <= M) && (n0 + BN <= N) && (K % BK == 0);
 
-  float4 ra[4], rb[NB4];
+  float4 ra[NA4], rb[NB4];
   auto load_tiles = [&](int k0) {
     if (interior) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < NA4; ++i) {
         const int f = t + 256 * i;
-        if (!TA) ra[i] = *reinterpret_cast<const float4*>(A + (int64_t)(m0 + (f >> 3)) * g.lda + k0 + 4 * (f & 7));
+        if (!TA) ra[i] = *reinterpret_cast<const float4*>(A + (int64_t)(m0 + f / KQ) * g.lda + k0 + 4 * (f % KQ));
         else ra[i] = *reinterpret_cast<const float4*>(A + (int64_t)(k0 + (f >> 5)) * g.lda + m0 + 4 * (f & 31));
       }
 #pragma unroll
       for (int i = 0; i < NB4; ++i) {
         const int f = t + 256 * i;
-        if (!TB) rb[i] = *reinterpret_cast<const float4*>(B + (int64_t)(n0 + (f >> 3)) * g.ldb + k0 + 4 * (f & 7));
+        if (!TB) rb[i] = *reinterpret_cast<const float4*>(B + (int64_t)(n0 + f / KQ) * g.ldb + k0 + 4 * (f % KQ));
         else rb[i] = *reinterpret_cast<const float4*>(B + (int64_t)(k0 + f / (BN / 4)) * g.ldb + n0 + 4 * (f % (BN / 4)));
       }
       return;
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NA4; ++i) {
       const int f = t + 256 * i;
-      if (!TA) {  // A[M,K]: 8 float4 per row
-        const int row = f >> 3, kq = f & 7;
+      if (!TA) {  // A[M,K]: KQ float4 per row
+        const int row = f / KQ, kq = f % KQ;
         ra[i] = ld_guard(A, (int64_t)(m0 + row) * g.lda + k0 + 4 * kq, k0 + 4 * kq, K, m0 + row < M);
       } else {    // A[K,M]: 32 float4 per k-row
         const int kr = f >> 5, mq = f & 31;
@@ -115,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
     for (int i = 0; i < NB4; ++i) {
       const int f = t + 256 * i;
       if (!TB) {  // B[N,K]
-        const int row = f >> 3, kq = f & 7;
+        const int row = f / KQ, kq = f % KQ;
         rb[i] = ld_guard(B, (int64_t)(n0 + row) * g.ldb + k0 + 4 * kq, k0 + 4 * kq, K, n0 + row < N);
       } else {    // B[K,N]: BN/4 float4 per k-row
         const int kr = f / (BN / 4), nq = f % (BN / 4);
@@ -127,10 +133,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
     float* as = As + buf * BK * SA;
     float* bs = Bs + buf * BK * SB;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NA4; ++i) {
       const int f = t + 256 * i;
       if (!TA) {
-        const int row = f >> 3, kq = f & 7;
+        const int row = f / KQ, kq = f % KQ;
         as[(4 * kq + 0) * SA + row] = ra[i].x;
         as[(4 * kq + 1) * SA + row] = ra[i].y;
         as[(4 * kq + 2) * SA + row] = ra[i].z;
@@ -144,7 +150,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
     for (int i = 0; i < NB4; ++i) {
       const int f = t + 256 * i;
       if (!TB) {
-        const int row = f >> 3, kq = f & 7;
+        const int row = f / KQ, kq = f % KQ;
         bs[(4 * kq + 0) * SB + row] = rb[i].x;
         bs[(4 * kq + 1) * SB + row] = rb[i].y;
         bs[(4 * kq + 2) * SB + row] = rb[i].z;

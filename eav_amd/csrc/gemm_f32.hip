@@ -12,7 +12,8 @@
 // reference (measured), 5x the 1e-3 parity bound; the f32 MFMA is bit-exact
 // fp32 at 157 TFLOP/s peak.
 //
-// Tile: 128 x BN x 16 (BN = 128 or 64; BK = 16 keeps the double-buffered LDS at 33 KB -> 3 blocks per CU), 256 threads = 2x2 waves, each wave 64 x BN/2 as 32x32 MFMA
+// Tile: BM x BN x 16 (BM = 128, or 64 when a 128-row grid would under-fill the chip; BN = 128 or 64; BK = 16
+// keeps the double-buffered LDS at 33 KB -> 3 blocks per CU), 256 threads = 2x2 waves, each wave 64 x BN/2 as 32x32 MFMA
 // tiles.  Both operands are staged K-major in LDS (As[k][m], Bs[k][n]) so that the 32 lanes of a
 // half-wave read 32 consecutive floats (conflict-free ds_read_b32); the transposing store of a
 // K-contiguous operand uses an odd row stride (129) and is conflict-free as well.  Global loads are
@@ -23,7 +24,6 @@
 
 namespace {
 
-constexpr int BM = 128;
 #ifndef EAV_GEMM_BK
 #define EAV_GEMM_BK 16
 #endif
@@ -56,8 +56,10 @@ __device__ __forceinline__ float4 ld_guard(const float* p, int64_t off, int i, i
   return v;
 }
 
-template <int BN, bool TA, bool TB>
+template <int BM, int BN, bool TA, bool TB>
 __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmArgs g) {
+  constexpr int WM = BM / 2;                     // wave tile height: 64 or 32
+  constexpr int MT = WM / 32;                    // 32-high MFMA row tiles per wave: 2 or 1
   constexpr int SA = TA ? (BM + 4) : (BM + 1);   // LDS row strides (floats) of the K-major images
   constexpr int SB = TB ? (BN + 4) : (BN + 1);
   constexpr int NA4 = BM * BK / 4 / 256;         // float4 loads per thread for A
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmArgs g) {
       for (int i = 0; i < NA4; ++i) {
         const int f = t + 256 * i;
         if (!TA) ra[i] = *reinterpret_cast<const float4*>(A + (int64_t)(m0 + f / KQ) * g.lda + k0 + 4 * (f % KQ));
-        else ra[i] = *reinterpret_cast<const float4*>(A + (int64_t)(k0 + (f >> 5)) * g.lda + m0 + 4 * (f & 31));
+        else ra[i] = *reinterpret_cast<const float4*>(A + (int64_t)(k0 + f / (BM / 4)) * g.lda + m0 + 4 * (f % (BM / 4)));
       }
 #pragma unroll
       for (int i = 0; i < NB4; ++i) {
@@ -112,8 +114,8 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmArgs g) {
       if (!TA) {  // A[M,K]: KQ float4 per row
         const int row = f / KQ, kq = f % KQ;
         ra[i] = ld_guard(A, (int64_t)(m0 + row) * g.lda + k0 + 4 * kq, k0 + 4 * kq, K, m0 + row < M);
-      } else {    // A[K,M]: 32 float4 per k-row
-        const int kr = f >> 5, mq = f & 31;
+      } else {    // A[K,M]: BM/4 float4 per k-row
+        const int kr = f / (BM / 4), mq = f % (BM / 4);
         ra[i] = ld_guard(A, (int64_t)(k0 + kr) * g.lda + m0 + 4 * mq, m0 + 4 * mq, M, k0 + kr < K);
       }
     }
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmArgs g) {
         as[(4 * kq + 2) * SA + row] = ra[i].z;
         as[(4 * kq + 3) * SA + row] = ra[i].w;
       } else {
-        const int kr = f >> 5, mq = f & 31;
+        const int kr = f / (BM / 4), mq = f % (BM / 4);
         *reinterpret_cast<float4*>(&as[kr * SA + 4 * mq]) = ra[i];
       }
     }
@@ -162,9 +164,9 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmArgs g) {
     }
   };
 
-  f32x16 acc[2][NT];
+  f32x16 acc[MT][NT];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < MT; ++a)
 #pragma unroll
     for (int b = 0; b < NT; ++b)
 #pragma unroll
@@ -177,31 +179,31 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmArgs g) {
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nk) load_tiles((kt + 1) * BK);
-    const float* as = As + buf * BK * SA + wm * 64 + n;
+    const float* as = As + buf * BK * SA + wm * WM + n;
     const float* bs = Bs + buf * BK * SB + wn * WN + n;
     // operands of k-step ks+1 are read while the MFMAs of step ks execute
-    float a0 = as[kk * SA], a1 = as[kk * SA + 32];
-    float bv[NT];
+    float av[MT], bv[NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a) av[a] = as[kk * SA + 32 * a];
 #pragma unroll
     for (int b = 0; b < NT; ++b) bv[b] = bs[kk * SB + 32 * b];
 #pragma unroll
     for (int ks = 0; ks < BK / 2; ++ks) {
-      float a0n = 0.f, a1n = 0.f, bn[NT];
+      float an[MT], bn[NT];
       if (ks + 1 < BK / 2) {
         const int k = 2 * (ks + 1) + kk;
-        a0n = as[k * SA];
-        a1n = as[k * SA + 32];
+#pragma unroll
+        for (int a = 0; a < MT; ++a) an[a] = as[k * SA + 32 * a];
 #pragma unroll
         for (int b = 0; b < NT; ++b) bn[b] = bs[k * SB + 32 * b];
       }
 #pragma unroll
-      for (int b = 0; b < NT; ++b) {
-        acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv[b], acc[0][b], 0, 0, 0);
-        acc[1][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv[b], acc[1][b], 0, 0, 0);
-      }
+      for (int b = 0; b < NT; ++b)
+#pragma unroll
+        for (int a = 0; a < MT; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
       if (ks + 1 < BK / 2) {
-        a0 = a0n;
-        a1 = a1n;
+#pragma unroll
+        for (int a = 0; a < MT; ++a) av[a] = an[a];
 #pragma unroll
         for (int b = 0; b < NT; ++b) bv[b] = bn[b];
       }
@@ -217,10 +219,10 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmArgs g) {
     if (col >= N) continue;
     const float bias = g.bias ? g.bias[col] : 0.f;
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
+    for (int a = 0; a < MT; ++a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 64 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * kk;
+        const int row = m0 + wm * WM + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * kk;
         if (row >= M) continue;
         float v = g.alpha * acc[a][b][r] + bias;
         const int64_t o = (int64_t)row * g.ldc + col;
@@ -234,19 +236,28 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmArgs g) {
   }
 }
 
-template <int BN, bool TA, bool TB>
-int launch(const GemmArgs& g, int batch, hipStream_t st) {
+template <int BM, int BN, bool TA, bool TB>
+int launch_bm(const GemmArgs& g, int batch, hipStream_t st) {
   constexpr int SA = TA ? (BM + 4) : (BM + 1), SB = TB ? (BN + 4) : (BN + 1);
   const size_t lds = (size_t)2 * BK * (SA + SB) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<BN, TA, TB>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<BM, BN, TA, TB>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM), batch);
-  hipLaunchKernelGGL((gemm_f32_kernel<BN, TA, TB>), grid, dim3(256), lds, st, g);
+  hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, TA, TB>), grid, dim3(256), lds, st, g);
   return 0;
+}
+
+// 128-row tiles by default; 64-row tiles when the 128-row grid would leave the chip under-filled (e.g. the
+// N = 768 projections at M = 9712: 456 blocks for 768 resident slots)
+template <int BN, bool TA, bool TB>
+int launch(const GemmArgs& g, int batch, hipStream_t st) {
+  const int64_t blocks128 = (int64_t)cdiv(g.M, 128) * cdiv(g.N, BN) * batch;
+  if (blocks128 < 640 && g.M > 64) return launch_bm<64, BN, TA, TB>(g, batch, st);
+  return launch_bm<128, BN, TA, TB>(g, batch, st);
 }
 
 }  // namespace
@@ -287,7 +298,7 @@ extern "C" int eav_gemm_f32(const float* A, const float* B, float* C, int M, int
 // nsplit K-slices write partial products to `ws` ([nsplit][M][N] floats), which are then summed in a
 // fixed order (fp64) into C - deterministic, no atomics.  eav_gemm_f32_splitk_plan returns nsplit.
 extern "C" int eav_gemm_f32_splitk_plan(int M, int N, int K) {
-  const int tiles = cdiv(M, BM) * cdiv(N, N <= 64 ? 64 : 128);
+  const int tiles = cdiv(M, 128) * cdiv(N, N <= 64 ? 64 : 128);
   int ns = cdiv(1024, tiles);
   const int maxs = cdiv(K, 256);
   if (ns > maxs) ns = maxs;

@@ -19,7 +19,6 @@ There is no CPU path: calling the model with a non-device tensor raises.
 """
 from __future__ import annotations
 
-import numpy as np
 import torch
 import torch.nn as nn
 
@@ -435,7 +434,3 @@ class Trainer_uni:
         avg_loss = total_loss / len(self.test_dataloader)
         accuracy = total_correct / len(self.test_dataloader.dataset)
         print(f"Validation - Loss: {avg_loss:.4f}, Accuracy: {accuracy:.4f}")
-
-
-def _as_numpy(a):
-    return a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)

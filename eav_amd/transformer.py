@@ -15,7 +15,6 @@ recomputed; attention probabilities are materialised per layer ([B*H, N, N] fp32
 from __future__ import annotations
 
 import json
-import math
 import os
 from types import SimpleNamespace
 

@@ -57,9 +57,13 @@ def test_grad_allreduce_gloo_world2(tmp_path):
         dist.destroy_process_group()
         print("rank", rank, "ok")
     """))
+    import socket
+    with socket.socket() as sock:          # a free rendezvous port (a fixed one can linger in TIME_WAIT)
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)],
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout

@@ -55,7 +55,7 @@ def test_grad_allreduce_gloo_world2(tmp_path):
         assert ed.subjects_for_rank(rank, world)[0] == 1 + rank
         dist.barrier()
         dist.destroy_process_group()
-        print("rank", rank, "ok")
+        open({str(tmp_path)!r} + f"/ok_{{rank}}", "w").write("ok")     # (stdout of the two ranks may interleave)
     """))
     import socket
     with socket.socket() as sock:          # a free rendezvous port (a fixed one can linger in TIME_WAIT)
@@ -66,4 +66,4 @@ def test_grad_allreduce_gloo_world2(tmp_path):
                         "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
+    assert (tmp_path / "ok_0").exists() and (tmp_path / "ok_1").exists(), r.stdout + r.stderr

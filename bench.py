@@ -115,6 +115,30 @@ def bench_encoder(kind, dev, world, sync_factory, steps=4, warmup=2):
     return res
 
 
+def measured_peaks(dev):
+    """What this chip sustains: register-only fp32 MFMA loop and a 1 GiB float4 copy (read + write bytes)."""
+    import torch
+    from eav_amd import _lib
+    sink = torch.zeros(4, device=dev)
+    blocks, iters = 256 * 8, 4000
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    _lib.call("eav_peak_mfma_f32", sink.data_ptr(), blocks, 200, _lib.stream_ptr())
+    ev[0].record()
+    _lib.call("eav_peak_mfma_f32", sink.data_ptr(), blocks, iters, _lib.stream_ptr())
+    ev[1].record()
+    n = 1 << 28
+    src, dst = torch.empty(n, device=dev), torch.empty(n, device=dev)
+    _lib.call("eav_peak_copy", src.data_ptr(), dst.data_ptr(), n, _lib.stream_ptr())
+    ev[2].record()
+    for _ in range(3):
+        _lib.call("eav_peak_copy", src.data_ptr(), dst.data_ptr(), n, _lib.stream_ptr())
+    ev[3].record()
+    torch.cuda.synchronize()
+    tf = blocks * 4 * iters * 4 * 4096.0 / (ev[0].elapsed_time(ev[1]) * 1e-3) / 1e12
+    tbs = 3 * 2 * 4.0 * n / (ev[2].elapsed_time(ev[3]) * 1e-3) / 1e12
+    return {"f32_mfma_tflops": round(tf, 1), "hbm_copy_tb_per_s": round(tbs, 2)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -186,6 +210,7 @@ def main():
         dt = float(t.item())
     kern_ms = {k: sum(a.elapsed_time(b) for a, b in v) / max(len(v), 1) for k, v in model.kernel_events.items()}
     model.kernel_events = None
+    peaks = measured_peaks(dev) if rank == 0 else None
     final_loss = float(loss.item())
     encoders = None
     if not args.no_encoders:
@@ -224,6 +249,8 @@ def main():
                          "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc, gfx950-corrected)",
                          "traffic_source": traffic_src,
                          "flop_per_launch": FIR_FLOP_PER_LAUNCH,
+                         "measured_peaks": peaks,
+                         "frac_of_measured_mfma_peak": round(achieved / peaks["f32_mfma_tflops"], 4),
                          "avg_kernel_ms": {k.replace("eav_eegnet_", ""): round(v, 4) for k, v in kern_ms.items()}},
         }
         if encoders is not None:

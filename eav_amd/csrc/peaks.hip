@@ -1,0 +1,46 @@
+// Measured-peak micro-benchmarks so that roofline fractions can be quoted against what THIS chip sustains,
+// next to the datasheet figures: a register-only fp32 MFMA loop and a float4 streaming copy.
+#include "eav_common.h"
+#include "../../include/eav_hip.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void peak_mfma_f32_kernel(float* __restrict__ sink, int iters) {
+  f32x16 a0, a1, a2, a3;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; a2[r] = 0.f; a3[r] = 0.f; }
+  const float x = 1.0f + (float)(threadIdx.x & 7) * 0.125f, y = 0.5f;
+  for (int i = 0; i < iters; ++i) {
+    a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a0, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a1, 0, 0, 0);
+    a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a2, 0, 0, 0);
+    a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a3, 0, 0, 0);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s += a0[r] + a1[r] + a2[r] + a3[r];
+  if (s == 12345.678f) sink[0] = s;      // keeps the loop alive, never true
+}
+
+__global__ __launch_bounds__(256) void peak_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int64_t n4) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) dst[i] = src[i];
+}
+
+}  // namespace
+
+// launches `blocks` x 4 waves, each issuing 4*iters v_mfma_f32_32x32x2_f32: FLOP = blocks*4*iters*4*4096
+extern "C" int eav_peak_mfma_f32(float* sink, int blocks, int iters, void* stream) {
+  EAV_REQUIRE(sink && blocks > 0 && iters > 0, "eav_peak_mfma_f32: bad arguments");
+  hipLaunchKernelGGL(peak_mfma_f32_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, sink, iters);
+  EAV_CHECK_LAUNCH("eav_peak_mfma_f32");
+  return EAV_OK;
+}
+
+extern "C" int eav_peak_copy(const float* src, float* dst, int64_t n, void* stream) {
+  EAV_REQUIRE(src && dst && n > 0 && (n & 3) == 0, "eav_peak_copy: bad arguments");
+  hipLaunchKernelGGL(peak_copy_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(dst), n / 4);
+  EAV_CHECK_LAUNCH("eav_peak_copy");
+  return EAV_OK;
+}

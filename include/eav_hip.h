@@ -194,6 +194,11 @@ int eav_decimate_fir_f64(const double* x, const double* h, double* y, int nch, i
 int eav_sosfilt_f64(const double* x, double* y, const double* sos, const double* H, const double* AL, double* zend,
                     double* zstart, int nch, int64_t n, int nsec, int Lc, void* stream);
 
+/* ---- measured peaks (bench.py): register-only fp32 MFMA loop (FLOP = blocks*4 waves*iters*4*4096) and a float4
+ *      streaming copy, to quote roofline fractions against what this chip sustains. */
+int eav_peak_mfma_f32(float* sink, int blocks, int iters, void* stream);
+int eav_peak_copy(const float* src, float* dst, int64_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -247,3 +247,41 @@ def test_graph_replay_equals_eager(drop):
     for k in finals[0][1]:
         assert torch.equal(finals[0][1][k], finals[1][1][k]), k
     assert len(set(finals[0][0])) == len(finals[0][0])       # the batches (and masks) really changed
+
+
+def test_forty_step_trajectory_stays_within_tolerance():
+    """40 optimiser steps (20 in train mode, 20 in eval mode as the reference does from epoch 2, Q4) on changing
+    batches: the HIP trajectory and the CPU oracle's stay within north_star's 1e-3 on the model output, and make
+    the same predictions ("5-class acc parity")."""
+    from eav_amd.optim import CrossEntropyLoss, FusedAdam
+    from oracle import eegnet_oracle as orc
+    S, B, n = 500, 16, 64
+    sd = eegnet_weights(77, S)
+    x, y = synth.eeg_batch(770, n, 30, S)
+    model = build(S, sd, 0.0).train()
+    opt, crit = FusedAdam(model.parameters(), lr=1e-3), CrossEntropyLoss()
+    P = {k: torch.from_numpy(sd[k].copy()) for k in orc.PARAM_NAMES}
+    Bf = {k: torch.from_numpy(sd[k].copy()) for k in orc.BUFFER_NAMES}
+    st = orc.Stepper(P, Bf, lr=1e-3, drop_p=0.0)
+    worst = 0.0
+    for s in range(40):
+        idx = [(5 * s + 3 * j) % n for j in range(B)]
+        training = s < 20
+        model.train(training)
+        xb, yb = torch.from_numpy(x[idx]), torch.from_numpy(y[idx])
+        scores = model(xb.cuda())
+        loss = crit(scores, yb.cuda())
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        probs, _, _ = st.step(xb, yb, training, None)
+        worst = max(worst, float((scores.detach().cpu() - probs).abs().max()))
+    model.eval()
+    with torch.no_grad():
+        got = model(torch.from_numpy(x).cuda()).cpu()
+        ref = orc.forward(st.P, st.Bf, torch.from_numpy(x), False, apply_renorm=False)
+    print(f"max |probs - oracle| over 40 steps: {worst:.2e}; final: {float((got - ref).abs().max()):.2e}")
+    assert worst < 1e-3 and float((got - ref).abs().max()) < 1e-3
+    margin = ref.sort(1).values[:, -1] - ref.sort(1).values[:, -2]
+    decided = margin > 2e-3                                   # ignore numerical ties
+    assert torch.equal(got.argmax(1)[decided], ref.argmax(1)[decided])

@@ -71,6 +71,13 @@ SIGNATURES = {
     "eav_ast_fbank": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _d, _d, _f, _f, _p],
     "eav_decimate_fir_f64": [_p, _p, _p, _i, _i64, _i64, _i, _i, _i, _p],
     "eav_sosfilt_f64": [_p, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _i, _p],
+    "eav_tconv_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "eav_tconv_wgrad": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "eav_spatial_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "eav_spatial_bwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "eav_sepconv_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "eav_pointwise_bwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "eav_dwt_bwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "eav_peak_mfma_f32": [_p, _i, _i, _p],
     "eav_peak_copy": [_p, _p, _i64, _p],
     "eav_resize_normalize_u8": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _d, _p, _p, _p],
@@ -82,6 +89,11 @@ PLAIN = {
     "eav_eegnet_fir_fwd_nparts": ([_i, _i, _i], _i),
     "eav_eegnet_fir_wgrad_nparts": ([_i, _i, _i], _i),
     "eav_conv64_ntiles": ([_i], _i),
+    "eav_tconv_fwd_nparts": ([_i, _i, _i], _i),
+    "eav_tconv_wgrad_nparts": ([_i, _i, _i], _i),
+    "eav_spatial_nparts": ([_i, _i], _i),
+    "eav_sepconv_fwd_nparts": ([_i, _i], _i),
+    "eav_pointwise_bwd_nparts": ([_i, _i], _i),
     "eav_conv64_fwd_nparts": ([_i, _i], _i),
     "eav_conv64_wgrad_nparts": ([_i, _i], _i),
     "eav_layernorm_bwd_nparts": ([_i], _i),

@@ -56,10 +56,10 @@ def labels(seed: int, n: int, num_classes: int = 5) -> np.ndarray:
     return (splitmix64(seed, n) % np.uint64(num_classes)).astype(np.int64)
 
 
-def eeg_batch(seed: int, batch: int, chans: int = 30, samples: int = 10000):
+def eeg_batch(seed: int, batch: int, chans: int = 30, samples: int = 10000, n_classes: int = 5):
     """x [B,1,chans,samples] fp32 N(0,1), y [B] int64 (BASELINE configs 1-2)."""
     x = normal(seed, (batch, 1, chans, samples))
-    y = labels(seed ^ 0x5EED, batch)
+    y = labels(seed ^ 0x5EED, batch, n_classes)
     return x, y
 
 

@@ -85,6 +85,38 @@ int eav_conv64_wgrad_nparts(int B, int T);
 /* part [nparts][64*64*16]; sum over parts = dL/dW[o,i,k]. */
 int eav_conv64_wgrad(const float* du, const float* in, float* part, int B, int T, int padl, void* stream);
 
+/* ---- canonical EEGNet (CNN_torch/CNN_EEG.py:7-67): run-time F1<=16, D<=8, F2<=64, K1<=512, K2<=32 ----------- */
+/* block1[0] nn.Conv2d(1,F1,(1,K),padding='same',bias=False) (CNN_EEG.py:22): x [B,C,S] -> y1 [B,F1,C,S];
+ * stat_part [eav_tconv_fwd_nparts()][2*F1] = per-filter sum / sum of squares (input of eav_bn_finalize). */
+int eav_tconv_fwd_nparts(int B, int C, int S);
+int eav_tconv_fwd(const float* x, const float* w, float* y1, float* stat_part, int B, int C, int S, int F1, int K,
+                  void* stream);
+/* its weight gradient with the block1[1] BatchNorm backward folded in; bn_params = mean, invstd, scale, shift,
+ * m1, m2 (F1 each); part [eav_tconv_wgrad_nparts()][F1*K]. */
+int eav_tconv_wgrad_nparts(int B, int C, int S);
+int eav_tconv_wgrad(const float* x, const float* y1, const float* g1, const float* bn_params, float* part, int B,
+                    int C, int S, int F1, int K, void* stream);
+/* block1[1..2]: BatchNorm affine -> depthwise nn.Conv2d(F1,D*F1,(Chans,1),groups=F1) (CNN_EEG.py:23-25):
+ * y1 -> z [B,D*F1,S]; stat_part [eav_spatial_nparts()][2*D*F1]. */
+int eav_spatial_nparts(int B, int S);
+int eav_spatial_fwd(const float* y1, const float* bn1, const float* wd, float* z, float* stat_part, int B, int C,
+                    int S, int F1, int D, void* stream);
+/* backward: g1 [B,F1,C,S] = dL/d(BN output); stat_part [nparts][2*F1]; w_part [nparts][D*F1*C]. */
+int eav_spatial_bwd(const float* y1, const float* dz, const float* bn1, const float* wd, float* g1, float* stat_part,
+                    float* w_part, int B, int C, int S, int F1, int D, void* stream);
+/* block2[0..1]: depthwise (1,K2) 'same' conv then pointwise 1x1 conv (CNN_EEG.py:35-37): a [B,C2,T] ->
+ * d3 [B,C2,T] (kept for the backward) and z [B,F2,T]; stat_part [eav_sepconv_fwd_nparts()][2*F2]. */
+int eav_sepconv_fwd_nparts(int B, int T);
+int eav_sepconv_fwd(const float* a, const float* wdw, const float* wp, float* d3, float* z, float* stat_part, int B,
+                    int C2, int F2, int T, int K2, void* stream);
+/* pointwise backward: dd3 [B,C2,T] and w_part [eav_pointwise_bwd_nparts()][F2*C2]. */
+int eav_pointwise_bwd_nparts(int B, int T);
+int eav_pointwise_bwd(const float* du, const float* d3, const float* wp, float* dd3, float* w_part, int B, int C2,
+                      int F2, int T, void* stream);
+/* depthwise temporal conv backward: da [B,C2,T] and w_part [B][C2*K2]. */
+int eav_dwt_bwd(const float* dd3, const float* a, const float* wdw, float* da, float* w_part, int B, int C2, int T,
+                int K2, void* stream);
+
 /* ---- head, loss, optimiser ---------------------------------------------------------------- */
 /* nn.Linear + nn.Softmax(dim=1) (EEGNet_tor.py:65-66); logits or probs may be NULL. */
 int eav_dense_softmax_fwd(const float* in, const float* w, const float* bias, float* logits, float* probs, int B,

@@ -50,3 +50,28 @@ def tf_weights(seed, shapes, std=0.02):
         else:
             out[k] = synth.normal(s, shp, 0.0, std)
     return out
+
+
+def cnn_eeg_weights(seed, nb, chans=64, samples=128, klen=64, F1=8, D=2, F2=16, k2=16):
+    """Deterministic state for the canonical EEGNet (keys of CNN_torch/CNN_EEG.py's state_dict)."""
+    C2, nflat = F1 * D, F2 * (samples // 4 // 8)
+    u = synth.uniform
+
+    def ku(s, shape, fan_in):
+        b = 1.0 / np.sqrt(fan_in)
+        return u(s, shape, -b, b)
+
+    out = {
+        "block1.0.weight": ku(seed + 1, (F1, 1, 1, klen), klen),
+        "block1.2.weight": ku(seed + 2, (C2, 1, chans, 1), chans),
+        "block2.0.weight": ku(seed + 3, (C2, 1, 1, k2), k2),
+        "block2.1.weight": ku(seed + 4, (F2, C2, 1, 1), C2),
+        "classifier.weight": ku(seed + 5, (nb, nflat), nflat),
+        "classifier.bias": ku(seed + 6, (nb,), nflat),
+    }
+    for i, (name, n) in enumerate((("block1.1", F1), ("block1.3", C2), ("block2.2", F2))):
+        out[name + ".weight"] = u(seed + 10 + 4 * i, (n,), 0.8, 1.2)
+        out[name + ".bias"] = u(seed + 11 + 4 * i, (n,), -0.1, 0.1)
+        out[name + ".running_mean"] = u(seed + 12 + 4 * i, (n,), -0.05, 0.05)
+        out[name + ".running_var"] = u(seed + 13 + 4 * i, (n,), 0.5, 1.5)
+    return out

@@ -152,3 +152,30 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
         _lib.load()
     with pytest.raises(_lib.EavError):
         _lib.call("eav_renorm_rows", 1, 1, 1, 1.0, None)
+
+
+def test_canonical_eegnet_constructor_state_matches_reference(golden_dir):
+    """eav_amd.cnn_eeg.EEGNet: same constructor signature as CNN_torch/CNN_EEG.py:12-13, same state_dict keys, and a
+    freshly constructed model is in the reference's state - default init drawn from the torch RNG in the same order,
+    BatchNorm buffers touched by the reference's train-mode shape probe (CNN_EEG.py:48-54)."""
+    from eav_amd.cnn_eeg import EEGNet, EEGNetTrainer
+    assert list(inspect.signature(EEGNet.__init__).parameters)[1:] == [
+        "nb_classes", "Chans", "Samples", "dropoutRate", "kernLength", "F1", "D", "F2", "norm_rate"]
+    assert list(inspect.signature(EEGNetTrainer.__init__).parameters)[1:] == [
+        "model", "train_dataset", "val_dataset", "batch_size", "epochs", "lr"]
+    for name in ("train_epoch", "validate_epoch", "train", "predict"):
+        assert callable(getattr(EEGNetTrainer, name))
+    g = np.load(os.path.join(golden_dir, "cnn_eeg_trainer.npz"))
+    torch.manual_seed(0)
+    m = EEGNet(nb_classes=int(g["nb"]), Chans=int(g["chans"]), Samples=int(g["S"]), dropoutRate=0.0)
+    sd = m.state_dict()
+    fresh = [k[len("fresh."):] for k in g.files if k.startswith("fresh.")]
+    assert len(fresh) == 7
+    for k in fresh:
+        assert np.array_equal(sd[k].numpy(), g["fresh." + k]), k
+    assert [k for k in sd if "num_batches" not in k and "running" not in k] == [
+        "block1.0.weight", "block1.1.weight", "block1.1.bias", "block1.2.weight", "block1.3.weight", "block1.3.bias",
+        "block2.0.weight", "block2.1.weight", "block2.2.weight", "block2.2.bias", "classifier.weight",
+        "classifier.bias"]
+    with pytest.raises(NotImplementedError):
+        EEGNet(nb_classes=4, F1=32)

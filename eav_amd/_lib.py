@@ -78,6 +78,16 @@ SIGNATURES = {
     "eav_sepconv_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "eav_pointwise_bwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "eav_dwt_bwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "eav_shallow_embed_fwd": [_p, _p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p],
+    "eav_shallow_embed_bwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "eav_relu_dropout": [_p, _i64, _f, _u64, _p, _p, _p],
+    "eav_relu_dropout_bwd": [_p, _p, _i64, _f, _p],
+    "eav_dropout_add": [_p, _p, _p, _i64, _f, _u64, _p, _p, _p],
+    "eav_add_strided": [_p, _i, _p, _i, _p, _i, _i64, _i, _p],
+    "eav_colstats": [_p, _p, _i64, _i, _i, _p],
+    "eav_sqpool_log_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _f, _u64, _p, _p, _p],
+    "eav_sqpool_log_bwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _f, _u64, _p, _p, _p],
+    "eav_bn_rows_bwd": [_p, _p, _p, _p, _i64, _i, _p],
     "eav_peak_mfma_f32": [_p, _i, _i, _p],
     "eav_peak_copy": [_p, _p, _i64, _p],
     "eav_resize_normalize_u8": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _d, _p, _p, _p],
@@ -90,6 +100,8 @@ PLAIN = {
     "eav_eegnet_fir_wgrad_nparts": ([_i, _i, _i], _i),
     "eav_conv64_ntiles": ([_i], _i),
     "eav_tconv_fwd_nparts": ([_i, _i, _i], _i),
+    "eav_shallow_embed_nparts": ([_i, _i], _i),
+    "eav_colstats_nparts": ([_i64], _i),
     "eav_tconv_wgrad_nparts": ([_i, _i, _i], _i),
     "eav_spatial_nparts": ([_i, _i], _i),
     "eav_sepconv_fwd_nparts": ([_i, _i], _i),

@@ -277,7 +277,7 @@ class GraphStep:
     bound by launch overhead, not by the GPU.  Everything that varies between steps lives in device memory
     (batch indices, dropout counter, Adam step count), so a replay needs no host-side argument updates."""
 
-    def __init__(self, model, optimizer, criterion, xs, ys, batch, grad_sync=None):
+    def __init__(self, model, optimizer, criterion, xs, ys, batch, grad_sync=None, post_step=None):
         if not getattr(optimizer, "capturable", False):
             raise _lib.EavError("GraphStep needs FusedAdam(capturable=True)")
         self.model, self.batch = model, batch
@@ -293,6 +293,8 @@ class GraphStep:
             if grad_sync is not None:
                 grad_sync()
             optimizer.step()
+            if post_step is not None:      # e.g. the max-norm projection of Transformer_EEG.py:195-199
+                post_step()
             return scores, loss
 
         self.warm_steps = 0

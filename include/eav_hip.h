@@ -199,6 +199,40 @@ int eav_token_rows(float* h, float* rows, int B, int ntok, int D, int nextra, in
 /* AST pooled = (cls + dist)/2 (HF AST :304); backward=1 writes dseq from dpooled. */
 int eav_pair_mean(float* seq, float* pooled, int B, int D, int backward, void* stream);
 
+/* ---- ShallowConvNet + single-head transformer (Transformer_torch/Transformer_EEG.py:14-148) ------------------- */
+/* conv(1->NF,(1,KC),valid) fused with PatchEmbedding's per-filter Linear(Chans->1) (:117,:28-35):
+ * x [B,C,S] -> u [B,NF,S] (channel-projected input, kept for the backward) and v [B,S-KC+1,NF] tokens. */
+int eav_shallow_embed_nparts(int B, int S);
+int eav_shallow_embed_fwd(const float* x, const float* wc, const float* wv /*[NF] rows, stride ldv*/, int ldv, float* u,
+                          float* v, int B, int C, int S, int NF, int KC, void* stream);
+/* weight gradients: part_c [nparts][NF*KC] (conv taps), part_v [nparts][NF*C] (channel projections). */
+int eav_shallow_embed_bwd(const float* dv, const float* x, const float* u, const float* wc, float* part_c,
+                          float* part_v, int B, int C, int S, int NF, int KC, void* stream);
+/* nn.ReLU -> nn.Dropout in place (:84-85) and its backward (act = the forward's output). */
+int eav_relu_dropout(float* h, int64_t n, float drop_p, uint64_t seed, const uint8_t* mask, const uint64_t* seed_dev,
+                     void* stream);
+int eav_relu_dropout_bwd(float* dact, const float* act, int64_t n, float drop_p, void* stream);
+/* out = resid + Dropout(y) (:103-104); resid NULL: out = Dropout(y) (also the backward of the dropout branch). */
+int eav_dropout_add(const float* y, const float* resid, float* out, int64_t n, float drop_p, uint64_t seed,
+                    const uint8_t* mask, const uint64_t* seed_dev, void* stream);
+/* out[m,0:n) = a[m,0:n) (+ b[m,0:n)) with leading dimensions - the "+ V" residual of MultiHeadAttention (:74-76). */
+int eav_add_strided(const float* a, int lda, const float* b, int ldb, float* out, int ldo, int64_t M, int n,
+                    void* stream);
+/* per-column sum / sum of squares of x [M,N<=256]: part [eav_colstats_nparts(M)][2N] (BatchNorm over tokens, :136). */
+int eav_colstats_nparts(int64_t M);
+int eav_colstats(const float* x, float* part, int64_t M, int N, int ld, void* stream);
+/* head (:136-144): BatchNorm affine -> square -> AvgPool(1,win)/stride -> log(clamp(lo,hi)) -> Dropout.
+ * v [B,T,NF] tokens -> pooled [B,NF,NP] (pre-log means, kept for the backward) and out [B,NF*NP]. */
+int eav_sqpool_log_fwd(const float* v, const float* bn, float* pooled, float* out, int B, int T, int NF, int NP,
+                       int win, int stride, float lo, float hi, float drop_p, uint64_t seed, const uint8_t* mask,
+                       const uint64_t* seed_dev, void* stream);
+/* g [B,T,NF] = dL/d(BatchNorm output); part [B][2*NF] = sums for eav_bn_bwd_finalize. */
+int eav_sqpool_log_bwd(const float* dy, const float* pooled, const float* v, const float* bn, float* g, float* part,
+                       int B, int T, int NF, int NP, int win, int stride, float lo, float hi, float drop_p,
+                       uint64_t seed, const uint8_t* mask, const uint64_t* seed_dev, void* stream);
+/* BatchNorm input gradient on token-major rows; bn = mean, invstd, scale, shift, m1, m2 (NF each). */
+int eav_bn_rows_bwd(const float* g, const float* v, const float* bn, float* dx, int64_t M, int NF, void* stream);
+
 /* ---- pre-processing (SURVEY section 8f "next" rows) ------------------------------------------------ */
 /* HF image processor on a batch of uint8 HWC frames (Transformer_Vision.py:52-59): Pillow-exact 8-bit
  * bilinear resize (coefficient tables kx/ky [out][ksize] int32 and bounds [out][2] = (first, count), built

@@ -75,3 +75,39 @@ def cnn_eeg_weights(seed, nb, chans=64, samples=128, klen=64, F1=8, D=2, F2=16, 
         out[name + ".running_mean"] = u(seed + 12 + 4 * i, (n,), -0.05, 0.05)
         out[name + ".running_var"] = u(seed + 13 + 4 * i, (n,), 0.5, 1.5)
     return out
+
+
+def shallow_tf_weights(seed, nb, num_layers=12):
+    """Deterministic state for ShallowConvNet + transformer (keys of Transformer_torch/Transformer_EEG.py's
+    state_dict): matrices U(+-1/sqrt(fan_in)), LayerNorm/BatchNorm gains around 1, small non-zero biases."""
+    u = synth.uniform
+    out, s = {}, [seed * 1000]
+
+    def nxt():
+        s[0] += 1
+        return s[0]
+
+    def ku(shape, fan_in):
+        b = 1.0 / np.sqrt(fan_in)
+        return u(nxt(), shape, -b, b)
+
+    out["conv.weight"] = ku((40, 1, 1, 13), 13)
+    out["bn.weight"] = u(nxt(), (40,), 0.8, 1.2)
+    out["bn.bias"] = u(nxt(), (40,), -0.1, 0.1)
+    out["bn.running_mean"] = u(nxt(), (40,), -0.05, 0.05)
+    out["bn.running_var"] = u(nxt(), (40,), 0.5, 1.5)
+    for i in range(40):
+        out[f"embedding.value_proj.{i}.weight"] = ku((1, 30), 30)
+    for l in range(num_layers):
+        p = f"transformer.{l}."
+        for n in "qkv":
+            out[p + f"attn.W_{n}.weight"] = ku((40, 40), 40)
+        out[p + "ffn.net.0.weight"] = ku((160, 40), 40)
+        out[p + "ffn.net.0.bias"] = ku((160,), 40)
+        out[p + "ffn.net.3.weight"] = ku((40, 160), 160)
+        out[p + "ffn.net.3.bias"] = ku((40,), 160)
+        for n in ("norm1", "norm2"):
+            out[p + n + ".weight"] = u(nxt(), (40,), 0.8, 1.2)
+            out[p + n + ".bias"] = u(nxt(), (40,), -0.1, 0.1)
+    out["fc.weight"] = ku((nb, 2600), 2600)
+    return out

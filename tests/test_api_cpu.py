@@ -179,3 +179,24 @@ def test_canonical_eegnet_constructor_state_matches_reference(golden_dir):
         "classifier.bias"]
     with pytest.raises(NotImplementedError):
         EEGNet(nb_classes=4, F1=32)
+
+
+def test_shallow_convnet_class_surface_and_default_init():
+    """eav_amd.transformer_eeg mirrors Transformer_torch/Transformer_EEG.py: class names, constructor signatures and the
+    176 parameter names in the reference's order (oracle.shallow_tf_oracle.param_names is pinned to the reference by
+    the golden tests)."""
+    from eav_amd import _lib, transformer_eeg as te
+    from oracle.shallow_tf_oracle import param_names
+    for name in ("PatchEmbedding", "MultiHeadAttention", "FeedForwardBlock", "TransformerLayer", "ShallowConvNet",
+                 "TrainerUni"):
+        assert hasattr(te, name)
+    assert list(inspect.signature(te.ShallowConvNet.__init__).parameters)[1:] == [
+        "nb_classes", "chans", "samples", "dropout", "num_layers"]
+    assert list(inspect.signature(te.TrainerUni.__init__).parameters)[1:] == [
+        "model", "data", "lr", "batch_size", "epochs", "subject", "device"]
+    torch.manual_seed(0)
+    m = te.ShallowConvNet(5)
+    assert [n for n, _ in m.named_parameters()] == param_names(12)
+    assert m.fc.weight.shape == (5, 2600) and m.fc.bias is None
+    with pytest.raises(_lib.EavError):
+        te.TrainerUni(m, data=[torch.zeros(4, 1, 30, 500), torch.zeros(4, dtype=torch.long)] * 2, device="cpu")

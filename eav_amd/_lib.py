@@ -99,10 +99,10 @@ PLAIN = {
     "eav_eegnet_fir_fwd_nparts": ([_i, _i, _i], _i),
     "eav_eegnet_fir_wgrad_nparts": ([_i, _i, _i], _i),
     "eav_conv64_ntiles": ([_i], _i),
-    "eav_tconv_fwd_nparts": ([_i, _i, _i], _i),
+    "eav_tconv_fwd_nparts": ([_i, _i, _i, _i, _i], _i),
     "eav_shallow_embed_nparts": ([_i, _i], _i),
     "eav_colstats_nparts": ([_i64], _i),
-    "eav_tconv_wgrad_nparts": ([_i, _i, _i], _i),
+    "eav_tconv_wgrad_nparts": ([_i, _i, _i, _i, _i], _i),
     "eav_spatial_nparts": ([_i, _i], _i),
     "eav_sepconv_fwd_nparts": ([_i, _i], _i),
     "eav_pointwise_bwd_nparts": ([_i, _i], _i),

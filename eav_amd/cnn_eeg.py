@@ -44,7 +44,7 @@ class _Workspace:
         self.a3, self.da3 = f(B, F2 * T3), f(B, F2 * T3)
         self.logits = f(B, m.nb_classes)
         self.bn1, self.bn2, self.bn3 = f(6 * F1), f(6 * C2), f(6 * F2)
-        self.np_t = _lib.plain("eav_tconv_fwd_nparts", B, C, S)
+        self.np_t = _lib.plain("eav_tconv_fwd_nparts", B, C, S, F1, K)
         self.part_t = f(self.np_t, 2 * F1)
         self.np_s = _lib.plain("eav_spatial_nparts", B, S)
         self.part_s = f(self.np_s, 2 * C2)
@@ -53,7 +53,7 @@ class _Workspace:
         self.part_pb = f(B, 2 * max(C2, F2))
         self.part_sst = f(self.np_s, 2 * F1)
         self.part_sw = f(self.np_s, C2 * C)
-        self.np_tw = _lib.plain("eav_tconv_wgrad_nparts", B, C, S)
+        self.np_tw = _lib.plain("eav_tconv_wgrad_nparts", B, C, S, F1, K)
         self.part_tw = f(self.np_tw, F1 * K)
         self.np_pw = _lib.plain("eav_pointwise_bwd_nparts", B, T2)
         self.part_pw = f(self.np_pw, F2 * C2)

@@ -172,7 +172,28 @@ __global__ __launch_bounds__(256) void tconv_wgrad_kernel(const float* __restric
 
 // ------------------------------------------------------------------------------------ spatial_fwd
 // z[b,f*D+d,t] = sum_c wd[f*D+d,c] * (scale_f * y1[b,f,c,t] + shift_f)      (BN1 affine folded in)
-// part[(b,tile)][fd] = sum z, [C2+fd] = sum z^2.
+// part[(b,tile)][fd] = sum z, [C2+fd] = sum z^2.   A thread owns 4 consecutive samples (float4 loads and stores).
+constexpr int SPT = 1024;   // samples per block of the spatial kernels
+
+__device__ __forceinline__ void ld4(const float* p, int i, int n, bool vec, float (&v)[4]) {
+  if (vec && i + 3 < n) {
+    const float4 a = *reinterpret_cast<const float4*>(p + i);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (i + e < n) ? p[i + e] : 0.f;
+  }
+}
+__device__ __forceinline__ void st4(float* p, int i, int n, bool vec, const float (&v)[4]) {
+  if (vec && i + 3 < n) {
+    *reinterpret_cast<float4*>(p + i) = make_float4(v[0], v[1], v[2], v[3]);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (i + e < n) p[i + e] = v[e];
+  }
+}
+
 __global__ __launch_bounds__(256) void spatial_fwd_kernel(const float* __restrict__ y1, const float* __restrict__ bn1,
                                                           const float* __restrict__ wd, float* __restrict__ z,
                                                           float* __restrict__ part, int C, int S, int F1, int D) {
@@ -185,23 +206,34 @@ __global__ __launch_bounds__(256) void spatial_fwd_kernel(const float* __restric
   }
   __syncthreads();
   const float sc = bn1[2 * F1 + f], sh = bn1[3 * F1 + f];
-  const int t = tile * 256 + tid;
-  const bool valid = t < S;
-  const float* src = y1 + ((int64_t)b * F1 + f) * C * S + t;
-  float acc[8];
+  const int t = tile * SPT + 4 * tid;
+  const bool vec = (S & 3) == 0;
+  const float* src = y1 + ((int64_t)b * F1 + f) * C * S;
+  float acc[8][4];
 #pragma unroll
-  for (int d = 0; d < 8; ++d) acc[d] = 0.f;
-  for (int c = 0; c < C; ++c) {
-    const float v = valid ? fmaf(sc, src[(int64_t)c * S], sh) : 0.f;
+  for (int d = 0; d < 8; ++d)
 #pragma unroll
-    for (int d = 0; d < 8; ++d) acc[d] = fmaf(wl[d][c], v, acc[d]);
+    for (int e = 0; e < 4; ++e) acc[d][e] = 0.f;
+  if (t < S) {
+    for (int c = 0; c < C; ++c) {
+      float v[4];
+      ld4(src + (int64_t)c * S, t, S, vec, v);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (t + e < S) ? fmaf(sc, v[e], sh) : 0.f;
+#pragma unroll
+      for (int d = 0; d < 8; ++d) {
+        const float w = wl[d][c];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[d][e] = fmaf(w, v[e], acc[d][e]);
+      }
+    }
   }
   float st[16];
 #pragma unroll
   for (int d = 0; d < 8; ++d) {
-    if (valid && d < D) z[((int64_t)b * C2 + f * D + d) * S + t] = acc[d];
-    st[d] = acc[d];
-    st[8 + d] = acc[d] * acc[d];
+    if (t < S && d < D) st4(z + ((int64_t)b * C2 + f * D + d) * S, t, S, vec, acc[d]);
+    st[d] = (acc[d][0] + acc[d][1]) + (acc[d][2] + acc[d][3]);
+    st[8 + d] = (acc[d][0] * acc[d][0] + acc[d][1] * acc[d][1]) + (acc[d][2] * acc[d][2] + acc[d][3] * acc[d][3]);
   }
   block_sum_256<16>(st, red);
   if (tid < 16 && (tid & 7) < D)
@@ -211,6 +243,7 @@ __global__ __launch_bounds__(256) void spatial_fwd_kernel(const float* __restric
 // ------------------------------------------------------------------------------------ spatial_bwd
 // g1[b,f,c,t] = sum_d wd[fd,c] * dz[b,fd,t]  (gradient w.r.t. the BN1 output);
 // stat_part[(b,tile)][f] = sum g1, [F1+f] = sum g1*xhat;  w_part[(b,tile)][fd*C+c] = sum_t dz[fd,t] * bn1out[c,t].
+// The per-(d,c) sums are taken over the thread's 4 samples first, then across the wave, then across the 4 waves.
 __global__ __launch_bounds__(256) void spatial_bwd_kernel(const float* __restrict__ y1, const float* __restrict__ dz,
                                                           const float* __restrict__ bn1, const float* __restrict__ wd,
                                                           float* __restrict__ g1, float* __restrict__ stat_part,
@@ -226,24 +259,36 @@ __global__ __launch_bounds__(256) void spatial_bwd_kernel(const float* __restric
   }
   __syncthreads();
   const float mean = bn1[f], invstd = bn1[F1 + f], sc = bn1[2 * F1 + f], sh = bn1[3 * F1 + f];
-  const int t = tile * 256 + tid;
-  const bool valid = t < S;
-  float dzv[8];
+  const int t = tile * SPT + 4 * tid;
+  const bool vec = (S & 3) == 0, live = t < S;
+  float dzv[8][4];
 #pragma unroll
-  for (int d = 0; d < 8; ++d) dzv[d] = (valid && d < D) ? dz[((int64_t)b * C2 + f * D + d) * S + t] : 0.f;
-  const int64_t base = ((int64_t)b * F1 + f) * C * S + t;
+  for (int d = 0; d < 8; ++d) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dzv[d][e] = 0.f;
+    if (live && d < D) ld4(dz + ((int64_t)b * C2 + f * D + d) * S, t, S, vec, dzv[d]);
+  }
+  const int64_t base = ((int64_t)b * F1 + f) * C * S;
   float st[2] = {0.f, 0.f};
   for (int c = 0; c < C; ++c) {
-    const float y = valid ? y1[base + (int64_t)c * S] : 0.f;
-    const float o = fmaf(sc, y, sh), xh = (y - mean) * invstd;
-    float g = 0.f;
+    float y[4] = {0.f, 0.f, 0.f, 0.f}, g[4] = {0.f, 0.f, 0.f, 0.f}, o[4];
+    if (live) ld4(y1 + base + (int64_t)c * S, t, S, vec, y);
 #pragma unroll
-    for (int d = 0; d < 8; ++d) g = fmaf(wl[d][c], dzv[d], g);
-    if (valid) g1[base + (int64_t)c * S] = g;
-    st[0] += g;
-    st[1] += g * xh;
+    for (int e = 0; e < 4; ++e) o[e] = fmaf(sc, y[e], sh);
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+      const float w = wl[d][c];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[e] = fmaf(w, dzv[d][e], g[e]);
+    }
+    if (live) st4(g1 + base + (int64_t)c * S, t, S, vec, g);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {       // dz is 0 beyond S, so g and the products below vanish there
+      st[0] += g[e];
+      st[1] += g[e] * (y[e] - mean) * invstd;
+    }
     for (int d = 0; d < D; ++d) {
-      const float s = wave_sum(dzv[d] * o);
+      const float s = wave_sum((dzv[d][0] * o[0] + dzv[d][1] * o[1]) + (dzv[d][2] * o[2] + dzv[d][3] * o[3]));
       if (lane == 0) wred[wave][d][c] = s;
     }
   }
@@ -410,12 +455,19 @@ static int tconv_ok(const char* who, int B, int C, int S, int F1, int K) {
   return EAV_OK;
 }
 
-extern "C" int eav_tconv_fwd_nparts(int B, int C, int S) { return B * C * cdiv(S, TT); }
+// F1 == 8 with <= 300 taps runs on the fp32 matrix cores (the Toeplitz-GEMM kernels of eegnet_fir.hip, templated on
+// the tap count); every other configuration takes the direct kernels of this file.
+static bool use_mfma_fir(int F1, int K) { return F1 == 8 && K <= 300; }
+
+extern "C" int eav_tconv_fwd_nparts(int B, int C, int S, int F1, int K) {
+  return use_mfma_fir(F1, K) ? eav_eegnet_fir_fwd_nparts(B, C, S) : B * C * cdiv(S, TT);
+}
 
 extern "C" int eav_tconv_fwd(const float* x, const float* w, float* y1, float* stat_part, int B, int C, int S, int F1,
                              int K, void* stream) {
   EAV_REQUIRE(x && w && y1 && stat_part, "eav_tconv_fwd: null pointer");
   if (int rc = tconv_ok("eav_tconv_fwd", B, C, S, F1, K)) return rc;
+  if (use_mfma_fir(F1, K)) return eav_eegnet_fir_fwd(x, w, y1, stat_part, B, C, S, K, stream);
   EAV_REQUIRE(C <= 65535 && B <= 65535, "eav_tconv_fwd: grid too large");
   const dim3 grid(cdiv(S, TT), C, B);
   const int padl = (K - 1) / 2;
@@ -429,7 +481,8 @@ extern "C" int eav_tconv_fwd(const float* x, const float* w, float* y1, float* s
   return EAV_OK;
 }
 
-extern "C" int eav_tconv_wgrad_nparts(int B, int C, int S) {
+extern "C" int eav_tconv_wgrad_nparts(int B, int C, int S, int F1, int K) {
+  if (use_mfma_fir(F1, K)) return eav_eegnet_fir_wgrad_nparts(B, C, S);
   const int64_t items = (int64_t)B * C * cdiv(S, WT);
   return (int)(items < 1024 ? items : 1024);
 }
@@ -438,7 +491,8 @@ extern "C" int eav_tconv_wgrad(const float* x, const float* y1, const float* g1,
                                int B, int C, int S, int F1, int K, void* stream) {
   EAV_REQUIRE(x && y1 && g1 && bn_params && part, "eav_tconv_wgrad: null pointer");
   if (int rc = tconv_ok("eav_tconv_wgrad", B, C, S, F1, K)) return rc;
-  const int nitems = B * C * cdiv(S, WT), nblk = eav_tconv_wgrad_nparts(B, C, S);
+  if (use_mfma_fir(F1, K)) return eav_eegnet_fir_wgrad(x, y1, g1, bn_params, part, B, C, S, K, stream);
+  const int nitems = B * C * cdiv(S, WT), nblk = eav_tconv_wgrad_nparts(B, C, S, F1, K);
   const int JW = K <= 64 ? 64 : (K <= 128 ? 128 : 256), NI = cdiv(K, JW), padl = (K - 1) / 2;
 #define EAV_TW(NG, NI_)                                                                                              \
   hipLaunchKernelGGL((tconv_wgrad_kernel<NG, NI_>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, y1, g1,         \
@@ -459,13 +513,13 @@ static int spatial_ok(const char* who, int B, int C, int S, int F1, int D) {
   return EAV_OK;
 }
 
-extern "C" int eav_spatial_nparts(int B, int S) { return B * cdiv(S, 256); }
+extern "C" int eav_spatial_nparts(int B, int S) { return B * cdiv(S, SPT); }
 
 extern "C" int eav_spatial_fwd(const float* y1, const float* bn1, const float* wd, float* z, float* stat_part, int B,
                                int C, int S, int F1, int D, void* stream) {
   EAV_REQUIRE(y1 && bn1 && wd && z && stat_part, "eav_spatial_fwd: null pointer");
   if (int rc = spatial_ok("eav_spatial_fwd", B, C, S, F1, D)) return rc;
-  hipLaunchKernelGGL(spatial_fwd_kernel, dim3(cdiv(S, 256), F1, B), dim3(256), 0, (hipStream_t)stream, y1, bn1, wd, z,
+  hipLaunchKernelGGL(spatial_fwd_kernel, dim3(cdiv(S, SPT), F1, B), dim3(256), 0, (hipStream_t)stream, y1, bn1, wd, z,
                      stat_part, C, S, F1, D);
   EAV_CHECK_LAUNCH("eav_spatial_fwd");
   return EAV_OK;
@@ -475,7 +529,7 @@ extern "C" int eav_spatial_bwd(const float* y1, const float* dz, const float* bn
                                float* stat_part, float* w_part, int B, int C, int S, int F1, int D, void* stream) {
   EAV_REQUIRE(y1 && dz && bn1 && wd && g1 && stat_part && w_part, "eav_spatial_bwd: null pointer");
   if (int rc = spatial_ok("eav_spatial_bwd", B, C, S, F1, D)) return rc;
-  hipLaunchKernelGGL(spatial_bwd_kernel, dim3(cdiv(S, 256), F1, B), dim3(256), 0, (hipStream_t)stream, y1, dz, bn1, wd,
+  hipLaunchKernelGGL(spatial_bwd_kernel, dim3(cdiv(S, SPT), F1, B), dim3(256), 0, (hipStream_t)stream, y1, dz, bn1, wd,
                      g1, stat_part, w_part, C, S, F1, D);
   EAV_CHECK_LAUNCH("eav_spatial_bwd");
   return EAV_OK;

@@ -26,15 +26,18 @@
 namespace {
 
 constexpr int F1 = 8;
-constexpr int NSTEP = 152;        // (300 + 3 shifts -> 304) / 2
 constexpr int TILE = 128;         // samples per MFMA tile
 constexpr int TPS = 16;           // tiles per LDS segment
-constexpr int SEG_M4 = TPS * 32 + 76;  // floats per polyphase plane
+// NSTEP = MFMA K-steps of 2 taps: (klen + 3 shifts) / 2 rounded up to even - 152 for the reference's 300 taps; shorter
+// kernels (the canonical EEGNet's 64 taps, CNN_EEG.py:13) run the 34- or 66-step instantiation.
 
 // ------------------------------------------------------------------------------------------ fwd
+template <int NSTEP>
 __global__ __launch_bounds__(256, 2) void fir_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w1,
                                                          float* __restrict__ y1, float* __restrict__ part, int rows,
                                                          int C, int S, int klen, int padl, int nseg, int ntiles) {
+  constexpr int HALO = 2 * NSTEP;                 // taps + shifts covered by one tile's window
+  constexpr int SEG_M4 = TPS * 32 + NSTEP / 2;    // floats per polyphase plane
   __shared__ __attribute__((aligned(16))) float xs[4 * SEG_M4];
   __shared__ float red[4 * 16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -55,7 +58,7 @@ __global__ __launch_bounds__(256, 2) void fir_fwd_kernel(const float* __restrict
   const int nwork = rows * nseg;
   // the padded input segment of the NEXT work item is fetched into registers before the MFMA phase of
   // the current one, so its HBM latency is hidden behind ~39k cycles of matrix work
-  constexpr int NLD = (TPS * TILE + 304 + 255) / 256;
+  constexpr int NLD = (TPS * TILE + HALO + 255) / 256;
   float xr[NLD];
   auto fetch = [&](int work) {
     const int row = work / nseg, seg = work - row * nseg;
@@ -63,7 +66,7 @@ __global__ __launch_bounds__(256, 2) void fir_fwd_kernel(const float* __restrict
     const int nt = min(TPS, ntiles - tile0);
     const int useg0 = tile0 * TILE;
     const float* xrow = x + (int64_t)row * S;
-    const int nload = nt * TILE + 304;
+    const int nload = nt * TILE + HALO;
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const int idx = threadIdx.x + 256 * i;
@@ -81,7 +84,7 @@ __global__ __launch_bounds__(256, 2) void fir_fwd_kernel(const float* __restrict
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const int idx = threadIdx.x + 256 * i;
-      if (idx < TPS * TILE + 304) xs[(idx & 3) * SEG_M4 + (idx >> 2)] = xr[i];
+      if (idx < TPS * TILE + HALO) xs[(idx & 3) * SEG_M4 + (idx >> 2)] = xr[i];
     }
     __syncthreads();
     if (work + (int)gridDim.x < nwork) fetch(work + gridDim.x);
@@ -138,17 +141,20 @@ __global__ __launch_bounds__(256, 2) void fir_fwd_kernel(const float* __restrict
 // own LDS images (wave-private region, no block barrier in the loop), prefetches the next item's y1/g1/x
 // into registers before its MFMA phase, and keeps its 16x160 accumulator tile in registers for its whole
 // work list.  Waves of a CU drift apart, so one wave's staging overlaps the others' matrix work.
-constexpr int WG_NT = 10;                 // 10 column tiles of 16 -> lags k = 2n+s, n < 160
+// WG_NT column tiles of 16 -> lags k = 2n+s, n < 16*WG_NT: 10 tiles for the reference's 300 taps, 2 / 4 for <= 64 / 128.
 constexpr int WG_CW = 252;                // max u-samples per wave item (63 K-steps of 4)
 constexpr int WG_QS = WG_CW + 8;          // dy row stride: 260 == 4 (mod 32), rows 16-B aligned
-constexpr int WG_XW = WG_CW + 4 + 320;    // x window per item
-constexpr int WG_WAVE_LDS = F1 * WG_QS + WG_XW;   // floats per wave
 
+template <int WG_NT>
 __global__ __launch_bounds__(256, 3) void fir_wgrad_kernel(
     const float* __restrict__ x, const float* __restrict__ y1, const float* __restrict__ g1,
     const float* __restrict__ bnp /* mean, invstd, scale, shift, m1, m2 (8 each) */, float* __restrict__ part, int rows,
     int C, int S, int klen, int padl, int nchunk, int CH) {
-  __shared__ __attribute__((aligned(16))) float lds[4 * WG_WAVE_LDS];
+  constexpr int LAGS = 32 * WG_NT;                    // lags covered (>= klen)
+  constexpr int WG_XW = WG_CW + 4 + LAGS;             // x window per item
+  constexpr int WG_WAVE_LDS = F1 * WG_QS + WG_XW;     // floats per wave
+  constexpr int RED = F1 * LAGS > 4 * WG_WAVE_LDS ? F1 * LAGS : 4 * WG_WAVE_LDS;
+  __shared__ __attribute__((aligned(16))) float lds[RED];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float* dyl = lds + wave * WG_WAVE_LDS;
   float* xl = dyl + F1 * WG_QS;
@@ -196,7 +202,7 @@ __global__ __launch_bounds__(256, 3) void fir_wgrad_kernel(
     for (int i = 0; i < NX; ++i) {
       const int idx = lane + 64 * i;
       const int tx = c0 + idx - padl;
-      rx[i] = (idx < CH + 320 && tx >= 0 && tx < S) ? xrow[tx] : 0.f;
+      rx[i] = (idx < CH + LAGS && tx >= 0 && tx < S) ? xrow[tx] : 0.f;
     }
   };
   auto commit = [&](int work) {
@@ -220,7 +226,7 @@ __global__ __launch_bounds__(256, 3) void fir_wgrad_kernel(
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
       const int idx = lane + 64 * i;
-      if (idx < CH + 320) xl[idx] = rx[i];
+      if (idx < CH + LAGS) xl[idx] = rx[i];
     }
   };
   if (gw < nwork) fetch(gw);
@@ -262,7 +268,7 @@ __global__ __launch_bounds__(256, 3) void fir_wgrad_kernel(
   // ---- combine the 4 waves' accumulators through LDS (fixed order), then one partial per block
   // C layout 16x16: col = lane&15, row = (lane>>4)*4 + reg = f*2 + s
   __syncthreads();
-  float* red = lds;  // needs 8*320 floats
+  float* red = lds;  // needs 8*LAGS floats
   for (int w = 0; w < 4; ++w) {
     if (wave == w) {
 #pragma unroll
@@ -272,7 +278,7 @@ __global__ __launch_bounds__(256, 3) void fir_wgrad_kernel(
           const int i = kq * 4 + r;            // row = f*2 + s
           const int k = 2 * (16 * nt + col) + (i & 1);
           const int f = i >> 1;
-          float* dst = red + f * 320 + k;
+          float* dst = red + f * LAGS + k;
           if (w == 0) *dst = acc[nt][r]; else *dst += acc[nt][r];
         }
       }
@@ -281,7 +287,7 @@ __global__ __launch_bounds__(256, 3) void fir_wgrad_kernel(
   }
   for (int idx = threadIdx.x; idx < F1 * klen; idx += 256) {
     const int f = idx / klen, k = idx - f * klen;
-    part[(int64_t)blockIdx.x * (F1 * klen) + idx] = red[f * 320 + k];
+    part[(int64_t)blockIdx.x * (F1 * klen) + idx] = red[f * LAGS + k];
   }
 }
 
@@ -301,8 +307,13 @@ extern "C" int eav_eegnet_fir_fwd(const float* x, const float* w1, float* y1, fl
   EAV_REQUIRE(klen >= 1 && klen <= 300, "eav_eegnet_fir_fwd: kernLength %d outside [1,300]", klen);
   const int ntiles = cdiv(S, TILE), nseg = cdiv(ntiles, TPS);
   const int nwork = B * C * nseg;
-  hipLaunchKernelGGL(fir_fwd_kernel, dim3(fir_grid(nwork)), dim3(256), 0, (hipStream_t)stream, x, w1, y1, stat_part,
-                     B * C, C, S, klen, (klen - 1) / 2, nseg, ntiles);
+#define EAV_FIR_FWD(NS)                                                                                         \
+  hipLaunchKernelGGL(fir_fwd_kernel<NS>, dim3(fir_grid(nwork)), dim3(256), 0, (hipStream_t)stream, x, w1, y1,  \
+                     stat_part, B * C, C, S, klen, (klen - 1) / 2, nseg, ntiles)
+  if (klen <= 65) EAV_FIR_FWD(34);
+  else if (klen <= 129) EAV_FIR_FWD(66);
+  else EAV_FIR_FWD(152);
+#undef EAV_FIR_FWD
   EAV_CHECK_LAUNCH("eav_eegnet_fir_fwd");
   return EAV_OK;
 }
@@ -328,8 +339,13 @@ extern "C" int eav_eegnet_fir_wgrad(const float* x, const float* y1, const float
   int nchunk, CH;
   wgrad_geometry(S, &nchunk, &CH);
   const int nwork = B * C * nchunk;
-  hipLaunchKernelGGL(fir_wgrad_kernel, dim3(wgrad_grid(nwork)), dim3(256), 0, (hipStream_t)stream, x, y1, g1,
-                     bn_params, part, B * C, C, S, klen, (klen - 1) / 2, nchunk, CH);
+#define EAV_FIR_WG(NT)                                                                                            \
+  hipLaunchKernelGGL(fir_wgrad_kernel<NT>, dim3(wgrad_grid(nwork)), dim3(256), 0, (hipStream_t)stream, x, y1, g1, \
+                     bn_params, part, B * C, C, S, klen, (klen - 1) / 2, nchunk, CH)
+  if (klen <= 64) EAV_FIR_WG(2);
+  else if (klen <= 128) EAV_FIR_WG(4);
+  else EAV_FIR_WG(10);
+#undef EAV_FIR_WG
   EAV_CHECK_LAUNCH("eav_eegnet_fir_wgrad");
   return EAV_OK;
 }

@@ -87,13 +87,14 @@ int eav_conv64_wgrad(const float* du, const float* in, float* part, int B, int T
 
 /* ---- canonical EEGNet (CNN_torch/CNN_EEG.py:7-67): run-time F1<=16, D<=8, F2<=64, K1<=512, K2<=32 ----------- */
 /* block1[0] nn.Conv2d(1,F1,(1,K),padding='same',bias=False) (CNN_EEG.py:22): x [B,C,S] -> y1 [B,F1,C,S];
- * stat_part [eav_tconv_fwd_nparts()][2*F1] = per-filter sum / sum of squares (input of eav_bn_finalize). */
-int eav_tconv_fwd_nparts(int B, int C, int S);
+ * stat_part [eav_tconv_fwd_nparts()][2*F1] = per-filter sum / sum of squares (input of eav_bn_finalize).
+ * F1 == 8 with K <= 300 runs the fp32-MFMA Toeplitz kernels of eav_eegnet_fir_*; other shapes a direct kernel. */
+int eav_tconv_fwd_nparts(int B, int C, int S, int F1, int K);
 int eav_tconv_fwd(const float* x, const float* w, float* y1, float* stat_part, int B, int C, int S, int F1, int K,
                   void* stream);
 /* its weight gradient with the block1[1] BatchNorm backward folded in; bn_params = mean, invstd, scale, shift,
  * m1, m2 (F1 each); part [eav_tconv_wgrad_nparts()][F1*K]. */
-int eav_tconv_wgrad_nparts(int B, int C, int S);
+int eav_tconv_wgrad_nparts(int B, int C, int S, int F1, int K);
 int eav_tconv_wgrad(const float* x, const float* y1, const float* g1, const float* bn_params, float* part, int B,
                     int C, int S, int F1, int K, void* stream);
 /* block1[1..2]: BatchNorm affine -> depthwise nn.Conv2d(F1,D*F1,(Chans,1),groups=F1) (CNN_EEG.py:23-25):

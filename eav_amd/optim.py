@@ -19,11 +19,14 @@ import torch
 from . import _lib
 
 
-def flatten_parameters(module: torch.nn.Module, order=None):
+def flatten_parameters(module: torch.nn.Module, order=None, pad_after=None):
     """Re-home every parameter of ``module`` as a view of one flat fp32 device
     buffer (and allocate a same-shaped flat gradient buffer).  Parameter objects
     are preserved, so optimisers created earlier stay valid.  Returns
-    (flat_param, flat_grad, {name: (offset, numel)})."""
+    (flat_param, flat_grad, {name: (offset, numel)}).
+
+    pad_after: {name: n} leaves n zero floats after that tensor in every flat buffer (e.g. to lay a [40,40] weight out
+    as the first rows of a zero-padded [64,40] GEMM operand); the padding stays zero under FusedAdam."""
     params = [(n, p) for n, p in module.named_parameters()]
     if order is not None:  # explicit flat layout (e.g. q/k/v weights adjacent for one fused GEMM)
         named = dict(params)
@@ -38,6 +41,10 @@ def flatten_parameters(module: torch.nn.Module, order=None):
             raise TypeError(f"{n}: only fp32 parameters are supported")
         offsets[n] = (total, p.numel())
         total += (p.numel() + 3) // 4 * 4  # keep every tensor 16-byte aligned
+        if pad_after and n in pad_after:
+            assert pad_after[n] % 4 == 0
+            total += pad_after[n]
+            p._eav_pad = pad_after[n]
     flat = torch.zeros(total, dtype=torch.float32, device=dev)
     gflat = torch.zeros(total, dtype=torch.float32, device=dev)
     for n, p in params:
@@ -106,17 +113,19 @@ class FusedAdam(torch.optim.Optimizer):
                         st["exp_avg_sq"] = torch.zeros_like(p)
                 st["step"] += 1
                 runs.append([p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
-                             p.numel(), st["step"], g])
-            # merge runs that are adjacent (up to 16-B alignment padding) in all four buffers
+                             p.numel(), st["step"], g, 4 * getattr(p, "_eav_pad", 0)])
+            # merge runs that are adjacent (up to 16-B alignment padding, plus declared zero padding - whose
+            # gradient and moments are zero, so the update leaves it zero) in all four buffers
             runs.sort(key=lambda r: r[0])
             merged = []
             for r in runs:
                 if merged:
                     q = merged[-1]
                     gap = r[0] - (q[0] + 4 * q[4])
-                    if (0 <= gap < 16 and r[5] == q[5] and r[1] - q[1] == r[0] - q[0]
+                    if (0 <= gap < 16 + q[7] and r[5] == q[5] and r[1] - q[1] == r[0] - q[0]
                             and r[2] - q[2] == r[0] - q[0] and r[3] - q[3] == r[0] - q[0]):
                         q[4] = (r[0] - q[0]) // 4 + r[4]
+                        q[7] = r[7]
                         continue
                 merged.append(r)
             for r in merged:

@@ -110,7 +110,10 @@ class ShallowConvNet(nn.Module):
         p0 = self.conv.weight
         if self._flat is None or self._flat[0].device != p0.device or getattr(p0, "_eav_flat", None) is None \
                 or p0.data_ptr() != self._flat[0].data_ptr():
-            self._flat = flatten_parameters(self)
+            # W_q / W_k / W_v [40,40] become rows 0..39 of three consecutive zero-padded [64,40] blocks: one [192,40]
+            # operand for a single fused q/k/v GEMM whose output columns match the 64-wide attention tile
+            pads = {f"transformer.{l}.attn.W_{n}.weight": (HD - NF) * NF for l in range(self.num_layers) for n in "qkv"}
+            self._flat = flatten_parameters(self, pad_after=pads)
             self._names = [n for n, _ in self.named_parameters()]
 
     def set_dropout_masks(self, masks):
@@ -136,7 +139,7 @@ class ShallowConvNet(nn.Module):
         ws = SimpleNamespace(key=(B, S), B=B, S=S, T=T, M=M)
         ws.u = f(B, NF, S)
         ws.h = [f(M, NF) for _ in range(L + 1)]
-        ws.qkv = [z(M, 3 * HD) for _ in range(L)]       # pad columns 40..63 of q, k, v stay zero forever
+        ws.qkv = [f(M, 3 * HD) for _ in range(L)]       # pad columns 40..63 of q, k, v are written as exact zeros
         ws.ao = [z(M, HD) for _ in range(L)]
         ws.lse = [f(B, T) for _ in range(L)]
         ws.a = [f(M, NF) for _ in range(L)]
@@ -160,7 +163,7 @@ class ShallowConvNet(nn.Module):
         ws.part_ln = f(ws.np_ln, 2 * NF)
         ws.np_col = _lib.plain("eav_colsum_nparts", M)
         ws.part_col = f(ws.np_col, 4 * NF)
-        shapes = [(NF, 4 * NF, M), (4 * NF, NF, M), (NF, NF, M)]
+        shapes = [(NF, 4 * NF, M), (4 * NF, NF, M), (3 * HD, NF, M)]
         ws.splitk = f(max(_lib.plain("eav_gemm_f32_splitk_plan", m, n, k) * m * n for m, n, k in shapes))
         ws.np_e = _lib.plain("eav_shallow_embed_nparts", B, S)
         ws.part_ec, ws.part_ev, ws.dwv = f(ws.np_e, NF * KC), f(ws.np_e, NF * 30), f(NF, 30)
@@ -205,8 +208,7 @@ class ShallowConvNet(nn.Module):
         for l in range(self.num_layers):
             p = f"transformer.{l}."
             hin, qkv, stp = P(ws.h[l]), P(ws.qkv[l]), P(ws.st[l])
-            for j, nm in enumerate("qkv"):                                                        # :62-64
-                self._gemm(hin, w(p + f"attn.W_{nm}.weight"), qkv + 4 * HD * j, M, NF, NF, NF, NF, 3 * HD)
+            self._gemm(hin, w(p + "attn.W_q.weight"), qkv, M, 3 * HD, NF, NF, NF, 3 * HD)            # :62-64, fused
             L("eav_attn_fwd", qkv, P(ws.ao[l]), P(ws.lse[l]), B, 1, T, HD, scale, st)             # :66-69
             L("eav_add_strided", P(ws.ao[l]), HD, qkv + 8 * HD, 3 * HD, P(ws.a[l]), NF, M, NF, st)    # out + res, :76
             L("eav_layernorm_fwd", P(ws.a[l]), w(p + "norm1.weight"), w(p + "norm1.bias"), P(ws.y), stp, stp + 4 * M,
@@ -294,10 +296,9 @@ class ShallowConvNet(nn.Module):
             L("eav_add_strided", da, NF, None, 0, P(ws.dao), HD, M, NF, st)
             L("eav_attn_bwd", qkv, P(ws.ao[l]), P(ws.dao), P(ws.lse[l]), P(ws.delta), dqkv, B, 1, T, HD, scale, st)
             L("eav_add_strided", dqkv + 8 * HD, 3 * HD, da, NF, dqkv + 8 * HD, 3 * HD, M, NF, st)   # the "+ V" branch
-            for j, nm in enumerate("qkv"):
-                k = p + f"attn.W_{nm}.weight"
-                self._wgrad(dqkv + 4 * HD * j, hin, gp(k), NF, NF, M, 3 * HD, NF)
-                self._gemm(dqkv + 4 * HD * j, w(k), dh, M, NF, NF, 3 * HD, NF, NF, tB=1, acc=1)
+            k = p + "attn.W_q.weight"          # the padded [192,40] block that starts at W_q (see _ensure_flat)
+            self._wgrad(dqkv, hin, gp(k), 3 * HD, NF, M, 3 * HD, NF)
+            self._gemm(dqkv, w(k), dh, M, NF, 3 * HD, 3 * HD, NF, NF, tB=1, acc=1)
         # conv taps and channel projections (the input needs no gradient)
         L("eav_shallow_embed_bwd", dh, P(x), P(ws.u), w("conv.weight"), P(ws.part_ec), P(ws.part_ev), B, 30, S, NF, KC,
           st)

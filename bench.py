@@ -115,6 +115,73 @@ def bench_encoder(kind, dev, world, sync_factory, steps=4, warmup=2):
     return res
 
 
+def bench_alt_eeg(dev):
+    """SURVEY.md section 8f row 4 - the two alternative EEG encoders, one GPU: train-step time of the canonical
+    EEGNet (CNN_torch/CNN_EEG.py) at the EAV recording shape and at the epoch shape, and of ShallowConvNet + 12-layer
+    transformer (Transformer_torch/Transformer_EEG.py) at its batch shape, each next to one CPU-oracle step."""
+    import torch
+    from eav_amd import synth
+    from eav_amd.cnn_eeg import EEGNet
+    from eav_amd.eegnet import GraphStep
+    from eav_amd.optim import CrossEntropyLoss, FusedAdam
+    from eav_amd.transformer_eeg import ShallowConvNet
+    res = {}
+
+    def run(name, model, x, y, steps=20):
+        model = model.to(dev).train()
+        opt, crit = FusedAdam(model.parameters(), lr=1e-3, capturable=True), CrossEntropyLoss()
+        xs, ys = torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
+        gs = GraphStep(model, opt, crit, xs, ys, xs.shape[0])      # gather + fwd + CE + bwd + Adam, hipGraph replay
+        idx = list(range(xs.shape[0]))
+        for _ in range(4):
+            gs.run(idx)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            gs.run(idx)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        res[name] = {"ms_per_step": round(dt * 1e3, 3), "samples_per_s": round(xs.shape[0] / dt, 1),
+                     "batch": int(xs.shape[0]), "input": list(x.shape[1:])}
+        del gs, model, opt
+        torch.cuda.empty_cache()
+
+    torch.manual_seed(0)
+    x, y = synth.eeg_batch(21, 64, 30, 10000)
+    run("canonical_eegnet_recording", EEGNet(5, Chans=30, Samples=10000), x[:, 0], y)
+    x, y = synth.eeg_batch(22, 32, 30, 500)
+    run("canonical_eegnet_epoch", EEGNet(5, Chans=30, Samples=500), x[:, 0], y)
+    run("shallow_transformer", ShallowConvNet(5), x, y)
+    return res
+
+
+def cpu_alt_eeg():
+    """One CPU-oracle train step of each alternative encoder at the epoch shape [32,30,500] (all host threads)."""
+    import torch
+    from eav_amd import synth
+    from oracle import cnn_eeg_oracle as co, shallow_tf_oracle as so
+    sys.path.insert(0, ROOT)
+    from tests.golden_util import cnn_eeg_weights, shallow_tf_weights
+    out = {}
+    x, y = synth.eeg_batch(22, 32, 30, 500)
+    xt, yt = torch.from_numpy(x), torch.from_numpy(y)
+    sd = cnn_eeg_weights(1, 5, 30, 500)
+    st = co.Stepper({k: torch.from_numpy(sd[k]) for k in co.PARAM_NAMES},
+                    {k: torch.from_numpy(sd[k]) for k in co.BUFFER_NAMES}, lr=1e-3, drop_p=0.0)
+    sd2 = shallow_tf_weights(1, 5)
+    st2 = so.Stepper({k: torch.from_numpy(sd2[k]) for k in so.param_names()},
+                     {k: torch.from_numpy(sd2[k]) for k in so.BUFFER_NAMES}, lr=1e-3, drop_p=0.0)
+    for name, stepper in (("canonical_eegnet_epoch", st), ("shallow_transformer", st2)):
+        stepper.step(xt, yt, True, None)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            stepper.step(xt, yt, True, None)
+        dt = (time.perf_counter() - t0) / 3
+        out[name] = {"samples_per_s": round(32 / dt, 1), "ms_per_step": round(dt * 1e3, 1),
+                     "cores": torch.get_num_threads(), "kind": "port"}
+    return out
+
+
 def measured_peaks(dev):
     """What this chip sustains: register-only fp32 MFMA loop and a 1 GiB float4 copy (read + write bytes)."""
     import torch
@@ -218,6 +285,7 @@ def main():
         torch.cuda.empty_cache()
         mk = (lambda g: eav_dist.GradSync([g])) if world > 1 else (lambda g: None)
         encoders = {k: bench_encoder(k, dev, world, mk) for k in ("ast", "vit")}
+    alt = bench_alt_eeg(dev) if (world == 1 and not args.no_encoders) else None
 
     if rank == 0:
         dom = max(kern_ms, key=kern_ms.get)
@@ -257,6 +325,13 @@ def main():
             out["encoders"] = {"note": "12-layer AST / ViT-B/16, synthetic input, fp32 MFMA GEMMs (exact fp32: bf16 "
                                        "operands miss the 1e-3 logit bound, DESIGN.md section 8); whole-job samples/s",
                                **encoders}
+        if alt is not None:
+            out["alt_eeg_encoders"] = {"note": "SURVEY 8f row 4: canonical EEGNet (CNN_EEG.py) and ShallowConvNet + "
+                                               "12-layer transformer (Transformer_EEG.py); fp32, hipGraph-replayed "
+                                               "train step (gather, fwd, CE, bwd, Adam), one GPU", **alt}
+            if not args.no_cpu_baseline:
+                for k, v in cpu_alt_eeg().items():
+                    out["alt_eeg_encoders"][k]["cpu_oracle"] = v
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

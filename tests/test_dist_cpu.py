@@ -53,6 +53,19 @@ def test_grad_allreduce_gloo_world2(tmp_path):
         assert torch.equal(g3, exp), g3
         assert torch.allclose(g2, torch.arange(1000, dtype=torch.float32) * 1.5)   # mean of identical replicas
         assert ed.subjects_for_rank(rank, world)[0] == 1 + rank
+        # attach(): any trainer whose model keeps a flat gradient buffer - here the alternative EEG encoders, whose flat
+        # layouts contain declared zero padding (ShallowConvNet) - gets the all-reduce and leaves hipGraph replay
+        from types import SimpleNamespace
+        from eav_amd.cnn_eeg import EEGNet
+        from eav_amd.transformer_eeg import ShallowConvNet
+        torch.manual_seed(0)
+        for model in (ShallowConvNet(5, num_layers=1), EEGNet(4)):
+            tr = ed.attach(SimpleNamespace(model=model, grad_sync=None, use_graph=True))
+            assert tr.use_graph is False and tr.grad_sync is not None
+            gflat = model._flat[1]
+            gflat.fill_(float(rank + 1))
+            tr.grad_sync()
+            assert torch.allclose(gflat, torch.full_like(gflat, 1.5))
         dist.barrier()
         dist.destroy_process_group()
         open({str(tmp_path)!r} + f"/ok_{{rank}}", "w").write("ok")     # (stdout of the two ranks may interleave)

@@ -26,6 +26,12 @@ constexpr int TQ = 128;         // rows per block (4 waves x 32)
 
 __device__ __forceinline__ int kappa(int ks, int kk) { return (ks & 3) + 8 * (ks >> 2) + 4 * kk; }
 
+// The softmax runs in base 2: scores are produced pre-multiplied by log2(e) (folded into the staged Q), so that each
+// probability costs one subtract and one native v_exp_f32 instead of the ~12-instruction expf expansion - the VALU
+// work between the MFMA phases was a third of a key-tile iteration.  lse stays in natural-log units at the ABI.
+constexpr float LOG2E = 1.44269504088896340736f, LN2 = 0.69314718055994530942f;
+__device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 // stage a [32][64] tile (rows r0.., zero beyond nrows) of a [*, ld] matrix into LDS with row stride `stride`
 __device__ __forceinline__ void fetch_tile(const float* __restrict__ base, int ld, int r0, int nrows, float4 (&reg)[2]) {
 #pragma unroll
@@ -47,7 +53,7 @@ __device__ __forceinline__ void commit_tile(float* __restrict__ lds, int stride,
 
 // ------------------------------------------------------------------------------------------ forward
 // grid (ceil(N/128), B*H).  out: ao [B*N, D] (head columns), lse [B*H, N] = m + log(l) of the scaled scores.
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ ao,
+__global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ ao,
                                                           float* __restrict__ lse, int N, int H, float scale) {
   __shared__ __attribute__((aligned(16))) float smem[2 * 32 * KS + 2 * 32 * HD];   // one array: carved below
   float (*Ks)[32 * KS] = reinterpret_cast<float (*)[32 * KS]>(smem);
@@ -62,7 +68,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const float* __restric
   const float* Vb = Qb + 2 * D;
   float qreg[HD / 2];
 #pragma unroll
-  for (int ks = 0; ks < HD / 2; ++ks) qreg[ks] = q < N ? scale * Qb[(int64_t)q * ld + 2 * ks + kk] : 0.f;
+  for (int ks = 0; ks < HD / 2; ++ks) qreg[ks] = q < N ? (scale * LOG2E) * Qb[(int64_t)q * ld + 2 * ks + kk] : 0.f;
   f32x16 o0, o1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
@@ -89,18 +95,20 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const float* __restric
     for (int ks = 0; ks < HD / 2; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kp[2 * ks], qreg[ks], s, 0, 0, 0);
     // online softmax over this lane's 16 keys (+ the 16 of lane^32)
     float mx = -INFINITY;
+    if (32 * kt + 32 > N) {                      // only the last key tile can be ragged (block-uniform branch)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      if (32 * kt + kappa(r, kk) >= N) s[r] = -INFINITY;
-      mx = fmaxf(mx, s[r]);
+      for (int r = 0; r < 16; ++r)
+        if (32 * kt + kappa(r, kk) >= N) s[r] = -INFINITY;
     }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float mn = fmaxf(m, mx);
-    const float alpha = expf(m - mn);
+    const float alpha = ex2(m - mn);
     float rs = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      s[r] = expf(s[r] - mn);
+      s[r] = ex2(s[r] - mn);
       rs += s[r];
     }
     rs += __shfl_xor(rs, 32, 64);
@@ -124,7 +132,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const float* __restric
   }
   // O[q][d] = O^T[d][q] / l, transposed through LDS so that every row is written as 256 contiguous bytes
   const float inv = 1.0f / l;
-  if (kk == 0 && q < N) lse[(int64_t)bh * N + q] = m + logf(l);
+  if (kk == 0 && q < N) lse[(int64_t)bh * N + q] = (m + log2f(l)) * LN2;
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
     __syncthreads();
@@ -207,10 +215,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(const float* __restr
   float qreg[HD / 2], doreg[HD / 2];
 #pragma unroll
   for (int ks = 0; ks < HD / 2; ++ks) {
-    qreg[ks] = q < N ? scale * Qb[(int64_t)q * ld + 2 * ks + kk] : 0.f;
+    qreg[ks] = q < N ? (scale * LOG2E) * Qb[(int64_t)q * ld + 2 * ks + kk] : 0.f;
     doreg[ks] = q < N ? dOb[(int64_t)q * D + 2 * ks + kk] : 0.f;
   }
-  const float lq = q < N ? lse[(int64_t)bh * N + q] : 0.f;
+  const float lq = q < N ? LOG2E * lse[(int64_t)bh * N + q] : 0.f;
   const float dq_ = q < N ? delta[(int64_t)bh * N + q] : 0.f;
   f32x16 g0, g1;
 #pragma unroll
@@ -238,11 +246,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(const float* __restr
       s = __builtin_amdgcn_mfma_f32_32x32x2f32(kp[2 * ks], qreg[ks], s, 0, 0, 0);       // S^T = K . Q^T
       dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[2 * ks], doreg[ks], dp, 0, 0, 0);    // dP^T = V . dO^T
     }
+    if (32 * kt + 32 > N) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float p = (32 * kt + kappa(r, kk) < N) ? expf(s[r] - lq) : 0.f;
-      s[r] = p * (dp[r] - dq_);                                                          // dS^T
+      for (int r = 0; r < 16; ++r)
+        if (32 * kt + kappa(r, kk) >= N) s[r] = -INFINITY;
     }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = ex2(s[r] - lq) * (dp[r] - dq_);                   // dS^T = P^T o (dP^T - delta)
     const float* kd = Ks[buf] + j;
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {                                                    // dQ^T += K^T . dS^T
@@ -301,13 +311,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const float* __rest
   };
   auto commit = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {      // Q is staged pre-multiplied by the softmax scale
-      rq[i].x *= scale; rq[i].y *= scale; rq[i].z *= scale; rq[i].w *= scale;
+    for (int i = 0; i < 2; ++i) {      // Q is staged pre-multiplied by scale * log2(e) (dK is rescaled by ln 2 at the end)
+      rq[i].x *= scale * LOG2E; rq[i].y *= scale * LOG2E; rq[i].z *= scale * LOG2E; rq[i].w *= scale * LOG2E;
     }
     commit_tile(Qs[buf], KS, rq);
     commit_tile(Os[buf], KS, ro);
     if (threadIdx.x < 32) {
-      Ls[buf * 32 + threadIdx.x] = rl;
+      Ls[buf * 32 + threadIdx.x] = rl * LOG2E;
       Ds[buf * 32 + threadIdx.x] = rd;
     }
   };
@@ -328,10 +338,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const float* __rest
       dp = __builtin_amdgcn_mfma_f32_32x32x2f32(op[2 * ks], vreg[ks], dp, 0, 0, 0);      // dP[q][key]
     }
     // register r <-> query row kappa(r, kk) of this tile
+    if (32 * qt + 32 > N) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (32 * qt + kappa(r, kk) >= N) s[r] = -INFINITY;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int qi = kappa(r, kk);
-      const float p = (32 * qt + qi < N) ? expf(s[r] - Ls[buf * 32 + qi]) : 0.f;
+      const float p = ex2(s[r] - Ls[buf * 32 + qi]);
       dp[r] = p * (dp[r] - Ds[buf * 32 + qi]);     // dS[q][key]
       s[r] = p;                                     // P[q][key]
     }
@@ -349,7 +364,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const float* __rest
     __syncthreads();
   }
   float* base = dqkv + (int64_t)b * N * ld + h * HD;
-  store_rows_T(smem + wave * (32 * 33), gk0, gk1, 1.0f, base + D, ld, blockIdx.x * TQ + wave * 32, N, lane);
+  store_rows_T(smem + wave * (32 * 33), gk0, gk1, LN2, base + D, ld, blockIdx.x * TQ + wave * 32, N, lane);
   store_rows_T(smem + wave * (32 * 33), gv0, gv1, 1.0f, base + 2 * D, ld, blockIdx.x * TQ + wave * 32, N, lane);
 }
 

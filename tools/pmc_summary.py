@@ -37,6 +37,12 @@ for k in sorted(set(f) | set(w)):
     wr = w.get(k, 0.0) * 1024.0
     out[short] = {"read_bytes": round(rd), "write_bytes": round(wr), "total_bytes": round(rd + wr),
                   "raw_FETCH_SIZE_KiB": round(f.get(k, 0.0), 1), "raw_WRITE_SIZE_KiB": round(w.get(k, 0.0), 1)}
+# templated kernels with a single instantiation in the run are also listed under their bare name
+bases = collections.Counter(k.split("<")[0] for k in out if "<" in k)
+for k in list(out):
+    b = k.split("<")[0]
+    if "<" in k and bases[b] == 1 and b not in out:
+        out[b] = dict(out[k], instantiation=k)
 json.dump({"note": "mean per launch; read = 2*FETCH_SIZE*1024 (gfx950 correction), write = WRITE_SIZE*1024",
            "kernels": out}, open(os.path.join(root, "profiles", f"{tag}_hbm_traffic.json"), "w"), indent=1)
 print("wrote", tag, len(out), "kernels")

@@ -71,6 +71,11 @@ SIGNATURES = {
     "eav_ast_fbank": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _d, _d, _f, _f, _p],
     "eav_decimate_fir_f64": [_p, _p, _p, _i, _i64, _i64, _i, _i, _i, _p],
     "eav_sosfilt_f64": [_p, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _i, _p],
+    "eav_absmax_scale": [_p, _i64, _f, _p, _p, _p],
+    "eav_eegnet_fir_fwd_split": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "eav_fir_dy_scale": [_p, _p, _i, _p, _p],
+    "eav_eegnet_dw_bwd_absmax": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
+    "eav_eegnet_fir_wgrad_split": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "eav_tconv_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "eav_tconv_wgrad": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "eav_spatial_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
@@ -102,6 +107,8 @@ PLAIN = {
     "eav_tconv_fwd_nparts": ([_i, _i, _i, _i, _i], _i),
     "eav_shallow_embed_nparts": ([_i, _i], _i),
     "eav_colstats_nparts": ([_i64], _i),
+    "eav_absmax_scale_nparts": ([_i64], _i),
+    "eav_eegnet_fir_wgrad_split_nparts": ([_i, _i, _i], _i),
     "eav_tconv_wgrad_nparts": ([_i, _i, _i, _i, _i], _i),
     "eav_spatial_nparts": ([_i, _i], _i),
     "eav_sepconv_fwd_nparts": ([_i, _i], _i),

@@ -63,6 +63,12 @@ class _Workspace:
         self.part_fw = f(self.np_fw, 8 * klen)
         self.np_cw = _lib.plain("eav_conv64_wgrad_nparts", B, T2)
         self.part_cw = f(self.np_cw, 64 * 1024)
+        # split-precision FIR (EEGNet_tor.fir_precision = "split"): power-of-two operand scales and their reductions
+        self.scale_x, self.scale_w, self.scale_dy = f(4), f(4), f(4)
+        self.part_amax = f(max(_lib.plain("eav_absmax_scale_nparts", B * C * S), 8))
+        self.part_gmax = f(B * nchunk, 8)
+        self.np_fws = _lib.plain("eav_eegnet_fir_wgrad_split_nparts", B, C, S)
+        self.part_fws = None       # allocated on first use of the split mode ([np_fws, 8*klen])
 
 
 class _EEGNetFn(torch.autograd.Function):
@@ -115,6 +121,10 @@ class EEGNet_tor(nn.Module):
         self._dropout_masks = None             # tests: (mask1 uint8 [B,64,S/4], mask2 uint8 [B,64,S/32])
         self.apply_max_norm = True
         self.kernel_events = None              # bench: {kernel name: [(start_event, end_event), ...]}
+        # "fp32": exact-fp32 MFMA FIR kernels (default).  "split": the two FIR products on the fp16 matrix cores with
+        # two-piece operands and fp32 accumulation (csrc/eegnet_fir_split.hip) - measured error against float64 below
+        # the fp32 kernels', ~2.5x faster; opt-in because its arithmetic is not a plain fp32 fma chain
+        self.fir_precision = "fp32"
         self._fwd_counter = None               # device uint64: number of training forwards (dropout stream)
 
     # ------------------------------------------------------------------ plumbing
@@ -193,7 +203,16 @@ class EEGNet_tor(nn.Module):
             if training:
                 bn.num_batches_tracked += 1
 
-        L("eav_eegnet_fir_fwd", P(x), w1, P(ws.y1), P(ws.part_fir), B, C, S, K, st)
+        if self.fir_precision not in ("fp32", "split"):
+            raise ValueError(f"fir_precision {self.fir_precision!r}: expected 'fp32' or 'split'")
+        split = self.fir_precision == "split"
+        if split:
+            L("eav_absmax_scale", P(x), B * C * S, 1.0, P(ws.part_amax), P(ws.scale_x), st)
+            L("eav_absmax_scale", w1, 8 * K, 1.0, P(ws.part_amax), P(ws.scale_w), st)
+            L("eav_eegnet_fir_fwd_split", P(x), w1, P(ws.scale_x), P(ws.scale_w), P(ws.y1), P(ws.part_fir), B, C, S, K,
+              st)
+        else:
+            L("eav_eegnet_fir_fwd", P(x), w1, P(ws.y1), P(ws.part_fir), B, C, S, K, st)
         bnfin(ws.part_fir, ws.np_fir, 8, B * C * S, g1w, g1b, bn1, ws.bn1)
         L("eav_eegnet_dw_fwd", P(ws.y1), P(ws.bn1), w2, P(ws.z), P(ws.part_dw), B, C, S, st)
         bnfin(ws.part_dw, B * ws.nchunk, 64, B * S, g2w, g2b, bn2, ws.bn2)
@@ -206,7 +225,7 @@ class EEGNet_tor(nn.Module):
         if self.apply_max_norm:  # the forward hooks of the reference (:33-34, :47-48), intended meaning
             L("eav_renorm_rows", w2, 64, C, self.norm_rate, st)
             L("eav_renorm_rows", wd, nb, ws.NF, self.norm_rate, st)
-        self._saved = (self._token, x, training, drop, seed1, seed2, masks, cnt)
+        self._saved = (self._token, x, training, drop, seed1, seed2, masks, cnt, split)
         return self._token
 
     def _launch_backward(self, dprobs, token):
@@ -214,7 +233,7 @@ class EEGNet_tor(nn.Module):
             raise _lib.EavError("EEGNet_tor.backward: the activations of this forward were overwritten by a later "
                                 "forward (one outstanding forward per backward)")
         L, P, st = self._call, _lib.ptr, _lib.stream_ptr()
-        _, x, training, drop, seed1, seed2, masks, cnt = self._saved
+        _, x, training, drop, seed1, seed2, masks, cnt, split = self._saved
         ws = self._ws
         B, C, S, K, nb = x.shape[0], self.Chans, self.Samples, self.kernLength, self.nb_classes
         T2, NF = ws.T2, ws.NF
@@ -247,13 +266,22 @@ class EEGNet_tor(nn.Module):
           cnt, st)
         # depthwiseConv <- ELU <- firstBN (uses the post-renorm depthwise weight, Q2)
         b1 = P(ws.bn1)
-        L("eav_eegnet_dw_bwd", P(ws.y1), P(ws.dz), b1, w2, P(ws.g1), P(ws.part_dst), P(ws.part_dw2), B, C, S, st)
+        L("eav_eegnet_dw_bwd_absmax", P(ws.y1), P(ws.dz), b1, w2, P(ws.g1), P(ws.part_dst), P(ws.part_dw2),
+          P(ws.part_gmax) if split else None, B, C, S, st)
         L("eav_reduce_partials", P(ws.part_dw2), B * ws.nchunk, 64 * C, 64 * C, 1.0, P(g["depthwiseConv.weight"]), st)
         L("eav_bn_bwd_finalize", P(ws.part_dst), B * ws.nchunk, 8, float(B * C * S), tr, P(g["firstBN.weight"]),
           P(g["firstBN.bias"]), b1 + 4 * 32, b1 + 4 * 40, st)
         # firstConv weight gradient (BN backward folded into the operand staging)
-        L("eav_eegnet_fir_wgrad", P(x), P(ws.y1), P(ws.g1), b1, P(ws.part_fw), B, C, S, K, st)
-        L("eav_reduce_partials", P(ws.part_fw), ws.np_fw, 8 * K, 8 * K, 1.0, P(g["firstConv.weight"]), st)
+        if split:
+            if ws.part_fws is None:
+                ws.part_fws = torch.empty(ws.np_fws, 8 * K, dtype=torch.float32, device=x.device)
+            L("eav_fir_dy_scale", b1, P(ws.part_gmax), ws.part_gmax.numel(), P(ws.scale_dy), st)
+            L("eav_eegnet_fir_wgrad_split", P(x), P(ws.y1), P(ws.g1), b1, P(ws.scale_x), P(ws.scale_dy),
+              P(ws.part_fws), B, C, S, K, st)
+            L("eav_reduce_partials", P(ws.part_fws), ws.np_fws, 8 * K, 8 * K, 1.0, P(g["firstConv.weight"]), st)
+        else:
+            L("eav_eegnet_fir_wgrad", P(x), P(ws.y1), P(ws.g1), b1, P(ws.part_fw), B, C, S, K, st)
+            L("eav_reduce_partials", P(ws.part_fw), ws.np_fw, 8 * K, 8 * K, 1.0, P(g["firstConv.weight"]), st)
         named = dict(self.named_parameters())
         return [g[k].view(named[k].shape) if named[k].requires_grad else None for k in _PARAM_ORDER]
 

@@ -51,6 +51,20 @@ int eav_eegnet_fir_fwd(const float* x, const float* w1, float* y1, float* stat_p
 int eav_eegnet_fir_wgrad_nparts(int B, int C, int S);
 int eav_eegnet_fir_wgrad(const float* x, const float* y1, const float* g1, const float* bn_params, float* part,
                          int B, int C, int S, int klen, void* stream);
+/* Opt-in fp32-grade fast path of the same two products on the fp16 matrix cores with split operands
+ * (v = hi + 2^-11 lo, three MFMAs per product, fp32 accumulate; csrc/eegnet_fir_split.hip).  scale_x / scale_w: device
+ * float[3] = {sigma, 1/sigma, max|v|} from eav_absmax_scale (power-of-two pre-scales keeping the pieces in fp16 range). */
+int eav_absmax_scale_nparts(int64_t n);
+int eav_absmax_scale(const float* v, int64_t n, float extra, float* part, float* scale, void* stream);
+int eav_eegnet_fir_fwd_split(const float* x, const float* w1, const float* scale_x, const float* scale_w, float* y1,
+                             float* stat_part, int B, int C, int S, int klen, void* stream);
+/* scale for dy = scale_f (g - m1_f - xhat m2_f) from the BatchNorm parameters and per-block maxima of |g1|
+ * (eav_eegnet_dw_bwd_absmax's absmax_part, [B*ceil(S/1024)][8]); out float[3] = {sigma, 1/sigma, bound}. */
+int eav_fir_dy_scale(const float* bn_params, const float* gmax_part, int nparts, float* out, void* stream);
+int eav_eegnet_fir_wgrad_split_nparts(int B, int C, int S);
+int eav_eegnet_fir_wgrad_split(const float* x, const float* y1, const float* g1, const float* bn_params,
+                               const float* scale_x, const float* scale_dy, float* part, int B, int C, int S, int klen,
+                               void* stream);
 /* firstBN -> ELU -> depthwiseConv (EEGNet_tor.py:52-54): y1 -> z [B,64,S];
  * stat_part [B*ceil(S/1024)][128]. */
 int eav_eegnet_dw_fwd(const float* y1, const float* bn1, const float* w2, float* z, float* stat_part, int B, int C,
@@ -59,6 +73,9 @@ int eav_eegnet_dw_fwd(const float* y1, const float* bn1, const float* w2, float*
  * w_part [B*ceil(S/1024)][64*C]. */
 int eav_eegnet_dw_bwd(const float* y1, const float* dz, const float* bn1, const float* w2, float* g1,
                       float* stat_part, float* w_part, int B, int C, int S, void* stream);
+/* same, also writing absmax_part [B*ceil(S/1024)][8] = max |g1| per block (may be NULL). */
+int eav_eegnet_dw_bwd_absmax(const float* y1, const float* dz, const float* bn1, const float* w2, float* g1,
+                             float* stat_part, float* w_part, float* absmax_part, int B, int C, int S, void* stream);
 
 /* ---- BN -> ELU -> AvgPool(1,P) -> Dropout (EEGNet_tor.py:55-58, 60-63), P in {4,8} -------- */
 /* bn = mean, invstd, scale, shift (CH each).  mask: optional uint8 keep-mask [B,CH,T/P]

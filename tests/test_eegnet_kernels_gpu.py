@@ -337,3 +337,77 @@ def test_gather_rows(L):
     for arr in (x, x4):
         d, t = gather_batch(dev(arr), dev(y), idx)
         assert torch.equal(d.cpu(), torch.from_numpy(arr)[idx.cpu()]) and torch.equal(t.cpu(), torch.from_numpy(y)[idx.cpu()])
+
+
+# ----------------------------------------------------------------------------- split-precision FIR (opt-in fast path)
+def _f64_fir(x, w, K):
+    xd = x.double().reshape(-1, 1, x.shape[-1])
+    padl = (K - 1) // 2
+    y = torch.nn.functional.conv1d(torch.nn.functional.pad(xd, (padl, K - 1 - padl)), w.double().reshape(8, 1, K))
+    return y.reshape(x.shape[0], x.shape[1], 8, x.shape[2]).permute(0, 2, 1, 3)
+
+
+@pytest.mark.parametrize("B,C,S,K,amp", [(2, 30, 10000, 300, 1.0), (3, 7, 1001, 64, 1.0), (2, 5, 333, 130, 1.0),
+                                         (2, 30, 2000, 300, 3.0e4), (2, 30, 2000, 300, 2.0e-5)])
+def test_fir_fwd_split_is_fp32_grade(L, B, C, S, K, amp):
+    """eav_eegnet_fir_fwd_split against a float64 convolution: its error must not exceed the exact-fp32 MFMA kernel's
+    (plus one part in 1e7 of the output range), for unit-scale, very large and very small input amplitudes (the
+    power-of-two pre-scale keeps the fp16 pieces in range)."""
+    _lib = L
+    x = torch.from_numpy(synth.normal(11, (B, C, S))).cuda() * amp
+    w = torch.from_numpy(synth.uniform(12, (8, K), -0.06, 0.06)).cuda()
+    P, st = _lib.ptr, _lib.stream_ptr()
+    npart = _lib.plain("eav_eegnet_fir_fwd_nparts", B, C, S)
+    ya, yb = torch.empty(B, 8, C, S, device="cuda"), torch.empty(B, 8, C, S, device="cuda")
+    pa, pb = torch.zeros(npart, 16, device="cuda"), torch.zeros(npart, 16, device="cuda")
+    sx, sw, pp = torch.empty(4, device="cuda"), torch.empty(4, device="cuda"), torch.empty(1024, device="cuda")
+    _lib.call("eav_eegnet_fir_fwd", P(x), P(w), P(ya), P(pa), B, C, S, K, st)
+    _lib.call("eav_absmax_scale", P(x), x.numel(), 1.0, P(pp), P(sx), st)
+    _lib.call("eav_absmax_scale", P(w), w.numel(), 1.0, P(pp), P(sw), st)
+    _lib.call("eav_eegnet_fir_fwd_split", P(x), P(w), P(sx), P(sw), P(yb), P(pb), B, C, S, K, st)
+    torch.cuda.synchronize()
+    ref = _f64_fir(x.cpu(), w.cpu(), K)
+    ea = (ya.cpu().double() - ref).abs().max().item()
+    eb = (yb.cpu().double() - ref).abs().max().item()
+    rng = ref.abs().max().item()
+    assert eb <= 1.25 * ea + 1e-7 * rng, (ea, eb, rng)
+    # BatchNorm partial statistics of the two kernels agree
+    sa, sb = pa.double().sum(0).cpu(), pb.double().sum(0).cpu()
+    assert torch.allclose(sa, sb, rtol=1e-5, atol=1e-5 * float(sa.abs().max()))
+
+
+@pytest.mark.parametrize("B,C,S,K,gamp", [(4, 30, 10000, 300, 1e-4), (3, 7, 1001, 64, 1.0), (2, 5, 333, 130, 1e-9),
+                                          (2, 9, 777, 300, 50.0)])
+def test_fir_wgrad_split_is_fp32_grade(L, B, C, S, K, gamp):
+    _lib = L
+    x = torch.from_numpy(synth.normal(21, (B, C, S))).cuda()
+    y1 = torch.from_numpy(synth.normal(22, (B, 8, C, S))).cuda() * 0.7 + 0.1
+    g1 = torch.from_numpy(synth.normal(23, (B, 8, C, S))).cuda() * gamp
+    bn = torch.from_numpy(synth.uniform(24, (6, 8), 0.5, 1.5)).cuda().contiguous()
+    bn[4] *= 0.1 * gamp
+    bn[5] *= 0.1 * gamp
+    P, st = _lib.ptr, _lib.stream_ptr()
+    na = _lib.plain("eav_eegnet_fir_wgrad_nparts", B, C, S)
+    nb = _lib.plain("eav_eegnet_fir_wgrad_split_nparts", B, C, S)
+    pa, pb = torch.empty(na, 8 * K, device="cuda"), torch.empty(nb, 8 * K, device="cuda")
+    da, db = torch.empty(8, K, device="cuda"), torch.empty(8, K, device="cuda")
+    sx, sg, sdy = (torch.empty(4, device="cuda") for _ in range(3))
+    pp = torch.empty(1024, device="cuda")
+    _lib.call("eav_eegnet_fir_wgrad", P(x), P(y1), P(g1), P(bn), P(pa), B, C, S, K, st)
+    _lib.call("eav_reduce_partials", P(pa), na, 8 * K, 8 * K, 1.0, P(da), st)
+    _lib.call("eav_absmax_scale", P(x), x.numel(), 1.0, P(pp), P(sx), st)
+    _lib.call("eav_absmax_scale", P(g1), g1.numel(), 1.0, P(pp), P(sg), st)
+    _lib.call("eav_fir_dy_scale", P(bn), P(sg) + 8, 1, P(sdy), st)
+    _lib.call("eav_eegnet_fir_wgrad_split", P(x), P(y1), P(g1), P(bn), P(sx), P(sdy), P(pb), B, C, S, K, st)
+    _lib.call("eav_reduce_partials", P(pb), nb, 8 * K, 8 * K, 1.0, P(db), st)
+    torch.cuda.synchronize()
+    mean, invstd, sc, _, m1, m2 = (bn[i].double().view(1, 8, 1, 1) for i in range(6))
+    dy = sc * (g1.double() - m1 - (y1.double() - mean) * invstd * m2)
+    padl = (K - 1) // 2
+    xp = torch.nn.functional.pad(x.double(), (padl, K - 1 - padl))
+    ref = torch.zeros(8, K, dtype=torch.float64, device="cuda")
+    for b in range(B):
+        ref += torch.einsum("fcs,csk->fk", dy[b], xp[b].unfold(-1, K, 1))
+    ea, eb = (da.double() - ref).abs().max().item(), (db.double() - ref).abs().max().item()
+    rng = ref.abs().max().item()
+    assert eb <= 1.25 * ea + 1e-7 * rng, (ea, eb, rng)

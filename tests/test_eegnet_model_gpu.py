@@ -39,12 +39,16 @@ def build(S, sd, drop=0.0):
     return m.cuda()
 
 
+@pytest.mark.parametrize("fir_precision", ["fp32", "split"])
 @pytest.mark.parametrize("case", ["s500_train", "s500_eval", "s500_maxnorm", "s500_dropout"])
-def test_steps_match_reference_golden(golden_dir, case):
+def test_steps_match_reference_golden(golden_dir, case, fir_precision):
+    """fir_precision="split" (the FIR products on the fp16 matrix cores with two-piece operands) is held to exactly the
+    same bounds as the exact-fp32 kernels."""
     from eav_amd.optim import CrossEntropyLoss, FusedAdam
     g = np.load(os.path.join(golden_dir, f"eegnet_{case}.npz"))
     B, S, lr = int(g["B"]), int(g["S"]), float(g["lr"])
     model = build(S, eegnet_weights(int(g["wseed"]), S, scale=float(g["wscale"])), float(g["drop_p"]))
+    model.fir_precision = fir_precision
     model.train(bool(int(g["train_mode"])))
     crit, opt = CrossEntropyLoss(), FusedAdam(model.parameters(), lr=lr)
     for s in range(int(g["steps"])):
@@ -101,7 +105,8 @@ def test_s10000_matches_reference_golden_and_oracle(golden_dir):
         close(named[k].grad, ref, 1e-3, 1e-3 * np.abs(ref).max(), f"grad.{k}")
 
 
-def test_full_size_batch_against_oracle():
+@pytest.mark.parametrize("fir_precision", ["fp32", "split"])
+def test_full_size_batch_against_oracle(fir_precision):
     """BASELINE config 2 shape: B=64, [64,1,30,10000] fp32 - probabilities, loss and
     gradients against the CPU oracle (a few seconds of host time)."""
     from eav_amd.optim import CrossEntropyLoss
@@ -109,6 +114,7 @@ def test_full_size_batch_against_oracle():
     B, S = 64, 10000
     sd = eegnet_weights(31, S)
     model = build(S, sd)
+    model.fir_precision = fir_precision
     model.train()
     x, y = synth.eeg_batch(311, B, 30, S)
     scores = model(torch.from_numpy(x).cuda())
@@ -128,6 +134,7 @@ def test_full_size_batch_against_oracle():
     # determinism: the same step twice is bit-identical (no float atomics anywhere)
     g1 = {k: named[k].grad.clone() for k in PN}
     model2 = build(S, sd)
+    model2.fir_precision = fir_precision
     model2.train()
     s2 = model2(torch.from_numpy(x).cuda())
     CrossEntropyLoss()(s2, torch.from_numpy(y).cuda()).backward()

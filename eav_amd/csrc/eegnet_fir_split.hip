@@ -32,6 +32,12 @@ __device__ __forceinline__ void split2(float v, _Float16& hi, _Float16& lo) {
   lo = (_Float16)((v - (float)hi) * LO_SCALE);
 }
 
+__device__ __forceinline__ uint32_t pack2(_Float16 a, _Float16 b) {
+  union { _Float16 h[2]; uint32_t u; } v;
+  v.h[0] = a; v.h[1] = b;
+  return v.u;
+}
+
 // ------------------------------------------------------------------------------------------ scales
 // part[blk] = max |v| over the block's slice; then scale[0] = sigma = 2^(12 - ceil(log2 max)), scale[1] = 1/sigma.
 __global__ __launch_bounds__(256) void absmax_part_kernel(const float* __restrict__ v, int64_t n, float* __restrict__ part) {
@@ -123,8 +129,8 @@ __global__ __launch_bounds__(256, 2) void fir_fwd_split_kernel(const float* __re
   float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
   const bool vec = (S & 3) == 0;
   const int nwork = rows * nseg;
-  constexpr int NLD = (SEG + 255) / 256;
-  float xr[NLD];
+  constexpr int NLD = (SEG / 2 + 255) / 256;          // sample PAIRS per thread (packed 4-byte LDS stores)
+  float2 xr[NLD];
   auto fetch = [&](int work) {
     const int row = work / nseg, seg = work - row * nseg;
     const int tile0 = seg * TPS;
@@ -134,9 +140,10 @@ __global__ __launch_bounds__(256, 2) void fir_fwd_split_kernel(const float* __re
     const int nload = nt * TILE + HALO;
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-      const int idx = threadIdx.x + 256 * i;
+      const int idx = 2 * (threadIdx.x + 256 * i);
       const int t = useg0 + idx - padl;
-      xr[i] = (idx < nload && t >= 0 && t < S) ? xrow[t] : 0.f;
+      xr[i].x = (idx < nload && t >= 0 && t < S) ? xrow[t] : 0.f;
+      xr[i].y = (idx + 1 < nload && t + 1 >= 0 && t + 1 < S) ? xrow[t + 1] : 0.f;
     }
   };
   if ((int)blockIdx.x < nwork) fetch(blockIdx.x);
@@ -147,12 +154,13 @@ __global__ __launch_bounds__(256, 2) void fir_fwd_split_kernel(const float* __re
     const int useg0 = tile0 * TILE;
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-      const int idx = threadIdx.x + 256 * i;
+      const int idx = 2 * (threadIdx.x + 256 * i);
       if (idx < SEG) {
-        _Float16 hi, lo;
-        split2(sigx * xr[i], hi, lo);
-        xh[idx] = hi;
-        xl[idx] = lo;
+        _Float16 h0, l0, h1, l1;
+        split2(sigx * xr[i].x, h0, l0);
+        split2(sigx * xr[i].y, h1, l1);
+        *reinterpret_cast<uint32_t*>(&xh[idx]) = pack2(h0, h1);
+        *reinterpret_cast<uint32_t*>(&xl[idx]) = pack2(l0, l1);
       }
     }
     __syncthreads();
@@ -229,11 +237,6 @@ __device__ __forceinline__ h8 as_h8(uint32_t a, uint32_t b, uint32_t c, uint32_t
   union { uint32_t u[4]; h8 h; } v;
   v.u[0] = a; v.u[1] = b; v.u[2] = c; v.u[3] = d;
   return v.h;
-}
-__device__ __forceinline__ uint32_t pack2(_Float16 a, _Float16 b) {
-  union { _Float16 h[2]; uint32_t u; } v;
-  v.h[0] = a; v.h[1] = b;
-  return v.u;
 }
 
 template <int NT>

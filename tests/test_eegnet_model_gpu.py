@@ -220,7 +220,8 @@ def test_ragged_shapes_against_oracle(B, C, S, K, train_mode):
 
 
 @pytest.mark.parametrize("drop", [0.0, 0.5])
-def test_graph_replay_equals_eager(drop):
+@pytest.mark.parametrize("fir_precision", ["fp32", "split"])
+def test_graph_replay_equals_eager(drop, fir_precision):
     """hipGraph replay of the whole training step == the eager schedule, bit for bit: parameters, BN running
     statistics and the dropout stream (device-resident counters) after 6 steps on changing batches."""
     from eav_amd.eegnet import EEGNet_tor, GraphStep
@@ -233,6 +234,7 @@ def test_graph_replay_equals_eager(drop):
     finals = []
     for use_graph in (False, True):
         m = build(S, sd, drop).train()
+        m.fir_precision = fir_precision      # the split mode's operand scales are device-resident: capturable too
         opt, crit = FusedAdam(m.parameters(), lr=1e-3, capturable=True), CrossEntropyLoss()
         losses = []
         if use_graph:
@@ -256,7 +258,8 @@ def test_graph_replay_equals_eager(drop):
     assert len(set(finals[0][0])) == len(finals[0][0])       # the batches (and masks) really changed
 
 
-def test_forty_step_trajectory_stays_within_tolerance():
+@pytest.mark.parametrize("fir_precision", ["fp32", "split"])
+def test_forty_step_trajectory_stays_within_tolerance(fir_precision):
     """40 optimiser steps (20 in train mode, 20 in eval mode as the reference does from epoch 2, Q4) on changing
     batches: the HIP trajectory and the CPU oracle's stay within north_star's 1e-3 on the model output, and make
     the same predictions ("5-class acc parity")."""
@@ -266,6 +269,7 @@ def test_forty_step_trajectory_stays_within_tolerance():
     sd = eegnet_weights(77, S)
     x, y = synth.eeg_batch(770, n, 30, S)
     model = build(S, sd, 0.0).train()
+    model.fir_precision = fir_precision
     opt, crit = FusedAdam(model.parameters(), lr=1e-3), CrossEntropyLoss()
     P = {k: torch.from_numpy(sd[k].copy()) for k in orc.PARAM_NAMES}
     Bf = {k: torch.from_numpy(sd[k].copy()) for k in orc.BUFFER_NAMES}

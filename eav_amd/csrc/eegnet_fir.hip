@@ -142,8 +142,8 @@ __global__ __launch_bounds__(256, 2) void fir_fwd_kernel(const float* __restrict
 // into registers before its MFMA phase, and keeps its 16x160 accumulator tile in registers for its whole
 // work list.  Waves of a CU drift apart, so one wave's staging overlaps the others' matrix work.
 // WG_NT column tiles of 16 -> lags k = 2n+s, n < 16*WG_NT: 10 tiles for the reference's 300 taps, 2 / 4 for <= 64 / 128.
-constexpr int WG_CW = 252;                // max u-samples per wave item (63 K-steps of 4)
-constexpr int WG_QS = WG_CW + 8;          // dy row stride: 260 == 4 (mod 32), rows 16-B aligned
+constexpr int WG_CW = 248;                // max u-samples per wave item (62 K-steps of 4; an even number of K-steps)
+constexpr int WG_QS = 260;                // dy row stride: 260 == 4 (mod 32), rows 16-B aligned; >= WG_CW + 4 + 8
 
 template <int WG_NT>
 __global__ __launch_bounds__(256, 3) void fir_wgrad_kernel(
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256, 3) void fir_wgrad_kernel(
     const float* __restrict__ bnp /* mean, invstd, scale, shift, m1, m2 (8 each) */, float* __restrict__ part, int rows,
     int C, int S, int klen, int padl, int nchunk, int CH) {
   constexpr int LAGS = 32 * WG_NT;                    // lags covered (>= klen)
-  constexpr int WG_XW = WG_CW + 4 + LAGS;             // x window per item
+  constexpr int WG_XW = WG_CW + 8 + LAGS;             // x window per item (incl. the look-ahead K-step)
   constexpr int WG_WAVE_LDS = F1 * WG_QS + WG_XW;     // floats per wave
   constexpr int RED = F1 * LAGS > 4 * WG_WAVE_LDS ? F1 * LAGS : 4 * WG_WAVE_LDS;
   __shared__ __attribute__((aligned(16))) float lds[RED];
@@ -240,27 +240,39 @@ __global__ __launch_bounds__(256, 3) void fir_wgrad_kernel(
     if (work + nwaves < nwork) fetch(work + nwaves);
     // software pipeline, two register sets: the 11 operands of the next K-step are read while the
     // 10 MFMAs of the current one run; sched_barrier pins loads-before-MFMAs.
+    // ksteps is even (wgrad_geometry): the body is straight-line - a mid-loop exit makes the compiler's wait-count
+    // pass fall back to lgkmcnt(0) at the loop head, which waits for the operands just requested for the NEXT step
+    // as well.  The last iteration's look-ahead reads one K-step past the chunk (inside the wave's LDS image, unused).
+    // Two operand sets, read one K-step ahead.  `landed()` (an empty asm that consumes the registers) makes the
+    // compiler place the LDS wait for a set right AFTER the ten MFMAs of the other set have been issued - 320 cycles
+    // after the reads went out - instead of in front of the MFMAs that follow the next set's reads, where its
+    // conservative loop-carried lgkmcnt(0) would also wait for the reads just requested.
     float av0 = ap[0], bv0[WG_NT], av1, bv1[WG_NT];
 #pragma unroll
     for (int nt = 0; nt < WG_NT; ++nt) bv0[nt] = bp[32 * nt];
-    for (int ks = 0; ks < ksteps; ks += 2) {
-      const int k1 = (ks + 1 < ksteps) ? ks + 1 : ks;
-      av1 = ap[4 * k1];
+    auto landed = [](float& a, float (&b)[WG_NT]) {
+      asm volatile("" : "+v"(a));
 #pragma unroll
-      for (int nt = 0; nt < WG_NT; ++nt) bv1[nt] = bp[4 * k1 + 32 * nt];
+      for (int nt = 0; nt < WG_NT; ++nt) asm volatile("" : "+v"(b[nt]));
+    };
+    landed(av0, bv0);
+    for (int ks = 0; ks < ksteps; ks += 2) {
+      av1 = ap[4 * (ks + 1)];
+#pragma unroll
+      for (int nt = 0; nt < WG_NT; ++nt) bv1[nt] = bp[4 * (ks + 1) + 32 * nt];
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int nt = 0; nt < WG_NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0, bv0[nt], acc[nt], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      if (ks + 1 >= ksteps) break;
-      const int k2 = (ks + 2 < ksteps) ? ks + 2 : ks + 1;
-      av0 = ap[4 * k2];
+      landed(av1, bv1);
+      av0 = ap[4 * (ks + 2)];
 #pragma unroll
-      for (int nt = 0; nt < WG_NT; ++nt) bv0[nt] = bp[4 * k2 + 32 * nt];
+      for (int nt = 0; nt < WG_NT; ++nt) bv0[nt] = bp[4 * (ks + 2) + 32 * nt];
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int nt = 0; nt < WG_NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1, bv1[nt], acc[nt], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
+      landed(av0, bv0);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // all reads of this image retired before it is overwritten
     __builtin_amdgcn_wave_barrier();
@@ -320,7 +332,7 @@ extern "C" int eav_eegnet_fir_fwd(const float* x, const float* w1, float* y1, fl
 
 static void wgrad_geometry(int S, int* nchunk, int* CH) {
   int n = cdiv(S + 1, WG_CW);
-  int ch = cdiv(cdiv(S + 1, n), 4) * 4;      // <= 252, multiple of 4
+  int ch = cdiv(cdiv(S + 1, n), 8) * 8;      // <= 248, multiple of 8: an even number of K-steps
   *nchunk = n;
   *CH = ch;
 }

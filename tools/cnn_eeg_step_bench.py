@@ -1,9 +1,13 @@
 """Eager step time of the canonical EEGNet (eav_amd/cnn_eeg.py) at three shapes; argv[1] selects one (for rocprofv3)."""
-import time, torch, numpy as np, sys
 import os
+import sys
+import time
+
+import torch
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from eav_amd.cnn_eeg import EEGNet
-from eav_amd.optim import CrossEntropyLoss, FusedAdam
+from eav_amd.cnn_eeg import EEGNet  # noqa: E402
+from eav_amd.optim import CrossEntropyLoss, FusedAdam  # noqa: E402
 SHAPES = [(64, 30, 10000, 64), (32, 30, 500, 64), (32, 64, 128, 64)]
 if len(sys.argv) > 1:
     SHAPES = [SHAPES[int(sys.argv[1])]]

@@ -3,7 +3,6 @@ float64 reference (torch CPU conv in double precision on a sample of rows)."""
 import os
 import sys
 
-import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -8,7 +8,6 @@ from contextlib import redirect_stdout
 
 import numpy as np
 import pytest
-import torch
 
 from eav_amd import synth
 from tests.golden_util import tf_weights

@@ -27,7 +27,10 @@ constexpr int TILE = 128;   // samples per MFMA tile
 constexpr int TPS = 16;     // tiles per LDS segment
 constexpr float LO_SCALE = 2048.f, LO_INV = 1.f / 2048.f;
 
+// The scales put every tensor's maximum at <= 2^12; the clamp only matters for a dy outlier beyond the 16-sigma bound
+// eav_fir_dy_scale assumes for the normalised activations (it then saturates instead of turning into inf/NaN).
 __device__ __forceinline__ void split2(float v, _Float16& hi, _Float16& lo) {
+  v = __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
   hi = (_Float16)v;
   lo = (_Float16)((v - (float)hi) * LO_SCALE);
 }

@@ -71,10 +71,13 @@ SIGNATURES = {
     "eav_ast_fbank": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _d, _d, _f, _f, _p],
     "eav_decimate_fir_f64": [_p, _p, _p, _i, _i64, _i64, _i, _i, _i, _p],
     "eav_sosfilt_f64": [_p, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _i, _p],
+    "eav_conv64_fwd_split": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     "eav_absmax_scale": [_p, _i64, _f, _p, _p, _p],
     "eav_eegnet_fir_fwd_split": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
-    "eav_fir_dy_scale": [_p, _p, _i, _p, _p],
-    "eav_eegnet_dw_bwd_absmax": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
+    "eav_fir_dy_scale": [_p, _p, _i, _p, _i, _p, _p],
+    "eav_absmax_finish": [_p, _i, _f, _p, _p],
+    "eav_bn_elu_pool_fwd_absmax": [_p, _p, _p, _p, _i, _i, _i, _i, _f, _u64, _p, _p, _p],
+    "eav_bn_elu_pool_bwd_apply_absmax": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _u64, _p, _p, _p],
     "eav_eegnet_fir_wgrad_split": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "eav_tconv_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "eav_tconv_wgrad": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],

@@ -42,24 +42,34 @@ __device__ __forceinline__ uint32_t pack2(_Float16 a, _Float16 b) {
 }
 
 // ------------------------------------------------------------------------------------------ scales
-// part[blk] = max |v| over the block's slice; then scale[0] = sigma = 2^(12 - ceil(log2 max)), scale[1] = 1/sigma.
-__global__ __launch_bounds__(256) void absmax_part_kernel(const float* __restrict__ v, int64_t n, float* __restrict__ part) {
+// One launch: every block writes max |v| of its slice to part[1 + blk]; the block that finishes last (device counter
+// at part[0], left at zero again for the next call) reduces the partials and writes
+// scale[0] = sigma = 2^(12 - ceil(log2 max)), scale[1] = 1/sigma, scale[2] = max.
+__global__ __launch_bounds__(256) void absmax_scale_kernel(const float* __restrict__ v, int64_t n, float extra,
+                                                           float* __restrict__ part, float* __restrict__ scale) {
   __shared__ float red[4];
+  __shared__ bool last;
+  const int nparts = gridDim.x;
   float m = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(v[i]));
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
   __syncthreads();
-  if (threadIdx.x == 0) part[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-}
-__global__ __launch_bounds__(256) void absmax_final_kernel(const float* __restrict__ part, int nparts, float extra,
-                                                           float* __restrict__ scale) {
-  __shared__ float red[4];
-  float m = 0.f;
-  for (int i = threadIdx.x; i < nparts; i += 256) m = fmaxf(m, part[i]);
+  if (threadIdx.x == 0) {
+    part[1 + blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __threadfence();
+    unsigned* counter = reinterpret_cast<unsigned*>(part);
+    last = atomicAdd(counter, 1u) == (unsigned)nparts - 1u;
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  m = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += 256) m = fmaxf(m, __builtin_nontemporal_load(part + 1 + i));
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  __syncthreads();
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -70,30 +80,59 @@ __global__ __launch_bounds__(256) void absmax_final_kernel(const float* __restri
     scale[0] = s;
     scale[1] = 1.f / s;
     scale[2] = m;
+    *reinterpret_cast<unsigned*>(part) = 0u;
   }
 }
 
-// sigma for dy = scale_f * (g - m1_f - xhat * m2_f): bound |dy| <= |scale_f| (max|g| + |m1_f| + 16 |m2_f|)
-// (|xhat| of a batch-normalised tensor stays far below 16; four more binades of fp16 headroom remain above 2^12)
-__global__ __launch_bounds__(256) void dy_scale_kernel(const float* __restrict__ bnp, const float* __restrict__ gpart,
-                                                       int nparts, float* __restrict__ out) {
-  __shared__ float red[4];
-  float gmax = 0.f;
-  for (int i = threadIdx.x; i < nparts; i += 256) gmax = fmaxf(gmax, gpart[i]);
+__device__ __forceinline__ float block_max_256(float m, float* red) {
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, o, 64));
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = gmax;
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
   __syncthreads();
-  if (threadIdx.x != 0) return;
-  gmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-  float m = 0.f;
-  for (int f = 0; f < F1; ++f) m = fmaxf(m, fabsf(bnp[16 + f]) * (gmax + fabsf(bnp[32 + f]) + 16.f * fabsf(bnp[40 + f])));
+  return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+__device__ __forceinline__ void write_scale(float m, float* __restrict__ out) {
   int e = 0;
   if (m > 0.f && isfinite(m)) frexpf(m, &e);
   const float s = ldexpf(1.f, 12 - e);
   out[0] = s;
   out[1] = 1.f / s;
   out[2] = m;
+}
+// scale from per-block maxima emitted by the producing kernel (no extra pass over the tensor)
+__global__ __launch_bounds__(256) void absmax_finish_kernel(const float* __restrict__ part, int nparts, float extra,
+                                                            float* __restrict__ out) {
+  __shared__ float red[4];
+  float m = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += 256) m = fmaxf(m, part[i]);
+  m = block_max_256(m, red);
+  if (threadIdx.x == 0) write_scale(m * extra, out);
+}
+// sigma for dy = scale_f * (g - m1_f - xhat * m2_f) where g = ELU'(.) * sum_d w2[f*8+d, c] * dz[f*8+d, t]:
+//   |g| <= max_c sum_d |w2[f*8+d, c]| * max|dz|     (ELU' <= 1),     |xhat| <= 16 assumed (saturating clamp beyond)
+__global__ __launch_bounds__(256) void dy_scale_kernel(const float* __restrict__ bnp, const float* __restrict__ dzpart,
+                                                       int nparts, const float* __restrict__ w2, int C,
+                                                       float* __restrict__ out) {
+  __shared__ float red[4];
+  __shared__ float wn[F1];
+  float dzmax = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += 256) dzmax = fmaxf(dzmax, dzpart[i]);
+  dzmax = block_max_256(dzmax, red);
+  if (threadIdx.x < F1) {
+    float m = 0.f;
+    for (int c = 0; c < C; ++c) {
+      float s = 0.f;
+      for (int d = 0; d < 8; ++d) s += fabsf(w2[(threadIdx.x * 8 + d) * C + c]);
+      m = fmaxf(m, s);
+    }
+    wn[threadIdx.x] = m;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  float m = 0.f;
+  for (int f = 0; f < F1; ++f)
+    m = fmaxf(m, fabsf(bnp[16 + f]) * (wn[f] * dzmax + fabsf(bnp[32 + f]) + 16.f * fabsf(bnp[40 + f])));
+  write_scale(m, out);
 }
 
 // ------------------------------------------------------------------------------------------ fwd
@@ -433,18 +472,20 @@ __global__ __launch_bounds__(128, 3) void fir_wgrad_split_kernel(
 
 static int fir_grid(int nwork) { return nwork < 512 ? nwork : 512; }
 
-extern "C" int eav_absmax_scale_nparts(int64_t n) {
+// floats the caller provides in `part` (zero-initialised ONCE; part[0] is the kernel's self-resetting counter)
+static int absmax_blocks(int64_t n) {
   int64_t b = (n + 256 * 16 - 1) / (256 * 16);
   return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
 }
+extern "C" int eav_absmax_scale_nparts(int64_t n) { return absmax_blocks(n) + 1; }
 
 // scale[0] = sigma (power of two with |sigma v| <= 2^12 for every element, allowing for the factor `extra` >= 1 the
-// caller expects on top of the tensor's own maximum), scale[1] = 1 / sigma.  part: eav_absmax_scale_nparts(n) floats.
+// caller expects on top of the tensor's own maximum), scale[1] = 1 / sigma, scale[2] = max.  part:
+// eav_absmax_scale_nparts(n) floats, ZERO-INITIALISED once by the caller (part[0] is a self-resetting counter).
 extern "C" int eav_absmax_scale(const float* v, int64_t n, float extra, float* part, float* scale, void* stream) {
   EAV_REQUIRE(v && part && scale && n > 0 && extra >= 1.f, "eav_absmax_scale: bad arguments");
-  const int nb = eav_absmax_scale_nparts(n);
-  hipLaunchKernelGGL(absmax_part_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, v, n, part);
-  hipLaunchKernelGGL(absmax_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, part, nb, extra, scale);
+  hipLaunchKernelGGL(absmax_scale_kernel, dim3(absmax_blocks(n)), dim3(256), 0, (hipStream_t)stream, v, n, extra, part,
+                     scale);
   EAV_CHECK_LAUNCH("eav_absmax_scale");
   return EAV_OK;
 }
@@ -467,9 +508,18 @@ extern "C" int eav_eegnet_fir_fwd_split(const float* x, const float* w1, const f
   return EAV_OK;
 }
 
-extern "C" int eav_fir_dy_scale(const float* bn_params, const float* gmax_part, int nparts, float* out, void* stream) {
-  EAV_REQUIRE(bn_params && gmax_part && nparts > 0 && out, "eav_fir_dy_scale: bad arguments");
-  hipLaunchKernelGGL(dy_scale_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, bn_params, gmax_part, nparts, out);
+extern "C" int eav_absmax_finish(const float* part, int nparts, float extra, float* scale, void* stream) {
+  EAV_REQUIRE(part && nparts > 0 && extra >= 1.f && scale, "eav_absmax_finish: bad arguments");
+  hipLaunchKernelGGL(absmax_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, part, nparts, extra, scale);
+  EAV_CHECK_LAUNCH("eav_absmax_finish");
+  return EAV_OK;
+}
+
+extern "C" int eav_fir_dy_scale(const float* bn_params, const float* dzmax_part, int nparts, const float* w2, int C,
+                                float* out, void* stream) {
+  EAV_REQUIRE(bn_params && dzmax_part && nparts > 0 && w2 && C > 0 && out, "eav_fir_dy_scale: bad arguments");
+  hipLaunchKernelGGL(dy_scale_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, bn_params, dzmax_part, nparts, w2, C,
+                     out);
   EAV_CHECK_LAUNCH("eav_fir_dy_scale");
   return EAV_OK;
 }

@@ -65,8 +65,9 @@ class _Workspace:
         self.part_cw = f(self.np_cw, 64 * 1024)
         # split-precision FIR (EEGNet_tor.fir_precision = "split"): power-of-two operand scales and their reductions
         self.scale_x, self.scale_w, self.scale_dy = f(4), f(4), f(4)
-        self.part_amax = f(max(_lib.plain("eav_absmax_scale_nparts", B * C * S), 8))
-        self.part_gmax = f(B * nchunk, 8)
+        self.scale_p2, self.scale_w3, self.scale_du3 = f(4), f(4), f(4)
+        self.part_amax = torch.zeros(1032, dtype=torch.float32, device=dev)   # [0] = the kernel's self-resetting counter
+        self.rowmax_p2, self.rowmax_du3, self.rowmax_dz = f(B * 64), f(B * 64), f(B * 64)   # maxima emitted by producers
         self.np_fws = _lib.plain("eav_eegnet_fir_wgrad_split_nparts", B, C, S)
         self.part_fws = None       # allocated on first use of the split mode ([np_fws, 8*klen])
 
@@ -121,9 +122,10 @@ class EEGNet_tor(nn.Module):
         self._dropout_masks = None             # tests: (mask1 uint8 [B,64,S/4], mask2 uint8 [B,64,S/32])
         self.apply_max_norm = True
         self.kernel_events = None              # bench: {kernel name: [(start_event, end_event), ...]}
-        # "fp32": exact-fp32 MFMA FIR kernels (default).  "split": the two FIR products on the fp16 matrix cores with
-        # two-piece operands and fp32 accumulation (csrc/eegnet_fir_split.hip) - measured error against float64 below
-        # the fp32 kernels', ~2.5x faster; opt-in because its arithmetic is not a plain fp32 fma chain
+        # "fp32": exact-fp32 MFMA kernels (default).  "split": the FIR products and the separableConv forward / data
+        # gradient on the fp16 matrix cores with two-piece operands and fp32 accumulation (csrc/eegnet_fir_split.hip,
+        # eegnet_conv64_split.hip) - measured error against float64 below the fp32 kernels', 2-3x faster kernels;
+        # opt-in because its arithmetic is not a plain fp32 fma chain
         self.fir_precision = "fp32"
         self._fwd_counter = None               # device uint64: number of training forwards (dropout stream)
 
@@ -216,9 +218,16 @@ class EEGNet_tor(nn.Module):
         bnfin(ws.part_fir, ws.np_fir, 8, B * C * S, g1w, g1b, bn1, ws.bn1)
         L("eav_eegnet_dw_fwd", P(ws.y1), P(ws.bn1), w2, P(ws.z), P(ws.part_dw), B, C, S, st)
         bnfin(ws.part_dw, B * ws.nchunk, 64, B * S, g2w, g2b, bn2, ws.bn2)
-        L("eav_bn_elu_pool_fwd", P(ws.z), P(ws.bn2), P(ws.p2), B, 64, S, 4, drop, seed1, m1, cnt, st)
+        L("eav_bn_elu_pool_fwd_absmax", P(ws.z), P(ws.bn2), P(ws.p2), P(ws.rowmax_p2) if split else None, B, 64, S, 4,
+          drop, seed1, m1, cnt, st)
         L("eav_conv64_prep_weights", w3, P(ws.wTf), P(ws.wTb), st)
-        L("eav_conv64_fwd", P(ws.p2), P(ws.wTf), P(ws.u3), P(ws.part_c3), B, ws.T2, 7, st)
+        if split:
+            L("eav_absmax_finish", P(ws.rowmax_p2), B * 64, 1.0, P(ws.scale_p2), st)
+            L("eav_absmax_scale", w3, 64 * 1024, 1.0, P(ws.part_amax), P(ws.scale_w3), st)
+            L("eav_conv64_fwd_split", P(ws.p2), P(ws.wTf), P(ws.scale_p2), P(ws.scale_w3), P(ws.u3), P(ws.part_c3), B,
+              ws.T2, 7, st)
+        else:
+            L("eav_conv64_fwd", P(ws.p2), P(ws.wTf), P(ws.u3), P(ws.part_c3), B, ws.T2, 7, st)
         bnfin(ws.part_c3, ws.np_c3, 64, B * ws.T2, g3w, g3b, bn3, ws.bn3)
         L("eav_bn_elu_pool_fwd", P(ws.u3), P(ws.bn3), P(ws.p3), B, 64, ws.T2, 8, drop, seed2, m2, cnt, st)
         L("eav_dense_softmax_fwd", P(ws.p3), wd, bd, None, P(ws.probs), B, ws.NF, nb, st)
@@ -251,10 +260,15 @@ class EEGNet_tor(nn.Module):
         L("eav_bn_elu_pool_bwd_reduce", P(ws.dp3), P(ws.u3), b3, P(ws.part_pb), B, 64, T2, 8, drop, seed2, m2, cnt, st)
         L("eav_bn_bwd_finalize", P(ws.part_pb), B, 64, float(B * T2), tr, P(g["separableBN.weight"]),
           P(g["separableBN.bias"]), b3 + 4 * 256, b3 + 4 * 320, st)
-        L("eav_bn_elu_pool_bwd_apply", P(ws.dp3), P(ws.u3), b3, b3 + 4 * 256, P(ws.du3), B, 64, T2, 8, drop, seed2,
-          m2, cnt, st)
+        L("eav_bn_elu_pool_bwd_apply_absmax", P(ws.dp3), P(ws.u3), b3, b3 + 4 * 256, P(ws.du3),
+          P(ws.rowmax_du3) if split else None, B, 64, T2, 8, drop, seed2, m2, cnt, st)
         # separableConv: data gradient (flipped/transposed taps, pad 8) and weight gradient
-        L("eav_conv64_fwd", P(ws.du3), P(ws.wTb), P(ws.dp2), None, B, T2, 8, st)
+        if split:
+            L("eav_absmax_finish", P(ws.rowmax_du3), B * 64, 1.0, P(ws.scale_du3), st)
+            L("eav_conv64_fwd_split", P(ws.du3), P(ws.wTb), P(ws.scale_du3), P(ws.scale_w3), P(ws.dp2), None, B, T2,
+              8, st)
+        else:
+            L("eav_conv64_fwd", P(ws.du3), P(ws.wTb), P(ws.dp2), None, B, T2, 8, st)
         L("eav_conv64_wgrad", P(ws.du3), P(ws.p2), P(ws.part_cw), B, T2, 7, st)
         L("eav_reduce_partials", P(ws.part_cw), ws.np_cw, 65536, 65536, 1.0, P(g["separableConv.weight"]), st)
         # block 1 tail: Dropout <- AvgPool4 <- ELU <- depthwiseBN
@@ -262,12 +276,11 @@ class EEGNet_tor(nn.Module):
         L("eav_bn_elu_pool_bwd_reduce", P(ws.dp2), P(ws.z), b2, P(ws.part_pb), B, 64, S, 4, drop, seed1, m1, cnt, st)
         L("eav_bn_bwd_finalize", P(ws.part_pb), B, 64, float(B * S), tr, P(g["depthwiseBN.weight"]),
           P(g["depthwiseBN.bias"]), b2 + 4 * 256, b2 + 4 * 320, st)
-        L("eav_bn_elu_pool_bwd_apply", P(ws.dp2), P(ws.z), b2, b2 + 4 * 256, P(ws.dz), B, 64, S, 4, drop, seed1, m1,
-          cnt, st)
+        L("eav_bn_elu_pool_bwd_apply_absmax", P(ws.dp2), P(ws.z), b2, b2 + 4 * 256, P(ws.dz),
+          P(ws.rowmax_dz) if split else None, B, 64, S, 4, drop, seed1, m1, cnt, st)
         # depthwiseConv <- ELU <- firstBN (uses the post-renorm depthwise weight, Q2)
         b1 = P(ws.bn1)
-        L("eav_eegnet_dw_bwd_absmax", P(ws.y1), P(ws.dz), b1, w2, P(ws.g1), P(ws.part_dst), P(ws.part_dw2),
-          P(ws.part_gmax) if split else None, B, C, S, st)
+        L("eav_eegnet_dw_bwd", P(ws.y1), P(ws.dz), b1, w2, P(ws.g1), P(ws.part_dst), P(ws.part_dw2), B, C, S, st)
         L("eav_reduce_partials", P(ws.part_dw2), B * ws.nchunk, 64 * C, 64 * C, 1.0, P(g["depthwiseConv.weight"]), st)
         L("eav_bn_bwd_finalize", P(ws.part_dst), B * ws.nchunk, 8, float(B * C * S), tr, P(g["firstBN.weight"]),
           P(g["firstBN.bias"]), b1 + 4 * 32, b1 + 4 * 40, st)
@@ -275,7 +288,7 @@ class EEGNet_tor(nn.Module):
         if split:
             if ws.part_fws is None:
                 ws.part_fws = torch.empty(ws.np_fws, 8 * K, dtype=torch.float32, device=x.device)
-            L("eav_fir_dy_scale", b1, P(ws.part_gmax), ws.part_gmax.numel(), P(ws.scale_dy), st)
+            L("eav_fir_dy_scale", b1, P(ws.rowmax_dz), B * 64, w2, C, P(ws.scale_dy), st)
             L("eav_eegnet_fir_wgrad_split", P(x), P(ws.y1), P(ws.g1), b1, P(ws.scale_x), P(ws.scale_dy),
               P(ws.part_fws), B, C, S, K, st)
             L("eav_reduce_partials", P(ws.part_fws), ws.np_fws, 8 * K, 8 * K, 1.0, P(g["firstConv.weight"]), st)

@@ -360,7 +360,7 @@ def test_fir_fwd_split_is_fp32_grade(L, B, C, S, K, amp):
     npart = _lib.plain("eav_eegnet_fir_fwd_nparts", B, C, S)
     ya, yb = torch.empty(B, 8, C, S, device="cuda"), torch.empty(B, 8, C, S, device="cuda")
     pa, pb = torch.zeros(npart, 16, device="cuda"), torch.zeros(npart, 16, device="cuda")
-    sx, sw, pp = torch.empty(4, device="cuda"), torch.empty(4, device="cuda"), torch.empty(1024, device="cuda")
+    sx, sw, pp = torch.empty(4, device="cuda"), torch.empty(4, device="cuda"), torch.zeros(1032, device="cuda")
     _lib.call("eav_eegnet_fir_fwd", P(x), P(w), P(ya), P(pa), B, C, S, K, st)
     _lib.call("eav_absmax_scale", P(x), x.numel(), 1.0, P(pp), P(sx), st)
     _lib.call("eav_absmax_scale", P(w), w.numel(), 1.0, P(pp), P(sw), st)
@@ -392,12 +392,15 @@ def test_fir_wgrad_split_is_fp32_grade(L, B, C, S, K, gamp):
     pa, pb = torch.empty(na, 8 * K, device="cuda"), torch.empty(nb, 8 * K, device="cuda")
     da, db = torch.empty(8, K, device="cuda"), torch.empty(8, K, device="cuda")
     sx, sg, sdy = (torch.empty(4, device="cuda") for _ in range(3))
-    pp = torch.empty(1024, device="cuda")
+    pp = torch.zeros(1032, device="cuda")
     _lib.call("eav_eegnet_fir_wgrad", P(x), P(y1), P(g1), P(bn), P(pa), B, C, S, K, st)
     _lib.call("eav_reduce_partials", P(pa), na, 8 * K, 8 * K, 1.0, P(da), st)
     _lib.call("eav_absmax_scale", P(x), x.numel(), 1.0, P(pp), P(sx), st)
     _lib.call("eav_absmax_scale", P(g1), g1.numel(), 1.0, P(pp), P(sg), st)
-    _lib.call("eav_fir_dy_scale", P(bn), P(sg) + 8, 1, P(sdy), st)
+    # dy-scale bound: max|g| enters as "max|dz| times the depthwise row norm"; a unit-norm stand-in weight makes it max|g|
+    w2u = torch.zeros(64, C, device="cuda")
+    w2u[:, 0] = 0.125
+    _lib.call("eav_fir_dy_scale", P(bn), P(sg) + 8, 1, P(w2u), C, P(sdy), st)
     _lib.call("eav_eegnet_fir_wgrad_split", P(x), P(y1), P(g1), P(bn), P(sx), P(sdy), P(pb), B, C, S, K, st)
     _lib.call("eav_reduce_partials", P(pb), nb, 8 * K, 8 * K, 1.0, P(db), st)
     torch.cuda.synchronize()

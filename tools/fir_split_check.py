@@ -16,7 +16,7 @@ npart = _lib.plain("eav_eegnet_fir_fwd_nparts", B, C, S)
 y_f32, y_sp = torch.empty(B, 8, C, S, device="cuda"), torch.empty(B, 8, C, S, device="cuda")
 part = torch.empty(npart, 16, device="cuda")
 sx, sw = torch.empty(2, device="cuda"), torch.empty(2, device="cuda")
-pp = torch.empty(1024, device="cuda")
+pp = torch.zeros(1032, device="cuda")
 
 
 def f32():

@@ -21,7 +21,7 @@ nps = _lib.plain("eav_eegnet_fir_wgrad_split_nparts", B, C, S)
 p32, ps = torch.empty(np32, 8 * K, device="cuda"), torch.empty(nps, 8 * K, device="cuda")
 d32, dsp = torch.empty(8, K, device="cuda"), torch.empty(8, K, device="cuda")
 sx, sg, sdy = torch.empty(3, device="cuda"), torch.empty(3, device="cuda"), torch.empty(3, device="cuda")
-pp = torch.empty(1024, device="cuda")
+pp = torch.zeros(1032, device="cuda")
 _lib.call("eav_absmax_scale", P(x), x.numel(), 1.0, P(pp), P(sx), st)
 
 
@@ -32,7 +32,10 @@ def f32():
 
 def split():
     _lib.call("eav_absmax_scale", P(g1), g1.numel(), 1.0, P(pp), P(sg), st)
-    _lib.call("eav_fir_dy_scale", P(bn), P(sg) + 8, 1, P(sdy), st)
+    # dy-scale bound: max|g| enters as "max|dz| times the depthwise row norm"; a unit-norm stand-in weight makes it max|g|
+    w2u = torch.zeros(64, C, device="cuda")
+    w2u[:, 0] = 0.125
+    _lib.call("eav_fir_dy_scale", P(bn), P(sg) + 8, 1, P(w2u), C, P(sdy), st)
     _lib.call("eav_eegnet_fir_wgrad_split", P(x), P(y1), P(g1), P(bn), P(sx), P(sdy), P(ps), B, C, S, K, st)
     _lib.call("eav_reduce_partials", P(ps), nps, 8 * K, 8 * K, 1.0, P(dsp), st)
 

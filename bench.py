@@ -347,10 +347,11 @@ def main():
                          "avg_kernel_ms": {k.replace("eav_eegnet_", ""): round(v, 4) for k, v in kern_ms.items()}},
         }
         y1_bytes = B_PER_GPU * 8 * CHANS * SAMPLES * 4
-        out["split_fir"] = {
-            "note": "opt-in EEGNet_tor.fir_precision='split': the two FIR products on the fp16 matrix cores with two-piece "
-                    "operands (hi + 2^-11 lo, 3 MFMAs per product, fp32 accumulate); measured error vs float64 below the "
-                    "exact-fp32 kernels'; same workload, same parity bounds; not the headline value",
+        out["split_precision"] = {
+            "note": "opt-in EEGNet_tor.fir_precision='split': the FIR and separableConv products (forward, data and weight "
+                    "gradients) on the fp16 matrix cores with two-piece operands (hi + 2^-11 lo, 3 MFMAs per product, fp32 "
+                    "accumulate); measured error vs float64 below the exact-fp32 kernels'; same workload, same parity "
+                    "bounds; not the headline value",
             "value": round(args.steps * B_PER_GPU * world / dts, 2), "unit": "samples/s",
             "ms_per_step": round(dts / args.steps * 1e3, 4),
             "avg_kernel_ms": {k.replace("eav_eegnet_", ""): round(v, 4) for k, v in split_ms.items()},

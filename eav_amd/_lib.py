@@ -72,6 +72,7 @@ SIGNATURES = {
     "eav_decimate_fir_f64": [_p, _p, _p, _i, _i64, _i64, _i, _i, _i, _p],
     "eav_sosfilt_f64": [_p, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _i, _p],
     "eav_conv64_fwd_split": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
+    "eav_conv64_wgrad_split": [_p, _p, _p, _p, _p, _i, _i, _i, _p],
     "eav_absmax_scale": [_p, _i64, _f, _p, _p, _p],
     "eav_eegnet_fir_fwd_split": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "eav_fir_dy_scale": [_p, _p, _i, _p, _i, _p, _p],

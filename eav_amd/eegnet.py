@@ -269,7 +269,11 @@ class EEGNet_tor(nn.Module):
               8, st)
         else:
             L("eav_conv64_fwd", P(ws.du3), P(ws.wTb), P(ws.dp2), None, B, T2, 8, st)
-        L("eav_conv64_wgrad", P(ws.du3), P(ws.p2), P(ws.part_cw), B, T2, 7, st)
+        if split:
+            L("eav_conv64_wgrad_split", P(ws.du3), P(ws.p2), P(ws.scale_du3), P(ws.scale_p2), P(ws.part_cw), B, T2, 7,
+              st)
+        else:
+            L("eav_conv64_wgrad", P(ws.du3), P(ws.p2), P(ws.part_cw), B, T2, 7, st)
         L("eav_reduce_partials", P(ws.part_cw), ws.np_cw, 65536, 65536, 1.0, P(g["separableConv.weight"]), st)
         # block 1 tail: Dropout <- AvgPool4 <- ELU <- depthwiseBN
         b2 = P(ws.bn2)

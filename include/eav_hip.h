@@ -113,6 +113,9 @@ int eav_conv64_wgrad(const float* du, const float* in, float* part, int B, int T
  * csrc/eegnet_conv64_split.hip); scale_x / scale_w: device float[3] from eav_absmax_scale over `in` / the weights. */
 int eav_conv64_fwd_split(const float* in, const float* wT, const float* scale_x, const float* scale_w, float* out,
                          float* stat_part, int B, int T, int padl, void* stream);
+/* split-precision form of eav_conv64_wgrad; part [eav_conv64_wgrad_nparts(B,T)][64*64*16]. */
+int eav_conv64_wgrad_split(const float* du, const float* in, const float* scale_du, const float* scale_in, float* part,
+                           int B, int T, int padl, void* stream);
 
 /* ---- canonical EEGNet (CNN_torch/CNN_EEG.py:7-67): run-time F1<=16, D<=8, F2<=64, K1<=512, K2<=32 ----------- */
 /* block1[0] nn.Conv2d(1,F1,(1,K),padding='same',bias=False) (CNN_EEG.py:22): x [B,C,S] -> y1 [B,F1,C,S];

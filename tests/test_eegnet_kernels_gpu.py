@@ -414,3 +414,42 @@ def test_fir_wgrad_split_is_fp32_grade(L, B, C, S, K, gamp):
     ea, eb = (da.double() - ref).abs().max().item(), (db.double() - ref).abs().max().item()
     rng = ref.abs().max().item()
     assert eb <= 1.25 * ea + 1e-7 * rng, (ea, eb, rng)
+
+
+@pytest.mark.parametrize("B,T,padl", [(8, 2500, 7), (3, 333, 8), (2, 125, 7)])
+def test_conv64_split_is_fp32_grade(L, B, T, padl):
+    """eav_conv64_fwd_split / eav_conv64_wgrad_split against float64: not worse than the exact-fp32 MFMA kernels."""
+    _lib = L
+    x = torch.from_numpy(synth.normal(31, (B, 64, T))).cuda()
+    du = torch.from_numpy(synth.normal(32, (B, 64, T))).cuda() * 3e-5
+    w = torch.from_numpy(synth.uniform(33, (64, 64, 16), -0.03, 0.03)).cuda()
+    P, st = _lib.ptr, _lib.stream_ptr()
+    wTf, wTb = torch.empty(1024, 64, device="cuda"), torch.empty(1024, 64, device="cuda")
+    _lib.call("eav_conv64_prep_weights", P(w), P(wTf), P(wTb), st)
+    sx, sw, sd = (torch.empty(4, device="cuda") for _ in range(3))
+    pp = torch.zeros(1032, device="cuda")
+    for t, s in ((x, sx), (w, sw), (du, sd)):
+        _lib.call("eav_absmax_scale", P(t), t.numel(), 1.0, P(pp), P(s), st)
+    npf = _lib.plain("eav_conv64_fwd_nparts", B, T)
+    ya, yb = torch.empty(B, 64, T, device="cuda"), torch.empty(B, 64, T, device="cuda")
+    pa, pb = torch.zeros(npf, 128, device="cuda"), torch.zeros(npf, 128, device="cuda")
+    _lib.call("eav_conv64_fwd", P(x), P(wTf), P(ya), P(pa), B, T, padl, st)
+    _lib.call("eav_conv64_fwd_split", P(x), P(wTf), P(sx), P(sw), P(yb), P(pb), B, T, padl, st)
+    npw = _lib.plain("eav_conv64_wgrad_nparts", B, T)
+    qa, qb = torch.empty(npw, 65536, device="cuda"), torch.empty(npw, 65536, device="cuda")
+    da, db = torch.empty(64, 64, 16, device="cuda"), torch.empty(64, 64, 16, device="cuda")
+    _lib.call("eav_conv64_wgrad", P(du), P(x), P(qa), B, T, padl, st)
+    _lib.call("eav_reduce_partials", P(qa), npw, 65536, 65536, 1.0, P(da), st)
+    _lib.call("eav_conv64_wgrad_split", P(du), P(x), P(sd), P(sx), P(qb), B, T, padl, st)
+    _lib.call("eav_reduce_partials", P(qb), npw, 65536, 65536, 1.0, P(db), st)
+    torch.cuda.synchronize()
+    xp = torch.nn.functional.pad(x.double(), (padl, 15 - padl))
+    ref = torch.nn.functional.conv1d(xp.cpu(), w.double().cpu())
+    ea, eb = (ya.cpu().double() - ref).abs().max().item(), (yb.cpu().double() - ref).abs().max().item()
+    assert eb <= 1.25 * ea + 1e-7 * ref.abs().max().item(), (ea, eb)
+    assert torch.allclose(pa.double().sum(0), pb.double().sum(0), rtol=1e-5, atol=1e-5 * float(pa.double().sum(0).abs().max()))
+    refw = torch.zeros(64, 64, 16, dtype=torch.float64, device="cuda")
+    for b in range(B):
+        refw += torch.einsum("ot,itk->oik", du[b].double(), xp[b].unfold(-1, 16, 1))
+    ea, eb = (da.double() - refw).abs().max().item(), (db.double() - refw).abs().max().item()
+    assert eb <= 1.25 * ea + 1e-7 * refw.abs().max().item(), (ea, eb)

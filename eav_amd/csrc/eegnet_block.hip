@@ -219,8 +219,7 @@ __global__ __launch_bounds__(256) void pool_bwd_apply_kernel(const float* __rest
 __global__ __launch_bounds__(256) void dw_bwd_kernel(const float* __restrict__ y1, const float* __restrict__ dz,
                                                      const float* __restrict__ bn1, const float* __restrict__ w2,
                                                      float* __restrict__ g1, float* __restrict__ part_st,
-                                                     float* __restrict__ part_w, float* __restrict__ part_max, int C,
-                                                     int S) {
+                                                     float* __restrict__ part_w, int C, int S) {
   __shared__ float wsh[DD * CHMAX];
   __shared__ float red[4 * 8];
   __shared__ float wacc[4 * DD * CHMAX];
@@ -235,7 +234,6 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const float* __restrict__ y
 #pragma unroll
   for (int d = 0; d < DD; ++d) ld4(dz + ((int64_t)b * F1 * DD + f * DD + d) * S, t < S ? t : S, S, vec, dzv[d]);
   float st[2] = {0.f, 0.f};
-  float gmax = 0.f;        // max |g1| of the block: the split-precision FIR weight gradient derives its fp16 scale from it
   const int64_t base = ((int64_t)b * F1 + f) * C * S;
   for (int c = 0; c < C; ++c) {
     float v[4], g[4], a[4];
@@ -253,7 +251,6 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const float* __restrict__ y
       g[e] = da * elu_grad_from_out(pre, a[e]);
       st[0] += g[e];
       st[1] += g[e] * ((v[e] - mean) * invstd);
-      gmax = fmaxf(gmax, fabsf(g[e]));
     }
     if (t < S) st4(g1 + base + (int64_t)c * S, t, S, vec, g);
     // depthwise weight gradient: 8 values per thread -> transposing butterfly over the wave
@@ -295,15 +292,6 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const float* __restrict__ y
   }
   block_sum_256<2>(st, red);
   if (threadIdx.x < 2) part_st[((int64_t)b * gridDim.x + chunk) * 16 + threadIdx.x * 8 + f] = st[0];
-  if (part_max) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, o, 64));
-    if (lane == 0) red[wave] = gmax;
-    __syncthreads();
-    if (threadIdx.x == 0)
-      part_max[((int64_t)b * gridDim.x + chunk) * 8 + f] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    __syncthreads();
-  }
   __syncthreads();
   float* dst = part_w + ((int64_t)b * gridDim.x + chunk) * (F1 * DD * C) + f * DD * C;
   for (int i = threadIdx.x; i < DD * C; i += 256)
@@ -322,21 +310,15 @@ extern "C" int eav_eegnet_dw_fwd(const float* y1, const float* bn1, const float*
   return EAV_OK;
 }
 
-extern "C" int eav_eegnet_dw_bwd_absmax(const float* y1, const float* dz, const float* bn1, const float* w2, float* g1,
-                                        float* stat_part, float* w_part, float* absmax_part, int B, int C, int S,
-                                        void* stream) {
+extern "C" int eav_eegnet_dw_bwd(const float* y1, const float* dz, const float* bn1, const float* w2, float* g1,
+                                 float* stat_part, float* w_part, int B, int C, int S, void* stream) {
   EAV_REQUIRE(y1 && dz && bn1 && w2 && g1 && stat_part && w_part && B > 0 && C > 0 && C <= CHMAX && S > 0,
               "eav_eegnet_dw_bwd: bad arguments (Chans must be <= %d)", CHMAX);
   dim3 grid(cdiv(S, 1024), F1, B);
   hipLaunchKernelGGL(dw_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, y1, dz, bn1, w2, g1, stat_part, w_part,
-                     absmax_part, C, S);
+                     C, S);
   EAV_CHECK_LAUNCH("eav_eegnet_dw_bwd");
   return EAV_OK;
-}
-
-extern "C" int eav_eegnet_dw_bwd(const float* y1, const float* dz, const float* bn1, const float* w2, float* g1,
-                                 float* stat_part, float* w_part, int B, int C, int S, void* stream) {
-  return eav_eegnet_dw_bwd_absmax(y1, dz, bn1, w2, g1, stat_part, w_part, nullptr, B, C, S, stream);
 }
 
 extern "C" int eav_bn_elu_pool_fwd(const float* in, const float* bn, float* out, int B, int CH, int T, int P,

@@ -12,7 +12,6 @@ namespace {
 
 constexpr int NCH = 64, KT = 16, KD = NCH * KT;  // 1024 = contraction length of the forward GEMM
 constexpr int TT = 128;                          // output samples per block
-constexpr int INS = TT + 16;                     // LDS row stride of the input tile (144)
 
 // ------------------------------------------------------------------------------------------ fwd
 // Weight-stationary schedule: 8 waves per block, wave (ot, ic) keeps the weights of output tile ot (32 channels)
@@ -22,13 +21,17 @@ constexpr int INS = TT + 16;                     // LDS row stride of the input 
 // order.  Blocks are persistent over (image, 128-sample tile) items with the next input tile prefetched into
 // registers; BatchNorm statistics accumulate in registers and are written once per block.
 constexpr int V2_THREADS = 512;
-constexpr int V2_NLD = (NCH * INS + V2_THREADS - 1) / V2_THREADS;   // 18 floats per thread per input tile
 
+// TT_ = output samples per work item: 128 normally; 32 when the launch would otherwise have fewer items than CUs
+// (the reference's own [32,1,30,500] batches: T = 125 -> one 128-sample item per image = 32 blocks on 256 CUs).
+template <int TT_>
 __global__ __launch_bounds__(V2_THREADS, 1) void conv64_fwd_kernel(const float* __restrict__ in,
                                                                       const float* __restrict__ wT,
                                                                       float* __restrict__ out, float* __restrict__ part,
                                                                       int B, int T, int padl, int ntile) {
-  __shared__ __attribute__((aligned(16))) float ins[NCH * INS];
+  constexpr int INS_ = TT_ + 16;                                      // LDS row stride of the input tile
+  constexpr int V2_NLD = (NCH * INS_ + V2_THREADS - 1) / V2_THREADS;  // floats per thread per input tile
+  __shared__ __attribute__((aligned(16))) float ins[NCH * INS_];
   __shared__ float red[2][8][16 * 64];                               // [buffer][wave][reg*64 + lane]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = lane & 31, kk = lane >> 5;
@@ -41,37 +44,37 @@ __global__ __launch_bounds__(V2_THREADS, 1) void conv64_fwd_kernel(const float* 
   const int nitems = B * ntile;
   auto fetch = [&](int item) {
     const int b = item / ntile, tile = item - b * ntile;
-    const int t0 = tile * TT;
+    const int t0 = tile * TT_;
     const float* src = in + (int64_t)b * NCH * T;
 #pragma unroll
     for (int i = 0; i < V2_NLD; ++i) {
       const int idx = threadIdx.x + V2_THREADS * i;
-      const int ch = idx / INS, u = idx - ch * INS;
+      const int ch = idx / INS_, u = idx - ch * INS_;
       const int t = t0 + u - padl;
-      rin[i] = (idx < NCH * INS && t >= 0 && t < T) ? src[(int64_t)ch * T + t] : 0.f;
+      rin[i] = (idx < NCH * INS_ && t >= 0 && t < T) ? src[(int64_t)ch * T + t] : 0.f;
     }
   };
   if ((int)blockIdx.x < nitems) fetch(blockIdx.x);
   int rb = 0;
   for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
     const int b = item / ntile, tile = item - b * ntile;
-    const int t0 = tile * TT;
+    const int t0 = tile * TT_;
     __syncthreads();                       // every wave is done with the previous input tile
 #pragma unroll
     for (int i = 0; i < V2_NLD; ++i) {
       const int idx = threadIdx.x + V2_THREADS * i;
-      if (idx < NCH * INS) ins[idx] = rin[i];
+      if (idx < NCH * INS_) ins[idx] = rin[i];
     }
     __syncthreads();
     if (item + (int)gridDim.x < nitems) fetch(item + gridDim.x);
-    for (int sub = 0; sub < TT / 32; ++sub) {
+    for (int sub = 0; sub < TT_ / 32; ++sub) {
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      const float* bp = ins + (16 * ic) * INS + 32 * sub + n + kk;
+      const float* bp = ins + (16 * ic) * INS_ + 32 * sub + n + kk;
 #pragma unroll
       for (int p = 0; p < 128; ++p)        // contraction row 2p+kk of the chunk: channel p>>3, tap 2(p&7)+kk
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[p], bp[(p >> 3) * INS + 2 * (p & 7)], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[p], bp[(p >> 3) * INS_ + 2 * (p & 7)], acc, 0, 0, 0);
       float* rw = red[rb][wave];
 #pragma unroll
       for (int r = 0; r < 16; ++r) rw[r * 64 + lane] = acc[r];
@@ -222,17 +225,24 @@ extern "C" int eav_conv64_prep_weights(const float* w, float* wT_fwd, float* wT_
 
 extern "C" int eav_conv64_ntiles(int T) { return cdiv(T, TT); }
 
+// few 128-sample items -> 32-sample items (4x the blocks; every block still keeps its weight slabs in registers)
+static bool conv64_small(int B, int T) { return B * cdiv(T, TT) < 128; }
+
 // number of statistics partials eav_conv64_fwd writes ([nparts][128])
 extern "C" int eav_conv64_fwd_nparts(int B, int T) {
-  const int nitems = B * cdiv(T, TT);
+  const int nitems = conv64_small(B, T) ? B * cdiv(T, 32) : B * cdiv(T, TT);
   return nitems < 256 ? nitems : 256;
 }
 
 extern "C" int eav_conv64_fwd(const float* in, const float* wT, float* out, float* stat_part, int B, int T, int padl,
                               void* stream) {
   EAV_REQUIRE(in && wT && out && B > 0 && T > 0 && padl >= 0 && padl <= 15, "eav_conv64_fwd: bad arguments");
-  hipLaunchKernelGGL(conv64_fwd_kernel, dim3(eav_conv64_fwd_nparts(B, T)), dim3(V2_THREADS), 0, (hipStream_t)stream,
-                     in, wT, out, stat_part, B, T, padl, cdiv(T, TT));
+  if (conv64_small(B, T))
+    hipLaunchKernelGGL(conv64_fwd_kernel<32>, dim3(eav_conv64_fwd_nparts(B, T)), dim3(V2_THREADS), 0,
+                       (hipStream_t)stream, in, wT, out, stat_part, B, T, padl, cdiv(T, 32));
+  else
+    hipLaunchKernelGGL(conv64_fwd_kernel<TT>, dim3(eav_conv64_fwd_nparts(B, T)), dim3(V2_THREADS), 0,
+                       (hipStream_t)stream, in, wT, out, stat_part, B, T, padl, cdiv(T, TT));
   EAV_CHECK_LAUNCH("eav_conv64_fwd");
   return EAV_OK;
 }

@@ -88,17 +88,27 @@ __global__ __launch_bounds__(256) void dense_softmax_bwd_kernel(const float* __r
     wv[j] = j < NC ? w[(int64_t)j * NF + i] : 0.f;
     acc[j] = 0.f;
   }
-  for (int b = 0; b < B; ++b) {
-    const float v = in[(int64_t)b * NF + i];
-    float d = 0.f;
+  // eight rows per trip: the eight input loads go out together (one latency per trip, not per row - at the reference's
+  // batch of 32 this kernel is pure load latency)
+  for (int b0 = 0; b0 < B; b0 += 8) {
+    float v[8];
 #pragma unroll
-    for (int j = 0; j < NCMAX; ++j)
-      if (j < NC) {
-        const float g = dl[b * NC + j];
-        acc[j] += g * v;
-        d += wv[j] * g;
+    for (int u = 0; u < 8; ++u) v[u] = b0 + u < B ? in[(int64_t)(b0 + u) * NF + i] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int b = b0 + u;
+      if (b < B) {
+        float d = 0.f;
+#pragma unroll
+        for (int j = 0; j < NCMAX; ++j)
+          if (j < NC) {
+            const float g = dl[b * NC + j];
+            acc[j] += g * v[u];
+            d += wv[j] * g;
+          }
+        if (din) din[(int64_t)b * NF + i] = d;
       }
-    if (din) din[(int64_t)b * NF + i] = d;
+    }
   }
 #pragma unroll
   for (int j = 0; j < NCMAX; ++j)

@@ -55,6 +55,11 @@ SIGNATURES = {
                       _i, _p, _p, _i, _i, _p],
     "eav_gemm_bf16_splitk": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "eav_gemm_f32_splitk": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "eav_sp_absmax": [_p, _i, _i, _i64, _p, _p],
+    "eav_sp_convert": [_p, _i, _i, _i64, _p, _p, _p, _p],
+    "eav_gemm_sp": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i64, _i64, _f, _p, _i, _p, _p, _i, _i, _p, _p],
+    "eav_gemm_sp_splitk": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "eav_gemm_sp_set_tile": [_i],
     "eav_attn_fwd": [_p, _p, _p, _i, _i, _i, _i, _f, _p],
     "eav_attn_bwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
     "eav_layernorm_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _f, _p],
@@ -122,6 +127,8 @@ PLAIN = {
     "eav_layernorm_bwd_nparts": ([_i], _i),
     "eav_gemm_f32_splitk_plan": ([_i, _i, _i], _i),
     "eav_colsum_nparts": ([_i], _i),
+    "eav_sp_kpad": ([_i], _i),
+    "eav_gemm_sp_splitk_plan": ([_i, _i, _i], _i),
 }
 
 EXPORTS = sorted(list(SIGNATURES) + list(PLAIN))

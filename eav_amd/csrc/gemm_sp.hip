@@ -1,0 +1,489 @@
+// fp32-grade GEMM on the gfx950 fp16 matrix cores with split operands ("sp16" planes).
+//
+// Every dense contraction of the AST / ViT training step (nn.Linear forward, data gradient, weight gradient, the
+// patch-embedding projection: Transformer_Audio.py:72, Transformer_Vision.py:92 through the HF modelling code) can
+// run here instead of on the exact-fp32 MFMA (gemm_f32.hip, 157 TFLOP/s peak).  An fp32 operand v is held as
+//     hi = fp16(sigma v),  lo = fp16(sigma v - hi)            sigma = 2^e with max|sigma v| in [2^14, 2^15)
+// and a product is three v_mfma_f32_32x32x16_f16 into ONE fp32 accumulator: hi.hi + lo.hi + hi.lo (fp16 x fp16
+// products are exact in fp32; the dropped lo.lo term is <= 2^-22 of the product).  The result is fp32-grade
+// (measured against float64 beside the exact-fp32 kernel: tests/test_gemm_sp_gpu.py) at a third of the 2.5 PFLOP/s
+// fp16 peak instead of 1/16.
+//
+// Operand format ("planes"): a matrix X[R, K] whose CONTRACTION index is the column index is stored as
+//     uint16 planes[R][Kp/8][2][8]      Kp = K rounded up to 32, zero beyond K
+// i.e. for every 8 consecutive k the 16-byte hi piece is followed by the 16-byte lo piece - one piece is exactly one
+// lane's MFMA operand fragment, and a 32-deep K-tile of a row is one 128-byte line.  There is ONE GEMM layout
+// (C[m,n] = sum_k A[m,k] B[n,k]); the data / weight gradient products use planes of the transposed tensors, which
+// eav_sp_convert writes in the same pass (the tensor is converted once per step where it is produced, not re-rounded
+// per tile).  sigma lives in a device "slot" of EAV_SP_SLOT floats: words 0..63 are shards of the bits of
+// max|v| (producers atomicMax one shard each - integer max of non-negative floats is order-independent, hence
+// deterministic, and 64 shards keep the L2 atomics off one address), eav_sp_convert reduces them to sigma (word 64)
+// and 1/sigma (word 65), the GEMM folds 1/(sigma_A sigma_B) into alpha.  Nothing crosses to the host.
+//
+// Kernel: BM x BN x 32 tiles (128 x 128 with 4 waves, 2 blocks per CU; 256 x 128 with 8 waves), each wave a 64 x 64
+// block of 2 x 2 MFMA tiles = 24 MFMAs per K-tile.  Operands go HBM/L2 -> LDS with global_load_lds_dwordx4 (no
+// VGPR round trip, no ds_write), double-buffered, ONE barrier per K-tile.  LDS image: row r, piece p (0..7) at
+// 16-byte slot r*8 + (p ^ ((r>>1)&7)); the XOR is applied to the per-lane SOURCE address (the LDS-DMA destination is
+// lane-linear) and again on the fragment read, which makes every ds_read_b128 conflict-free.  Workgroup ids are
+// remapped so that each XCD's L2 sees a compact group of tiles (8 tile-rows x all tile-columns at a time).
+#include <algorithm>
+
+#include "eav_common.h"
+#include "../../include/eav_hip.h"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+struct SpArgs {
+  const unsigned char* A;   // planes [M][Kp/8][2][8]
+  const unsigned char* B;   // planes [N][Kp/8][2][8]
+  float* C;
+  const float* slotA;       // slot: [0..63] shards of the bits of max|x|, [64] sigma, [65] 1/sigma
+  const float* slotB;
+  const float* bias;        // [N] or null
+  const float* resid;       // [M,N] (ldr) or null, added after the activation
+  float* pre;               // [M,N] (ldc) or null: value before the activation
+  unsigned* amax;           // or null: atomicMax of the bits of |stored value|
+  int M, N, nkt;            // nkt = Kp / 32
+  int64_t ldA, ldB;         // row strides in bytes
+  int ldc, ldr;
+  int64_t sA, sC;           // batch strides (blockIdx.z): A in bytes, C / pre in floats (B is shared)
+  float alpha;
+  int gelu, accumulate;
+  int kt_per_split;         // > 0: split-K, slice z covers K-tiles [z*kt_per_split, ...), C[z] = partial slab
+  int tm, tn;
+};
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+template <int WM, int WN, bool TWOACC>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_kernel(SpArgs g) {
+  constexpr int NW = WM * WN, BM = 64 * WM, BN = 64 * WN;
+  constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
+  constexpr int NCH = (BM + BN) / 8;      // 1-KB chunks (8 rows x 128 B) per stage
+  constexpr int CPW = NCH / NW;           // chunks per wave
+  static_assert(NCH % NW == 0, "chunks must divide over the waves");
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+
+  // ---- workgroup -> tile: XCD-contiguous, then groups of 8 tile-rows
+  const int nb = g.tm * g.tn;
+  int lin;
+  {
+    const int id = blockIdx.x, q = nb >> 3, r = nb & 7, xcd = id & 7, j = id >> 3;
+    lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  const int gsz = 8 * g.tn, grp = lin / gsz, first_m = grp * 8;
+  const int gm = min(8, g.tm - first_m), rem = lin - grp * gsz;
+  const int tile_m = first_m + rem % gm, tile_n = rem / gm;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int z = blockIdx.z;
+  const unsigned char* Ab = g.A;
+  float* C = g.C;
+  int kt0 = 0, kt1 = g.nkt;
+  if (g.kt_per_split > 0) {
+    kt0 = z * g.kt_per_split;
+    kt1 = min(g.nkt, kt0 + g.kt_per_split);
+    C += (int64_t)z * g.M * g.ldc;
+  } else {
+    Ab += z * g.sA;
+    C += z * g.sC;
+  }
+
+  // ---- per-lane global source pointers of this wave's chunks (row clamped: ragged tiles re-read the last row)
+  const unsigned char* gp[CPW];
+#pragma unroll
+  for (int i = 0; i < CPW; ++i) {
+    const int c = wave + NW * i;                       // wave-uniform chunk id
+    const int row = 8 * c + (lane >> 3);               // row in the combined [A tile; B tile] image
+    const int p = (lane & 7) ^ ((row >> 1) & 7);       // piece held by this lane's slot
+    if (8 * c < BM) {
+      const int gr = min(m0 + row, g.M - 1);
+      gp[i] = Ab + (int64_t)gr * g.ldA + (int64_t)kt0 * 128 + p * 16;
+    } else {
+      const int gr = min(n0 + row - BM, g.N - 1);
+      gp[i] = g.B + (int64_t)gr * g.ldB + (int64_t)kt0 * 128 + p * 16;
+    }
+  }
+  auto issue = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) {
+      const int c = wave + NW * i;
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)gp[i], (lds_ptr_t)(smem + buf * STAGE + c * 1024), 16, 0, 0);
+      gp[i] += 128;
+    }
+  };
+
+  // ---- fragment addressing
+  const int wm = wave / WN, wn = wave - wm * WN;
+  const int r32 = lane & 31, kh = lane >> 5, gq = (r32 >> 1) & 7;
+  int lowp[2][2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int hl = 0; hl < 2; ++hl) lowp[ks][hl] = ((2 * (2 * ks + kh) + hl) ^ gq) * 16;
+  const int offA = (wm * 64 + r32) * 128, offB = A_BYTES + (wn * 64 + r32) * 128;
+
+  f32x16 acc[2][2], acx[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = acx[i][j][r] = 0.f;
+
+  if (kt0 < kt1) issue(0);
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int buf = (kt - kt0) & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();          // stage kt has landed for every wave; buffer buf^1 is free again
+    if (kt + 1 < kt1) issue(buf ^ 1);
+    const unsigned char* sa = smem + buf * STAGE + offA;
+    const unsigned char* sb = smem + buf * STAGE + offB;
+    f16x8 ah[2][2], al[2][2], bh[2][2], bl[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        ah[ks][i] = *reinterpret_cast<const f16x8*>(sa + i * 4096 + lowp[ks][0]);
+        bh[ks][i] = *reinterpret_cast<const f16x8*>(sb + i * 4096 + lowp[ks][0]);
+        al[ks][i] = *reinterpret_cast<const f16x8*>(sa + i * 4096 + lowp[ks][1]);
+        bl[ks][i] = *reinterpret_cast<const f16x8*>(sb + i * 4096 + lowp[ks][1]);
+      }
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
+      if (TWOACC) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks][i], bh[ks][j], acx[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks][i], bl[ks][j], acx[i][j], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks][i], bl[ks][j], acc[i][j], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_s_setprio(0);
+  }
+  if (TWOACC) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] += acx[i][j][r] * (1.f / 2048.f);
+  }
+
+  // ---- epilogue
+  const float alpha = g.alpha * g.slotA[65] * g.slotB[65];
+  const int M = g.M, N = g.N;
+  float vmax = 0.f;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = n0 + wn * 64 + 32 * j + r32;
+    if (col >= N) continue;
+    const float bias = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (row >= M) continue;
+        float v = alpha * acc[i][j][r] + bias;
+        const int64_t o = (int64_t)row * g.ldc + col;
+        if (g.pre) g.pre[(g.kt_per_split > 0 ? 0 : z * g.sC) + o] = v;
+        if (g.gelu) v = gelu_erf(v);
+        if (g.resid) v += g.resid[(int64_t)row * g.ldr + col];
+        if (g.accumulate) v += C[o];
+        C[o] = v;
+        vmax = fmaxf(vmax, fabsf(v));
+      }
+    }
+  }
+  if (g.amax) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+    if (lane == 0 && vmax == vmax)
+      atomicMax(g.amax + ((blockIdx.x * NW + wave + 17 * blockIdx.z) & 63), __float_as_uint(vmax));
+  }
+}
+
+int g_force_tile = 0;   // test / tuning hook: 0 = heuristic, 1 = 128x128, 2 = 256x128
+// 11 (default): lo = fp16((t - hi) 2^11), cross terms in a second accumulator folded in with 2^-11 - both pieces stay
+// normal fp16 numbers for elements down to 2^-29 of the tensor maximum.  0: lo = fp16(t - hi), one accumulator (64 fewer
+// VGPRs, same speed at 2 waves per SIMD; full precision only down to 2^-15 of the maximum) - kept as a tuning hook.
+int g_loshift = 11;
+
+template <int WM, int WN>
+void launch(const SpArgs& g, int nz, hipStream_t st) {
+  if (g_loshift)
+    hipLaunchKernelGGL((gemm_sp_kernel<WM, WN, true>), dim3(g.tm * g.tn, 1, nz), dim3(64 * WM * WN), 0, st, g);
+  else
+    hipLaunchKernelGGL((gemm_sp_kernel<WM, WN, false>), dim3(g.tm * g.tn, 1, nz), dim3(64 * WM * WN), 0, st, g);
+}
+
+void dispatch(SpArgs& g, int nz, hipStream_t st) {
+  const int tiles128 = cdiv(g.M, 128) * cdiv(g.N, 128) * nz;
+  const bool big = g_force_tile == 2 || (g_force_tile == 0 && tiles128 >= 2048 && g.M >= 1024);
+  if (big) {
+    g.tm = cdiv(g.M, 256); g.tn = cdiv(g.N, 128);
+    launch<4, 2>(g, nz, st);
+  } else {
+    g.tm = cdiv(g.M, 128); g.tn = cdiv(g.N, 128);
+    launch<2, 2>(g, nz, st);
+  }
+}
+
+__global__ void sp_splitk_reduce_kernel(const float* __restrict__ ws, int nsplit, int64_t n, float* __restrict__ out,
+                                        int accumulate) {
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n) return;
+  double a = 0, b = 0, c = 0, d = 0;
+  for (int s = 0; s < nsplit; ++s) {
+    const float4 v = *reinterpret_cast<const float4*>(ws + (int64_t)s * n + i);
+    a += v.x; b += v.y; c += v.z; d += v.w;
+  }
+  float4 o = make_float4((float)a, (float)b, (float)c, (float)d);
+  if (accumulate) {
+    const float4 p = *reinterpret_cast<const float4*>(out + i);
+    o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
+  }
+  *reinterpret_cast<float4*>(out + i) = o;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// max |v| of a strided matrix into slot[0] (bits; atomicMax on non-negative floats = integer max: order-independent)
+__global__ __launch_bounds__(256) void sp_absmax_kernel(const float* __restrict__ src, int R, int C4, int64_t ld,
+                                                        unsigned* __restrict__ slot) {
+  // grid (column chunks of 256 float4, row slabs): no index division, 16 B per lane along the row
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  float m = 0.f;
+  if (c < C4) {
+    const float* p = src + 4 * (int64_t)c;
+    int r = blockIdx.y;
+    for (; r + 3 * (int)gridDim.y < R; r += 4 * gridDim.y) {
+      const float4 a = *reinterpret_cast<const float4*>(p + (int64_t)r * ld);
+      const float4 b = *reinterpret_cast<const float4*>(p + (int64_t)(r + gridDim.y) * ld);
+      const float4 cc = *reinterpret_cast<const float4*>(p + (int64_t)(r + 2 * gridDim.y) * ld);
+      const float4 d = *reinterpret_cast<const float4*>(p + (int64_t)(r + 3 * gridDim.y) * ld);
+      m = fmaxf(m, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
+      m = fmaxf(m, fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w))));
+      m = fmaxf(m, fmaxf(fmaxf(fabsf(cc.x), fabsf(cc.y)), fmaxf(fabsf(cc.z), fabsf(cc.w))));
+      m = fmaxf(m, fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fmaxf(fabsf(d.z), fabsf(d.w))));
+    }
+    for (; r < R; r += gridDim.y) {
+      const float4 a = *reinterpret_cast<const float4*>(p + (int64_t)r * ld);
+      m = fmaxf(m, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m == m)
+    atomicMax(slot + (((blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)) & 63), __float_as_uint(m));
+}
+
+// sigma = 2^(14 - floor(log2 amax)): max|sigma v| in [2^14, 2^15); 1 for an all-zero / non-finite tensor
+__device__ __forceinline__ float sigma_from_bits(unsigned bits) {
+  const int e = (int)((bits >> 23) & 0xff);
+  if (bits == 0u || e == 0xff) return 1.f;
+  int se = 14 - (e - 127);
+  se = max(-126, min(126, se));
+  return __uint_as_float((unsigned)(se + 127) << 23);
+}
+
+__device__ __forceinline__ void split8(const float (&tv)[8], uint4& hi, uint4& lo, float lomul) {
+  _Float16 h[8], l[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    h[e] = (_Float16)tv[e];
+    l[e] = (_Float16)((tv[e] - (float)h[e]) * lomul);
+  }
+  hi = *reinterpret_cast<const uint4*>(h);
+  lo = *reinterpret_cast<const uint4*>(l);
+}
+
+// src [R, C] fp32 (row stride ld) -> dst planes [R][Cp/8][2][8] (contraction over columns) and / or
+// dstT planes [C][Rp/8][2][8] (contraction over rows).  One 64 x 64 tile per block.
+__global__ __launch_bounds__(256) void sp_convert_kernel(const float* __restrict__ src, int R, int C, int64_t ld,
+                                                         float* __restrict__ slot, unsigned char* __restrict__ dst,
+                                                         int Cp, unsigned char* __restrict__ dstT, int Rp,
+                                                         float lomul) {
+  __shared__ float tile[64][65];
+  unsigned bits = 0u;
+#pragma unroll
+  for (int i = 0; i < 64; ++i) bits = max(bits, __float_as_uint(slot[i]));
+  const float sigma = sigma_from_bits(bits);
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    slot[64] = sigma;
+    slot[65] = 1.f / sigma;
+  }
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int t = threadIdx.x;
+  {
+    const int cg = t & 7, rr = t >> 3;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int row = r0 + rr + 32 * pass, col = c0 + 8 * cg;
+      float tv[8];
+      if (row < R && col + 7 < C) {
+        const float4 a = *reinterpret_cast<const float4*>(src + (int64_t)row * ld + col);
+        const float4 b = *reinterpret_cast<const float4*>(src + (int64_t)row * ld + col + 4);
+        tv[0] = a.x; tv[1] = a.y; tv[2] = a.z; tv[3] = a.w; tv[4] = b.x; tv[5] = b.y; tv[6] = b.z; tv[7] = b.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) tv[e] = (row < R && col + e < C) ? src[(int64_t)row * ld + col + e] : 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) tv[e] *= sigma;
+      if (dst && row < R && col < Cp) {
+        uint4 hi, lo;
+        split8(tv, hi, lo, lomul);
+        uint4* o = reinterpret_cast<uint4*>(dst + (int64_t)row * Cp * 4 + (col >> 3) * 32);
+        o[0] = hi;
+        o[1] = lo;
+      }
+      if (dstT) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) tile[rr + 32 * pass][8 * cg + e] = tv[e];
+      }
+    }
+  }
+  if (!dstT) return;
+  __syncthreads();
+  {
+    const int rg = t & 7, cc = t >> 3;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int col = c0 + cc + 32 * pass, row = r0 + 8 * rg;
+      if (col >= C || row >= Rp) continue;
+      float tv[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) tv[e] = tile[8 * rg + e][cc + 32 * pass];
+      uint4 hi, lo;
+      split8(tv, hi, lo, lomul);
+      uint4* o = reinterpret_cast<uint4*>(dstT + (int64_t)col * Rp * 4 + (row >> 3) * 32);
+      o[0] = hi;
+      o[1] = lo;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int eav_sp_kpad(int K) { return (K + 31) / 32 * 32; }
+
+extern "C" int eav_sp_absmax(const float* src, int R, int C, int64_t ld, float* slot, void* stream) {
+  EAV_REQUIRE(src && slot && R > 0 && C > 0, "eav_sp_absmax: bad arguments");
+  EAV_REQUIRE((C & 3) == 0 && (ld & 3) == 0 && ((uintptr_t)src & 15) == 0,
+              "eav_sp_absmax: columns / leading dimension must be multiples of 4, src 16-byte aligned");
+  const int gx = cdiv(C / 4, 256);
+  const int gy = std::max(1, std::min(cdiv(R, 16), 1024 / gx));
+  hipLaunchKernelGGL(sp_absmax_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, src, R, C / 4, ld,
+                     reinterpret_cast<unsigned*>(slot));
+  EAV_CHECK_LAUNCH("eav_sp_absmax");
+  return EAV_OK;
+}
+
+extern "C" int eav_sp_convert(const float* src, int R, int C, int64_t ld, float* slot, void* dst, void* dstT,
+                              void* stream) {
+  EAV_REQUIRE(src && slot && R > 0 && C > 0 && (dst || dstT), "eav_sp_convert: bad arguments");
+  EAV_REQUIRE((ld & 3) == 0 && (((uintptr_t)src | (uintptr_t)dst | (uintptr_t)dstT) & 15) == 0,
+              "eav_sp_convert: leading dimension must be a multiple of 4, buffers 16-byte aligned");
+  hipLaunchKernelGGL(sp_convert_kernel, dim3(cdiv(eav_sp_kpad(C), 64), cdiv(eav_sp_kpad(R), 64)), dim3(256), 0,
+                     (hipStream_t)stream, src, R, C, ld, slot, (unsigned char*)dst, eav_sp_kpad(C),
+                     (unsigned char*)dstT, eav_sp_kpad(R), g_loshift ? 2048.f : 1.f);
+  EAV_CHECK_LAUNCH("eav_sp_convert");
+  return EAV_OK;
+}
+
+extern "C" int eav_gemm_sp_set_tile(int which) {
+  g_force_tile = which & 3;
+  g_loshift = (which & 4) ? 0 : 11;
+  return EAV_OK;
+}
+
+extern "C" int eav_gemm_sp(const void* A, const void* B, float* C, const float* slotA, const float* slotB, int M, int N,
+                           int K, int ldc, int batch, int64_t sA_bytes, int64_t sC, float alpha, const float* bias,
+                           int gelu, float* pre, const float* resid, int ldr, int accumulate, float* amax_slot,
+                           void* stream) {
+  EAV_REQUIRE(A && B && C && slotA && slotB && M > 0 && N > 0 && K > 0 && batch > 0, "eav_gemm_sp: bad arguments");
+  EAV_REQUIRE((((uintptr_t)A | (uintptr_t)B) & 15) == 0 && (sA_bytes & 15) == 0,
+              "eav_gemm_sp: operand planes must be 16-byte aligned");
+  EAV_REQUIRE(!(resid && batch > 1), "eav_gemm_sp: residual epilogue is not batched");
+  SpArgs g;
+  const int Kp = eav_sp_kpad(K);
+  g.A = (const unsigned char*)A; g.B = (const unsigned char*)B; g.C = C; g.slotA = slotA; g.slotB = slotB;
+  g.bias = bias; g.resid = resid; g.pre = pre; g.amax = reinterpret_cast<unsigned*>(amax_slot);
+  g.M = M; g.N = N; g.nkt = Kp / 32; g.ldA = (int64_t)Kp * 4; g.ldB = (int64_t)Kp * 4; g.ldc = ldc; g.ldr = ldr;
+  g.sA = sA_bytes; g.sC = sC; g.alpha = alpha; g.gelu = gelu; g.accumulate = accumulate; g.kt_per_split = 0;
+  dispatch(g, batch, (hipStream_t)stream);
+  EAV_CHECK_LAUNCH("eav_gemm_sp");
+  return EAV_OK;
+}
+
+// split-K plan for the weight-gradient shapes (small M x N output, long contraction): enough slices to put ~2
+// workgroups on every CU, at least 8 K-tiles per slice
+extern "C" int eav_gemm_sp_splitk_plan(int M, int N, int K) {
+  const int tiles = cdiv(M, 128) * cdiv(N, 128);
+  int ns = cdiv(512, tiles);
+  const int maxs = std::max(1, eav_sp_kpad(K) / 32 / 8);
+  if (ns > maxs) ns = maxs;
+  if (ns > 32) ns = 32;
+  return ns < 1 ? 1 : ns;
+}
+
+extern "C" int eav_gemm_sp_splitk(const void* A, const void* B, float* C, float* ws, const float* slotA,
+                                  const float* slotB, int M, int N, int K, int accumulate, void* stream) {
+  EAV_REQUIRE(A && B && C && ws && slotA && slotB && M > 0 && N > 0 && K > 0, "eav_gemm_sp_splitk: bad arguments");
+  EAV_REQUIRE((N & 3) == 0 && (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)ws) & 15) == 0,
+              "eav_gemm_sp_splitk: N must be a multiple of 4, buffers 16-byte aligned");
+  const int nsplit = eav_gemm_sp_splitk_plan(M, N, K);
+  SpArgs g;
+  const int Kp = eav_sp_kpad(K);
+  g.A = (const unsigned char*)A; g.B = (const unsigned char*)B; g.slotA = slotA; g.slotB = slotB;
+  g.bias = nullptr; g.resid = nullptr; g.pre = nullptr; g.amax = nullptr;
+  g.M = M; g.N = N; g.nkt = Kp / 32; g.ldA = (int64_t)Kp * 4; g.ldB = (int64_t)Kp * 4; g.ldc = N; g.ldr = 0;
+  g.sA = 0; g.sC = 0; g.alpha = 1.f; g.gelu = 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (nsplit <= 1) {
+    g.C = C; g.accumulate = accumulate; g.kt_per_split = 0;
+    dispatch(g, 1, st);
+    EAV_CHECK_LAUNCH("eav_gemm_sp_splitk");
+    return EAV_OK;
+  }
+  g.C = ws; g.accumulate = 0;
+  g.kt_per_split = cdiv(g.nkt, nsplit);
+  const int nz = cdiv(g.nkt, g.kt_per_split);
+  dispatch(g, nz, st);
+  EAV_CHECK_LAUNCH("eav_gemm_sp_splitk");
+  const int64_t n = (int64_t)M * N;
+  hipLaunchKernelGGL(sp_splitk_reduce_kernel, dim3((unsigned)cdiv64(n, 1024)), dim3(256), 0, st, ws, nz, n, C,
+                     accumulate);
+  EAV_CHECK_LAUNCH("eav_gemm_sp_splitk(reduce)");
+  return EAV_OK;
+}

@@ -87,6 +87,7 @@ class FusedAdam(torch.optim.Optimizer):
             _lib.call("eav_counter_inc", self._dev_step.data_ptr(), _lib.stream_ptr())
         for group in self.param_groups:
             runs = []  # (p_ptr, g_ptr, m_ptr, v_ptr, numel, step) candidates for merging
+            touched = {}
             for p in group["params"]:
                 g = p.grad
                 if g is None:
@@ -98,6 +99,8 @@ class FusedAdam(torch.optim.Optimizer):
                 if not g.is_contiguous():
                     g = g.contiguous()
                 st = self.state[p]
+                if getattr(p, "_eav_flat", None) is not None:
+                    touched[p._eav_flat[0].data_ptr()] = p._eav_flat[0]
                 if not st:
                     st["step"] = 0
                     flat = getattr(p, "_eav_flat", None)
@@ -130,6 +133,12 @@ class FusedAdam(torch.optim.Optimizer):
                 merged.append(r)
             for r in merged:
                 self._launch(r[0], r[1], r[2], r[3], r[4], group, r[5])
+                # tell whoever caches derived copies of these parameters (transformer.Encoder's fp16 operand
+                # planes) which byte ranges of the flat buffer just changed
+                for fl in touched.values():
+                    lo = fl.data_ptr()
+                    if lo <= r[0] < lo + 4 * fl.numel():
+                        fl._eav_dirty = getattr(fl, "_eav_dirty", []) + [(r[0], r[0] + 4 * r[4])]
         return loss
 
 

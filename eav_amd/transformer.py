@@ -168,10 +168,13 @@ class Encoder(nn.Module):
         self._token = 0
         self._saved = None
         self.kernel_events = None
-        # GEMM operand precision: "fp32" (default; exact-fp32 MFMA, meets the 1e-3 logit bound), "bf16"
-        # (bf16 MFMA operands everywhere, fp32 accumulate: ~5e-3 logit drift) or "bf16_bwd" (fp32 forward
-        # - logits unchanged - and bf16 operands for the backward products only).
+        # GEMM operand precision: "fp32" (default; exact-fp32 MFMA), "split" (fp32-grade on the fp16 matrix cores:
+        # every operand as fp16 hi + lo planes, three MFMAs per product - csrc/gemm_sp.hip; same parity bounds as
+        # fp32), "bf16" (bf16 MFMA operands everywhere, fp32 accumulate: ~5e-3 logit drift) or "bf16_bwd" (fp32
+        # forward - logits unchanged - and bf16 operands for the backward products only).
         self.precision = "fp32"
+        self._wplanes = None          # split mode: {weight key: (planes, planes of the transpose, slot index)}
+        self._wplanes_key = None
         self._phase = "fwd"
         # multi-GPU: called as hook(lo, hi) from inside the backward whenever flat_grad[lo:hi] is final
         self.grad_ready_hook = None
@@ -274,7 +277,7 @@ class Encoder(nn.Module):
 
     def _gemm_name(self):
         p = self.precision
-        if p not in ("fp32", "bf16", "bf16_bwd"):
+        if p not in ("fp32", "split", "bf16", "bf16_bwd"):
             raise ValueError(f"unknown precision {p!r}")
         low = p == "bf16" or (p == "bf16_bwd" and self._phase == "bwd")
         return "eav_gemm_bf16" if low else "eav_gemm_f32"
@@ -285,11 +288,14 @@ class Encoder(nn.Module):
         M = B * N
         ldn = (N + 3) // 4 * 4
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
-        ws = SimpleNamespace(B=B, M=M, ldn=ldn, full=full_backward)
+        sp = self.precision == "split"
+        ws = SimpleNamespace(B=B, M=M, ldn=ldn, full=full_backward, sp=sp)
         nsave = Lr if full_backward else 1
+        if sp:
+            self._alloc_split(ws, dev, nsave)
         ws.col = f(B * c.npatch, c.kp)
         ws.hs = [f(M, D) for _ in range(Lr + 1)] if full_backward else [f(M, D), f(M, D)]
-        ws.y1 = [f(M, D) for _ in range(nsave)]
+        ws.y1 = [f(M, D) for _ in range(1 if sp else nsave)]     # split mode keeps planes, not fp32 copies
         ws.qkv = [f(M, 3 * D) for _ in range(nsave)]
         ws.fused = self._fused_attention()
         if ws.fused:      # flash-style kernels: only the log-sum-exp per (image, head, query) is kept
@@ -299,9 +305,9 @@ class Encoder(nn.Module):
             ws.P = [torch.zeros(B * H, N, ldn, dtype=torch.float32, device=dev) for _ in range(nsave)]
         ws.ao = [f(M, D) for _ in range(nsave)]
         ws.hmid = [f(M, D) for _ in range(nsave)]
-        ws.y2 = [f(M, D) for _ in range(nsave)]
+        ws.y2 = [f(M, D) for _ in range(1 if sp else nsave)]
         ws.pre = [f(M, FF) for _ in range(nsave)]
-        ws.act = [f(M, FF) for _ in range(nsave)]
+        ws.act = [f(M, FF) for _ in range(1 if sp else nsave)]
         ws.st = [f(4, M) for _ in range(nsave)]           # mean1, rstd1, mean2, rstd2
         R = B * c.nextra
         ws.rows, ws.seqr, ws.stf = f(R, D), f(R, D), f(2, R)
@@ -318,12 +324,114 @@ class Encoder(nn.Module):
             ws.np_cs = _lib.plain("eav_colsum_nparts", M)
             ws.part_cs = f(ws.np_cs, max(FF, 3 * D))
             shapes = [(D, FF, M), (FF, D, M), (3 * D, D, M), (D, D, M), (D, c.kp, B * c.npatch)]
-            ws.splitk = f(max(_lib.plain("eav_gemm_f32_splitk_plan", m, n, k) * m * n for m, n, k in shapes))
+            plan = "eav_gemm_sp_splitk_plan" if sp else "eav_gemm_f32_splitk_plan"
+            ws.splitk = f(max(_lib.plain(plan, m, n, k) * m * n for m, n, k in shapes))
         ws.drows, ws.dseqr = f(R, D), f(R, D)
         ws.dpooled, ws.dhl = f(B, D), f(B, D)
         ws.np_lnr = _lib.plain("eav_layernorm_bwd_nparts", R)
         ws.part_lnr = f(ws.np_lnr, 2 * D)
         return ws
+
+    # ------------------------------------------------------------------ split-operand (fp16 hi/lo planes) plumbing
+    SLOT = 80   # floats per scale slot (include/eav_hip.h EAV_SP_SLOT)
+
+    def _alloc_split(self, ws, dev, nsave):
+        c = self.cfg
+        D, FF, Lr, M = c.hidden, c.ff, c.layers, ws.M
+        MP = ws.B * c.npatch
+        kp = lambda k: _lib.plain("eav_sp_kpad", k)  # noqa: E731
+        h = lambda r, k: torch.empty(r, 2 * kp(k), dtype=torch.float16, device=dev)  # noqa: E731
+        full = ws.full
+        # forward operands (planes; the transposes feed the weight-gradient products)
+        ws.colp = h(MP, c.kp)
+        ws.y1p = [h(M, D) for _ in range(nsave)]
+        ws.aop = [h(M, D) for _ in range(nsave)]
+        ws.y2p = [h(M, D) for _ in range(nsave)]
+        ws.actp = [h(M, FF) for _ in range(nsave)]
+        ws.fslots = torch.zeros(1 + 4 * Lr, self.SLOT, dtype=torch.float32, device=dev)
+        if full:
+            ws.colpT = h(c.kp, MP)
+            ws.y1pT = [h(D, M) for _ in range(nsave)]
+            ws.aopT = [h(D, M) for _ in range(nsave)]
+            ws.y2pT = [h(D, M) for _ in range(nsave)]
+            ws.actpT = [h(FF, M) for _ in range(nsave)]
+            # backward operands: one set, reused by every layer
+            ws.dhp, ws.dhpT = h(M, D), h(D, M)
+            ws.dactp, ws.dactpT = h(M, FF), h(FF, M)
+            ws.dqkvp, ws.dqkvpT = h(M, 3 * D), h(3 * D, M)
+            ws.dembpT = h(D, MP)
+            ws.bslots = torch.zeros(1 + 4 * Lr, self.SLOT, dtype=torch.float32, device=dev)
+
+    def _weight_keys(self):
+        """[(cache key, parameter name of the [out, in] matrix, out, in)] of every GEMM weight."""
+        c = self.cfg
+        keys = [("patch", f"{c.prefix}.embeddings.patch_embeddings.projection.weight", c.hidden, c.kp)]
+        for i in range(c.layers):
+            L = f"{c.prefix}.layers.{i}"
+            keys += [(f"qkv{i}", f"{L}.attention.q_proj.weight", 3 * c.hidden, c.hidden),
+                     (f"o{i}", f"{L}.attention.o_proj.weight", c.hidden, c.hidden),
+                     (f"fc1{i}", f"{L}.mlp.fc1.weight", c.ff, c.hidden),
+                     (f"fc2{i}", f"{L}.mlp.fc2.weight", c.hidden, c.ff)]
+        return keys
+
+    def _refresh_weight_planes(self, dev, need_T):
+        """(Re)build the fp16 hi/lo planes of the GEMM weights (and of their transposes, for the data-gradient
+        products) that changed: FusedAdam records the byte ranges it updated (`_eav_dirty`), any torch in-place write
+        to the flat buffer (load_state_dict, .copy_) bumps its version and invalidates everything."""
+        flat = self._flat[0]
+        key = (flat.data_ptr(), flat._version)
+        dirty = getattr(flat, "_eav_dirty", [])
+        flat._eav_dirty = []
+        have_T = self._wplanes is not None and self._wplanes["_T"]
+        keys = self._weight_keys()
+        kp = lambda k: _lib.plain("eav_sp_kpad", k)  # noqa: E731
+        everything = self._wplanes is None or self._wplanes["_dev"] != dev or (need_T and not have_T) \
+            or self._wplanes_key != key
+        if everything and (self._wplanes is None or self._wplanes["_dev"] != dev or (need_T and not have_T)):
+            wp = {"_T": need_T, "_dev": dev,
+                  "_slots": torch.zeros(len(keys), self.SLOT, dtype=torch.float32, device=dev)}
+            for n, (k, _, out, inn) in enumerate(keys):
+                wp[k] = (torch.empty(out, 2 * kp(inn), dtype=torch.float16, device=dev),
+                         torch.empty(inn, 2 * kp(out), dtype=torch.float16, device=dev) if need_T else None, n)
+            self._wplanes = wp
+        wp = self._wplanes
+        st = _lib.stream_ptr()
+        stale = []
+        for k, pname, out, inn in keys:
+            src = _lib.ptr(self._pmap[pname])
+            if everything or any(lo < src + 4 * out * inn and src < hi for lo, hi in dirty):
+                stale.append((k, src, out, inn))
+        if len(stale) == len(keys):
+            wp["_slots"].zero_()
+        for k, src, out, inn in stale:
+            pl, plT, n = wp[k]
+            if len(stale) != len(keys):
+                wp["_slots"][n].zero_()
+            slot = wp["_slots"].data_ptr() + 4 * self.SLOT * n
+            _lib.call("eav_sp_absmax", src, out, inn, inn, slot, st)
+            _lib.call("eav_sp_convert", src, out, inn, inn, slot, _lib.ptr(pl), _lib.ptr(plT), st)
+        self._wplanes_key = key
+
+    def _wp(self, key, transposed=False):
+        pl, plT, n = self._wplanes[key]
+        return _lib.ptr(plT if transposed else pl), self._wplanes["_slots"].data_ptr() + 4 * self.SLOT * n
+
+    def _to_planes(self, src, R, C, ld, slot, dst, dstT, amax_done=False):
+        """fp32 [R, C] -> planes (contraction over columns) and / or planes of the transpose (contraction over rows)."""
+        if not amax_done:
+            self._call("eav_sp_absmax", src, R, C, ld, slot, self._st)
+        self._call("eav_sp_convert", src, R, C, ld, slot, _lib.ptr(dst), _lib.ptr(dstT), self._st)
+
+    def _gemm_sp(self, A, slotA, B, slotB, C, M, N, K, ldc, batch=1, sA=0, sC=0, alpha=1.0, bias=None, gelu=0,
+                 pre=None, resid=None, ldr=0, acc=0, amax=None):
+        """C[M,N] = epilogue(alpha A[M,K] . B[N,K]^T) on planes."""
+        self._call("eav_gemm_sp", A, B, C, slotA, slotB, M, N, K, ldc, batch, sA, sC, float(alpha), bias, gelu, pre,
+                   resid, ldr, acc, amax, self._st)
+
+    def _wgrad_sp(self, AT, slotA, BT, slotB, C, M, N, K):
+        """C[M,N] = sum over the K tokens: planes of the transposes, A^T [M,K], B^T [N,K]; split-K."""
+        self._call("eav_gemm_sp_splitk", _lib.ptr(AT), _lib.ptr(BT), C, _lib.ptr(self._ws.splitk), slotA, slotB, M, N,
+                   K, 0, self._st)
 
     def _launch_forward(self, x):
         c = self.cfg
@@ -336,18 +444,32 @@ class Encoder(nn.Module):
         pm = self._pmap
         full = self._want_full
         ws = self._ws
+        sp = self.precision == "split"
         if ws is None or ws.B != B or ws.hs[0].device != x.device or (full and not ws.full) \
-                or ws.fused != self._fused_attention():
+                or ws.fused != self._fused_attention() or ws.sp != sp:
             ws = self._ws = self._alloc(B, x.device, full)
+        if sp:
+            self._refresh_weight_planes(x.device, full)
+            ws.fslots.zero_()
+            fslot = lambda n: ws.fslots.data_ptr() + 4 * self.SLOT * n  # noqa: E731
+            kpb = lambda k: 4 * _lib.plain("eav_sp_kpad", k)            # noqa: E731  plane row stride in bytes
         M, ldn = ws.M, ws.ldn
         pre = c.prefix
         w = lambda k: P(pm[k])  # noqa: E731
         # patch embedding: im2col rows x projection weight -> token rows [nextra:], then cls/dist + positions
         L("eav_im2col", P(x), P(ws.col), B, c.C, c.H, c.W, c.patch, c.sy, c.sx, c.transposed, st)
         h0 = ws.hs[0]
-        self._gemm(P(ws.col), w(f"{pre}.embeddings.patch_embeddings.projection.weight"), P(h0) + 4 * c.nextra * D,
-                   c.npatch, D, c.kp, c.kp, c.kp, D, batch=B, sA=(c.npatch * c.kp, 0), sC=(N * D, 0),
-                   bias=w(f"{pre}.embeddings.patch_embeddings.projection.bias"))
+        if sp:
+            self._to_planes(P(ws.col), B * c.npatch, c.kp, c.kp, fslot(0), ws.colp, ws.colpT if ws.full else None)
+            wpl, wsl = self._wp("patch")
+            self._gemm_sp(P(ws.colp), fslot(0), wpl, wsl, P(h0) + 4 * c.nextra * D, c.npatch, D, c.kp, D, batch=B,
+                          sA=c.npatch * kpb(c.kp), sC=N * D,
+                          bias=w(f"{pre}.embeddings.patch_embeddings.projection.bias"))
+        else:
+            self._gemm(P(ws.col), w(f"{pre}.embeddings.patch_embeddings.projection.weight"),
+                       P(h0) + 4 * c.nextra * D, c.npatch, D, c.kp, c.kp, c.kp, D, batch=B,
+                       sA=(c.npatch * c.kp, 0), sC=(N * D, 0),
+                       bias=w(f"{pre}.embeddings.patch_embeddings.projection.bias"))
         L("eav_embed_finish", P(h0), w(f"{pre}.embeddings.cls_token"),
           w(f"{pre}.embeddings.distillation_token") if c.kind == "ast" else None,
           w(f"{pre}.embeddings.position_embeddings"), B, N, D, c.nextra, st)
@@ -358,6 +480,9 @@ class Encoder(nn.Module):
             hout = ws.hs[i + 1] if ws.full else ws.hs[(i + 1) & 1]
             Lk = f"{pre}.layers.{i}"
             stp = P(ws.st[j])
+            if sp:
+                self._layer_forward_split(i, j, hin, hout, Lk, stp, fslot, scale)
+                continue
             L("eav_layernorm_fwd", P(hin), w(f"{Lk}.layernorm_before.weight"), w(f"{Lk}.layernorm_before.bias"),
               P(ws.y1[j]), stp, stp + 4 * M, M, D, c.eps, st)
             qkv = P(ws.qkv[j])
@@ -399,6 +524,116 @@ class Encoder(nn.Module):
         self._token += 1
         self._saved = (self._token, x, full, None)
         return self._token
+
+    def _layer_forward_split(self, i, j, hin, hout, Lk, stp, fslot, scale):
+        """One encoder layer with every projection on the split-operand GEMM; the attention core stays on the fp32
+        kernels.  LayerNorm / attention / GELU outputs are converted to planes once (plus the transposed planes when
+        a backward will follow); only the planes are kept per layer."""
+        c, ws = self.cfg, self._ws
+        P, L, st = _lib.ptr, self._call, self._st
+        D, FF, N, H, M = c.hidden, c.ff, c.ntok, c.heads, ws.M
+        hd = D // H
+        w = lambda k: P(self._pmap[k])  # noqa: E731
+        T = (lambda lst: lst[j]) if ws.full else (lambda lst: None)  # noqa: E731
+        s_y1, s_ao, s_y2, s_act = (fslot(1 + 4 * i + k) for k in range(4))
+        y, ao, act = ws.y1[0], ws.ao[j], ws.act[0]
+        L("eav_layernorm_fwd", P(hin), w(f"{Lk}.layernorm_before.weight"), w(f"{Lk}.layernorm_before.bias"), P(y), stp,
+          stp + 4 * M, M, D, c.eps, st)
+        self._to_planes(P(y), M, D, D, s_y1, ws.y1p[j], T(ws.y1pT) if ws.full else None)
+        qkv = P(ws.qkv[j])
+        wpl, wsl = self._wp(f"qkv{i}")
+        self._gemm_sp(P(ws.y1p[j]), s_y1, wpl, wsl, qkv, M, 3 * D, D, 3 * D, bias=w(f"{Lk}.attention.q_proj.bias"))
+        if ws.fused:
+            L("eav_attn_fwd", qkv, P(ao), P(ws.lse[j]), ws.B, H, N, hd, scale, st)
+        else:
+            ldn = ws.ldn
+            Pm = P(ws.P[j])
+            self._gemm_f32(qkv, qkv + 4 * D, Pm, N, N, hd, 3 * D, 3 * D, ldn, batch=ws.B * H, heads=H,
+                           sA=(N * 3 * D, hd), sB=(N * 3 * D, hd), sC=(H * N * ldn, N * ldn), alpha=scale)
+            L("eav_softmax_fwd", Pm, ws.B * H * N, N, ldn, st)
+            self._gemm_f32(Pm, qkv + 8 * D, P(ao), N, hd, N, ldn, 3 * D, D, tB=1, batch=ws.B * H, heads=H,
+                           sA=(H * N * ldn, N * ldn), sB=(N * 3 * D, hd), sC=(N * D, hd))
+        self._to_planes(P(ao), M, D, D, s_ao, ws.aop[j], T(ws.aopT) if ws.full else None)
+        wpl, wsl = self._wp(f"o{i}")
+        self._gemm_sp(P(ws.aop[j]), s_ao, wpl, wsl, P(ws.hmid[j]), M, D, D, D, bias=w(f"{Lk}.attention.o_proj.bias"),
+                      resid=P(hin), ldr=D)
+        L("eav_layernorm_fwd", P(ws.hmid[j]), w(f"{Lk}.layernorm_after.weight"), w(f"{Lk}.layernorm_after.bias"),
+          P(y), stp + 8 * M, stp + 12 * M, M, D, c.eps, st)
+        self._to_planes(P(y), M, D, D, s_y2, ws.y2p[j], T(ws.y2pT) if ws.full else None)
+        wpl, wsl = self._wp(f"fc1{i}")
+        self._gemm_sp(P(ws.y2p[j]), s_y2, wpl, wsl, P(act), M, FF, D, FF, bias=w(f"{Lk}.mlp.fc1.bias"), gelu=1,
+                      pre=P(ws.pre[j]) if ws.full else None, amax=s_act)
+        self._to_planes(P(act), M, FF, FF, s_act, ws.actp[j], T(ws.actpT) if ws.full else None, amax_done=True)
+        wpl, wsl = self._wp(f"fc2{i}")
+        self._gemm_sp(P(ws.actp[j]), s_act, wpl, wsl, P(hout), M, D, FF, D, bias=w(f"{Lk}.mlp.fc2.bias"),
+                      resid=P(ws.hmid[j]), ldr=D)
+
+    def _gemm_f32(self, A, B, C, M, N, K, lda, ldb, ldc, tA=0, tB=0, batch=1, heads=1, sA=(0, 0), sB=(0, 0),
+                  sC=(0, 0), alpha=1.0):
+        self._call("eav_gemm_f32", A, B, C, M, N, K, lda, ldb, ldc, tA, tB, batch, heads, sA[0], sA[1], sB[0], sB[1],
+                   sC[0], sC[1], float(alpha), None, 0, None, None, 0, 0, self._st)
+
+    def _layer_backward_split(self, i, Lk, stp, gp, bslot, fslot, scale):
+        """Backward of one layer: dh (gradient w.r.t. the layer output, fp32) in ws.dh on entry, gradient w.r.t. the
+        layer input on exit.  Every weight gradient is a split-K GEMM over the transposed planes; data gradients use
+        the planes of the transposed weights."""
+        c, ws = self.cfg, self._ws
+        P, L, st = _lib.ptr, self._call, self._st
+        D, FF, N, H, M = c.hidden, c.ff, c.ntok, c.heads, ws.M
+        hd = D // H
+        w = lambda k: P(self._pmap[k])  # noqa: E731
+        dh, dy, dao, dact, dqkv = P(ws.dh), P(ws.dy), P(ws.dao), P(ws.dact), P(ws.dqkv)
+        s_y1, s_ao, s_y2, s_act = (fslot(1 + 4 * i + k) for k in range(4))
+        b_dh2, b_dact, b_dh1, b_dqkv = (bslot(1 + 4 * i + k) for k in range(4))
+        # fc2: h_out = h_mid + act.W2^T + b2
+        self._to_planes(dh, M, D, D, b_dh2, ws.dhp, ws.dhpT)
+        self._wgrad_sp(ws.dhpT, b_dh2, ws.actpT[i], s_act, gp(f"{Lk}.mlp.fc2.weight"), D, FF, M)
+        self._bias_grad(dh, M, D, D, gp(f"{Lk}.mlp.fc2.bias"))
+        wpl, wsl = self._wp(f"fc2{i}", transposed=True)
+        self._gemm_sp(P(ws.dhp), b_dh2, wpl, wsl, dact, M, FF, D, FF)
+        L("eav_gelu_bwd", dact, P(ws.pre[i]), M * FF, st)
+        # fc1
+        self._to_planes(dact, M, FF, FF, b_dact, ws.dactp, ws.dactpT)
+        self._wgrad_sp(ws.dactpT, b_dact, ws.y2pT[i], s_y2, gp(f"{Lk}.mlp.fc1.weight"), FF, D, M)
+        self._bias_grad(dact, M, FF, FF, gp(f"{Lk}.mlp.fc1.bias"))
+        wpl, wsl = self._wp(f"fc1{i}", transposed=True)
+        self._gemm_sp(P(ws.dactp), b_dact, wpl, wsl, dy, M, D, FF, D)
+        L("eav_layernorm_bwd", dy, P(ws.hmid[i]), w(f"{Lk}.layernorm_after.weight"), stp + 8 * M, stp + 12 * M, dh, 1,
+          P(ws.part_ln), M, D, st)
+        self._reduce(ws.part_ln, ws.np_ln, 2 * D, D, gp(f"{Lk}.layernorm_after.weight"))
+        L("eav_reduce_partials", P(ws.part_ln) + 4 * D, ws.np_ln, 2 * D, D, 1.0, gp(f"{Lk}.layernorm_after.bias"), st)
+        # o_proj
+        self._to_planes(dh, M, D, D, b_dh1, ws.dhp, ws.dhpT)
+        self._wgrad_sp(ws.dhpT, b_dh1, ws.aopT[i], s_ao, gp(f"{Lk}.attention.o_proj.weight"), D, D, M)
+        self._bias_grad(dh, M, D, D, gp(f"{Lk}.attention.o_proj.bias"))
+        wpl, wsl = self._wp(f"o{i}", transposed=True)
+        self._gemm_sp(P(ws.dhp), b_dh1, wpl, wsl, dao, M, D, D, D)
+        # attention core (fp32 kernels)
+        qkv = P(ws.qkv[i])
+        if ws.fused:
+            L("eav_attn_bwd", qkv, P(ws.ao[i]), dao, P(ws.lse[i]), P(ws.delta), dqkv, ws.B, H, N, hd, scale, st)
+        else:
+            ldn = ws.ldn
+            Pm, dP = P(ws.P[i]), P(ws.dP)
+            sP, sQ, sO = (H * N * ldn, N * ldn), (N * 3 * D, hd), (N * D, hd)
+            g = self._gemm_f32
+            g(Pm, dao, dqkv + 8 * D, N, hd, N, ldn, D, 3 * D, tA=1, tB=1, batch=ws.B * H, heads=H, sA=sP, sB=sO, sC=sQ)
+            g(dao, qkv + 8 * D, dP, N, N, hd, D, 3 * D, ldn, batch=ws.B * H, heads=H, sA=sO, sB=sQ, sC=sP)
+            L("eav_softmax_bwd", Pm, dP, ws.B * H * N, N, ldn, st)
+            g(dP, qkv + 4 * D, dqkv, N, hd, N, ldn, 3 * D, 3 * D, tB=1, batch=ws.B * H, heads=H, sA=sP, sB=sQ, sC=sQ,
+              alpha=scale)
+            g(dP, qkv, dqkv + 4 * D, N, hd, N, ldn, 3 * D, 3 * D, tA=1, tB=1, batch=ws.B * H, heads=H, sA=sP, sB=sQ,
+              sC=sQ, alpha=scale)
+        # fused q/k/v projection
+        self._to_planes(dqkv, M, 3 * D, 3 * D, b_dqkv, ws.dqkvp, ws.dqkvpT)
+        self._wgrad_sp(ws.dqkvpT, b_dqkv, ws.y1pT[i], s_y1, gp(f"{Lk}.attention.q_proj.weight"), 3 * D, D, M)
+        self._bias_grad(dqkv, M, 3 * D, 3 * D, gp(f"{Lk}.attention.q_proj.bias"))
+        wpl, wsl = self._wp(f"qkv{i}", transposed=True)
+        self._gemm_sp(P(ws.dqkvp), b_dqkv, wpl, wsl, dy, M, D, 3 * D, D)
+        L("eav_layernorm_bwd", dy, P(ws.hs[i]), w(f"{Lk}.layernorm_before.weight"), stp, stp + 4 * M, dh, 1,
+          P(ws.part_ln), M, D, st)
+        self._reduce(ws.part_ln, ws.np_ln, 2 * D, D, gp(f"{Lk}.layernorm_before.weight"))
+        L("eav_reduce_partials", P(ws.part_ln) + 4 * D, ws.np_ln, 2 * D, D, 1.0, gp(f"{Lk}.layernorm_before.bias"), st)
 
     def _wgrad(self, A, B, C, M, N, K, lda, ldb):
         """C[M,N] = A^T.B for A stored [K,M], B stored [K,N] (weight gradient: contraction over tokens)."""
@@ -455,9 +690,21 @@ class Encoder(nn.Module):
             L("eav_token_rows", P(ws.dh), P(ws.drows), B, N, D, c.nextra, 1, st)
             scale = hd ** -0.5
             dh, dy, dao, dact, dqkv = P(ws.dh), P(ws.dy), P(ws.dao), P(ws.dact), P(ws.dqkv)
+            sp = ws.sp
+            if sp:
+                ws.bslots.zero_()
+                bslot = lambda n: ws.bslots.data_ptr() + 4 * self.SLOT * n  # noqa: E731
+                fslot = lambda n: ws.fslots.data_ptr() + 4 * self.SLOT * n  # noqa: E731
             for i in reversed(range(c.layers)):
                 Lk = f"{pre}.layers.{i}"
                 stp = P(ws.st[i])
+                if sp:
+                    self._layer_backward_split(i, Lk, stp, gp, bslot, fslot, scale)
+                    if self.grad_ready_hook is not None:
+                        lo = offs[f"{Lk}.attention.q_proj.weight"][0]
+                        hi = offs[f"{Lk}.mlp.fc2.bias"][0] + offs[f"{Lk}.mlp.fc2.bias"][1]
+                        self.grad_ready_hook(lo, hi)
+                    continue
                 # fc2: h_out = h_mid + act.W2^T + b2
                 self._wgrad(dh, P(ws.act[i]), gp(f"{Lk}.mlp.fc2.weight"), D, FF, M, D, FF)
                 self._bias_grad(dh, M, D, D, gp(f"{Lk}.mlp.fc2.bias"))
@@ -513,8 +760,13 @@ class Encoder(nn.Module):
             if c.kind == "ast":
                 gflat[offs[f"{pre}.embeddings.distillation_token"][0]:][:D].copy_(gpos[D:2 * D])
             MP = B * c.npatch
-            self._wgrad(P(ws.demb), P(ws.col), gp(f"{pre}.embeddings.patch_embeddings.projection.weight"), D, c.kp, MP,
-                        D, c.kp)
+            if sp:
+                self._to_planes(P(ws.demb), MP, D, D, bslot(0), None, ws.dembpT)
+                self._wgrad_sp(ws.dembpT, bslot(0), ws.colpT, fslot(0),
+                               gp(f"{pre}.embeddings.patch_embeddings.projection.weight"), D, c.kp, MP)
+            else:
+                self._wgrad(P(ws.demb), P(ws.col), gp(f"{pre}.embeddings.patch_embeddings.projection.weight"), D, c.kp,
+                            MP, D, c.kp)
             self._call("eav_colsum", P(ws.demb), P(ws.part_cs), MP, D, D, st)
             self._call("eav_reduce_partials", P(ws.part_cs), _lib.plain("eav_colsum_nparts", MP), D, D, 1.0,
                        gp(f"{pre}.embeddings.patch_embeddings.projection.bias"), st)

@@ -196,6 +196,29 @@ int eav_gemm_bf16(const float* A, const float* B, float* C, int M, int N, int K,
                   int ldr, int accumulate, void* stream);
 int eav_gemm_bf16_splitk(const float* A, const float* B, float* C, float* ws, int M, int N, int K, int lda, int ldb,
                          int transA, int transB, void* stream);
+/* fp32-grade GEMM on the fp16 matrix cores with split operands (csrc/gemm_sp.hip) - the same call sites as eav_gemm_f32
+ * (nn.Linear forward / data gradient / weight gradient inside HF's ASTLayer / ViTLayer, Transformer_Audio.py:72,
+ * Transformer_Vision.py:92).  Operands are "sp16 planes": X[R,K] with the contraction index along K stored as
+ * uint16 [R][Kp/8][2][8] (8 hi halves, then 8 lo halves; Kp = eav_sp_kpad(K), zero beyond K) of sigma*X, hi =
+ * fp16(sigma x), lo = fp16(sigma x - hi).  A device slot of EAV_SP_SLOT floats per tensor holds 64 shards of the bits of
+ * max|x| (words 0..63), sigma (word 64) and 1/sigma (word 65): zero it, let producers atomicMax the shards
+ * (eav_sp_absmax or a GEMM's amax_slot), then eav_sp_convert writes the planes of X (dst: contraction over columns)
+ * and / or of X^T (dstT: contraction over rows) and fills sigma. */
+#define EAV_SP_SLOT 80
+int eav_sp_kpad(int K);
+int eav_sp_absmax(const float* src, int R, int C, int64_t ld, float* slot, void* stream);
+int eav_sp_convert(const float* src, int R, int C, int64_t ld, float* slot, void* dst, void* dstT, void* stream);
+/* C[z][m,n] = epilogue(alpha * sum_k A[z][m,k] B[n,k]) from planes A [M,Kp], B [N,Kp]; epilogue as eav_gemm_f32
+ * (bias, erf-GELU with pre-activation store, residual, accumulate); amax_slot (optional) receives max |C| bits. */
+int eav_gemm_sp(const void* A, const void* B, float* C, const float* slotA, const float* slotB, int M, int N, int K,
+                int ldc, int batch, int64_t sA_bytes, int64_t sC, float alpha, const float* bias, int gelu, float* pre,
+                const float* resid, int ldr, int accumulate, float* amax_slot, void* stream);
+/* long-contraction form (weight gradients): eav_gemm_sp_splitk_plan(M,N,K) K-slices, ws [nsplit][M][N] partials summed
+ * in fixed order (deterministic); C[M,N] dense (ldc = N). */
+int eav_gemm_sp_splitk_plan(int M, int N, int K);
+int eav_gemm_sp_splitk(const void* A, const void* B, float* C, float* ws, const float* slotA, const float* slotB, int M,
+                       int N, int K, int accumulate, void* stream);
+int eav_gemm_sp_set_tile(int which);   /* tuning hook: 0 heuristic, 1 = 128x128 tiles, 2 = 256x128 */
 /* Fused multi-head self-attention (head_dim 64), exact fp32 MFMA, flash-style: softmax(Q K^T scale) V per
  * (image, head) of qkv [B*N, 3*H*64] (HF eager_attention_forward).  ao [B*N, H*64]; lse [B*H, N] saved for
  * the backward. */

@@ -32,14 +32,19 @@ def _batch(kind, cfg, seed, B):
     return synth.mel_batch(seed, B, cfg.W, cfg.H) if kind == "ast" else synth.frame_batch(seed, B, cfg.H)
 
 
+PRECISIONS = ["fp32", "split"]     # "split": fp16 hi/lo operand planes on the fp16 matrix cores, SAME bounds as fp32
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("kind", ["ast", "vit"])
-def test_reduced_model_training_steps_match_hf(golden_dir, kind):
+def test_reduced_model_training_steps_match_hf(golden_dir, kind, precision):
     from eav_amd import transformer as T
     from eav_amd.optim import CrossEntropyLoss, FusedAdam
     g = np.load(os.path.join(golden_dir, f"{kind}_reduced.npz"))
     cfg = T.make_config(kind, hidden=64, layers=2, heads=4, ff=128)
     W = _weights(kind, int(g["wseed"]), float(g["std"]), hidden=64, layers=2, heads=4, ff=128)
     model = T.Encoder(cfg, W).cuda().train()
+    model.precision = precision
     lr = float(g["lr"])
     opt = FusedAdam(model.parameters(), lr=lr, weight_decay=0.01, decoupled=True)
     crit = CrossEntropyLoss()
@@ -73,13 +78,15 @@ def test_reduced_model_training_steps_match_hf(golden_dir, kind):
         assert opt.state[p]["step"] == (2 if k.startswith("classifier.") else 1), k
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("kind", ["ast", "vit"])
-def test_full_size_logits_match_hf(golden_dir, kind):
+def test_full_size_logits_match_hf(golden_dir, kind, precision):
     from eav_amd import transformer as T
     g = np.load(os.path.join(golden_dir, f"{kind}_full.npz"))
     cfg = T.make_config(kind)
     W = _weights(kind, int(g["wseed"]), 0.02)
     model = T.Encoder(cfg, W).cuda().eval()
+    model.precision = precision
     assert sum(p.numel() for p in model.parameters()) == int(g["nparams"])
     x, _ = _batch(kind, cfg, int(g["xseed"]), int(g["B"]))
     with torch.no_grad():
@@ -87,8 +94,9 @@ def test_full_size_logits_match_hf(golden_dir, kind):
     close(logits, g["logits"], 1e-4, 1e-4, "full-size logits")        # north_star bound is 1e-3
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("kind", ["ast", "vit"])
-def test_full_size_gradients_match_oracle(kind):
+def test_full_size_gradients_match_oracle(kind, precision):
     """12-layer model, B=2: every gradient of the unfrozen step against the CPU oracle (autograd)."""
     from eav_amd import transformer as T
     from eav_amd.optim import CrossEntropyLoss
@@ -97,6 +105,7 @@ def test_full_size_gradients_match_oracle(kind):
     ocfg = vo.cfg_ast() if kind == "ast" else vo.cfg_vit()
     W = _weights(kind, 17, 0.02)
     model = T.Encoder(cfg, W).cuda().train()
+    model.precision = precision
     x, y = _batch(kind, cfg, 71, 2)
     out = model(torch.from_numpy(x).cuda())
     loss = CrossEntropyLoss()(out.logits, torch.from_numpy(y).cuda())
@@ -168,7 +177,8 @@ def test_reduced_precision_modes(golden_dir, kind):
         assert 1e-5 < rel < 5e-2
 
 
-def test_batch_size_changes_and_eval_mode():
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_batch_size_changes_and_eval_mode(precision):
     """Ragged last batch (workspace re-allocation), batch 1, eval forward after a training step."""
     from eav_amd import transformer as T
     from oracle import vit_oracle as vo
@@ -176,6 +186,7 @@ def test_batch_size_changes_and_eval_mode():
     ocfg = vo.cfg_vit(hidden=64, layers=2, heads=4, ff=128, image=64)
     W = tf_weights(21, vo.param_shapes(ocfg), std=0.08)
     model = T.Encoder(cfg, W).cuda().train()
+    model.precision = precision
     P = {k: torch.from_numpy(v) for k, v in W.items()}
     for B in (3, 1, 2, 3):
         x, y = synth.frame_batch(80 + B, B, 64)

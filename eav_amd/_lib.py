@@ -60,6 +60,9 @@ SIGNATURES = {
     "eav_gemm_sp": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i64, _i64, _f, _p, _i, _p, _p, _i, _i, _p, _p],
     "eav_gemm_sp_splitk": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "eav_gemm_sp_set_tile": [_i],
+    "eav_attn_sp_prep": [_p, _p, _p, _p, _i, _i, _i, _i, C.c_uint, _p],
+    "eav_attn_fwd_sp": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
+    "eav_attn_bwd_sp": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
     "eav_attn_fwd": [_p, _p, _p, _i, _i, _i, _i, _f, _p],
     "eav_attn_bwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
     "eav_layernorm_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _f, _p],
@@ -128,6 +131,7 @@ PLAIN = {
     "eav_gemm_f32_splitk_plan": ([_i, _i, _i], _i),
     "eav_colsum_nparts": ([_i], _i),
     "eav_sp_kpad": ([_i], _i),
+    "eav_attn_sp_npad": ([_i], _i),
     "eav_gemm_sp_splitk_plan": ([_i, _i, _i], _i),
 }
 

@@ -1,0 +1,633 @@
+// Fused multi-head self-attention (head_dim 64) on the fp16 matrix cores with split operands: the fp32-grade fast
+// path of attention.hip (same arithmetic: HF eager_attention_forward, modeling_audio_spectrogram_transformer.py:102-127
+// = modeling_vit.py, softmax(Q K^T hd^-0.5) V per (image, head), no mask, dropout 0; and its backward).
+//
+// Operands are fp16 hi + lo pieces of sigma*x (sigma = per-tensor power of two, gemm_sp.hip) and every product is three
+// v_mfma_f32_32x32x16_f16 (hi.hi + lo.hi + hi.lo) into an fp32 accumulator - 24 / 36 / 48 MFMAs of 32 cycles per
+// 32 x 32 score tile in forward / dQ / dK,dV, against 64 / 96 / 128 of 64 cycles on the exact-fp32 MFMA.
+//
+// Data layout.  eav_attn_sp_prep converts an fp32 activation [B*N, ncols] (qkv, or dO) ONCE into
+//   row planes  [B*N][ncols/8][2][8] f16   (8 hi halves then 8 lo halves per 8 columns: contraction over head_dim)
+//   T planes    [B][ncols/64][64][Npad/8][2][8] f16  (per 64-column head chunk, transposed: contraction over tokens;
+//                                                    Npad = N rounded up to 32, zero beyond N)
+// with lo = fp16(sigma x - hi) (no 2^11 lift: one accumulator per product).  Probabilities are split in registers
+// (p 2^14); dS uses a safe power-of-two bound with a lifted lo in the dQ kernel, which also measures max|dS| so that the
+// dK,dV kernel can use the exact scale with a single accumulator.
+//
+// Kernel structure (all three): a block is NW waves x 32 stationary rows (queries for fwd / dQ, keys for dK,dV); the
+// streamed 32-row tiles go HBM/L2 -> LDS by global_load_lds_dwordx4 (double-buffered, one barrier per tile) in the
+// XOR-swizzled 16-byte-slot images of gemm_sp.hip (conflict-free ds_read_b128 fragments).  The score tile is computed
+// with the streamed rows on the MFMA M axis in the order pi(i) = i with bits 2 and 3 swapped: then in the accumulator
+// layout every lane owns one stationary row and its registers 8s..8s+7 are 8 CONSECUTIVE streamed rows - exactly one
+// B-operand fragment of the next product (no shuffles, no LDS round trip for P / dS), and softmax row statistics are
+// register-local plus one exchange with lane^32.
+#include "eav_common.h"
+#include "../../include/eav_hip.h"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+typedef unsigned char u8;
+
+constexpr float LOG2E = 1.44269504088896340736f, LN2 = 0.69314718055994530942f;
+constexpr float SP = 16384.f;             // probabilities are split as p * 2^14
+constexpr float DS_DOWN = 1.f / 4194304.f;  // 2^-22: |dS| in operand units is < 2^37 (see attn_bwd_q_sp_kernel)
+__device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ int pi_row(int j) { return (j & ~12) | ((j & 4) << 1) | ((j & 8) >> 1); }
+
+__device__ __forceinline__ float sigma_from_bits(unsigned bits) {
+  const int e = (int)((bits >> 23) & 0xff);
+  if (bits == 0u || e == 0xff) return 1.f;
+  int se = 14 - (e - 127);
+  se = max(-126, min(126, se));
+  return __uint_as_float((unsigned)(se + 127) << 23);
+}
+__device__ __forceinline__ unsigned slot_bits(const float* slot) {
+  unsigned bits = 0u;
+#pragma unroll
+  for (int i = 0; i < 64; ++i) bits = max(bits, __float_as_uint(slot[i]));
+  return bits;
+}
+
+// 8 fp32 -> one hi and one lo operand fragment (8 halves each); lo = fp16((t - hi) * lomul)
+__device__ __forceinline__ void split_frag(const float* t, float lomul, f16x8& hi, f16x8& lo) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    hi[e] = (_Float16)t[e];
+    lo[e] = (_Float16)((t[e] - (float)hi[e]) * lomul);
+  }
+}
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+
+// ---- LDS images -----------------------------------------------------------------------------------------------
+// "row tile": 32 rows x 64 head_dim = 32 x 256 B (16 pieces of 16 B per row), slot = row*16 + (p ^ (row & 15))
+// "T tile"  : 64 head_dim rows x 32 tokens = 64 x 128 B (8 pieces per row), slot = d*8 + (p ^ ((d >> 1) & 7))
+// both 8 KB = 8 global_load_lds instructions of 1 KB.  src_row: pointer to the row's first byte of this tile.
+// chunk c of a row tile = rows 4c..4c+3; of a T tile = rows 8c..8c+7.
+__device__ __forceinline__ void glds_row_chunk(u8* lds_tile, int c, const u8* base, int64_t row_stride, int row0,
+                                               int max_row, int lane) {
+  const int r = 4 * c + (lane >> 4);
+  const int p = (lane & 15) ^ (r & 15);
+  const u8* src = base + (int64_t)min(row0 + r, max_row) * row_stride + p * 16;
+  __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(lds_tile + c * 1024), 16, 0, 0);
+}
+__device__ __forceinline__ void glds_t_chunk(u8* lds_tile, int c, const u8* base, int64_t row_stride, int lane) {
+  const int d = 8 * c + (lane >> 3);
+  const int p = (lane & 7) ^ ((d >> 1) & 7);
+  const u8* src = base + (int64_t)d * row_stride + p * 16;
+  __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(lds_tile + c * 1024), 16, 0, 0);
+}
+// A-operand fragment of a row tile: MFMA row i <-> tile row pi(i), head_dim 16s + 8h2 .. +7
+__device__ __forceinline__ f16x8 frag_row(const u8* tile, int prow, int s, int h2, int hl) {
+  return *reinterpret_cast<const f16x8*>(tile + prow * 256 + (((4 * s + 2 * h2 + hl) ^ (prow & 15)) << 4));
+}
+// A-operand fragment of a T tile: MFMA row i <-> head_dim row d, tokens 16s + 8h2 .. +7
+__device__ __forceinline__ f16x8 frag_t(const u8* tile, int d, int s, int h2, int hl) {
+  return *reinterpret_cast<const f16x8*>(tile + d * 128 + (((4 * s + 2 * h2 + hl) ^ ((d >> 1) & 7)) << 4));
+}
+// B-operand fragments of a stationary row straight from the row planes in global memory (4 head_dim steps, hi / lo)
+__device__ __forceinline__ void load_row_frags(const u8* rowptr, int h2, f16x8 (&hi)[4], f16x8 (&lo)[4]) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const uint4* p = reinterpret_cast<const uint4*>(rowptr + 64 * s + 32 * h2);
+    const uint4 a = p[0], b = p[1];
+    hi[s] = *reinterpret_cast<const f16x8*>(&a);
+    lo[s] = *reinterpret_cast<const f16x8*>(&b);
+  }
+}
+
+// out[(row0 + r) * ld + 32*half + ..] = acc^T: lane = row, registers = 32 columns per accumulator; through an LDS patch
+__device__ __forceinline__ float store_rows_T(float* __restrict__ patch, const f32x16& a0, const f32x16& a1, float mul,
+                                              float* __restrict__ out, int ld, int row0, int nrows, int lane) {
+  const int j = lane & 31, h2 = lane >> 5;
+  float vmax = 0.f;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float v = (half ? a1[r] : a0[r]) * mul;
+      patch[j * 33 + (r & 3) + 8 * (r >> 2) + 4 * h2] = v;
+      if (row0 + j < nrows) vmax = fmaxf(vmax, fabsf(v));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = lane + 64 * i;
+      const int row = idx >> 3, c4 = idx & 7;
+      if (row0 + row < nrows) {
+        const float* src = patch + row * 33 + 4 * c4;
+        *reinterpret_cast<float4*>(out + (int64_t)(row0 + row) * ld + 32 * half + 4 * c4) =
+            make_float4(src[0], src[1], src[2], src[3]);
+      }
+    }
+  }
+  return vmax;
+}
+__device__ __forceinline__ void emit_amax(unsigned* slot, float vmax, int lane, int salt) {
+  if (!slot) return;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+  if (lane == 0 && vmax == vmax) atomicMax(slot + (salt & 63), __float_as_uint(vmax));
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+// grid (ceil(N / (32 NW)), B*H).  rowp: row planes of qkv [B*N, 3D]; tp: T planes (chunk 2H + h = V of head h).
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 2) void attn_fwd_sp_kernel(const u8* __restrict__ rowp, const u8* __restrict__ tp,
+                                                                 const float* __restrict__ slot, float* __restrict__ ao,
+                                                                 float* __restrict__ lse, unsigned* __restrict__ amax,
+                                                                 int N, int Npad, int H, float scale) {
+  constexpr int STAGE = 16384;   // K row tile | V^T tile
+  __shared__ __attribute__((aligned(1024))) u8 smem[2 * STAGE > NW * 32 * 33 * 4 ? 2 * STAGE : NW * 32 * 33 * 4];
+  const int D = H * 64;
+  const int64_t ldrow = (int64_t)3 * D * 4, ldt = (int64_t)Npad * 4;
+  const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 31, h2 = lane >> 5;
+  const int q0 = blockIdx.x * 32 * NW + wave * 32;
+  const u8* rows_b = rowp + (int64_t)b * N * ldrow;
+  f16x8 qh[4], ql[4];
+  load_row_frags(rows_b + (int64_t)min(q0 + j, N - 1) * ldrow + h * 256, h2, qh, ql);
+  const u8* kbase = rows_b + (int64_t)(D + h * 64) * 4;
+  const u8* vbase = tp + ((int64_t)(b * 3 * H + 2 * H + h) * 64) * ldt;
+  auto issue = [&](int kt, int buf) {
+    u8* st = smem + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < 8 / NW; ++i) {
+      const int c = wave + NW * i;
+      glds_row_chunk(st, c, kbase, ldrow, 32 * kt, N - 1, lane);
+      glds_t_chunk(st + 8192, c, vbase + (int64_t)kt * 128, ldt, lane);
+    }
+  };
+  const float isg = slot[65];
+  const float c1 = scale * LOG2E * isg * isg;
+  f32x16 o0, o1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+  float m = -INFINITY, l = 0.f;
+  const int nkt = (N + 31) / 32;
+  const int prow = pi_row(j);
+  issue(0, 0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int buf = kt & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + 1 < nkt) issue(kt + 1, buf ^ 1);
+    if (q0 >= N) continue;                 // wave-uniform: a wave without a valid row only helps to stage the tiles
+    const u8* kt_ = smem + buf * STAGE;
+    const u8* vt_ = kt_ + 8192;
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {       // S^T[key][q] = K-tile . Q^T
+      const f16x8 kh = frag_row(kt_, prow, st, h2, 0), kl = frag_row(kt_, prow, st, h2, 1);
+      s = MFMA16(kh, qh[st], s);
+      s = MFMA16(kl, qh[st], s);
+      s = MFMA16(kh, ql[st], s);
+    }
+    // register r <-> key 32 kt + (r&7) + 8 h2 + 16 (r>>3)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] *= c1;
+    if (32 * kt + 32 > N) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (32 * kt + (r & 7) + 8 * h2 + 16 * (r >> 3) >= N) s[r] = -INFINITY;
+    }
+    float mx = s[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mn = fmaxf(m, mx);
+    const float alpha = ex2(m - mn);
+    float rs = 0.f;
+    float pt[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = ex2(s[r] - mn);
+      rs += p;
+      pt[r] = p * SP;
+    }
+    rs += __shfl_xor(rs, 32, 64);
+    l = l * alpha + rs;
+    m = mn;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+    f16x8 ph[2], pl[2];
+    split_frag(pt, 1.f, ph[0], pl[0]);
+    split_frag(pt + 8, 1.f, ph[1], pl[1]);
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {       // O^T[d][q] += V^T[d][key] . P^T[key][q]
+      const f16x8 v0h = frag_t(vt_, j, st, h2, 0), v0l = frag_t(vt_, j, st, h2, 1);
+      const f16x8 v1h = frag_t(vt_, j + 32, st, h2, 0), v1l = frag_t(vt_, j + 32, st, h2, 1);
+      o0 = MFMA16(v0h, ph[st], o0);
+      o1 = MFMA16(v1h, ph[st], o1);
+      o0 = MFMA16(v0l, ph[st], o0);
+      o1 = MFMA16(v1l, ph[st], o1);
+      o0 = MFMA16(v0h, pl[st], o0);
+      o1 = MFMA16(v1h, pl[st], o1);
+    }
+  }
+  const float inv = l > 0.f ? isg / (l * SP) : 0.f;
+  if (h2 == 0 && q0 + j < N) lse[(int64_t)bh * N + q0 + j] = (m + log2f(l)) * LN2;
+  __syncthreads();   // every wave is done with the tiles before the patch area is reused
+  const float vmax = store_rows_T(reinterpret_cast<float*>(smem) + wave * (32 * 33), o0, o1, inv,
+                                  ao + (int64_t)b * N * D + h * 64, D, q0, N, lane);
+  emit_amax(amax, vmax, lane, (blockIdx.y * gridDim.x + blockIdx.x) * NW + wave);
+}
+
+// ------------------------------------------------------------------------------------------------ backward: dQ
+// Query tile stationary.  Streams K rows, V rows and K^T.  dS^T = P^T o (dP^T - delta) in operand units
+// (sigma_do sigma_qkv dS) is bounded by 2^37: |dP| <= 64 * 2^15 * 2^15 and |delta| = |dO . O| <= the same because O is
+// a convex combination of V rows; it is split as t = dS 2^-22 with a lifted lo (second accumulator), and max |t| is
+// published for the dK,dV kernel.
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 2) void attn_bwd_q_sp_kernel(
+    const u8* __restrict__ rowp, const u8* __restrict__ tp, const u8* __restrict__ dorow, const float* __restrict__ slot,
+    const float* __restrict__ slot_do, const float* __restrict__ lse, const float* __restrict__ delta,
+    float* __restrict__ dqkv, unsigned* __restrict__ amax_ds, unsigned* __restrict__ amax_out, int N, int Npad, int H,
+    float scale) {
+  constexpr int STAGE = 24576;   // K rows | V rows | K^T
+  __shared__ __attribute__((aligned(1024))) u8 smem[2 * STAGE];
+  const int D = H * 64;
+  const int64_t ldrow = (int64_t)3 * D * 4, lddo = (int64_t)D * 4, ldt = (int64_t)Npad * 4;
+  const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 31, h2 = lane >> 5;
+  const int q0 = blockIdx.x * 32 * NW + wave * 32;
+  const int q = min(q0 + j, N - 1);
+  const u8* rows_b = rowp + (int64_t)b * N * ldrow;
+  f16x8 qh[4], ql[4], gh[4], gl[4];
+  load_row_frags(rows_b + (int64_t)q * ldrow + h * 256, h2, qh, ql);
+  load_row_frags(dorow + ((int64_t)b * N + q) * lddo + h * 256, h2, gh, gl);
+  const u8* kbase = rows_b + (int64_t)(D + h * 64) * 4;
+  const u8* vrbase = rows_b + (int64_t)(2 * D + h * 64) * 4;
+  const u8* ktbase = tp + ((int64_t)(b * 3 * H + H + h) * 64) * ldt;
+  auto issue = [&](int kt, int buf) {
+    u8* st = smem + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < 8 / NW; ++i) {
+      const int c = wave + NW * i;
+      glds_row_chunk(st, c, kbase, ldrow, 32 * kt, N - 1, lane);
+      glds_row_chunk(st + 8192, c, vrbase, ldrow, 32 * kt, N - 1, lane);
+      glds_t_chunk(st + 16384, c, ktbase + (int64_t)kt * 128, ldt, lane);
+    }
+  };
+  const float isg = slot[65], isd = slot_do[65];
+  const float c1 = scale * LOG2E * isg * isg;
+  const float lq = LOG2E * lse[(int64_t)bh * N + q];
+  const float dq_ = delta[(int64_t)bh * N + q] * slot[64] * slot_do[64];   // delta in operand units
+  f32x16 g0, g1, x0, x1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { g0[r] = 0.f; g1[r] = 0.f; x0[r] = 0.f; x1[r] = 0.f; }
+  float tmax = 0.f;
+  const int nkt = (N + 31) / 32;
+  const int prow = pi_row(j);
+  issue(0, 0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int buf = kt & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + 1 < nkt) issue(kt + 1, buf ^ 1);
+    if (q0 >= N) continue;
+    const u8* kt_ = smem + buf * STAGE;
+    const u8* vr_ = kt_ + 8192;
+    const u8* kT_ = kt_ + 16384;
+    f32x16 s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      const f16x8 kh = frag_row(kt_, prow, st, h2, 0), kl = frag_row(kt_, prow, st, h2, 1);
+      const f16x8 vh = frag_row(vr_, prow, st, h2, 0), vl = frag_row(vr_, prow, st, h2, 1);
+      s = MFMA16(kh, qh[st], s);          // S^T = K . Q^T
+      dp = MFMA16(vh, gh[st], dp);        // dP^T = V . dO^T
+      s = MFMA16(kl, qh[st], s);
+      dp = MFMA16(vl, gh[st], dp);
+      s = MFMA16(kh, ql[st], s);
+      dp = MFMA16(vh, gl[st], dp);
+    }
+    float t[16];
+    const bool ragged = 32 * kt + 32 > N;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float p = ex2(s[r] * c1 - lq);
+      if (ragged && 32 * kt + (r & 7) + 8 * h2 + 16 * (r >> 3) >= N) p = 0.f;
+      t[r] = p * (dp[r] - dq_) * DS_DOWN;
+      tmax = fmaxf(tmax, fabsf(t[r]));
+    }
+    f16x8 th[2], tl[2];
+    split_frag(t, 2048.f, th[0], tl[0]);
+    split_frag(t + 8, 2048.f, th[1], tl[1]);
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {       // dQ^T[d][q] += K^T[d][key] . dS^T[key][q]
+      const f16x8 k0h = frag_t(kT_, j, st, h2, 0), k0l = frag_t(kT_, j, st, h2, 1);
+      const f16x8 k1h = frag_t(kT_, j + 32, st, h2, 0), k1l = frag_t(kT_, j + 32, st, h2, 1);
+      g0 = MFMA16(k0h, th[st], g0);
+      g1 = MFMA16(k1h, th[st], g1);
+      g0 = MFMA16(k0l, th[st], g0);
+      g1 = MFMA16(k1l, th[st], g1);
+      x0 = MFMA16(k0h, tl[st], x0);
+      x1 = MFMA16(k1h, tl[st], x1);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { g0[r] += x0[r] * (1.f / 2048.f); g1[r] += x1[r] * (1.f / 2048.f); }
+  emit_amax(amax_ds, tmax, lane, (blockIdx.y * gridDim.x + blockIdx.x) * NW + wave);
+  __syncthreads();
+  const float mul = scale * (1.f / DS_DOWN) * isd * isg * isg;
+  const float vmax = store_rows_T(reinterpret_cast<float*>(smem) + wave * (32 * 33), g0, g1, mul,
+                                  dqkv + (int64_t)b * N * 3 * D + h * 64, 3 * D, q0, N, lane);
+  emit_amax(amax_out, vmax, lane, (blockIdx.y * gridDim.x + blockIdx.x) * NW + wave);
+}
+
+// ------------------------------------------------------------------------------------------------ backward: dK, dV
+// Key tile stationary.  Streams Q rows, dO rows, Q^T and dO^T.  S[q][key] = Q-tile . K^T (queries on the MFMA M axis in
+// pi order), so register r of lane (key, h2) is query 32 qt + (r&7) + 8 h2 + 16 (r>>3).
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 2) void attn_bwd_kv_sp_kernel(
+    const u8* __restrict__ rowp, const u8* __restrict__ tp, const u8* __restrict__ dorow, const u8* __restrict__ dotp,
+    const float* __restrict__ slot, const float* __restrict__ slot_do, const float* __restrict__ slot_ds,
+    const float* __restrict__ lse, const float* __restrict__ delta, float* __restrict__ dqkv,
+    unsigned* __restrict__ amax_out, int N, int Npad, int H, float scale) {
+  constexpr int STAGE = 32768 + 256;   // Q rows | dO rows | Q^T | dO^T | lse[32], delta[32] of the query tile
+  __shared__ __attribute__((aligned(1024))) u8 smem[2 * STAGE];
+  const int D = H * 64;
+  const int64_t ldrow = (int64_t)3 * D * 4, lddo = (int64_t)D * 4, ldt = (int64_t)Npad * 4;
+  const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 31, h2 = lane >> 5;
+  const int k0 = blockIdx.x * 32 * NW + wave * 32;
+  const int key = min(k0 + j, N - 1);
+  const u8* rows_b = rowp + (int64_t)b * N * ldrow;
+  f16x8 kh[4], kl[4], vh[4], vl[4];
+  load_row_frags(rows_b + (int64_t)key * ldrow + (D + h * 64) * 4, h2, kh, kl);
+  load_row_frags(rows_b + (int64_t)key * ldrow + (2 * D + h * 64) * 4, h2, vh, vl);
+  const u8* qbase = rows_b + (int64_t)(h * 64) * 4;
+  const u8* gbase = dorow + (int64_t)b * N * lddo + (int64_t)(h * 64) * 4;
+  const u8* qtbase = tp + ((int64_t)(b * 3 * H + h) * 64) * ldt;
+  const u8* gtbase = dotp + ((int64_t)(b * H + h) * 64) * ldt;
+  const float* lse_b = lse + (int64_t)bh * N;
+  const float* del_b = delta + (int64_t)bh * N;
+  auto issue = [&](int qt, int buf) {
+    u8* st = smem + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < 8 / NW; ++i) {
+      const int c = wave + NW * i;
+      glds_row_chunk(st, c, qbase, ldrow, 32 * qt, N - 1, lane);
+      glds_row_chunk(st + 8192, c, gbase, lddo, 32 * qt, N - 1, lane);
+      glds_t_chunk(st + 16384, c, qtbase + (int64_t)qt * 128, ldt, lane);
+      glds_t_chunk(st + 24576, c, gtbase + (int64_t)qt * 128, ldt, lane);
+    }
+    if (wave == 0) {   // through LDS as well: an ordinary load here would make hipcc drain the LDS-DMA queue at its use
+      const float* src = (lane < 32 ? lse_b : del_b) + min(32 * qt + (lane & 31), N - 1);
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(st + 32768), 4, 0, 0);
+    }
+  };
+  const float isg = slot[65], isd = slot_do[65];
+  const float c1 = scale * LOG2E * isg * isg;
+  const float dsc = slot[64] * slot_do[64];
+  const float s2 = sigma_from_bits(slot_bits(slot_ds));   // exact scale of t = dS 2^-22 (measured by the dQ kernel)
+  f32x16 gk0, gk1, gv0, gv1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { gk0[r] = 0.f; gk1[r] = 0.f; gv0[r] = 0.f; gv1[r] = 0.f; }
+  const int nqt = (N + 31) / 32;
+  const int prow = pi_row(j);
+  issue(0, 0);
+  for (int qt = 0; qt < nqt; ++qt) {
+    const int buf = qt & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (qt + 1 < nqt) issue(qt + 1, buf ^ 1);
+    if (k0 >= N) continue;
+    const u8* qr_ = smem + buf * STAGE;
+    const u8* gr_ = qr_ + 8192;
+    const u8* qT_ = qr_ + 16384;
+    const u8* gT_ = qr_ + 24576;
+    f32x16 s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      const f16x8 ah = frag_row(qr_, prow, st, h2, 0), al = frag_row(qr_, prow, st, h2, 1);
+      const f16x8 bh_ = frag_row(gr_, prow, st, h2, 0), bl_ = frag_row(gr_, prow, st, h2, 1);
+      s = MFMA16(ah, kh[st], s);          // S[q][key] = Q . K^T
+      dp = MFMA16(bh_, vh[st], dp);       // dP[q][key] = dO . V^T
+      s = MFMA16(al, kh[st], s);
+      dp = MFMA16(bl_, vh[st], dp);
+      s = MFMA16(ah, kl[st], s);
+      dp = MFMA16(bh_, vl[st], dp);
+    }
+    float pt[16], t[16];
+    const float* ls = reinterpret_cast<const float*>(qr_ + 32768);
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const int ql = 16 * g + 8 * h2;                    // 8 consecutive queries <-> registers 8g .. 8g+7
+      const float4 l0 = *reinterpret_cast<const float4*>(ls + ql), l1 = *reinterpret_cast<const float4*>(ls + ql + 4);
+      const float4 d0 = *reinterpret_cast<const float4*>(ls + 32 + ql);
+      const float4 d1 = *reinterpret_cast<const float4*>(ls + 36 + ql);
+      const float lqv[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+      const float dlv[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int r = 8 * g + e;
+        const float p = (32 * qt + ql + e < N) ? ex2(s[r] * c1 - lqv[e] * LOG2E) : 0.f;
+        pt[r] = p * SP;
+        t[r] = p * (dp[r] - dlv[e] * dsc) * (DS_DOWN * s2);
+      }
+    }
+    f16x8 ph[2], pl[2], th[2], tl[2];
+    split_frag(pt, 1.f, ph[0], pl[0]);
+    split_frag(pt + 8, 1.f, ph[1], pl[1]);
+    split_frag(t, 1.f, th[0], tl[0]);
+    split_frag(t + 8, 1.f, th[1], tl[1]);
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      {                                    // dV^T[d][key] += dO^T[d][q] . P[q][key]
+        const f16x8 a0h = frag_t(gT_, j, st, h2, 0), a0l = frag_t(gT_, j, st, h2, 1);
+        const f16x8 a1h = frag_t(gT_, j + 32, st, h2, 0), a1l = frag_t(gT_, j + 32, st, h2, 1);
+        gv0 = MFMA16(a0h, ph[st], gv0);
+        gv1 = MFMA16(a1h, ph[st], gv1);
+        gv0 = MFMA16(a0l, ph[st], gv0);
+        gv1 = MFMA16(a1l, ph[st], gv1);
+        gv0 = MFMA16(a0h, pl[st], gv0);
+        gv1 = MFMA16(a1h, pl[st], gv1);
+      }
+      {                                    // dK^T[d][key] += Q^T[d][q] . dS[q][key]
+        const f16x8 a0h = frag_t(qT_, j, st, h2, 0), a0l = frag_t(qT_, j, st, h2, 1);
+        const f16x8 a1h = frag_t(qT_, j + 32, st, h2, 0), a1l = frag_t(qT_, j + 32, st, h2, 1);
+        gk0 = MFMA16(a0h, th[st], gk0);
+        gk1 = MFMA16(a1h, th[st], gk1);
+        gk0 = MFMA16(a0l, th[st], gk0);
+        gk1 = MFMA16(a1l, th[st], gk1);
+        gk0 = MFMA16(a0h, tl[st], gk0);
+        gk1 = MFMA16(a1h, tl[st], gk1);
+      }
+    }
+  }
+  __syncthreads();
+  float* base = dqkv + (int64_t)b * N * 3 * D + h * 64;
+  float* patch = reinterpret_cast<float*>(smem) + wave * (32 * 33);
+  const float mk = scale * (1.f / DS_DOWN) / s2 * isd * isg * isg;
+  const float mv = isd / SP;
+  float vmax = store_rows_T(patch, gk0, gk1, mk, base + D, 3 * D, k0, N, lane);
+  vmax = fmaxf(vmax, store_rows_T(patch, gv0, gv1, mv, base + 2 * D, 3 * D, k0, N, lane));
+  emit_amax(amax_out, vmax, lane, (blockIdx.y * gridDim.x + blockIdx.x) * NW + wave);
+}
+
+// delta[bh][q] = sum_d dO[q, h*64+d] * O[q, h*64+d]   (one wave per (row, head))
+__global__ __launch_bounds__(256) void attn_delta_sp_kernel(const float* __restrict__ o, const float* __restrict__ dout,
+                                                            float* __restrict__ delta, int B, int N, int H) {
+  const int lane = threadIdx.x & 63;
+  const int64_t id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);      // (b*N + q)*H + h
+  if (id >= (int64_t)B * N * H) return;
+  const int h = (int)(id % H);
+  const int64_t row = id / H;
+  const int b = (int)(row / N), q = (int)(row - (int64_t)b * N);
+  const int64_t off = row * (H * 64) + h * 64 + lane;
+  const float v = wave_sum(o[off] * dout[off]);
+  if (lane == 0) delta[((int64_t)b * H + h) * N + q] = v;
+}
+
+// ------------------------------------------------------------------------------------------------ operand preparation
+// src [B*N, ncols] fp32 -> row planes and / or T planes (see the header).  One 64-token x 64-column tile per block;
+// grid (ncols/64, ceil(Npad/64), B).  tmask bit s set: write the T planes of column section s (sections of secw columns).
+__global__ __launch_bounds__(256) void attn_sp_prep_kernel(const float* __restrict__ src, float* __restrict__ slot,
+                                                           u8* __restrict__ rowp, u8* __restrict__ tp, int N, int Npad,
+                                                           int ncols, int secw, unsigned tmask) {
+  __shared__ float tile[64][65];
+  const float sigma = sigma_from_bits(slot_bits(slot));
+  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
+    slot[64] = sigma;
+    slot[65] = 1.f / sigma;
+  }
+  const int chunk = blockIdx.x, t0 = blockIdx.y * 64, b = blockIdx.z;
+  const int c0 = chunk * 64;
+  const bool wantT = tp && ((tmask >> (c0 / secw)) & 1u);
+  const int t = threadIdx.x;
+  {
+    const int cg = t & 7, rr = t >> 3;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int tok = t0 + rr + 32 * pass, col = c0 + 8 * cg;
+      float tv[8];
+      if (tok < N) {
+        const float* p = src + ((int64_t)b * N + tok) * ncols + col;
+        const float4 a = *reinterpret_cast<const float4*>(p), c = *reinterpret_cast<const float4*>(p + 4);
+        tv[0] = a.x; tv[1] = a.y; tv[2] = a.z; tv[3] = a.w; tv[4] = c.x; tv[5] = c.y; tv[6] = c.z; tv[7] = c.w;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) tv[e] *= sigma;
+        if (rowp) {
+          f16x8 hi, lo;
+          split_frag(tv, 1.f, hi, lo);
+          uint4* o = reinterpret_cast<uint4*>(rowp + ((int64_t)b * N + tok) * ncols * 4 + (col >> 3) * 32);
+          o[0] = *reinterpret_cast<const uint4*>(&hi);
+          o[1] = *reinterpret_cast<const uint4*>(&lo);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) tv[e] = 0.f;
+      }
+      if (wantT) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) tile[rr + 32 * pass][8 * cg + e] = tv[e];
+      }
+    }
+  }
+  if (!wantT) return;
+  __syncthreads();
+  {
+    const int rg = t & 7, cc = t >> 3;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int d = cc + 32 * pass, tok = t0 + 8 * rg;
+      if (tok >= Npad) continue;
+      float tv[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) tv[e] = tile[8 * rg + e][d];
+      f16x8 hi, lo;
+      split_frag(tv, 1.f, hi, lo);
+      uint4* o = reinterpret_cast<uint4*>(tp + (((int64_t)b * (ncols / 64) + chunk) * 64 + d) * Npad * 4 + (tok >> 3) * 32);
+      o[0] = *reinterpret_cast<const uint4*>(&hi);
+      o[1] = *reinterpret_cast<const uint4*>(&lo);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int eav_attn_sp_npad(int N) { return (N + 31) / 32 * 32; }
+
+extern "C" int eav_attn_sp_prep(const float* src, float* slot, void* rowp, void* tp, int B, int N, int ncols, int secw,
+                                unsigned tmask, void* stream) {
+  EAV_REQUIRE(src && slot && (rowp || tp) && B > 0 && N > 0 && ncols > 0 && ncols % 64 == 0 && secw > 0 &&
+                  secw % 64 == 0 && ncols % secw == 0,
+              "eav_attn_sp_prep: columns and sections must be multiples of the head dimension 64");
+  const int Npad = eav_attn_sp_npad(N);
+  hipLaunchKernelGGL(attn_sp_prep_kernel, dim3(ncols / 64, cdiv(Npad, 64), B), dim3(256), 0, (hipStream_t)stream, src,
+                     slot, (u8*)rowp, (u8*)tp, N, Npad, ncols, secw, tmask);
+  EAV_CHECK_LAUNCH("eav_attn_sp_prep");
+  return EAV_OK;
+}
+
+extern "C" int eav_attn_fwd_sp(const void* rowp, const void* tp, const float* slot, float* ao, float* lse,
+                               float* amax_slot, int B, int H, int N, int head_dim, float scale, void* stream) {
+  EAV_REQUIRE(rowp && tp && slot && ao && lse && B > 0 && H > 0 && N > 0, "eav_attn_fwd_sp: bad arguments");
+  EAV_REQUIRE(head_dim == 64, "eav_attn_fwd_sp: head_dim %d unsupported (needs 64)", head_dim);
+  const int Npad = eav_attn_sp_npad(N);
+  hipStream_t st = (hipStream_t)stream;
+  if (N > 512) {
+    hipLaunchKernelGGL(attn_fwd_sp_kernel<4>, dim3(cdiv(N, 128), B * H), dim3(256), 0, st, (const u8*)rowp,
+                       (const u8*)tp, slot, ao, lse, (unsigned*)amax_slot, N, Npad, H, scale);
+  } else {
+    hipLaunchKernelGGL(attn_fwd_sp_kernel<2>, dim3(cdiv(N, 64), B * H), dim3(128), 0, st, (const u8*)rowp,
+                       (const u8*)tp, slot, ao, lse, (unsigned*)amax_slot, N, Npad, H, scale);
+  }
+  EAV_CHECK_LAUNCH("eav_attn_fwd_sp");
+  return EAV_OK;
+}
+
+// delta: scratch [B*H, N].  slot_ds: scratch slot (zeroed by the caller).  dqkv [B*N, 3*H*64] fp32.
+extern "C" int eav_attn_bwd_sp(const void* rowp, const void* tp, const void* dorow, const void* dotp, const float* slot,
+                               const float* slot_do, float* slot_ds, const float* ao, const float* dout,
+                               const float* lse, float* delta, float* dqkv, float* amax_slot, int B, int H, int N,
+                               int head_dim, float scale, void* stream) {
+  EAV_REQUIRE(rowp && tp && dorow && dotp && slot && slot_do && slot_ds && ao && dout && lse && delta && dqkv && B > 0 &&
+                  H > 0 && N > 0, "eav_attn_bwd_sp: bad arguments");
+  EAV_REQUIRE(head_dim == 64, "eav_attn_bwd_sp: head_dim %d unsupported (needs 64)", head_dim);
+  const int Npad = eav_attn_sp_npad(N);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(attn_delta_sp_kernel, dim3((unsigned)cdiv64((int64_t)B * N * H, 4)), dim3(256), 0, st, ao, dout,
+                     delta, B, N, H);
+  EAV_CHECK_LAUNCH("eav_attn_bwd_sp(delta)");
+  if (N > 512) {
+    dim3 grid(cdiv(N, 128), B * H);
+    hipLaunchKernelGGL(attn_bwd_q_sp_kernel<4>, grid, dim3(256), 0, st, (const u8*)rowp, (const u8*)tp,
+                       (const u8*)dorow, slot, slot_do, lse, delta, dqkv, (unsigned*)slot_ds, (unsigned*)amax_slot, N,
+                       Npad, H, scale);
+    EAV_CHECK_LAUNCH("eav_attn_bwd_sp(dQ)");
+    hipLaunchKernelGGL(attn_bwd_kv_sp_kernel<4>, grid, dim3(256), 0, st, (const u8*)rowp, (const u8*)tp,
+                       (const u8*)dorow, (const u8*)dotp, slot, slot_do, slot_ds, lse, delta, dqkv,
+                       (unsigned*)amax_slot, N, Npad, H, scale);
+  } else {
+    dim3 grid(cdiv(N, 64), B * H);
+    hipLaunchKernelGGL(attn_bwd_q_sp_kernel<2>, grid, dim3(128), 0, st, (const u8*)rowp, (const u8*)tp,
+                       (const u8*)dorow, slot, slot_do, lse, delta, dqkv, (unsigned*)slot_ds, (unsigned*)amax_slot, N,
+                       Npad, H, scale);
+    EAV_CHECK_LAUNCH("eav_attn_bwd_sp(dQ)");
+    // the dK,dV kernel holds 66 KB of tiles per block: 4-wave blocks keep 2 waves per SIMD (a wave past the last key
+    // only stages tiles)
+    hipLaunchKernelGGL(attn_bwd_kv_sp_kernel<4>, dim3(cdiv(N, 128), B * H), dim3(256), 0, st, (const u8*)rowp,
+                       (const u8*)tp, (const u8*)dorow, (const u8*)dotp, slot, slot_do, slot_ds, lse, delta, dqkv,
+                       (unsigned*)amax_slot, N, Npad, H, scale);
+  }
+  EAV_CHECK_LAUNCH("eav_attn_bwd_sp(dK,dV)");
+  return EAV_OK;
+}

@@ -291,13 +291,14 @@ class Encoder(nn.Module):
         sp = self.precision == "split"
         ws = SimpleNamespace(B=B, M=M, ldn=ldn, full=full_backward, sp=sp)
         nsave = Lr if full_backward else 1
-        if sp:
-            self._alloc_split(ws, dev, nsave)
         ws.col = f(B * c.npatch, c.kp)
         ws.hs = [f(M, D) for _ in range(Lr + 1)] if full_backward else [f(M, D), f(M, D)]
         ws.y1 = [f(M, D) for _ in range(1 if sp else nsave)]     # split mode keeps planes, not fp32 copies
-        ws.qkv = [f(M, 3 * D) for _ in range(nsave)]
         ws.fused = self._fused_attention()
+        # split mode + fused attention: the backward reads the fp16 planes of qkv, the fp32 tensor is transient
+        ws.qkv = [f(M, 3 * D) for _ in range(1 if (sp and ws.fused) else nsave)]
+        if sp:
+            self._alloc_split(ws, dev, nsave)
         if ws.fused:      # flash-style kernels: only the log-sum-exp per (image, head, query) is kept
             ws.lse = [f(B * H, N) for _ in range(nsave)]
             ws.delta = f(B * H, N)
@@ -334,6 +335,7 @@ class Encoder(nn.Module):
 
     # ------------------------------------------------------------------ split-operand (fp16 hi/lo planes) plumbing
     SLOT = 80   # floats per scale slot (include/eav_hip.h EAV_SP_SLOT)
+    FS, BS = 5, 6   # slots per layer: forward y1, qkv, ao, y2, act; backward dh(fc2), dact, dh(o), dao, dS, dqkv
 
     def _alloc_split(self, ws, dev, nsave):
         c = self.cfg
@@ -348,7 +350,12 @@ class Encoder(nn.Module):
         ws.aop = [h(M, D) for _ in range(nsave)]
         ws.y2p = [h(M, D) for _ in range(nsave)]
         ws.actp = [h(M, FF) for _ in range(nsave)]
-        ws.fslots = torch.zeros(1 + 4 * Lr, self.SLOT, dtype=torch.float32, device=dev)
+        ws.fslots = torch.zeros(1 + self.FS * Lr, self.SLOT, dtype=torch.float32, device=dev)
+        H, N = c.heads, c.ntok
+        Npad = _lib.plain("eav_attn_sp_npad", N)
+        if ws.fused:   # attention operands: row planes of qkv and per-head transposed planes (csrc/attention_sp.hip)
+            ws.qkvrow = [torch.empty(M, 6 * D, dtype=torch.float16, device=dev) for _ in range(nsave)]
+            ws.qkvT = [torch.empty(ws.B, 3 * H, 64, 2 * Npad, dtype=torch.float16, device=dev) for _ in range(nsave)]
         if full:
             ws.colpT = h(c.kp, MP)
             ws.y1pT = [h(D, M) for _ in range(nsave)]
@@ -360,7 +367,10 @@ class Encoder(nn.Module):
             ws.dactp, ws.dactpT = h(M, FF), h(FF, M)
             ws.dqkvp, ws.dqkvpT = h(M, 3 * D), h(3 * D, M)
             ws.dembpT = h(D, MP)
-            ws.bslots = torch.zeros(1 + 4 * Lr, self.SLOT, dtype=torch.float32, device=dev)
+            ws.bslots = torch.zeros(1 + self.BS * Lr, self.SLOT, dtype=torch.float32, device=dev)
+            if ws.fused:
+                ws.dorow = torch.empty(M, 2 * D, dtype=torch.float16, device=dev)
+                ws.doT = torch.empty(ws.B, H, 64, 2 * Npad, dtype=torch.float16, device=dev)
 
     def _weight_keys(self):
         """[(cache key, parameter name of the [out, in] matrix, out, in)] of every GEMM weight."""
@@ -535,16 +545,20 @@ class Encoder(nn.Module):
         hd = D // H
         w = lambda k: P(self._pmap[k])  # noqa: E731
         T = (lambda lst: lst[j]) if ws.full else (lambda lst: None)  # noqa: E731
-        s_y1, s_ao, s_y2, s_act = (fslot(1 + 4 * i + k) for k in range(4))
+        s_y1, s_qkv, s_ao, s_y2, s_act = (fslot(1 + self.FS * i + k) for k in range(5))
         y, ao, act = ws.y1[0], ws.ao[j], ws.act[0]
         L("eav_layernorm_fwd", P(hin), w(f"{Lk}.layernorm_before.weight"), w(f"{Lk}.layernorm_before.bias"), P(y), stp,
           stp + 4 * M, M, D, c.eps, st)
         self._to_planes(P(y), M, D, D, s_y1, ws.y1p[j], T(ws.y1pT) if ws.full else None)
-        qkv = P(ws.qkv[j])
+        qkv = P(ws.qkv[0 if ws.fused else j])
         wpl, wsl = self._wp(f"qkv{i}")
-        self._gemm_sp(P(ws.y1p[j]), s_y1, wpl, wsl, qkv, M, 3 * D, D, 3 * D, bias=w(f"{Lk}.attention.q_proj.bias"))
+        self._gemm_sp(P(ws.y1p[j]), s_y1, wpl, wsl, qkv, M, 3 * D, D, 3 * D, bias=w(f"{Lk}.attention.q_proj.bias"),
+                      amax=s_qkv if ws.fused else None)
         if ws.fused:
-            L("eav_attn_fwd", qkv, P(ao), P(ws.lse[j]), ws.B, H, N, hd, scale, st)
+            # row planes of Q | K | V and the per-head transposes (V^T for the forward; Q^T, K^T for the backward)
+            L("eav_attn_sp_prep", qkv, s_qkv, P(ws.qkvrow[j]), P(ws.qkvT[j]), ws.B, N, 3 * D, D, 7 if ws.full else 4, st)
+            L("eav_attn_fwd_sp", P(ws.qkvrow[j]), P(ws.qkvT[j]), s_qkv, P(ao), P(ws.lse[j]), s_ao, ws.B, H, N, hd,
+              scale, st)
         else:
             ldn = ws.ldn
             Pm = P(ws.P[j])
@@ -553,7 +567,7 @@ class Encoder(nn.Module):
             L("eav_softmax_fwd", Pm, ws.B * H * N, N, ldn, st)
             self._gemm_f32(Pm, qkv + 8 * D, P(ao), N, hd, N, ldn, 3 * D, D, tB=1, batch=ws.B * H, heads=H,
                            sA=(H * N * ldn, N * ldn), sB=(N * 3 * D, hd), sC=(N * D, hd))
-        self._to_planes(P(ao), M, D, D, s_ao, ws.aop[j], T(ws.aopT) if ws.full else None)
+        self._to_planes(P(ao), M, D, D, s_ao, ws.aop[j], T(ws.aopT) if ws.full else None, amax_done=ws.fused)
         wpl, wsl = self._wp(f"o{i}")
         self._gemm_sp(P(ws.aop[j]), s_ao, wpl, wsl, P(ws.hmid[j]), M, D, D, D, bias=w(f"{Lk}.attention.o_proj.bias"),
                       resid=P(hin), ldr=D)
@@ -583,8 +597,8 @@ class Encoder(nn.Module):
         hd = D // H
         w = lambda k: P(self._pmap[k])  # noqa: E731
         dh, dy, dao, dact, dqkv = P(ws.dh), P(ws.dy), P(ws.dao), P(ws.dact), P(ws.dqkv)
-        s_y1, s_ao, s_y2, s_act = (fslot(1 + 4 * i + k) for k in range(4))
-        b_dh2, b_dact, b_dh1, b_dqkv = (bslot(1 + 4 * i + k) for k in range(4))
+        s_y1, s_qkv, s_ao, s_y2, s_act = (fslot(1 + self.FS * i + k) for k in range(5))
+        b_dh2, b_dact, b_dh1, b_dao, b_ds, b_dqkv = (bslot(1 + self.BS * i + k) for k in range(6))
         # fc2: h_out = h_mid + act.W2^T + b2
         self._to_planes(dh, M, D, D, b_dh2, ws.dhp, ws.dhpT)
         self._wgrad_sp(ws.dhpT, b_dh2, ws.actpT[i], s_act, gp(f"{Lk}.mlp.fc2.weight"), D, FF, M)
@@ -607,12 +621,14 @@ class Encoder(nn.Module):
         self._wgrad_sp(ws.dhpT, b_dh1, ws.aopT[i], s_ao, gp(f"{Lk}.attention.o_proj.weight"), D, D, M)
         self._bias_grad(dh, M, D, D, gp(f"{Lk}.attention.o_proj.bias"))
         wpl, wsl = self._wp(f"o{i}", transposed=True)
-        self._gemm_sp(P(ws.dhp), b_dh1, wpl, wsl, dao, M, D, D, D)
-        # attention core (fp32 kernels)
-        qkv = P(ws.qkv[i])
+        self._gemm_sp(P(ws.dhp), b_dh1, wpl, wsl, dao, M, D, D, D, amax=b_dao if ws.fused else None)
+        # attention core
         if ws.fused:
-            L("eav_attn_bwd", qkv, P(ws.ao[i]), dao, P(ws.lse[i]), P(ws.delta), dqkv, ws.B, H, N, hd, scale, st)
+            L("eav_attn_sp_prep", dao, b_dao, P(ws.dorow), P(ws.doT), ws.B, N, D, D, 1, st)
+            L("eav_attn_bwd_sp", P(ws.qkvrow[i]), P(ws.qkvT[i]), P(ws.dorow), P(ws.doT), s_qkv, b_dao, b_ds,
+              P(ws.ao[i]), dao, P(ws.lse[i]), P(ws.delta), dqkv, b_dqkv, ws.B, H, N, hd, scale, st)
         else:
+            qkv = P(ws.qkv[i])
             ldn = ws.ldn
             Pm, dP = P(ws.P[i]), P(ws.dP)
             sP, sQ, sO = (H * N * ldn, N * ldn), (N * 3 * D, hd), (N * D, hd)
@@ -625,7 +641,7 @@ class Encoder(nn.Module):
             g(dP, qkv, dqkv + 4 * D, N, hd, N, ldn, 3 * D, 3 * D, tA=1, tB=1, batch=ws.B * H, heads=H, sA=sP, sB=sQ,
               sC=sQ, alpha=scale)
         # fused q/k/v projection
-        self._to_planes(dqkv, M, 3 * D, 3 * D, b_dqkv, ws.dqkvp, ws.dqkvpT)
+        self._to_planes(dqkv, M, 3 * D, 3 * D, b_dqkv, ws.dqkvp, ws.dqkvpT, amax_done=ws.fused)
         self._wgrad_sp(ws.dqkvpT, b_dqkv, ws.y1pT[i], s_y1, gp(f"{Lk}.attention.q_proj.weight"), 3 * D, D, M)
         self._bias_grad(dqkv, M, 3 * D, 3 * D, gp(f"{Lk}.attention.q_proj.bias"))
         wpl, wsl = self._wp(f"qkv{i}", transposed=True)

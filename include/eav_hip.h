@@ -219,6 +219,22 @@ int eav_gemm_sp_splitk_plan(int M, int N, int K);
 int eav_gemm_sp_splitk(const void* A, const void* B, float* C, float* ws, const float* slotA, const float* slotB, int M,
                        int N, int K, int accumulate, void* stream);
 int eav_gemm_sp_set_tile(int which);   /* tuning hook: 0 heuristic, 1 = 128x128 tiles, 2 = 256x128 */
+/* The same fused attention on the fp16 matrix cores with split operands (csrc/attention_sp.hip; fp32-grade, 3 MFMAs per
+ * product).  eav_attn_sp_prep converts an fp32 activation src [B*N, ncols] (qkv or dO; slot holds its max|x| shards, see
+ * EAV_SP_SLOT) into row planes [B*N][ncols/8][2][8] f16 and, for the column sections (of secw columns) selected by
+ * tmask, per-head transposed planes [B][ncols/64][64][Npad/8][2][8] (Npad = eav_attn_sp_npad(N), zero beyond N); here
+ * lo = fp16(sigma x - hi) without the 2^11 lift of the GEMM planes.  amax_slot (optional) receives max|output| shards. */
+int eav_attn_sp_npad(int N);
+int eav_attn_sp_prep(const float* src, float* slot, void* rowp, void* tp, int B, int N, int ncols, int secw,
+                     unsigned tmask, void* stream);
+int eav_attn_fwd_sp(const void* rowp, const void* tp, const float* slot, float* ao, float* lse, float* amax_slot, int B,
+                    int H, int N, int head_dim, float scale, void* stream);
+/* dorow / dotp: planes of dO [B*N, H*64]; slot_ds: zeroed scratch slot (max|dS| travels from the dQ to the dK,dV kernel);
+ * ao, dout: fp32 O and dO for delta = rowsum(dO o O); delta: scratch [B*H, N]; dqkv [B*N, 3*H*64] fp32. */
+int eav_attn_bwd_sp(const void* rowp, const void* tp, const void* dorow, const void* dotp, const float* slot,
+                    const float* slot_do, float* slot_ds, const float* ao, const float* dout, const float* lse,
+                    float* delta, float* dqkv, float* amax_slot, int B, int H, int N, int head_dim, float scale,
+                    void* stream);
 /* Fused multi-head self-attention (head_dim 64), exact fp32 MFMA, flash-style: softmax(Q K^T scale) V per
  * (image, head) of qkv [B*N, 3*H*64] (HF eager_attention_forward).  ao [B*N, H*64]; lse [B*H, N] saved for
  * the backward. */

@@ -57,6 +57,10 @@ SIGNATURES = {
     "eav_gemm_f32_splitk": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "eav_sp_absmax": [_p, _i, _i, _i64, _p, _p],
     "eav_sp_convert": [_p, _i, _i, _i64, _p, _p, _p, _p],
+    "eav_sp_convert_colsum": [_p, _i, _i, _i64, _p, _p, _p, _p, _p],
+    "eav_layernorm_fwd_amax": [_p, _p, _p, _p, _p, _p, _i, _i, _f, _p, _p],
+    "eav_layernorm_bwd_amax": [_p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _p, _p],
+    "eav_gelu_bwd_amax": [_p, _p, _i64, _p, _p],
     "eav_gemm_sp": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i64, _i64, _f, _p, _i, _p, _p, _i, _i, _p, _p],
     "eav_gemm_sp_splitk": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "eav_gemm_sp_set_tile": [_i],
@@ -131,6 +135,7 @@ PLAIN = {
     "eav_gemm_f32_splitk_plan": ([_i, _i, _i], _i),
     "eav_colsum_nparts": ([_i], _i),
     "eav_sp_kpad": ([_i], _i),
+    "eav_sp_convert_colsum_nparts": ([_i], _i),
     "eav_attn_sp_npad": ([_i], _i),
     "eav_gemm_sp_splitk_plan": ([_i, _i, _i], _i),
 }

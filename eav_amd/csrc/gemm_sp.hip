@@ -27,6 +27,7 @@
 // lane-linear) and again on the fragment read, which makes every ds_read_b128 conflict-free.  Workgroup ids are
 // remapped so that each XCD's L2 sees a compact group of tiles (8 tile-rows x all tile-columns at a time).
 #include <algorithm>
+#include <type_traits>
 
 #include "eav_common.h"
 #include "../../include/eav_hip.h"
@@ -59,13 +60,13 @@ struct SpArgs {
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
-template <int WM, int WN, bool TWOACC>
+template <int WM, int WN, bool TWOACC, int ABL = 0>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_kernel(SpArgs g) {
   constexpr int NW = WM * WN, BM = 64 * WM, BN = 64 * WN;
   constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
   constexpr int NCH = (BM + BN) / 8;      // 1-KB chunks (8 rows x 128 B) per stage
   constexpr int CPW = NCH / NW;           // chunks per wave
-  static_assert(NCH % NW == 0, "chunks must divide over the waves");
+  static_assert(NCH % NW == 0 && NCH / NW <= 8, "chunks must divide over the waves (at most 8 each)");
   __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
 
   const int t = threadIdx.x, lane = t & 63;
@@ -138,58 +139,116 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = acx[i][j][r] = 0.f;
 
-  if (kt0 < kt1) issue(0);
-  for (int kt = kt0; kt < kt1; ++kt) {
-    const int buf = (kt - kt0) & 1;
+  // ---- main loop: software-pipelined and explicitly interleaved (sched_barrier pins the order as written).
+  // Two fragment register sets: f0 = K-step 0 of a tile, f1 = K-step 1.  Iteration t:
+  //   phase A: 12 MFMAs on f0(t)   || ds_read f1(t) from buffer t&1
+  //   lgkmcnt(0), vmcnt(0) [stage t+1 landed], barrier
+  //   phase B: 12 MFMAs on f1(t)   || ds_read f0(t+1) from buffer (t+1)&1 || LDS-DMA of stage t+2 into buffer t&1
+  // so LDS reads, the next stage's DMA issue and their address arithmetic all hide behind MFMA issue slots; a stage has
+  // a whole tile's MFMA time to land.  Every wave's reads of buffer t&1 are complete (lgkmcnt(0)) before the barrier that
+  // precedes its re-fill.
+  struct Frags { f16x8 ah[2], al[2], bh[2], bl[2]; };
+  Frags f0, f1;
+#define SB() __builtin_amdgcn_sched_barrier(0)
+#define MM(c, a, b) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#define LDA(i, ks, hl) (*reinterpret_cast<const f16x8*>(sa + (i) * 4096 + lowp[ks][hl]))
+#define LDB(i, ks, hl) (*reinterpret_cast<const f16x8*>(sb + (i) * 4096 + lowp[ks][hl]))
+  auto issue1 = [&](int buf, int i) {
+    if (i < CPW) {
+      const int c = wave + NW * i;
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)gp[i], (lds_ptr_t)(smem + buf * STAGE + c * 1024), 16, 0, 0);
+      gp[i] += 128;
+    }
+  };
+  const int nk = kt1 - kt0;
+  if (nk > 0) {
+    issue(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();          // stage kt has landed for every wave; buffer buf^1 is free again
-    if (kt + 1 < kt1) issue(buf ^ 1);
+    __builtin_amdgcn_s_barrier();
+    if (nk > 1) issue(1);
+    const unsigned char* sa = smem + offA;
+    const unsigned char* sb = smem + offB;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      f0.ah[i] = LDA(i, 0, 0); f0.bh[i] = LDB(i, 0, 0); f0.al[i] = LDA(i, 0, 1); f0.bl[i] = LDB(i, 0, 1);
+    }
+  }
+  auto iter = [&](auto more_c, auto more2_c, int t) {
+    constexpr bool more = decltype(more_c)::value, more2 = decltype(more2_c)::value;
+    const int buf = t & 1;
     const unsigned char* sa = smem + buf * STAGE + offA;
     const unsigned char* sb = smem + buf * STAGE + offB;
-    f16x8 ah[2][2], al[2][2], bh[2][2], bl[2][2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        ah[ks][i] = *reinterpret_cast<const f16x8*>(sa + i * 4096 + lowp[ks][0]);
-        bh[ks][i] = *reinterpret_cast<const f16x8*>(sb + i * 4096 + lowp[ks][0]);
-        al[ks][i] = *reinterpret_cast<const f16x8*>(sa + i * 4096 + lowp[ks][1]);
-        bl[ks][i] = *reinterpret_cast<const f16x8*>(sb + i * 4096 + lowp[ks][1]);
-      }
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
-      if (TWOACC) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks][i], bh[ks][j], acx[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks][i], bl[ks][j], acx[i][j], 0, 0, 0);
-      } else {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks][i], bl[ks][j], acc[i][j], 0, 0, 0);
-      }
+    // ---------------- phase A
+    SB();
+    MM(acc[0][0], f0.ah[0], f0.bh[0]); SB(); f1.ah[0] = LDA(0, 1, 0); SB();
+    MM(acc[0][1], f0.ah[0], f0.bh[1]); SB(); f1.bh[0] = LDB(0, 1, 0); SB();
+    MM(acc[1][0], f0.ah[1], f0.bh[0]); SB(); f1.ah[1] = LDA(1, 1, 0); SB();
+    MM(acc[1][1], f0.ah[1], f0.bh[1]); SB(); f1.bh[1] = LDB(1, 1, 0); SB();
+    if (TWOACC) {
+      MM(acx[0][0], f0.al[0], f0.bh[0]); SB(); f1.al[0] = LDA(0, 1, 1); SB();
+      MM(acx[0][1], f0.al[0], f0.bh[1]); SB(); f1.al[1] = LDA(1, 1, 1); SB();
+      MM(acx[1][0], f0.al[1], f0.bh[0]); SB(); f1.bl[0] = LDB(0, 1, 1); SB();
+      MM(acx[1][1], f0.al[1], f0.bh[1]); SB(); f1.bl[1] = LDB(1, 1, 1); SB();
+      MM(acx[0][0], f0.ah[0], f0.bl[0]);
+      MM(acx[0][1], f0.ah[0], f0.bl[1]);
+      MM(acx[1][0], f0.ah[1], f0.bl[0]);
+      MM(acx[1][1], f0.ah[1], f0.bl[1]);
+    } else {
+      MM(acc[0][0], f0.al[0], f0.bh[0]); SB(); f1.al[0] = LDA(0, 1, 1); SB();
+      MM(acc[0][1], f0.al[0], f0.bh[1]); SB(); f1.al[1] = LDA(1, 1, 1); SB();
+      MM(acc[1][0], f0.al[1], f0.bh[0]); SB(); f1.bl[0] = LDB(0, 1, 1); SB();
+      MM(acc[1][1], f0.al[1], f0.bh[1]); SB(); f1.bl[1] = LDB(1, 1, 1); SB();
+      MM(acc[0][0], f0.ah[0], f0.bl[0]);
+      MM(acc[0][1], f0.ah[0], f0.bl[1]);
+      MM(acc[1][0], f0.ah[1], f0.bl[0]);
+      MM(acc[1][1], f0.ah[1], f0.bl[1]);
     }
-    __builtin_amdgcn_s_setprio(0);
+    SB();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    SB();
+    // ---------------- phase B
+    const unsigned char* sa2 = smem + (buf ^ 1) * STAGE + offA;
+    const unsigned char* sb2 = smem + (buf ^ 1) * STAGE + offB;
+#define LDA2(i, hl) (*reinterpret_cast<const f16x8*>(sa2 + (i) * 4096 + lowp[0][hl]))
+#define LDB2(i, hl) (*reinterpret_cast<const f16x8*>(sb2 + (i) * 4096 + lowp[0][hl]))
+    MM(acc[0][0], f1.ah[0], f1.bh[0]); SB(); if (more) f0.ah[0] = LDA2(0, 0); if (more2 && ABL != 1) issue1(buf, 0); SB();
+    MM(acc[0][1], f1.ah[0], f1.bh[1]); SB(); if (more) f0.bh[0] = LDB2(0, 0); if (more2 && ABL != 1) issue1(buf, 1); SB();
+    MM(acc[1][0], f1.ah[1], f1.bh[0]); SB(); if (more) f0.ah[1] = LDA2(1, 0); if (more2 && ABL != 1) issue1(buf, 2); SB();
+    MM(acc[1][1], f1.ah[1], f1.bh[1]); SB(); if (more) f0.bh[1] = LDB2(1, 0); if (more2 && ABL != 1) issue1(buf, 3); SB();
+    if (TWOACC) {
+      MM(acx[0][0], f1.al[0], f1.bh[0]); SB(); if (more) f0.al[0] = LDA2(0, 1); if (more2 && ABL != 1) issue1(buf, 4); SB();
+      MM(acx[0][1], f1.al[0], f1.bh[1]); SB(); if (more) f0.al[1] = LDA2(1, 1); if (more2 && ABL != 1) issue1(buf, 5); SB();
+      MM(acx[1][0], f1.al[1], f1.bh[0]); SB(); if (more) f0.bl[0] = LDB2(0, 1); if (more2 && ABL != 1) issue1(buf, 6); SB();
+      MM(acx[1][1], f1.al[1], f1.bh[1]); SB(); if (more) f0.bl[1] = LDB2(1, 1); if (more2 && ABL != 1) issue1(buf, 7); SB();
+      MM(acx[0][0], f1.ah[0], f1.bl[0]);
+      MM(acx[0][1], f1.ah[0], f1.bl[1]);
+      MM(acx[1][0], f1.ah[1], f1.bl[0]);
+      MM(acx[1][1], f1.ah[1], f1.bl[1]);
+    } else {
+      MM(acc[0][0], f1.al[0], f1.bh[0]); SB(); if (more) f0.al[0] = LDA2(0, 1); if (more2 && ABL != 1) issue1(buf, 4); SB();
+      MM(acc[0][1], f1.al[0], f1.bh[1]); SB(); if (more) f0.al[1] = LDA2(1, 1); if (more2 && ABL != 1) issue1(buf, 5); SB();
+      MM(acc[1][0], f1.al[1], f1.bh[0]); SB(); if (more) f0.bl[0] = LDB2(0, 1); if (more2 && ABL != 1) issue1(buf, 6); SB();
+      MM(acc[1][1], f1.al[1], f1.bh[1]); SB(); if (more) f0.bl[1] = LDB2(1, 1); if (more2 && ABL != 1) issue1(buf, 7); SB();
+      MM(acc[0][0], f1.ah[0], f1.bl[0]);
+      MM(acc[0][1], f1.ah[0], f1.bl[1]);
+      MM(acc[1][0], f1.ah[1], f1.bl[0]);
+      MM(acc[1][1], f1.ah[1], f1.bl[1]);
+    }
+    SB();
+  };
+  {
+    int t = 0;
+    for (; t + 2 < nk; ++t) iter(std::true_type{}, std::true_type{}, t);
+    if (t + 1 < nk) { iter(std::true_type{}, std::false_type{}, t); ++t; }
+    if (t < nk) iter(std::false_type{}, std::false_type{}, t);
   }
+#undef LDA2
+#undef LDB2
+#undef LDA
+#undef LDB
+#undef MM
+#undef SB
   if (TWOACC) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -238,18 +297,24 @@ int g_force_tile = 0;   // test / tuning hook: 0 = heuristic, 1 = 128x128, 2 = 2
 // normal fp16 numbers for elements down to 2^-29 of the tensor maximum.  0: lo = fp16(t - hi), one accumulator (64 fewer
 // VGPRs, same speed at 2 waves per SIMD; full precision only down to 2^-15 of the maximum) - kept as a tuning hook.
 int g_loshift = 11;
+int g_abl = 0;          // ablation (tuning only): 1 = no LDS-DMA after the first stage, 2 = LDS-DMA only
 
 template <int WM, int WN>
 void launch(const SpArgs& g, int nz, hipStream_t st) {
-  if (g_loshift)
+  if (g_abl == 1)
+    hipLaunchKernelGGL((gemm_sp_kernel<WM, WN, true, 1>), dim3(g.tm * g.tn, 1, nz), dim3(64 * WM * WN), 0, st, g);
+  else if (g_abl == 2)
+    hipLaunchKernelGGL((gemm_sp_kernel<WM, WN, true, 2>), dim3(g.tm * g.tn, 1, nz), dim3(64 * WM * WN), 0, st, g);
+  else if (g_loshift)
     hipLaunchKernelGGL((gemm_sp_kernel<WM, WN, true>), dim3(g.tm * g.tn, 1, nz), dim3(64 * WM * WN), 0, st, g);
   else
     hipLaunchKernelGGL((gemm_sp_kernel<WM, WN, false>), dim3(g.tm * g.tn, 1, nz), dim3(64 * WM * WN), 0, st, g);
 }
 
 void dispatch(SpArgs& g, int nz, hipStream_t st) {
-  const int tiles128 = cdiv(g.M, 128) * cdiv(g.N, 128) * nz;
-  const bool big = g_force_tile == 2 || (g_force_tile == 0 && tiles128 >= 2048 && g.M >= 1024);
+  // measured (tools/gemm_sp_bench.py): the 256 x 128 / 8-wave form only wins on huge square problems (8192^3: +2 %) and
+  // loses up to 15 % on the encoder shapes, so the heuristic always takes 128 x 128; the big tile stays as a tuning hook
+  const bool big = g_force_tile == 2;
   if (big) {
     g.tm = cdiv(g.M, 256); g.tn = cdiv(g.N, 128);
     launch<4, 2>(g, nz, st);
@@ -332,7 +397,7 @@ __device__ __forceinline__ void split8(const float (&tv)[8], uint4& hi, uint4& l
 __global__ __launch_bounds__(256) void sp_convert_kernel(const float* __restrict__ src, int R, int C, int64_t ld,
                                                          float* __restrict__ slot, unsigned char* __restrict__ dst,
                                                          int Cp, unsigned char* __restrict__ dstT, int Rp,
-                                                         float lomul) {
+                                                         float lomul, float* __restrict__ colsum_part) {
   __shared__ float tile[64][65];
   unsigned bits = 0u;
 #pragma unroll
@@ -367,14 +432,23 @@ __global__ __launch_bounds__(256) void sp_convert_kernel(const float* __restrict
         o[0] = hi;
         o[1] = lo;
       }
-      if (dstT) {
+      if (dstT || colsum_part) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) tile[rr + 32 * pass][8 * cg + e] = tv[e];
       }
     }
   }
-  if (!dstT) return;
+  if (!dstT && !colsum_part) return;
   __syncthreads();
+  if (colsum_part && t < 64 && c0 + t < C) {   // bias gradient partial: column sums of this 64-row tile (sigma is 2^e: exact)
+    float a = 0.f, b = 0.f, c = 0.f, d = 0.f;
+#pragma unroll
+    for (int r = 0; r < 64; r += 4) {
+      a += tile[r][t]; b += tile[r + 1][t]; c += tile[r + 2][t]; d += tile[r + 3][t];
+    }
+    colsum_part[(int64_t)blockIdx.y * C + c0 + t] = ((a + b) + (c + d)) * (1.f / sigma);
+  }
+  if (!dstT) return;
   {
     const int rg = t & 7, cc = t >> 3;
 #pragma unroll
@@ -416,14 +490,31 @@ extern "C" int eav_sp_convert(const float* src, int R, int C, int64_t ld, float*
               "eav_sp_convert: leading dimension must be a multiple of 4, buffers 16-byte aligned");
   hipLaunchKernelGGL(sp_convert_kernel, dim3(cdiv(eav_sp_kpad(C), 64), cdiv(eav_sp_kpad(R), 64)), dim3(256), 0,
                      (hipStream_t)stream, src, R, C, ld, slot, (unsigned char*)dst, eav_sp_kpad(C),
-                     (unsigned char*)dstT, eav_sp_kpad(R), g_loshift ? 2048.f : 1.f);
+                     (unsigned char*)dstT, eav_sp_kpad(R), g_loshift ? 2048.f : 1.f, (float*)nullptr);
   EAV_CHECK_LAUNCH("eav_sp_convert");
+  return EAV_OK;
+}
+
+// eav_sp_convert that also emits the bias-gradient partials of the same pass over src: colsum_part
+// [eav_sp_convert_colsum_nparts(R)][C], row p = column sums of rows [64p, 64p+64) (finish with eav_reduce_partials).
+extern "C" int eav_sp_convert_colsum_nparts(int R) { return cdiv(eav_sp_kpad(R), 64); }
+
+extern "C" int eav_sp_convert_colsum(const float* src, int R, int C, int64_t ld, float* slot, void* dst, void* dstT,
+                                     float* colsum_part, void* stream) {
+  EAV_REQUIRE(src && slot && R > 0 && C > 0 && colsum_part, "eav_sp_convert_colsum: bad arguments");
+  EAV_REQUIRE((ld & 3) == 0 && (((uintptr_t)src | (uintptr_t)dst | (uintptr_t)dstT) & 15) == 0,
+              "eav_sp_convert_colsum: leading dimension must be a multiple of 4, buffers 16-byte aligned");
+  hipLaunchKernelGGL(sp_convert_kernel, dim3(cdiv(eav_sp_kpad(C), 64), cdiv(eav_sp_kpad(R), 64)), dim3(256), 0,
+                     (hipStream_t)stream, src, R, C, ld, slot, (unsigned char*)dst, eav_sp_kpad(C),
+                     (unsigned char*)dstT, eav_sp_kpad(R), g_loshift ? 2048.f : 1.f, colsum_part);
+  EAV_CHECK_LAUNCH("eav_sp_convert_colsum");
   return EAV_OK;
 }
 
 extern "C" int eav_gemm_sp_set_tile(int which) {
   g_force_tile = which & 3;
   g_loshift = (which & 4) ? 0 : 11;
+  g_abl = (which >> 4) & 3;
   return EAV_OK;
 }
 

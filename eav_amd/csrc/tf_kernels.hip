@@ -15,7 +15,7 @@ constexpr int LN_MAXQ = 4;  // float4 per lane: D <= 1024
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ y,
                                                             float* __restrict__ mean_o, float* __restrict__ rstd_o,
-                                                            int M, int D, float eps) {
+                                                            int M, int D, float eps, unsigned* __restrict__ amax) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -43,18 +43,26 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
   float4* dst = reinterpret_cast<float4*>(y + (int64_t)row * D);
   const float4* g4 = reinterpret_cast<const float4*>(gamma);
   const float4* b4 = reinterpret_cast<const float4*>(beta);
+  float vmax = 0.f;
 #pragma unroll
   for (int i = 0; i < LN_MAXQ; ++i) {
     const int q = lane + 64 * i;
     if (q < nq) {
       const float4 g = g4[q], b = b4[q];
-      dst[q] = make_float4((v[i].x - mean) * rstd * g.x + b.x, (v[i].y - mean) * rstd * g.y + b.y,
-                           (v[i].z - mean) * rstd * g.z + b.z, (v[i].w - mean) * rstd * g.w + b.w);
+      const float4 o = make_float4((v[i].x - mean) * rstd * g.x + b.x, (v[i].y - mean) * rstd * g.y + b.y,
+                                   (v[i].z - mean) * rstd * g.z + b.z, (v[i].w - mean) * rstd * g.w + b.w);
+      dst[q] = o;
+      vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
     }
   }
   if (lane == 0) {
     if (mean_o) mean_o[row] = mean;
     if (rstd_o) rstd_o[row] = rstd;
+  }
+  if (amax) {   // max |y| of the row into one of the 64 shards of the operand-scale slot (gemm_sp.hip)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+    if (lane == 0 && vmax == vmax) atomicMax(amax + (row & 63), __float_as_uint(vmax));
   }
 }
 
@@ -64,7 +72,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ mean_i,
                                                             const float* __restrict__ rstd_i, float* __restrict__ dx,
-                                                            int accumulate, float* __restrict__ part, int M, int D) {
+                                                            int accumulate, float* __restrict__ part, int M, int D,
+                                                            unsigned* __restrict__ amax) {
   extern __shared__ float sh[];  // [4][2*D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nq = D >> 2;
@@ -77,6 +86,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     ag[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     ab[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
+  float vmax = 0.f;
   for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
     const float mean = mean_i[row], rstd = rstd_i[row];
     const float4* xs = reinterpret_cast<const float4*>(x + (int64_t)row * D);
@@ -111,8 +121,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
           o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
         }
         dst[q] = o;
+        vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
       }
     }
+  }
+  if (amax) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+    if (lane == 0 && vmax == vmax) atomicMax(amax + ((blockIdx.x * 4 + wave) & 63), __float_as_uint(vmax));
   }
   if (!part) return;
   float4* shw = reinterpret_cast<float4*>(sh + wave * 2 * D);
@@ -190,8 +206,9 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restric
 // ------------------------------------------------------------------------------- GELU backward
 // d/dx [0.5 x (1 + erf(x/sqrt2))] = 0.5 (1 + erf(x/sqrt2)) + x exp(-x^2/2)/sqrt(2 pi);  in place on dact
 __global__ __launch_bounds__(256) void gelu_bwd_kernel(float* __restrict__ dact, const float* __restrict__ pre,
-                                                       int64_t n4) {
+                                                       int64_t n4, unsigned* __restrict__ amax) {
   const int64_t stride = (int64_t)gridDim.x * 256;
+  float vmax = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
     float4 d = reinterpret_cast<float4*>(dact)[i];
     const float4 x = reinterpret_cast<const float4*>(pre)[i];
@@ -200,6 +217,13 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(float* __restrict__ dact,
     };
     d.x *= gp(x.x); d.y *= gp(x.y); d.z *= gp(x.z); d.w *= gp(x.w);
     reinterpret_cast<float4*>(dact)[i] = d;
+    vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fmaxf(fabsf(d.z), fabsf(d.w))));
+  }
+  if (amax) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+    if ((threadIdx.x & 63) == 0 && vmax == vmax)
+      atomicMax(amax + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & 63), __float_as_uint(vmax));
   }
 }
 
@@ -314,8 +338,20 @@ extern "C" int eav_layernorm_fwd(const float* x, const float* gamma, const float
   EAV_REQUIRE(x && gamma && beta && y && M > 0 && D > 0 && (D & 3) == 0 && D <= 1024,
               "eav_layernorm_fwd: need D %% 4 == 0 and D <= 1024");
   hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y,
-                     mean, rstd, M, D, eps);
+                     mean, rstd, M, D, eps, (unsigned*)nullptr);
   EAV_CHECK_LAUNCH("eav_layernorm_fwd");
+  return EAV_OK;
+}
+
+// the *_amax forms also accumulate max |output| into an operand-scale slot (EAV_SP_SLOT floats, zeroed by the caller) for
+// the split-operand GEMM that consumes the output
+extern "C" int eav_layernorm_fwd_amax(const float* x, const float* gamma, const float* beta, float* y, float* mean,
+                                      float* rstd, int M, int D, float eps, float* amax_slot, void* stream) {
+  EAV_REQUIRE(x && gamma && beta && y && amax_slot && M > 0 && D > 0 && (D & 3) == 0 && D <= 1024,
+              "eav_layernorm_fwd_amax: need D %% 4 == 0 and D <= 1024");
+  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y,
+                     mean, rstd, M, D, eps, reinterpret_cast<unsigned*>(amax_slot));
+  EAV_CHECK_LAUNCH("eav_layernorm_fwd_amax");
   return EAV_OK;
 }
 
@@ -327,8 +363,20 @@ extern "C" int eav_layernorm_bwd(const float* dy, const float* x, const float* g
   EAV_REQUIRE(dy && x && gamma && mean && rstd && dx && M > 0 && D > 0 && (D & 3) == 0 && D <= 1024,
               "eav_layernorm_bwd: need D %% 4 == 0 and D <= 1024");
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(eav_layernorm_bwd_nparts(M)), dim3(256), 8 * D * sizeof(float),
-                     (hipStream_t)stream, dy, x, gamma, mean, rstd, dx, accumulate, part, M, D);
+                     (hipStream_t)stream, dy, x, gamma, mean, rstd, dx, accumulate, part, M, D, (unsigned*)nullptr);
   EAV_CHECK_LAUNCH("eav_layernorm_bwd");
+  return EAV_OK;
+}
+
+extern "C" int eav_layernorm_bwd_amax(const float* dy, const float* x, const float* gamma, const float* mean,
+                                      const float* rstd, float* dx, int accumulate, float* part, int M, int D,
+                                      float* amax_slot, void* stream) {
+  EAV_REQUIRE(dy && x && gamma && mean && rstd && dx && amax_slot && M > 0 && D > 0 && (D & 3) == 0 && D <= 1024,
+              "eav_layernorm_bwd_amax: need D %% 4 == 0 and D <= 1024");
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(eav_layernorm_bwd_nparts(M)), dim3(256), 8 * D * sizeof(float),
+                     (hipStream_t)stream, dy, x, gamma, mean, rstd, dx, accumulate, part, M, D,
+                     reinterpret_cast<unsigned*>(amax_slot));
+  EAV_CHECK_LAUNCH("eav_layernorm_bwd_amax");
   return EAV_OK;
 }
 
@@ -354,8 +402,17 @@ extern "C" int eav_softmax_bwd(const float* P, float* dP, int64_t rows, int N, i
 
 extern "C" int eav_gelu_bwd(float* dact, const float* pre, int64_t n, void* stream) {
   EAV_REQUIRE(dact && pre && n > 0 && (n & 3) == 0, "eav_gelu_bwd: n must be a positive multiple of 4");
-  hipLaunchKernelGGL(gelu_bwd_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, dact, pre, n / 4);
+  hipLaunchKernelGGL(gelu_bwd_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, dact, pre, n / 4,
+                     (unsigned*)nullptr);
   EAV_CHECK_LAUNCH("eav_gelu_bwd");
+  return EAV_OK;
+}
+
+extern "C" int eav_gelu_bwd_amax(float* dact, const float* pre, int64_t n, float* amax_slot, void* stream) {
+  EAV_REQUIRE(dact && pre && amax_slot && n > 0 && (n & 3) == 0, "eav_gelu_bwd_amax: n must be a positive multiple of 4");
+  hipLaunchKernelGGL(gelu_bwd_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, dact, pre, n / 4,
+                     reinterpret_cast<unsigned*>(amax_slot));
+  EAV_CHECK_LAUNCH("eav_gelu_bwd_amax");
   return EAV_OK;
 }
 

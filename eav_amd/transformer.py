@@ -367,6 +367,8 @@ class Encoder(nn.Module):
             ws.dactp, ws.dactpT = h(M, FF), h(FF, M)
             ws.dqkvp, ws.dqkvpT = h(M, 3 * D), h(3 * D, M)
             ws.dembpT = h(D, MP)
+            ws.np_cs2 = _lib.plain("eav_sp_convert_colsum_nparts", M)
+            ws.part_cs2 = torch.empty(ws.np_cs2, max(FF, 3 * D), dtype=torch.float32, device=dev)
             ws.bslots = torch.zeros(1 + self.BS * Lr, self.SLOT, dtype=torch.float32, device=dev)
             if ws.fused:
                 ws.dorow = torch.empty(M, 2 * D, dtype=torch.float16, device=dev)
@@ -431,6 +433,13 @@ class Encoder(nn.Module):
         if not amax_done:
             self._call("eav_sp_absmax", src, R, C, ld, slot, self._st)
         self._call("eav_sp_convert", src, R, C, ld, slot, _lib.ptr(dst), _lib.ptr(dstT), self._st)
+
+    def _to_planes_bias(self, src, R, C, slot, dst, dstT, bias_grad):
+        """Conversion pass that also produces the bias gradient (column sums of src) - src's max|x| is already in slot."""
+        ws = self._ws
+        self._call("eav_sp_convert_colsum", src, R, C, C, slot, _lib.ptr(dst), _lib.ptr(dstT), _lib.ptr(ws.part_cs2),
+                   self._st)
+        self._call("eav_reduce_partials", _lib.ptr(ws.part_cs2), ws.np_cs2, C, C, 1.0, bias_grad, self._st)
 
     def _gemm_sp(self, A, slotA, B, slotB, C, M, N, K, ldc, batch=1, sA=0, sC=0, alpha=1.0, bias=None, gelu=0,
                  pre=None, resid=None, ldr=0, acc=0, amax=None):
@@ -547,9 +556,9 @@ class Encoder(nn.Module):
         T = (lambda lst: lst[j]) if ws.full else (lambda lst: None)  # noqa: E731
         s_y1, s_qkv, s_ao, s_y2, s_act = (fslot(1 + self.FS * i + k) for k in range(5))
         y, ao, act = ws.y1[0], ws.ao[j], ws.act[0]
-        L("eav_layernorm_fwd", P(hin), w(f"{Lk}.layernorm_before.weight"), w(f"{Lk}.layernorm_before.bias"), P(y), stp,
-          stp + 4 * M, M, D, c.eps, st)
-        self._to_planes(P(y), M, D, D, s_y1, ws.y1p[j], T(ws.y1pT) if ws.full else None)
+        L("eav_layernorm_fwd_amax", P(hin), w(f"{Lk}.layernorm_before.weight"), w(f"{Lk}.layernorm_before.bias"), P(y),
+          stp, stp + 4 * M, M, D, c.eps, s_y1, st)
+        self._to_planes(P(y), M, D, D, s_y1, ws.y1p[j], T(ws.y1pT) if ws.full else None, amax_done=True)
         qkv = P(ws.qkv[0 if ws.fused else j])
         wpl, wsl = self._wp(f"qkv{i}")
         self._gemm_sp(P(ws.y1p[j]), s_y1, wpl, wsl, qkv, M, 3 * D, D, 3 * D, bias=w(f"{Lk}.attention.q_proj.bias"),
@@ -571,9 +580,9 @@ class Encoder(nn.Module):
         wpl, wsl = self._wp(f"o{i}")
         self._gemm_sp(P(ws.aop[j]), s_ao, wpl, wsl, P(ws.hmid[j]), M, D, D, D, bias=w(f"{Lk}.attention.o_proj.bias"),
                       resid=P(hin), ldr=D)
-        L("eav_layernorm_fwd", P(ws.hmid[j]), w(f"{Lk}.layernorm_after.weight"), w(f"{Lk}.layernorm_after.bias"),
-          P(y), stp + 8 * M, stp + 12 * M, M, D, c.eps, st)
-        self._to_planes(P(y), M, D, D, s_y2, ws.y2p[j], T(ws.y2pT) if ws.full else None)
+        L("eav_layernorm_fwd_amax", P(ws.hmid[j]), w(f"{Lk}.layernorm_after.weight"),
+          w(f"{Lk}.layernorm_after.bias"), P(y), stp + 8 * M, stp + 12 * M, M, D, c.eps, s_y2, st)
+        self._to_planes(P(y), M, D, D, s_y2, ws.y2p[j], T(ws.y2pT) if ws.full else None, amax_done=True)
         wpl, wsl = self._wp(f"fc1{i}")
         self._gemm_sp(P(ws.y2p[j]), s_y2, wpl, wsl, P(act), M, FF, D, FF, bias=w(f"{Lk}.mlp.fc1.bias"), gelu=1,
                       pre=P(ws.pre[j]) if ws.full else None, amax=s_act)
@@ -599,27 +608,25 @@ class Encoder(nn.Module):
         dh, dy, dao, dact, dqkv = P(ws.dh), P(ws.dy), P(ws.dao), P(ws.dact), P(ws.dqkv)
         s_y1, s_qkv, s_ao, s_y2, s_act = (fslot(1 + self.FS * i + k) for k in range(5))
         b_dh2, b_dact, b_dh1, b_dao, b_ds, b_dqkv = (bslot(1 + self.BS * i + k) for k in range(6))
-        # fc2: h_out = h_mid + act.W2^T + b2
-        self._to_planes(dh, M, D, D, b_dh2, ws.dhp, ws.dhpT)
+        # fc2: h_out = h_mid + act.W2^T + b2.  max|dh| is already in b_dh2 (left there by the producer of dh); every
+        # conversion pass also yields the bias gradient of its tensor
+        self._to_planes_bias(dh, M, D, b_dh2, ws.dhp, ws.dhpT, gp(f"{Lk}.mlp.fc2.bias"))
         self._wgrad_sp(ws.dhpT, b_dh2, ws.actpT[i], s_act, gp(f"{Lk}.mlp.fc2.weight"), D, FF, M)
-        self._bias_grad(dh, M, D, D, gp(f"{Lk}.mlp.fc2.bias"))
         wpl, wsl = self._wp(f"fc2{i}", transposed=True)
         self._gemm_sp(P(ws.dhp), b_dh2, wpl, wsl, dact, M, FF, D, FF)
-        L("eav_gelu_bwd", dact, P(ws.pre[i]), M * FF, st)
+        L("eav_gelu_bwd_amax", dact, P(ws.pre[i]), M * FF, b_dact, st)
         # fc1
-        self._to_planes(dact, M, FF, FF, b_dact, ws.dactp, ws.dactpT)
+        self._to_planes_bias(dact, M, FF, b_dact, ws.dactp, ws.dactpT, gp(f"{Lk}.mlp.fc1.bias"))
         self._wgrad_sp(ws.dactpT, b_dact, ws.y2pT[i], s_y2, gp(f"{Lk}.mlp.fc1.weight"), FF, D, M)
-        self._bias_grad(dact, M, FF, FF, gp(f"{Lk}.mlp.fc1.bias"))
         wpl, wsl = self._wp(f"fc1{i}", transposed=True)
         self._gemm_sp(P(ws.dactp), b_dact, wpl, wsl, dy, M, D, FF, D)
-        L("eav_layernorm_bwd", dy, P(ws.hmid[i]), w(f"{Lk}.layernorm_after.weight"), stp + 8 * M, stp + 12 * M, dh, 1,
-          P(ws.part_ln), M, D, st)
+        L("eav_layernorm_bwd_amax", dy, P(ws.hmid[i]), w(f"{Lk}.layernorm_after.weight"), stp + 8 * M, stp + 12 * M, dh,
+          1, P(ws.part_ln), M, D, b_dh1, st)
         self._reduce(ws.part_ln, ws.np_ln, 2 * D, D, gp(f"{Lk}.layernorm_after.weight"))
         L("eav_reduce_partials", P(ws.part_ln) + 4 * D, ws.np_ln, 2 * D, D, 1.0, gp(f"{Lk}.layernorm_after.bias"), st)
         # o_proj
-        self._to_planes(dh, M, D, D, b_dh1, ws.dhp, ws.dhpT)
+        self._to_planes_bias(dh, M, D, b_dh1, ws.dhp, ws.dhpT, gp(f"{Lk}.attention.o_proj.bias"))
         self._wgrad_sp(ws.dhpT, b_dh1, ws.aopT[i], s_ao, gp(f"{Lk}.attention.o_proj.weight"), D, D, M)
-        self._bias_grad(dh, M, D, D, gp(f"{Lk}.attention.o_proj.bias"))
         wpl, wsl = self._wp(f"o{i}", transposed=True)
         self._gemm_sp(P(ws.dhp), b_dh1, wpl, wsl, dao, M, D, D, D, amax=b_dao if ws.fused else None)
         # attention core
@@ -641,13 +648,15 @@ class Encoder(nn.Module):
             g(dP, qkv, dqkv + 4 * D, N, hd, N, ldn, 3 * D, 3 * D, tA=1, tB=1, batch=ws.B * H, heads=H, sA=sP, sB=sQ,
               sC=sQ, alpha=scale)
         # fused q/k/v projection
-        self._to_planes(dqkv, M, 3 * D, 3 * D, b_dqkv, ws.dqkvp, ws.dqkvpT, amax_done=ws.fused)
+        if not ws.fused:
+            self._call("eav_sp_absmax", dqkv, M, 3 * D, 3 * D, b_dqkv, st)
+        self._to_planes_bias(dqkv, M, 3 * D, b_dqkv, ws.dqkvp, ws.dqkvpT, gp(f"{Lk}.attention.q_proj.bias"))
         self._wgrad_sp(ws.dqkvpT, b_dqkv, ws.y1pT[i], s_y1, gp(f"{Lk}.attention.q_proj.weight"), 3 * D, D, M)
-        self._bias_grad(dqkv, M, 3 * D, 3 * D, gp(f"{Lk}.attention.q_proj.bias"))
         wpl, wsl = self._wp(f"qkv{i}", transposed=True)
         self._gemm_sp(P(ws.dqkvp), b_dqkv, wpl, wsl, dy, M, D, 3 * D, D)
-        L("eav_layernorm_bwd", dy, P(ws.hs[i]), w(f"{Lk}.layernorm_before.weight"), stp, stp + 4 * M, dh, 1,
-          P(ws.part_ln), M, D, st)
+        # the gradient w.r.t. this layer's input is the next (lower) layer's dh: leave its max in that layer's slot
+        L("eav_layernorm_bwd_amax", dy, P(ws.hs[i]), w(f"{Lk}.layernorm_before.weight"), stp, stp + 4 * M, dh, 1,
+          P(ws.part_ln), M, D, bslot(1 + self.BS * (i - 1)) if i > 0 else bslot(0), st)
         self._reduce(ws.part_ln, ws.np_ln, 2 * D, D, gp(f"{Lk}.layernorm_before.weight"))
         L("eav_reduce_partials", P(ws.part_ln) + 4 * D, ws.np_ln, 2 * D, D, 1.0, gp(f"{Lk}.layernorm_before.bias"), st)
 
@@ -711,6 +720,9 @@ class Encoder(nn.Module):
                 ws.bslots.zero_()
                 bslot = lambda n: ws.bslots.data_ptr() + 4 * self.SLOT * n  # noqa: E731
                 fslot = lambda n: ws.fslots.data_ptr() + 4 * self.SLOT * n  # noqa: E731
+                # dh of the top layer comes from the head (token-row scatter): one pass for its maximum; every other dh
+                # gets its maximum from the LayerNorm backward that produces it
+                self._call("eav_sp_absmax", P(ws.dh), M, D, D, bslot(1 + self.BS * (c.layers - 1)), st)
             for i in reversed(range(c.layers)):
                 Lk = f"{pre}.layers.{i}"
                 stp = P(ws.st[i])
@@ -777,7 +789,8 @@ class Encoder(nn.Module):
                 gflat[offs[f"{pre}.embeddings.distillation_token"][0]:][:D].copy_(gpos[D:2 * D])
             MP = B * c.npatch
             if sp:
-                self._to_planes(P(ws.demb), MP, D, D, bslot(0), None, ws.dembpT)
+                # demb is a row subset of dh, whose maximum layer 0's LayerNorm backward left in bslot(0)
+                self._to_planes(P(ws.demb), MP, D, D, bslot(0), None, ws.dembpT, amax_done=True)
                 self._wgrad_sp(ws.dembpT, bslot(0), ws.colpT, fslot(0),
                                gp(f"{pre}.embeddings.patch_embeddings.projection.weight"), D, c.kp, MP)
             else:

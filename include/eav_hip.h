@@ -208,6 +208,17 @@ int eav_gemm_bf16_splitk(const float* A, const float* B, float* C, float* ws, in
 int eav_sp_kpad(int K);
 int eav_sp_absmax(const float* src, int R, int C, int64_t ld, float* slot, void* stream);
 int eav_sp_convert(const float* src, int R, int C, int64_t ld, float* slot, void* dst, void* dstT, void* stream);
+/* the same pass also emitting bias-gradient partials: colsum_part [eav_sp_convert_colsum_nparts(R)][C] (column sums of
+ * 64-row tiles; finish with eav_reduce_partials) */
+int eav_sp_convert_colsum_nparts(int R);
+int eav_sp_convert_colsum(const float* src, int R, int C, int64_t ld, float* slot, void* dst, void* dstT,
+                          float* colsum_part, void* stream);
+/* producers that also accumulate max|output| into an operand-scale slot (zeroed by the caller) */
+int eav_layernorm_fwd_amax(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                           int M, int D, float eps, float* amax_slot, void* stream);
+int eav_layernorm_bwd_amax(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                           float* dx, int accumulate, float* part, int M, int D, float* amax_slot, void* stream);
+int eav_gelu_bwd_amax(float* dact, const float* pre, int64_t n, float* amax_slot, void* stream);
 /* C[z][m,n] = epilogue(alpha * sum_k A[z][m,k] B[n,k]) from planes A [M,Kp], B [N,Kp]; epilogue as eav_gemm_f32
  * (bias, erf-GELU with pre-activation store, residual, accumulate); amax_slot (optional) receives max |C| bits. */
 int eav_gemm_sp(const void* A, const void* B, float* C, const float* slotA, const float* slotB, int M, int N, int K,

@@ -90,7 +90,7 @@ def bench(name, M, N, K, epi=False):
     bias = torch.randn(N, device="cuda") if epi else None
     pre = torch.empty(M, N, device="cuda") if epi else None
     out = []
-    for tile in (1, 2, 5):
+    for tile in (1, 2, 17, 18):
         _lib.call("eav_gemm_sp_set_tile", tile)
         ms = timeit(lambda: _lib.call("eav_gemm_sp", P(pa), P(pb), P(C), P(sa), P(sb), M, N, K, N, 1, 0, 0, 1.0,
                                       P(bias), 1 if epi else 0, P(pre), None, 0, 0, None, None))

@@ -26,6 +26,8 @@ from . import _lib
 from .optim import flatten_parameters
 
 
+DEFAULT_PRECISION = "split"
+
 # ----------------------------------------------------------------------------- configuration
 def make_config(kind, hidden=768, layers=12, heads=12, ff=3072, eps=1e-12, num_labels=5, patch=16, mel=128,
                 frames=1024, fstride=10, tstride=10, image=224, channels=3):
@@ -168,11 +170,12 @@ class Encoder(nn.Module):
         self._token = 0
         self._saved = None
         self.kernel_events = None
-        # GEMM operand precision: "fp32" (default; exact-fp32 MFMA), "split" (fp32-grade on the fp16 matrix cores:
-        # every operand as fp16 hi + lo planes, three MFMAs per product - csrc/gemm_sp.hip; same parity bounds as
-        # fp32), "bf16" (bf16 MFMA operands everywhere, fp32 accumulate: ~5e-3 logit drift) or "bf16_bwd" (fp32
-        # forward - logits unchanged - and bf16 operands for the backward products only).
-        self.precision = "fp32"
+        # GEMM / attention operand precision: "split" (default: fp32-grade on the fp16 matrix cores - every operand as
+        # fp16 hi + lo planes, three MFMAs per product, csrc/gemm_sp.hip + attention_sp.hip; measured against float64
+        # it is not worse than the exact-fp32 kernels and it passes the same parity bounds), "fp32" (exact-fp32 MFMA),
+        # "bf16" (bf16 MFMA operands everywhere, fp32 accumulate: ~5e-3 logit drift) or "bf16_bwd" (fp32 forward -
+        # logits unchanged - and bf16 operands for the backward products only).  EAV_ENCODER_PRECISION overrides.
+        self.precision = os.environ.get("EAV_ENCODER_PRECISION", DEFAULT_PRECISION)
         self._wplanes = None          # split mode: {weight key: (planes, planes of the transpose, slot index)}
         self._wplanes_key = None
         self._phase = "fwd"

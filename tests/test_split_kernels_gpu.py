@@ -1,0 +1,235 @@
+"""Split-operand kernels (csrc/gemm_sp.hip, csrc/attention_sp.hip) through the C ABI: every result is compared with a
+float64 reference BESIDE the exact-fp32 MFMA kernel of the same product - the split path must not be worse than the
+fp32 kernel (same style as test_fir_fwd_split_is_fp32_grade) - plus the operand format itself, the epilogues and the
+ragged / padded edges."""
+import numpy as np
+import pytest
+import torch
+
+from eav_amd import _lib
+
+pytestmark = pytest.mark.gpu
+P = _lib.ptr
+SLOT = 80
+
+
+def kpad(k):
+    return (k + 31) // 32 * 32
+
+
+def planes(x, want=True, wantT=False):
+    R, C = x.shape
+    slot = torch.zeros(SLOT, device="cuda")
+    _lib.call("eav_sp_absmax", P(x), R, C, x.stride(0), P(slot), None)
+    d = torch.zeros(R, 2 * kpad(C), dtype=torch.float16, device="cuda") if want else None
+    dT = torch.zeros(C, 2 * kpad(R), dtype=torch.float16, device="cuda") if wantT else None
+    _lib.call("eav_sp_convert", P(x), R, C, x.stride(0), P(slot), P(d), P(dT), None)
+    return slot, d, dT
+
+
+def gemm_sp(A, B, **kw):
+    M, K = A.shape
+    N = B.shape[0]
+    sa, pa, _ = planes(A)
+    sb, pb, _ = planes(B)
+    C = kw.pop("C", None)
+    if C is None:
+        C = torch.empty(M, N, device="cuda")
+    _lib.call("eav_gemm_sp", P(pa), P(pb), P(C), P(sa), P(sb), M, N, K, N, 1, 0, 0, kw.get("alpha", 1.0),
+              P(kw.get("bias")), kw.get("gelu", 0), P(kw.get("pre")), P(kw.get("resid")), N if "resid" in kw else 0,
+              kw.get("acc", 0), P(kw.get("amax")), None)
+    return C
+
+
+def gemm_f32(A, B):
+    M, K = A.shape
+    N = B.shape[0]
+    C = torch.empty(M, N, device="cuda")
+    _lib.call("eav_gemm_f32", P(A), P(B), P(C), M, N, K, K, K, N, 0, 0, 1, 1, 0, 0, 0, 0, 0, 0, 1.0, None, 0, None, None,
+              0, 0, None)
+    return C
+
+
+def test_planes_encode_the_tensor():
+    """hi + lo 2^-11 reproduces sigma*x to fp32 accuracy, sigma is the power of two that puts max|x| in [2^14, 2^15),
+    the K padding is zero, and the transposed planes hold the same numbers."""
+    torch.manual_seed(0)
+    x = torch.randn(77, 100, device="cuda") * 3.7
+    slot, d, dT = planes(x, True, True)
+    sigma = float(slot[64])
+    assert sigma == 2.0 ** (14 - np.floor(np.log2(float(x.abs().max()))))
+    assert float(slot[65]) == 1.0 / sigma
+    v = d.view(77, kpad(100) // 8, 2, 8).double()
+    rec = (v[:, :, 0, :] + v[:, :, 1, :] / 2048.0).reshape(77, kpad(100))
+    assert (rec[:, 100:] == 0).all()
+    err = (rec[:, :100] - x.double() * sigma).abs().max().item() / (float(x.abs().max()) * sigma)
+    assert err < 2.0 ** -22, err
+    vT = dT.view(100, kpad(77) // 8, 2, 8).double()
+    recT = (vT[:, :, 0, :] + vT[:, :, 1, :] / 2048.0).reshape(100, kpad(77))
+    assert (recT[:, 77:] == 0).all()
+    assert torch.equal(recT[:, :77], rec[:, :100].t())
+
+
+@pytest.mark.parametrize("shape", [(512, 384, 768), (1000, 200, 100), (9712, 768, 3072), (300, 130, 40), (64, 5, 36)])
+@pytest.mark.parametrize("amp", [(1.0, 0.02), (2e-5, 3e4)])
+def test_gemm_sp_is_fp32_grade(shape, amp):
+    M, N, K = shape
+    torch.manual_seed(M + N + K)
+    A = torch.randn(M, K, device="cuda") * amp[0]
+    B = torch.randn(N, K, device="cuda") * amp[1]
+    ref = A.double() @ B.double().t()
+    den = A.double().abs() @ B.double().abs().t()
+    e_sp = ((gemm_sp(A, B).double() - ref).abs() / den).max().item()
+    e_32 = ((gemm_f32(A, B).double() - ref).abs() / den).max().item()
+    assert e_sp <= 1.05 * e_32 + 1e-9, (e_sp, e_32)
+    assert e_sp < 5e-7
+
+
+def test_gemm_sp_rows_far_below_the_tensor_maximum():
+    """Per-tensor scale: a row 2^-20 below the maximum still comes out to ~1e-6 of its own magnitude (lo is lifted by 2^11,
+    so both pieces stay normal fp16 numbers down to 2^-29 of the maximum)."""
+    torch.manual_seed(3)
+    A = torch.randn(256, 512, device="cuda")
+    A[7] *= 2.0 ** -20
+    B = torch.randn(128, 512, device="cuda")
+    ref = A.double() @ B.double().t()
+    den = A.double().abs() @ B.double().abs().t()
+    err = ((gemm_sp(A, B).double() - ref).abs() / den)
+    assert err[7].max().item() < 2e-6 and err.max().item() < 2e-6
+
+
+def test_gemm_sp_epilogues_and_batch():
+    torch.manual_seed(5)
+    M, N, K = 300, 200, 96
+    A = torch.randn(M, K, device="cuda")
+    B = torch.randn(N, K, device="cuda") * 0.1
+    bias = torch.randn(N, device="cuda")
+    resid = torch.randn(M, N, device="cuda")
+    pre = torch.empty(M, N, device="cuda")
+    amax = torch.zeros(SLOT, device="cuda")
+    lin = 0.5 * (A.double() @ B.double().t()) + bias.double()
+    want = torch.nn.functional.gelu(lin) + resid.double()
+    got = gemm_sp(A, B, alpha=0.5, bias=bias, gelu=1, pre=pre, resid=resid, amax=amax)
+    assert (got.double() - want).abs().max().item() < 2e-5
+    assert (pre.double() - lin).abs().max().item() < 2e-5
+    assert float(amax[:64].view(torch.int32).max().view(torch.float32)) == float(got.abs().max())
+    acc = gemm_sp(A, B, C=got.clone(), acc=1)
+    assert (acc.double() - (want + A.double() @ B.double().t())).abs().max().item() < 3e-5
+    # batched over A and C (the patch-embedding call: per-image row blocks, shared weight)
+    nb, m = 3, 100
+    sa, pa, _ = planes(A)
+    sb, pb, _ = planes(B)
+    C = torch.zeros(nb, m + 2, N, device="cuda")
+    _lib.call("eav_gemm_sp", P(pa), P(pb), P(C) + 4 * 2 * N, P(sa), P(sb), m, N, K, N, nb, m * 4 * kpad(K), (m + 2) * N,
+              1.0, None, 0, None, None, 0, 0, None, None)
+    ref = (A.double() @ B.double().t()).view(nb, m, N)
+    assert (C[:, 2:].double() - ref).abs().max().item() < 2e-5 and (C[:, :2] == 0).all()
+
+
+@pytest.mark.parametrize("shape", [(9712, 768, 256), (1214, 200, 136), (50, 64, 64)])
+def test_weight_gradient_through_transposed_planes(shape):
+    tokens, N, K = shape
+    torch.manual_seed(7)
+    dY = torch.randn(tokens, N, device="cuda") * 1e-3
+    X = torch.randn(tokens, K, device="cuda")
+    sa, _, aT = planes(dY, False, True)
+    sb, _, bT = planes(X, False, True)
+    C = torch.empty(N, K, device="cuda")
+    ns = _lib.plain("eav_gemm_sp_splitk_plan", N, K, tokens)
+    ws = torch.empty(max(ns, 1) * N * K, device="cuda")
+    _lib.call("eav_gemm_sp_splitk", P(aT), P(bT), P(C), P(ws), P(sa), P(sb), N, K, tokens, 0, None)
+    ref = dY.double().t() @ X.double()
+    den = dY.double().abs().t() @ X.double().abs()
+    assert ((C.double() - ref).abs() / den).max().item() < 2e-7
+    C2 = C.clone()
+    _lib.call("eav_gemm_sp_splitk", P(aT), P(bT), P(C2), P(ws), P(sa), P(sb), N, K, tokens, 1, None)
+    assert torch.allclose(C2, 2 * C, rtol=1e-6, atol=0)
+    C3 = torch.empty_like(C)   # bit-reproducible (fixed-order split-K reduction)
+    _lib.call("eav_gemm_sp_splitk", P(aT), P(bT), P(C3), P(ws), P(sa), P(sb), N, K, tokens, 0, None)
+    assert torch.equal(C3, C)
+
+
+def test_convert_colsum_and_producer_amax():
+    torch.manual_seed(9)
+    R, C = 1000, 192
+    x = torch.randn(R, C, device="cuda")
+    slot = torch.zeros(SLOT, device="cuda")
+    _lib.call("eav_sp_absmax", P(x), R, C, C, P(slot), None)
+    npart = _lib.plain("eav_sp_convert_colsum_nparts", R)
+    part = torch.zeros(npart, C, device="cuda")
+    d = torch.empty(R, 2 * kpad(C), dtype=torch.float16, device="cuda")
+    _lib.call("eav_sp_convert_colsum", P(x), R, C, C, P(slot), P(d), None, P(part), None)
+    assert (part.double().sum(0) - x.double().sum(0)).abs().max().item() < 1e-4
+    _, d2, _ = planes(x)
+    assert torch.equal(d, d2)
+    # LayerNorm forward / backward and GELU backward leave max|output| in the slot
+    g, b = torch.rand(C, device="cuda") + 0.5, torch.randn(C, device="cuda")
+    y, mean, rstd = torch.empty_like(x), torch.empty(R, device="cuda"), torch.empty(R, device="cuda")
+    s1 = torch.zeros(SLOT, device="cuda")
+    _lib.call("eav_layernorm_fwd_amax", P(x), P(g), P(b), P(y), P(mean), P(rstd), R, C, 1e-12, P(s1), None)
+    assert float(s1[:64].view(torch.int32).max().view(torch.float32)) == float(y.abs().max())
+    dy, dx = torch.randn_like(x), torch.zeros_like(x)
+    s2 = torch.zeros(SLOT, device="cuda")
+    _lib.call("eav_layernorm_bwd_amax", P(dy), P(x), P(g), P(mean), P(rstd), P(dx), 0, None, R, C, P(s2), None)
+    assert float(s2[:64].view(torch.int32).max().view(torch.float32)) == float(dx.abs().max())
+    s3 = torch.zeros(SLOT, device="cuda")
+    da = dy.clone()
+    _lib.call("eav_gelu_bwd_amax", P(da), P(x), R * C, P(s3), None)
+    assert float(s3[:64].view(torch.int32).max().view(torch.float32)) == float(da.abs().max())
+
+
+def _attn_ref(qkv, dO, B, H, N):
+    D = H * 64
+    x = qkv.double().view(B, N, 3, H, 64).permute(2, 0, 3, 1, 4).clone().requires_grad_(True)
+    s = (x[0] @ x[1].transpose(-1, -2)) * 0.125
+    o = torch.softmax(s, -1) @ x[2]
+    out = o.permute(0, 2, 1, 3).reshape(B * N, D)
+    out.backward(dO.double())
+    return out.detach(), x.grad.permute(1, 3, 0, 2, 4).reshape(B * N, 3 * D), torch.logsumexp(s, -1).reshape(B * H, N).detach()
+
+
+def _attn_prep(x, B, N, ncols, secw, tmask):
+    Npad = _lib.plain("eav_attn_sp_npad", N)
+    slot = torch.zeros(SLOT, device="cuda")
+    _lib.call("eav_sp_absmax", P(x), B * N, ncols, ncols, P(slot), None)
+    rowp = torch.empty(B * N, 2 * ncols, dtype=torch.float16, device="cuda")
+    tp = torch.empty(B, ncols // 64, 64, 2 * Npad, dtype=torch.float16, device="cuda")
+    _lib.call("eav_attn_sp_prep", P(x), P(slot), P(rowp), P(tp), B, N, ncols, secw, tmask, None)
+    return slot, rowp, tp
+
+
+@pytest.mark.parametrize("cfg", [(1, 2, 64, 1.0, False), (2, 3, 197, 1.0, False), (1, 2, 1214, 1.0, False),
+                                 (2, 2, 300, 3.0, True), (1, 1, 33, 1.0, False)])
+def test_attention_sp_is_fp32_grade(cfg):
+    B, H, N, qs, spike = cfg
+    D = H * 64
+    torch.manual_seed(B * 1000 + N)
+    qkv = torch.randn(B * N, 3 * D, device="cuda") * qs
+    if spike:      # one key aligned with one query: the running maximum jumps inside a key tile (rescale branch)
+        qkv[5, D:D + 64] = qkv[3, :64] * 6.0
+    dO = torch.randn(B * N, D, device="cuda") * 1e-3
+    ro, rg, rl = _attn_ref(qkv, dO, B, H, N)
+    # split
+    s_qkv, rowp, tp = _attn_prep(qkv, B, N, 3 * D, D, 7)
+    ao, lse = torch.empty(B * N, D, device="cuda"), torch.empty(B * H, N, device="cuda")
+    amax = torch.zeros(SLOT, device="cuda")
+    _lib.call("eav_attn_fwd_sp", P(rowp), P(tp), P(s_qkv), P(ao), P(lse), P(amax), B, H, N, 64, 0.125, None)
+    assert float(amax[:64].view(torch.int32).max().view(torch.float32)) == float(ao.abs().max())
+    s_do, dorow, dotp = _attn_prep(dO, B, N, D, D, 1)
+    s_ds, delta = torch.zeros(SLOT, device="cuda"), torch.empty(B * H, N, device="cuda")
+    dqkv = torch.empty(B * N, 3 * D, device="cuda")
+    _lib.call("eav_attn_bwd_sp", P(rowp), P(tp), P(dorow), P(dotp), P(s_qkv), P(s_do), P(s_ds), P(ao), P(dO), P(lse),
+              P(delta), P(dqkv), None, B, H, N, 64, 0.125, None)
+    # exact-fp32 kernels
+    ao32, lse32 = torch.empty_like(ao), torch.empty_like(lse)
+    _lib.call("eav_attn_fwd", P(qkv), P(ao32), P(lse32), B, H, N, 64, 0.125, None)
+    dq32 = torch.empty_like(dqkv)
+    _lib.call("eav_attn_bwd", P(qkv), P(ao32), P(dO), P(lse32), P(delta), P(dq32), B, H, N, 64, 0.125, None)
+
+    def rel(a, r):
+        return ((a.double() - r).abs().max() / r.abs().max()).item()
+    assert rel(ao, ro) <= 1.5 * rel(ao32, ro) + 2e-7
+    assert (lse.double() - rl).abs().max().item() <= 1.5 * (lse32.double() - rl).abs().max().item() + 1e-6
+    for i in range(3):
+        sl = slice(i * D, (i + 1) * D)
+        assert rel(dqkv[:, sl], rg[:, sl]) <= 1.5 * rel(dq32[:, sl], rg[:, sl]) + 3e-7, i

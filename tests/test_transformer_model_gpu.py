@@ -195,7 +195,7 @@ def test_batch_size_changes_and_eval_mode(precision):
         with torch.no_grad():
             ref = vo.forward(P, torch.from_numpy(x), ocfg)
         close(out.logits, ref.numpy(), 1e-4, 1e-4, f"logits B={B}")
-        assert abs(float(out.loss) - float(torch.nn.functional.cross_entropy(ref, torch.from_numpy(y)))) < 1e-4
+        assert abs(float(out.loss.detach()) - float(torch.nn.functional.cross_entropy(ref, torch.from_numpy(y)))) < 1e-4
     model.eval()
     with torch.no_grad():
         x, _ = synth.frame_batch(99, 5, 64)

@@ -45,8 +45,10 @@ def _compare_lines(got, ref):
     assert g == r, (g, r)
 
 
-def test_audio_trainer_matches_reference(golden_dir, tmp_path, monkeypatch):
+@pytest.mark.parametrize("precision", ["split", "fp32"])
+def test_audio_trainer_matches_reference(golden_dir, tmp_path, monkeypatch, precision):
     from eav_amd.audio import AudioModelTrainer
+    monkeypatch.setenv("EAV_ENCODER_PRECISION", precision)
     g = np.load(os.path.join(golden_dir, "ast_trainer.npz"))
     path = _save_model_dir(tmp_path, "ast", int(g["wseed"]))
     monkeypatch.chdir(tmp_path)
@@ -70,8 +72,10 @@ def test_audio_trainer_matches_reference(golden_dir, tmp_path, monkeypatch):
     assert open("training_performance_audio.txt").read().count("Epoch") == 2      # Q17
 
 
-def test_vision_trainer_matches_reference(golden_dir, tmp_path, monkeypatch):
+@pytest.mark.parametrize("precision", ["split", "fp32"])
+def test_vision_trainer_matches_reference(golden_dir, tmp_path, monkeypatch, precision):
     from eav_amd.vision import ImageClassifierTrainer, trial_vote
+    monkeypatch.setenv("EAV_ENCODER_PRECISION", precision)
     g = np.load(os.path.join(golden_dir, "vit_trainer.npz"))
     path = _save_model_dir(tmp_path, "vit", int(g["wseed"]))
     monkeypatch.chdir(tmp_path)

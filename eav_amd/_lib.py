@@ -44,7 +44,8 @@ SIGNATURES = {
     "eav_conv64_wgrad": [_p, _p, _p, _i, _i, _i, _p],
     "eav_dense_softmax_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _p],
     "eav_dense_softmax_bwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
-    "eav_ce_fwd_bwd": [_p, _p, _p, _p, _p, _i, _i, _p],
+    "eav_ce_fwd_bwd": [_p, _p, _p, _p, _p, _p, _i, _i, _p],
+    "eav_scale_by_scalar": [_p, _p, _i64, _p],
     "eav_adam_step": [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _i64, _i, _p, _p],
     "eav_counter_inc": [_p, _p],
     "eav_gather_rows": [_p, _p, _p, _i, _i64, _p],

@@ -154,9 +154,13 @@ class EEGNet(nn.Module):
         L, P, st = _lib.call, _lib.ptr, _lib.stream_ptr()
         B, C, S, K, K2 = x.shape[0], self.Chans, self.Samples, self.kernLength, self.K2
         F1, D, F2, C2 = self.F1, self.D, self.F2, self.F1 * self.D
-        if self._ws is None or self._ws.key != (B, C, S) or self._ws.y1.device != x.device:
-            self._ws = _Workspace(self, B, x.device)
-        ws = self._ws
+        # one workspace per batch size, never freed: captured hipGraphs hold its raw pointers (see EEGNet_tor._workspace)
+        wkey = (B, C, S, str(x.device))
+        if not hasattr(self, "_wss"):
+            self._wss = {}
+        if wkey not in self._wss:
+            self._wss[wkey] = _Workspace(self, B, x.device)
+        ws = self._ws = self._wss[wkey]
         training = bool(self.training)
         w1, g1w, g1b, wd, g2w, g2b, wdw, wp, g3w, g3b, wc, bc = [P(p) for p in self._params()]
         drop = self.dropoutRate if training else 0.0
@@ -188,7 +192,7 @@ class EEGNet(nn.Module):
         bnfin(ws.part_c, ws.np_c, F2, B * ws.T2, g3w, g3b, self.block2[2], ws.bn3)
         L("eav_bn_elu_pool_fwd", P(ws.z3), P(ws.bn3), P(ws.a3), B, F2, ws.T2, 8, drop, seed2, m2, cnt, st)
         L("eav_dense_softmax_fwd", P(ws.a3), wc, bc, P(ws.logits), None, B, ws.NF, self.nb_classes, st)
-        self._saved = (self._token, x, training, drop, seed1, seed2, masks, cnt)
+        self._saved = (self._token, x, training, drop, seed1, seed2, masks, cnt, ws)
         return self._token
 
     def _launch_backward(self, dlogits, token):
@@ -196,8 +200,7 @@ class EEGNet(nn.Module):
             raise _lib.EavError("EEGNet.backward: the activations of this forward were overwritten by a later forward "
                                 "(one outstanding forward per backward)")
         L, P, st = _lib.call, _lib.ptr, _lib.stream_ptr()
-        _, x, training, drop, seed1, seed2, masks, cnt = self._saved
-        ws = self._ws
+        _, x, training, drop, seed1, seed2, masks, cnt, ws = self._saved
         B, C, S, K, K2 = x.shape[0], self.Chans, self.Samples, self.kernLength, self.K2
         F1, D, F2, C2, T2, NF = self.F1, self.D, self.F2, self.F1 * self.D, ws.T2, ws.NF
         flat, gflat, offs = self._flat

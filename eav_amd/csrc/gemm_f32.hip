@@ -240,12 +240,12 @@ template <int BM, int BN, bool TA, bool TB>
 int launch_bm(const GemmArgs& g, int batch, hipStream_t st) {
   constexpr int SA = TA ? (BM + 4) : (BM + 1), SB = TB ? (BN + 4) : (BN + 1);
   const size_t lds = (size_t)2 * BK * (SA + SB) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<BM, BN, TA, TB>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  // once per instantiation, race-free (function-local static initialisation is thread-safe in C++11): the library
+  // keeps no mutable global state
+  static const hipError_t attr_rc = hipFuncSetAttribute(
+      reinterpret_cast<const void*>(&gemm_f32_kernel<BM, BN, TA, TB>), hipFuncAttributeMaxDynamicSharedMemorySize,
+      (int)((size_t)2 * BK * (SA + SB) * sizeof(float)));
+  (void)attr_rc;
   dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM), batch);
   hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, TA, TB>), grid, dim3(256), lds, st, g);
   return 0;

@@ -118,7 +118,8 @@ __global__ __launch_bounds__(256) void dense_softmax_bwd_kernel(const float* __r
 // mean cross-entropy over B rows of `in` (treated as logits) + gradient (softmax - onehot)/B
 __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ in, const int64_t* __restrict__ y,
                                                  float* __restrict__ loss, float* __restrict__ din,
-                                                 int* __restrict__ ncorrect, int B, int NC) {
+                                                 int* __restrict__ ncorrect, int* __restrict__ bad_label, int B,
+                                                 int NC) {
   __shared__ float red[8];
   float st[2] = {0.f, 0.f};
   for (int b = threadIdx.x; b < B; b += 256) {
@@ -130,8 +131,11 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ in, c
     float s = 0.f;
     for (int j = 0; j < NC; ++j) s += expf(r[j] - mx);
     const float lse = mx + logf(s);
-    const int yy = (int)y[b];
-    st[0] += lse - r[yy];
+    const int64_t yl = y[b];
+    const bool ok = yl >= 0 && yl < NC;        // torch asserts on class indices outside [0, NC); never index with one
+    if (!ok && bad_label) *bad_label = yl >= 0 ? (int)min(yl, (int64_t)0x7ffffffe) + 1 : (int)max(yl, (int64_t)-0x7fffffff);
+    const int yy = ok ? (int)yl : -1;
+    st[0] += ok ? lse - r[yy] : 0.f;
     st[1] += (am == yy) ? 1.f : 0.f;
     if (din)
       for (int j = 0; j < NC; ++j) din[(int64_t)b * NC + j] = (expf(r[j] - lse) - (j == yy ? 1.f : 0.f)) / (float)B;
@@ -192,11 +196,29 @@ extern "C" int eav_dense_softmax_bwd(const float* dout, const float* probs, cons
   return EAV_OK;
 }
 
-extern "C" int eav_ce_fwd_bwd(const float* in, const int64_t* y, float* loss, float* din, int* ncorrect, int B,
-                              int NC, void* stream) {
+extern "C" int eav_ce_fwd_bwd(const float* in, const int64_t* y, float* loss, float* din, int* ncorrect,
+                              int* bad_label, int B, int NC, void* stream) {
   EAV_REQUIRE(in && y && B > 0 && NC > 0, "eav_ce_fwd_bwd: bad arguments");
-  hipLaunchKernelGGL(ce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, in, y, loss, din, ncorrect, B, NC);
+  hipLaunchKernelGGL(ce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, in, y, loss, din, ncorrect, bad_label, B,
+                     NC);
   EAV_CHECK_LAUNCH("eav_ce_fwd_bwd");
+  return EAV_OK;
+}
+
+// v[i] *= *scalar (device scalar): applies the upstream gradient of the loss to its stored input gradient
+__global__ __launch_bounds__(256) void scale_by_scalar_kernel(float* __restrict__ v, const float* __restrict__ sc,
+                                                              int64_t n) {
+  const float s = *sc;
+  if (s == 1.f) return;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) v[i] *= s;
+}
+
+extern "C" int eav_scale_by_scalar(float* v, const float* scalar, int64_t n, void* stream) {
+  EAV_REQUIRE(v && scalar && n > 0, "eav_scale_by_scalar: bad arguments");
+  int64_t blocks = cdiv64(n, 256);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(scale_by_scalar_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, v, scalar, n);
+  EAV_CHECK_LAUNCH("eav_scale_by_scalar");
   return EAV_OK;
 }
 

@@ -45,49 +45,64 @@ def subjects_for_rank(rank, world, n_subjects=42, first=1):
 
 
 class GradSync:
-    """All-reduce (mean) of flat gradient buffers; call between backward and optimizer.step().
+    """All-reduce of flat gradient buffers into the gradient of the GLOBAL batch; call between backward and
+    optimizer.step().
 
-    Two ways to use it.  (1) `sync()` after the backward: one all-reduce per flat buffer (EEGNet: 0.68 MB,
-    pure latency).  (2) Overlapped: hand `sync.bucket` to a model as its `grad_ready_hook`; the encoders call
-    it from inside the backward as soon as a layer's contiguous slice of the flat gradient buffer is final
-    (last layer first), so the RCCL transfers of ~28 MB buckets run on the communicator's stream under the
+    Every rank's loss is the mean over its local shard, so the global-batch gradient is sum_r (n_r / n) g_r: each
+    rank scales its gradient by `weight` = n_r / n (set_batch(); default 1 / world for equal shards) and the
+    collective is a plain SUM.  Two ways to use it.  (1) `sync()` after the backward: one all-reduce per flat buffer
+    (EEGNet: 0.68 MB, pure latency).  (2) Overlapped: hand `sync.bucket` to a model as its `grad_ready_hook`; the
+    encoders call it from inside the backward as soon as a layer's contiguous slice of the flat gradient buffer is
+    final (last layer first), so the RCCL transfers of ~28 MB buckets run on the communicator's stream under the
     remaining backward kernels; `sync()` then only waits for the outstanding work and reduces what is left."""
 
     def __init__(self, flat_grads, group=None):
         self.flat_grads = list(flat_grads)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.weight = 1.0 / self.world
         self._pending = []
         self._done = []          # (buffer index, lo, hi) ranges already submitted during this backward
         self.active = None       # optional {buffer index: [(lo, hi), ...]}: the only slices that carry gradients
                                  # (frozen fine-tuning phase: the classifier head), default = whole buffers
+        self.bytes_reduced = 0   # bookkeeping for tests / the bench report
+
+    def set_batch(self, local_n, global_n):
+        """This rank contributed local_n of the global batch's global_n items (uneven shards, ragged last batch)."""
+        self.weight = float(local_n) / float(global_n)
+
+    def _reduce(self, view, async_op):
+        if self.weight != 1.0:
+            view.mul_(self.weight)
+        self.bytes_reduced += 4 * view.numel()
+        return dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
 
     def bucket(self, lo, hi, buffer=0):
         """Asynchronously all-reduce flat_grads[buffer][lo:hi] (elements)."""
         if self.world == 1 or hi <= lo:
             return
-        view = self.flat_grads[buffer][lo:hi]
-        self._pending.append((dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True), view))
+        self._pending.append(self._reduce(self.flat_grads[buffer][lo:hi], True))
         self._done.append((buffer, lo, hi))
 
     def __call__(self):
         if self.world == 1:
             return
-        inv = 1.0 / self.world
-        for work, view in self._pending:
+        for work in self._pending:
             work.wait()
-            view.mul_(inv)
         for i, g in enumerate(self.flat_grads):
-            covered = sorted((lo, hi) for b, lo, hi in self._done if b == i)
             wanted = sorted(self.active[i]) if self.active is not None and i in self.active else [(0, g.numel())]
             for wlo, whi in wanted:
+                # the parts of [wlo, whi) that no bucket covered, walked in order
+                covered = sorted((max(lo, wlo), min(hi, whi)) for b, lo, hi in self._done if b == i)
                 pos = wlo
-                for lo, hi in covered + [(whi, whi)]:
-                    lo, hi = max(lo, wlo), min(hi, whi)
-                    if lo > pos:                  # a gap no bucket covered
-                        dist.all_reduce(g[pos:lo], op=dist.ReduceOp.SUM, group=self.group)
-                        g[pos:lo].mul_(inv)
+                for lo, hi in covered:
+                    if hi <= lo:              # bucket entirely outside the wanted range
+                        continue
+                    if lo > pos:
+                        self._reduce(g[pos:lo], False)
                     pos = max(pos, hi)
+                if pos < whi:
+                    self._reduce(g[pos:whi], False)
         self._pending, self._done = [], []
 
     def set_active(self, ranges, buffer=0):
@@ -110,8 +125,8 @@ def attach(trainer):
     trainer.grad_sync = GradSync([model._flat[1]])
     if hasattr(model, "grad_ready_hook"):
         model.grad_ready_hook = trainer.grad_sync.bucket     # overlap the all-reduce with the backward
-    if hasattr(trainer, "use_graph"):
-        trainer.use_graph = False     # the RCCL all-reduce stays outside hipGraph capture
+    # hipGraph replay stays on (Trainer_uni / GraphStep): with a grad_sync the step is captured as TWO graphs - batch
+    # gather + forward + loss + backward, and the fused Adam update - with the all-reduce issued eagerly between them
     return trainer
 
 

@@ -22,6 +22,23 @@ from . import _lib
 SELECTED_CLASSES = [1, 3, 5, 7, 9]
 
 
+def read_subject_recording(parent_directory, subject):
+    """(signal [channel, time, trial], one-hot labels [10, trial]) of one subject, or None when the signal file is
+    absent.  Host file I/O, outside the accelerated path."""
+    from scipy.io import loadmat
+    stem = f'subject{int(subject):02d}'
+    folder = os.path.join(parent_directory, stem, 'EEG')
+    signal_path, label_path = (os.path.join(folder, stem + suffix) for suffix in ('_eeg.mat', '_eeg_label.mat'))
+    if not os.path.isfile(signal_path):
+        return None
+    contents = loadmat(signal_path)
+    recording = next((np.asarray(contents[name]) for name in ('seg1', 'seg') if name in contents), None)
+    if recording is None:
+        raise KeyError(f"{signal_path}: neither 'seg1' nor 'seg' present")
+    labels = np.asarray(loadmat(label_path)['label'])
+    return np.swapaxes(recording, 0, 1), labels          # stored time-major -> channel-major
+
+
 def resample_poly_design(up, down):
     """(h float64, center, n_out(n_in)) of scipy.signal.resample_poly(x, up, down) for up == 1:
     y[m] = sum_j h[j] x[m*down + center - j]  (window ('kaiser', 5.0), half_len = 10*max(up,down))."""
@@ -114,21 +131,16 @@ class DataLoadEEG:
         return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64).to(self.device)
 
     def load_mat_data(self):
-        # Dataload_eeg.py:54-83 (host file I/O, unchanged)
-        import scipy.io
-        subject_str = f'subject{self.subject:02d}'
-        eeg_folder = os.path.join(self.parent_directory, subject_str, 'EEG')
-        base_name = subject_str.rstrip('__')
-        eeg_file_path = os.path.join(eeg_folder, base_name + '_eeg.mat')
-        label_file_path = os.path.join(eeg_folder, base_name + '_eeg_label.mat')
-        if not os.path.exists(eeg_file_path):
-            print(f'[Error] EEG data not found for {subject_str}')
+        """Reads one subject's recording from disk (the file layout Dataload_eeg.py:54-83 expects:
+        <parent>/subjectNN/EEG/subjectNN_eeg.mat with variable `seg1` or `seg` [time, channel, trial] and
+        subjectNN_eeg_label.mat with `label` [10, trials]); leaves self.seg as [channel, time, trial]."""
+        found = read_subject_recording(self.parent_directory, self.subject)
+        tag = f'subject{self.subject:02d}'
+        if found is None:
+            print(f'[Error] EEG data not found for {tag}')
             return
-        mat = scipy.io.loadmat(eeg_file_path)
-        cnt_ = np.array(mat.get('seg1')) if 'seg1' in mat else np.array(mat.get('seg'))
-        self.label = np.array(scipy.io.loadmat(label_file_path).get('label'))
-        self.seg = np.transpose(cnt_, [1, 0, 2])
-        print(f'[Info] Loaded EEG data for {subject_str}')
+        self.seg, self.label = found
+        print(f'[Info] Loaded EEG data for {tag}')
 
     def downsampling(self):
         # Dataload_eeg.py:85-102

@@ -48,7 +48,6 @@ class _Workspace:
         self.p2, self.dp2 = f(B, 64, T2), f(B, 64, T2)
         self.u3, self.du3 = f(B, 64, T2), f(B, 64, T2)
         self.p3, self.dp3 = f(B, 64 * T3), f(B, 64 * T3)
-        self.probs = f(B, nb)
         self.bn1, self.bn2, self.bn3 = f(6 * 8), f(6 * 64), f(6 * 64)
         self.wTf, self.wTb = f(1024, 64), f(1024, 64)
         self.np_fir = _lib.plain("eav_eegnet_fir_fwd_nparts", B, C, S)
@@ -77,7 +76,9 @@ class _EEGNetFn(torch.autograd.Function):
     def forward(ctx, x, model, *params):
         ctx.model = model
         ctx.token = model._launch_forward(x)
-        return model._ws.probs.clone()
+        # the probabilities tensor this forward wrote: no copy kernel.  (A detached alias, not the saved object itself:
+        # returning the very tensor that the model also keeps for its backward crashes hipGraph capture in torch 2.10.)
+        return model._saved[-1].detach()
 
     @staticmethod
     def backward(ctx, dprobs):
@@ -115,6 +116,7 @@ class EEGNet_tor(nn.Module):
         if dropoutType != 'Dropout' and dropoutRate > 0:
             raise NotImplementedError("eav_amd.EEGNet_tor: only element-wise Dropout is implemented")
         self._ws = None
+        self._wss = {}                         # workspaces by (B, Chans, Samples, device): see _workspace()
         self._flat = None
         self._token = 0
         self._saved = None
@@ -174,12 +176,20 @@ class EEGNet_tor(nn.Module):
         else:
             _lib.call(name, *args)
 
+    def _workspace(self, B, dev):
+        """One workspace per problem size, kept for the life of the model: a captured hipGraph (GraphStep) has the
+        raw device pointers of the workspace it was captured with baked in, so a workspace must never be freed or
+        re-allocated when another batch size (the partial last batch, validation) comes through."""
+        key = (B, self.Chans, self.Samples, str(dev))
+        ws = self._wss.get(key)
+        if ws is None:
+            ws = self._wss[key] = _Workspace(B, self.Chans, self.Samples, self.kernLength, self.nb_classes, dev)
+        return ws
+
     def _launch_forward(self, x):
         L, P, st = self._call, _lib.ptr, _lib.stream_ptr()
         B, C, S, K, nb = x.shape[0], self.Chans, self.Samples, self.kernLength, self.nb_classes
-        if self._ws is None or self._ws.key != (B, C, S) or self._ws.y1.device != x.device:
-            self._ws = _Workspace(B, C, S, K, nb, x.device)
-        ws = self._ws
+        ws = self._ws = self._workspace(B, x.device)
         training = bool(self.training)
         w1, g1w, g1b, w2, g2w, g2b, w3, g3w, g3b, wd, bd = [P(p) for p in self._params()]
         bn1, bn2, bn3 = self.firstBN, self.depthwiseBN, self.separableBN
@@ -202,8 +212,8 @@ class EEGNet_tor(nn.Module):
             b0 = P(buf)
             L("eav_bn_finalize", P(part), nparts, nch, float(count), gw, gb, P(bn.running_mean), P(bn.running_var),
               int(training), float(bn.momentum), float(bn.eps), b0, b0 + 4 * nch, b0 + 8 * nch, b0 + 12 * nch, st)
-            if training:
-                bn.num_batches_tracked += 1
+            if training:       # nn.BatchNorm2d's step counter, bumped by a library kernel (no torch op in a captured step)
+                L("eav_counter_inc", P(bn.num_batches_tracked), st)
 
         if self.fir_precision not in ("fp32", "split"):
             raise ValueError(f"fir_precision {self.fir_precision!r}: expected 'fp32' or 'split'")
@@ -230,11 +240,12 @@ class EEGNet_tor(nn.Module):
             L("eav_conv64_fwd", P(ws.p2), P(ws.wTf), P(ws.u3), P(ws.part_c3), B, ws.T2, 7, st)
         bnfin(ws.part_c3, ws.np_c3, 64, B * ws.T2, g3w, g3b, bn3, ws.bn3)
         L("eav_bn_elu_pool_fwd", P(ws.u3), P(ws.bn3), P(ws.p3), B, 64, ws.T2, 8, drop, seed2, m2, cnt, st)
-        L("eav_dense_softmax_fwd", P(ws.p3), wd, bd, None, P(ws.probs), B, ws.NF, nb, st)
+        probs = torch.empty(B, nb, dtype=torch.float32, device=x.device)   # fresh per forward: returned, kept for backward
+        L("eav_dense_softmax_fwd", P(ws.p3), wd, bd, None, P(probs), B, ws.NF, nb, st)
         if self.apply_max_norm:  # the forward hooks of the reference (:33-34, :47-48), intended meaning
             L("eav_renorm_rows", w2, 64, C, self.norm_rate, st)
             L("eav_renorm_rows", wd, nb, ws.NF, self.norm_rate, st)
-        self._saved = (self._token, x, training, drop, seed1, seed2, masks, cnt, split)
+        self._saved = (self._token, x, training, drop, seed1, seed2, masks, cnt, split, ws, probs)
         return self._token
 
     def _launch_backward(self, dprobs, token):
@@ -242,8 +253,7 @@ class EEGNet_tor(nn.Module):
             raise _lib.EavError("EEGNet_tor.backward: the activations of this forward were overwritten by a later "
                                 "forward (one outstanding forward per backward)")
         L, P, st = self._call, _lib.ptr, _lib.stream_ptr()
-        _, x, training, drop, seed1, seed2, masks, cnt, split = self._saved
-        ws = self._ws
+        _, x, training, drop, seed1, seed2, masks, cnt, split, ws, probs = self._saved
         B, C, S, K, nb = x.shape[0], self.Chans, self.Samples, self.kernLength, self.nb_classes
         T2, NF = ws.T2, ws.NF
         flat, gflat, offs = self._flat
@@ -253,7 +263,7 @@ class EEGNet_tor(nn.Module):
         m2 = P(masks[1]) if masks is not None else None
         tr = int(training)
 
-        L("eav_dense_softmax_bwd", P(dprobs), P(ws.probs), P(ws.p3), wd, P(g["dense.weight"]), P(g["dense.bias"]),
+        L("eav_dense_softmax_bwd", P(dprobs), P(probs), P(ws.p3), wd, P(g["dense.weight"]), P(g["dense.bias"]),
           P(ws.dp3), B, NF, nb, st)
         # block 2: Dropout <- AvgPool8 <- ELU <- separableBN
         b3 = P(ws.bn3)
@@ -325,46 +335,64 @@ class GraphStep:
     def __init__(self, model, optimizer, criterion, xs, ys, batch, grad_sync=None, post_step=None):
         if not getattr(optimizer, "capturable", False):
             raise _lib.EavError("GraphStep needs FusedAdam(capturable=True)")
-        self.model, self.batch = model, batch
+        self.model, self.batch, self.grad_sync = model, batch, grad_sync
         dev = xs.device
         self.idx = torch.zeros(batch, dtype=torch.long, device=dev)
 
-        def body():
+        def compute():       # batch gather + forward + loss + backward
             data, targets = gather_batch(xs, ys, self.idx)
             scores = model(data)
             loss = criterion(scores, targets)
             optimizer.zero_grad(set_to_none=True)
             loss.backward()
-            if grad_sync is not None:
-                grad_sync()
-            optimizer.step()
-            if post_step is not None:      # e.g. the max-norm projection of Transformer_EEG.py:195-199
-                post_step()
             return scores, loss
 
+        def update():        # fused Adam (+ e.g. the max-norm projection of Transformer_EEG.py:195-199)
+            optimizer.step()
+            if post_step is not None:
+                post_step()
+
         self.warm_steps = 0
-        self.graph = None
-        self._body = body
+        self.graph = None          # compute (and, without a grad_sync, update) graph
+        self.graph_update = None   # data parallel: the update is its own graph, the all-reduce runs between the two
+        self._compute, self._update = compute, update
+
+    def _eager(self):
+        scores, loss = self._compute()
+        if self.grad_sync is not None:
+            self.grad_sync()
+        self._update()
+        return scores, loss
 
     def run(self, idx):
         """idx: sequence of `batch` dataset indices.  The first two calls run eagerly (they are real training
-        steps), the third is captured, later ones are replays."""
+        steps), the third is captured, later ones are replays.  Under data parallelism (grad_sync) the collective is
+        not captured: replay(compute) -> all-reduce on the live stream -> replay(update)."""
         self.idx.copy_(torch.as_tensor(idx, dtype=torch.long))     # pageable source: staged, no host race
         if self.graph is None:
             if self.warm_steps < 2:
                 self.warm_steps += 1
-                scores, loss = self._body()
+                scores, loss = self._eager()
                 return scores.detach(), loss.detach()     # keep no reference to the autograd graph
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
-                scores, loss = self._body()
+                scores, loss = self._compute()
                 self.scores, self.loss = scores.detach(), loss.detach()
+                if self.grad_sync is None:
+                    self._update()
             del scores, loss
-            # capture does not execute: replay once so that this call is a real step too
-            self.graph.replay()
-            return self.scores, self.loss
+            if self.grad_sync is not None:
+                # the gradients the update graph reads live in the model's flat buffer (static address); capture the
+                # update on its own (its launches are recorded, not executed)
+                self.graph_update = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph_update, pool=self.graph.pool()):
+                    self._update()
+            # capture does not execute: fall through to a replay so that this call is a real step too
         self.graph.replay()
+        if self.grad_sync is not None:
+            self.grad_sync()
+            self.graph_update.replay()
         return self.scores, self.loss
 
 
@@ -464,6 +492,7 @@ class Trainer_uni:
                 if batch_idx % 100 == 0:
                     print(f"Epoch [{epoch+1}/{self.num_epochs}], Step [{batch_idx}/{len(self.train_dataloader)}], "
                           f"Loss: {loss.item():.4f}")
+            self.criterion.check()        # out-of-range labels recorded by the captured steps of this epoch
             if self.test_dataloader:
                 self.validate()
 

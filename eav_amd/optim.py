@@ -98,6 +98,14 @@ class FusedAdam(torch.optim.Optimizer):
                     raise _lib.EavError("FusedAdam needs parameters on a ROCm device (no CPU fallback)")
                 if not g.is_contiguous():
                     g = g.contiguous()
+                fl = getattr(p, "_eav_flat", None)
+                if fl is not None and g.data_ptr() != fl[1].data_ptr() + 4 * fl[2]:
+                    # the models return views of their flat gradient buffer, which each backward OVERWRITES; autograd
+                    # adopts the view only when p.grad was None - anything else means torch accumulated into a copy
+                    # (zero_grad(set_to_none=False), or two backward() calls before one step)
+                    raise _lib.EavError("FusedAdam: p.grad is not the model's flat gradient buffer - use "
+                                        "optimizer.zero_grad() (set_to_none=True) and one backward() per step; gradient "
+                                        "accumulation across backward() calls is not supported")
                 st = self.state[p]
                 if getattr(p, "_eav_flat", None) is not None:
                     touched[p._eav_flat[0].data_ptr()] = p._eav_flat[0]
@@ -144,29 +152,57 @@ class FusedAdam(torch.optim.Optimizer):
 
 class _CEFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, scores, targets):
-        if not scores.is_cuda:
-            raise _lib.EavError("CrossEntropyLoss needs device tensors (no CPU fallback)")
-        scores = scores.contiguous().float()
+    def forward(ctx, scores, targets, flag):
         B, NC = scores.shape
         loss = torch.empty((), dtype=torch.float32, device=scores.device)
-        dsc = torch.empty_like(scores)
-        _lib.call("eav_ce_fwd_bwd", scores.data_ptr(), targets.contiguous().data_ptr(), loss.data_ptr(),
-                  dsc.data_ptr(), None, B, NC, _lib.stream_ptr())
-        ctx.save_for_backward(dsc)
+        need_grad = ctx.needs_input_grad[0]
+        dsc = torch.empty_like(scores) if need_grad else None      # no gradient buffer under no_grad (validate())
+        _lib.call("eav_ce_fwd_bwd", scores.data_ptr(), targets.data_ptr(), loss.data_ptr(), _lib.ptr(dsc), None,
+                  flag.data_ptr(), B, NC, _lib.stream_ptr())
+        ctx.dsc = dsc
         return loss
 
     @staticmethod
     def backward(ctx, gout):
-        (dsc,) = ctx.saved_tensors
-        return dsc * gout, None
+        # d loss / d scores was produced by the forward launch; the incoming gradient (1.0 for loss.backward()) is
+        # applied in place by the library - no torch kernel inside a captured step
+        _lib.call("eav_scale_by_scalar", ctx.dsc.data_ptr(), gout.contiguous().data_ptr(), ctx.dsc.numel(),
+                  _lib.stream_ptr())
+        return ctx.dsc, None, None
 
 
 class CrossEntropyLoss:
     """``nn.CrossEntropyLoss()`` (mean reduction) as one fused HIP kernel that
-    produces the loss and its input gradient together."""
+    produces the loss and its input gradient together.
+
+    Like torch, it rejects class indices outside [0, classes): the kernel records the first offending label in a
+    device flag (an out-of-range label contributes nothing instead of reading out of bounds) and ``check()`` - called
+    automatically from ``__call__`` unless a hipGraph is being captured - raises on it."""
+
+    def __init__(self):
+        self._flag = None
+
+    def check(self):
+        if self._flag is not None:
+            bad = int(self._flag.item())
+            if bad != 0:
+                self._flag.zero_()
+                raise _lib.EavError(f"CrossEntropyLoss: target {bad - 1 if bad > 0 else bad} is outside [0, classes) "
+                                    "(the reference's labels 1,3,5,7,9 must be mapped to 0..4 first)")
 
     def __call__(self, scores, targets):
+        if not isinstance(scores, torch.Tensor) or not scores.is_cuda or not targets.is_cuda:
+            raise _lib.EavError("CrossEntropyLoss needs device tensors (no CPU fallback)")
+        if scores.dim() != 2 or scores.dtype != torch.float32 or not scores.is_contiguous():
+            raise _lib.EavError(f"CrossEntropyLoss: scores must be a contiguous fp32 [batch, classes] tensor, got "
+                                f"{tuple(scores.shape)} {scores.dtype}")
+        if targets.dim() != 1 or targets.numel() != scores.shape[0]:
+            raise _lib.EavError(f"CrossEntropyLoss: {targets.numel()} targets for {scores.shape[0]} rows of scores")
         if targets.dtype != torch.int64:
             targets = targets.long()
-        return _CEFn.apply(scores, targets)
+        if self._flag is None or self._flag.device != scores.device:
+            self._flag = torch.zeros((), dtype=torch.int32, device=scores.device)
+        loss = _CEFn.apply(scores, targets.contiguous(), self._flag)
+        if not torch.cuda.is_current_stream_capturing():
+            self.check()
+        return loss

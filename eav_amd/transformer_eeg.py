@@ -184,9 +184,14 @@ class ShallowConvNet(nn.Module):
         L, P = _lib.call, _lib.ptr
         st = self._st = _lib.stream_ptr()
         B, S = x.shape[0], x.shape[3]
-        if self._ws is None or self._ws.key != (B, S) or self._ws.u.device != x.device:
-            self._ws = self._alloc(B, S, x.device)
-        ws = self._ws
+        # one workspace per batch size, never freed: captured hipGraphs hold its raw pointers, and the zero pad columns
+        # of ws.ao / ws.dao must survive from step to step (see EEGNet_tor._workspace)
+        wkey = (B, S, str(x.device))
+        if not hasattr(self, "_wss"):
+            self._wss = {}
+        if wkey not in self._wss:
+            self._wss[wkey] = self._alloc(B, S, x.device)
+        ws = self._ws = self._wss[wkey]
         T, M = ws.T, ws.M
         n = dict(self.named_parameters())
         w = lambda k: P(n[k])  # noqa: E731
@@ -236,7 +241,7 @@ class ShallowConvNet(nn.Module):
           mk(3 * self.num_layers), cnt, st)
         L("eav_dense_softmax_fwd", P(ws.feat), w("fc.weight"), P(ws.zero_bias), None, P(ws.probs), B, NF * 65,
           self.nb_classes, st)
-        self._saved = (self._token, x, training, drop, masks, cnt)
+        self._saved = (self._token, x, training, drop, masks, cnt, ws)
         return self._token
 
     def _launch_backward(self, dprobs, token):
@@ -245,8 +250,8 @@ class ShallowConvNet(nn.Module):
                                 "forward (one outstanding forward per backward)")
         L, P = _lib.call, _lib.ptr
         st = self._st = _lib.stream_ptr()
-        _, x, training, drop, masks, cnt = self._saved
-        ws = self._ws
+        _, x, training, drop, masks, cnt, ws = self._saved
+        self._ws = ws
         B, S, T, M = ws.B, ws.S, ws.T, ws.M
         flat, gflat, offs = self._flat
         n = dict(self.named_parameters())

@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define EAV_ABI_VERSION 1
+#define EAV_ABI_VERSION 2
 
 const char* eav_last_error(void);
 int eav_abi_version(void);
@@ -157,9 +157,13 @@ int eav_dense_softmax_fwd(const float* in, const float* w, const float* bias, fl
 /* probs != NULL: dout is dL/dprobs (softmax backward applied first); NULL: dout is dL/dlogits. */
 int eav_dense_softmax_bwd(const float* dout, const float* probs, const float* in, const float* w, float* dw,
                           float* dbias, float* din, int B, int NF, int NC, void* stream);
-/* nn.CrossEntropyLoss (mean) on [B,NC] rows + gradient; *ncorrect += #argmax hits (may be NULL). */
-int eav_ce_fwd_bwd(const float* in, const int64_t* y, float* loss, float* din, int* ncorrect, int B, int NC,
-                   void* stream);
+/* nn.CrossEntropyLoss (mean) on [B,NC] rows + gradient (din may be NULL); *ncorrect += #argmax hits (may be NULL).
+ * A class index outside [0,NC) never indexes anything: it is reported through *bad_label (device int, may be NULL;
+ * label+1 for label >= 0, the label itself if negative) - torch raises at this point, the Python wrapper does too. */
+int eav_ce_fwd_bwd(const float* in, const int64_t* y, float* loss, float* din, int* ncorrect, int* bad_label, int B,
+                   int NC, void* stream);
+/* v[i] *= *scalar (device scalar): the upstream gradient applied to the stored d loss / d scores. */
+int eav_scale_by_scalar(float* v, const float* scalar, int64_t n, void* stream);
 /* torch.optim.Adam (decoupled=0) / AdamW (decoupled=1) update of one flat tensor; step >= 1.
  * step_dev (optional, device int64): take the step count from device memory instead (graph-capturable). */
 int eav_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,

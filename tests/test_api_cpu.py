@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/eav_hip.h but not exported"
     assert sorted(_lib.EXPORTS) == names, set(_lib.EXPORTS) ^ set(names)
-    assert lib.eav_abi_version() == 1
+    assert lib.eav_abi_version() == 2
 
 
 def test_argument_validation_without_gpu():

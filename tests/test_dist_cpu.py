@@ -52,6 +52,22 @@ def test_grad_allreduce_gloo_world2(tmp_path):
         exp = torch.full((100,), float(rank + 1)); exp[10:20] = 1.5; exp[50:60] = 1.5
         assert torch.equal(g3, exp), g3
         assert torch.allclose(g2, torch.arange(1000, dtype=torch.float32) * 1.5)   # mean of identical replicas
+        # a bucket submitted from inside the backward that lies ABOVE the active range must not be reduced a second
+        # time, and nothing outside the active range may change at sync time
+        g4 = torch.full((100,), float(rank + 1))
+        s4 = ed.GradSync([g4])
+        s4.set_active([(10, 20)])
+        s4.bucket(60, 80)
+        s4()
+        exp = torch.full((100,), float(rank + 1)); exp[10:20] = 1.5; exp[60:80] = 1.5
+        assert torch.equal(g4, exp), g4
+        # uneven shards: rank 0 holds 3 of the 4 items of the global batch -> gradient = 3/4 g0 + 1/4 g1
+        g5 = torch.full((8,), float(rank + 1))
+        s5 = ed.GradSync([g5])
+        s5.set_batch(3 if rank == 0 else 1, 4)
+        s5()
+        assert torch.allclose(g5, torch.full((8,), 0.75 * 1 + 0.25 * 2)), g5
+        assert s5.bytes_reduced == 32
         assert ed.subjects_for_rank(rank, world)[0] == 1 + rank
         # attach(): any trainer whose model keeps a flat gradient buffer - here the alternative EEG encoders, whose flat
         # layouts contain declared zero padding (ShallowConvNet) - gets the all-reduce and leaves hipGraph replay
@@ -61,7 +77,7 @@ def test_grad_allreduce_gloo_world2(tmp_path):
         torch.manual_seed(0)
         for model in (ShallowConvNet(5, num_layers=1), EEGNet(4)):
             tr = ed.attach(SimpleNamespace(model=model, grad_sync=None, use_graph=True))
-            assert tr.use_graph is False and tr.grad_sync is not None
+            assert tr.use_graph is True and tr.grad_sync is not None      # graph replay survives data parallelism
             gflat = model._flat[1]
             gflat.fill_(float(rank + 1))
             tr.grad_sync()

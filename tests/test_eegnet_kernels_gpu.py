@@ -293,7 +293,7 @@ def test_dense_softmax_ce(L, B, NF, NC):
     loss = torch.empty((), device="cuda")
     dpr = torch.empty(B, NC, device="cuda")
     nc = torch.zeros((), dtype=torch.int32, device="cuda")
-    L.call("eav_ce_fwd_bwd", probs.data_ptr(), dev(y).data_ptr(), loss.data_ptr(), dpr.data_ptr(), nc.data_ptr(), B, NC, None)
+    L.call("eav_ce_fwd_bwd", probs.data_ptr(), dev(y).data_ptr(), loss.data_ptr(), dpr.data_ptr(), nc.data_ptr(), None, B, NC, None)
     pr2 = pr.detach().clone().requires_grad_(True)
     lref = F.cross_entropy(pr2, torch.from_numpy(y))          # CE on probabilities: the double softmax (Q3)
     lref.backward()

@@ -296,3 +296,36 @@ def test_forty_step_trajectory_stays_within_tolerance(fir_precision):
     margin = ref.sort(1).values[:, -1] - ref.sort(1).values[:, -2]
     decided = margin > 2e-3                                   # ignore numerical ties
     assert torch.equal(got.argmax(1)[decided], ref.argmax(1)[decided])
+
+
+def test_trainer_graph_replay_survives_other_batch_sizes(capsys):
+    """Trainer_uni over 3 epochs with 4 full batches + a partial one per epoch and validate() (a third batch size) in
+    between: the captured graphs keep replaying into THEIR workspaces (a workspace is kept per batch size and never
+    freed), so graph and eager training end bit-equal - and a caching-allocator flush in the middle changes nothing."""
+    from eav_amd.eegnet import Trainer_uni
+    S, B, ntr, nte = 500, 8, 36, 10                      # 36 = 4 x 8 + 4: four replayed batches + one eager partial
+    sd = eegnet_weights(91, S)
+    x, y = synth.eeg_batch(910, ntr + nte, 30, S)
+    data = [x[:ntr], y[:ntr], x[ntr:], y[ntr:]]
+    finals = []
+    for use_graph in (False, True):
+        torch.manual_seed(1234)                          # same DataLoader index order in both runs
+        m = build(S, sd, 0.5)
+        tr = Trainer_uni(m, data, lr=1e-3, batch_size=B, num_epochs=3, device="cuda")
+        tr.use_graph = use_graph
+        if use_graph:
+            real_validate = tr.validate
+
+            def validate_and_flush():
+                real_validate()
+                torch.cuda.empty_cache()                 # hands unused blocks back: pinned workspaces must be unaffected
+            tr.validate = validate_and_flush
+        tr.train()
+        torch.cuda.synchronize()
+        if use_graph:
+            assert any(g.graph is not None for g in tr._graphs.values())
+            assert len(m._wss) >= 3                      # 8 (graph), 4 (partial), 10 (validation)
+        finals.append(({k: v.clone() for k, v in m.state_dict().items()}, capsys.readouterr().out))
+    assert finals[0][1] == finals[1][1]                  # identical printed losses / accuracies
+    for k in finals[0][0]:
+        assert torch.equal(finals[0][0][k], finals[1][0][k]), k

@@ -1,17 +1,23 @@
 #!/usr/bin/env python3
-"""Headline benchmark: EEGNet_tor training step on MI355X (BASELINE.json configs[1]).
+"""Benchmark of the EAV per-modality training step on MI355X (BASELINE.json metric and configs).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling weak|strong]
 
-One step = gather a batch of 64 trials from the HBM-resident synthetic subject, forward,
-CrossEntropy on the softmax output, backward, (gradient all-reduce over RCCL when N > 1), fused
-Adam - i.e. the body of Trainer_uni.train() (CNN_torch/EEGNet_tor.py:99-110), fp32, nothing skipped.
-Prints ONE JSON line on rank 0 (contract in the task description).
+With --gpus N > 1 and no torchrun environment the script starts
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py ...` itself, as a CHILD process and
+before anything touches the GPU, and relays the child's JSON line and exit code.
+
+Headline line (one JSON object on rank 0): EEGNet_tor train step on x[64,1,30,10000] fp32 per GPU (configs[1]) -
+batch gather from the HBM-resident synthetic subject, forward, CrossEntropy on the softmax output, backward, (gradient
+all-reduce when N > 1), fused Adam: the body of Trainer_uni.train() (CNN_torch/EEGNet_tor.py:99-110), nothing skipped.
+`modalities` holds one object per modality (EEGNet / AST / ViT) with its own throughput, dominant-kernel roofline and
+same-run CPU baseline; `multi_gpu` holds the strong-scaling and subject-sharded (42 subjects) legs when N > 1.
 """
 import argparse
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 
@@ -20,12 +26,17 @@ sys.path.insert(0, ROOT)
 
 B_PER_GPU, CHANS, SAMPLES, KLEN, TRIALS = 64, 30, 10000, 300, 200
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 MFMA = fp32 vector peak
+PEAK_F16_MFMA_TFLOPS = 2500.0  # dense fp16 / bf16 MFMA
 FIR_FLOP_PER_LAUNCH = 2.0 * KLEN * 8 * CHANS * SAMPLES * B_PER_GPU   # 92.16 GFLOP (fwd) = wgrad
+# forward GFLOP per sample: an unfrozen train step = 3x; dense-projection (GEMM) share of it
+ENC = {"ast": dict(B=8, gflop_fwd=261.03, gemm_share=8.592 / 10.856, cpu_B=8, cpu_steps=2),
+       "vit": dict(B=128, gflop_fwd=35.13, gemm_share=1.395 / 1.454, cpu_B=32, cpu_steps=3)}
 
 
-def cpu_baseline(steps=3, batch=32):
-    """The oracle (pure fp32 torch CPU restatement, validated against the imported reference) timed
-    on this box's host cores on a bounded sample of the same workload."""
+# ---------------------------------------------------------------------------------------------- CPU baselines (oracle)
+def cpu_baseline_eegnet(steps=2, batch=B_PER_GPU):
+    """The oracle (pure fp32 torch CPU restatement, validated against the imported reference) timed on this box's
+    host cores on a bounded sample of the same workload, same batch size."""
     import torch
     from eav_amd import synth
     from oracle import eegnet_oracle as orc
@@ -48,13 +59,40 @@ def cpu_baseline(steps=3, batch=32):
                       f"after 1 warm-up, {dt:.1f} s"}
 
 
-# fwd GFLOP per sample: AST 261.03, ViT-B/16 35.13; an unfrozen step = 3x
-ENC = {"ast": dict(B=8, gflop_fwd=261.03, cpu=(0.50, 1.87)), "vit": dict(B=128, gflop_fwd=35.13, cpu=(3.78, 21.1))}
+def cpu_baseline_encoder(kind):
+    """oracle/vit_oracle.Stepper (restated HF forward + autograd + AdamW, pinned to the HF classes) - the unfrozen and
+    the frozen step of the 12-layer model on this box's host cores."""
+    import torch
+    from eav_amd import synth
+    from oracle import vit_oracle as vo
+    from tests.golden_util import tf_weights
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    cfg = vo.cfg_ast() if kind == "ast" else vo.cfg_vit()
+    W = tf_weights(17, vo.param_shapes(cfg), std=0.02)
+    st = vo.Stepper({k: torch.from_numpy(v) for k, v in W.items()}, cfg, lr=5e-6)
+    B, steps = ENC[kind]["cpu_B"], ENC[kind]["cpu_steps"]
+    x, y = (synth.mel_batch(5, B) if kind == "ast" else synth.frame_batch(5, B))
+    xt, yt = torch.from_numpy(x), torch.from_numpy(y)
+    out = {}
+    for phase, freeze in (("unfrozen", False), ("frozen", True)):
+        st.step(xt, yt, freeze)                     # warm-up
+        ts = []
+        for _ in range(steps):
+            t0 = time.perf_counter()
+            st.step(xt, yt, freeze)
+            ts.append(time.perf_counter() - t0)
+        med = statistics.median(ts)
+        out[phase] = {"value": round(B / med, 3), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+                      "sample": f"median of {steps} {phase} train steps of oracle/vit_oracle.Stepper on batch {B} after 1 "
+                                f"warm-up ({sum(ts):.1f} s)"}
+    return out
 
 
-def bench_encoder(kind, dev, world, sync_factory, steps=4, warmup=2):
-    """Frozen (classifier only) and unfrozen AdamW train steps of the 12-layer AST / ViT-B/16 on synthetic
-    input (BASELINE.json configs[2], configs[3]); batch sizes are the reference drivers' (8 / 128)."""
+# ---------------------------------------------------------------------------------------------- encoders (AST / ViT)
+def bench_encoder(kind, dev, world, sync_factory, steps=4, warmup=2, blocks=3):
+    """Frozen (classifier only) and unfrozen AdamW train steps of the 12-layer AST / ViT-B/16 on synthetic input
+    (BASELINE.json configs[2], configs[3]); batch sizes are the reference drivers' (8 / 128).  Default precision
+    "split" (fp32-grade on the fp16 matrix cores), exact-fp32 MFMA beside it."""
     import torch
     from eav_amd import synth, transformer as T
     from eav_amd.optim import CrossEntropyLoss, FusedAdam
@@ -71,8 +109,11 @@ def bench_encoder(kind, dev, world, sync_factory, steps=4, warmup=2):
     if sync is not None:
         model.grad_ready_hook = sync.bucket          # all-reduce buckets overlap the backward
     res = {}
-    runs = (("frozen", True, "fp32"), ("unfrozen", False, "fp32"), ("unfrozen_bf16_bwd", False, "bf16_bwd"),
-            ("unfrozen_bf16", False, "bf16"))
+    runs = (("unfrozen", False, "split"), ("frozen", True, "split"), ("unfrozen_fp32", False, "fp32"),
+            ("frozen_fp32", True, "fp32"))
+    notes = {"split": "fp16 MFMA, operands split into hi + lo fp16 planes, 3 MFMAs per product, fp32 accumulate: "
+                      "fp32-grade (not worse than the exact-fp32 kernels against float64; logits within 1e-4 of HF)",
+             "fp32": "exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)"}
     for phase, freeze, prec in runs:
         model.precision = prec
         for k, p in model.named_parameters():
@@ -89,32 +130,46 @@ def bench_encoder(kind, dev, world, sync_factory, steps=4, warmup=2):
             opt.step()
         for _ in range(warmup):
             step()
-        gemm_names = ("eav_gemm_f32", "eav_gemm_f32_splitk", "eav_gemm_bf16", "eav_gemm_bf16_splitk")
-        model.kernel_events = {k: [] for k in gemm_names}
+        per_block = []
+        for _ in range(blocks):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            torch.cuda.synchronize()
+            per_block.append((time.perf_counter() - t0) / steps)
+        dt = statistics.median(per_block)
+        # dominant kernel family, timed live with HIP events on the launch stream in a separate pass
+        names = {"split": ("eav_gemm_sp", "eav_gemm_sp_splitk"), "fp32": ("eav_gemm_f32", "eav_gemm_f32_splitk")}[prec]
+        model.kernel_events = {k: [] for k in names}
+        step()
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / steps
-        gemm_ms = sum(a.elapsed_time(b) for v in model.kernel_events.values() for a, b in v) / steps
+        gemm_ms = sum(a.elapsed_time(b) for v in model.kernel_events.values() for a, b in v)
         model.kernel_events = None
         gflop = ENC[kind]["gflop_fwd"] * (1 if freeze else 3) * B
-        peak = PEAK_F32_MFMA_TFLOPS if prec == "fp32" else None
-        res[phase] = {"samples_per_s": round(B * world / dt, 2), "ms_per_step": round(dt * 1e3, 3), "batch_per_gpu": B,
-                      "precision": {"fp32": "f32 MFMA (exact fp32; logits within 1e-4 of the reference)",
-                                    "bf16_bwd": "f32 MFMA forward (logits exact), bf16 MFMA operands in the backward",
-                                    "bf16": "bf16 MFMA operands, fp32 accumulate (logit drift ~5e-3: outside the 1e-3 "
-                                            "bound)"}[prec],
-                      "gemm_ms_per_step": round(gemm_ms, 3), "achieved_tflops": round(gflop / dt / 1e3, 2)}
-        if peak:
-            res[phase]["frac_of_f32_mfma_peak"] = round(gflop / dt / 1e3 / peak, 4)
-    model.precision = "fp32"
+        gemm_gflop = gflop * ENC[kind]["gemm_share"]
+        peak = PEAK_F16_MFMA_TFLOPS if prec == "split" else PEAK_F32_MFMA_TFLOPS
+        ach = gemm_gflop / gemm_ms if gemm_ms > 0 else 0.0          # GFLOP / ms = TFLOP/s
+        res[phase] = {
+            "value": round(B * world / dt, 2), "unit": "samples/s", "ms_per_step": round(dt * 1e3, 3),
+            "ms_per_step_blocks": [round(t * 1e3, 3) for t in per_block], "batch_per_gpu": B, "precision": notes[prec],
+            "step_tflops": round(gflop / dt / 1e3, 2),
+            "roofline": {"bound": "mfma", "kernel": "gemm_sp_kernel" if prec == "split" else "gemm_f32_kernel",
+                         "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                         "traffic": None,
+                         "note": "algorithmic 2MNK flops of every dense projection of the step / summed kernel time "
+                                 "(HIP events around each launch, separate pass)" +
+                                 ("; the split kernel issues 3x these flops on the fp16 matrix cores: issue rate "
+                                  f"{round(3 * ach, 1)} TFLOP/s = {round(3 * ach / peak, 4)} of peak"
+                                  if prec == "split" else ""),
+                         "gemm_ms_per_step": round(gemm_ms, 3)}}
+    model.precision = T.DEFAULT_PRECISION
     del model, opt
     torch.cuda.empty_cache()
     return res
 
 
+# ---------------------------------------------------------------------------------------------- alternative EEG encoders
 def bench_alt_eeg(dev):
     """SURVEY.md section 8f row 4 - the two alternative EEG encoders, one GPU: train-step time of the canonical
     EEGNet (CNN_torch/CNN_EEG.py) at the EAV recording shape and at the epoch shape, and of ShallowConvNet + 12-layer
@@ -160,7 +215,6 @@ def cpu_alt_eeg():
     import torch
     from eav_amd import synth
     from oracle import cnn_eeg_oracle as co, shallow_tf_oracle as so
-    sys.path.insert(0, ROOT)
     from tests.golden_util import cnn_eeg_weights, shallow_tf_weights
     out = {}
     x, y = synth.eeg_batch(22, 32, 30, 500)
@@ -206,21 +260,117 @@ def measured_peaks(dev):
     return {"f32_mfma_tflops": round(tf, 1), "hbm_copy_tb_per_s": round(tbs, 2)}
 
 
+# ---------------------------------------------------------------------------------------------- self-launch
+def relaunch_under_torchrun(args):
+    """--gpus N without a torchrun environment: start one rank per GPU as a child (this parent never initialises the GPU
+    and never exec()s), relay the JSON line and the exit code."""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    if lines:
+        print(lines[-1], flush=True)
+    else:
+        sys.stdout.write(proc.stdout)
+    return proc.returncode
+
+
+# ---------------------------------------------------------------------------------------------- EEGNet
+class EEGRun:
+    """EEGNet replica + HBM-resident synthetic subject + the eager training step of Trainer_uni.train()."""
+
+    def __init__(self, dev, rank, world, batch, nsteps, seed=0, subject=None):
+        import torch
+        from eav_amd import dist as eav_dist, synth
+        from eav_amd.eegnet import EEGNet_tor
+        from eav_amd.optim import CrossEntropyLoss, FusedAdam
+        self.torch, self.dev, self.world, self.batch = torch, dev, world, batch
+        xs, ys = synth.eeg_subject(1 + rank if subject is None else subject, TRIALS, CHANS, SAMPLES)
+        self.xs = torch.from_numpy(xs).unsqueeze(1).to(dev)
+        self.ys = torch.from_numpy(ys).to(dev)
+        torch.manual_seed(seed)                               # identical replicas on every rank
+        self.model = EEGNet_tor(nb_classes=5, Chans=CHANS, Samples=SAMPLES, kernLength=KLEN, F1=8, D=8, F2=64,
+                                dropoutRate=0.5).to(dev).train()
+        self.crit = CrossEntropyLoss()
+        self.opt = FusedAdam(self.model.parameters(), lr=1e-5)
+        self.model._ensure_flat()
+        self.sync = eav_dist.GradSync([self.model._flat[1]]) if world > 1 else None
+        gen = torch.Generator().manual_seed(1234 + rank)
+        self.batches = [torch.randperm(TRIALS, generator=gen)[:batch].to(dev) for _ in range(nsteps)]
+
+    def reset_model(self, seed):
+        """New subject: fresh weights, optimiser state kept allocated (Mode S trains one model per subject)."""
+        torch = self.torch
+        from eav_amd.eegnet import EEGNet_tor
+        torch.manual_seed(seed)
+        fresh = EEGNet_tor(nb_classes=5, Chans=CHANS, Samples=SAMPLES, kernLength=KLEN, dropoutRate=0.5)
+        with torch.no_grad():
+            for (k, p), (_, q) in zip(self.model.named_parameters(), fresh.named_parameters()):
+                p.copy_(q)
+            for (k, b), (_, c) in zip(self.model.named_buffers(), fresh.named_buffers()):
+                b.copy_(c)
+        for st in self.opt.state.values():
+            st["step"] = 0
+            st["exp_avg"].zero_()
+            st["exp_avg_sq"].zero_()
+
+    def step(self, i):
+        from eav_amd.eegnet import gather_batch
+        data, targets = gather_batch(self.xs, self.ys, self.batches[i % len(self.batches)])
+        scores = self.model(data)
+        loss = self.crit(scores, targets)
+        self.opt.zero_grad()
+        loss.backward()
+        if self.sync is not None:
+            self.sync()
+        self.opt.step()
+        return loss
+
+    def timed(self, nsteps, first=0):
+        """Exactly nsteps steps bracketed by barrier + synchronize on both sides; max over ranks (seconds)."""
+        import torch.distributed as dist
+        torch = self.torch
+        if self.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(nsteps):
+            loss = self.step(first + i)
+        torch.cuda.synchronize()
+        if self.world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if self.world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=self.dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, loss
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="N > 1: weak = 64 samples per GPU per step (default), strong = global batch 64 split over N")
+    ap.add_argument("--repeats", type=int, default=4, help="extra K-step blocks timed after the headline block")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-encoders", action="store_true", help="skip the AST / ViT sections of the report")
+    ap.add_argument("--no-encoders", action="store_true", help="skip the AST / ViT / alternative-encoder sections")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(relaunch_under_torchrun(args))
 
     import torch
     import torch.distributed as dist
     from eav_amd import dist as eav_dist
-    from eav_amd import synth
-    from eav_amd.eegnet import EEGNet_tor, gather_batch
-    from eav_amd.optim import CrossEntropyLoss, FusedAdam
 
     # EAV_DIST_BACKEND=gloo + EAV_FORCE_DEVICE=0 let two ranks share one GPU (logic test on a 1-GPU box)
     backend = os.environ.get("EAV_DIST_BACKEND", "nccl")
@@ -228,89 +378,106 @@ def main():
         os.environ["LOCAL_RANK"] = os.environ["EAV_FORCE_DEVICE"]
     rank, world, local = eav_dist.init_from_env(backend)
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    # synthetic subject (one per rank: subject-level sharding of the data), resident in HBM
-    xs, ys = synth.eeg_subject(1 + rank, TRIALS, CHANS, SAMPLES)
-    xs = torch.from_numpy(xs).unsqueeze(1).to(dev)
-    ys = torch.from_numpy(ys).to(dev)
-    torch.manual_seed(0)                                  # identical replicas on every rank
-    model = EEGNet_tor(nb_classes=5, Chans=CHANS, Samples=SAMPLES, kernLength=KLEN, F1=8, D=8, F2=64,
-                       dropoutRate=0.5).to(dev).train()
-    crit = CrossEntropyLoss()
-    opt = FusedAdam(model.parameters(), lr=1e-5)
-    model._ensure_flat()
-    sync = eav_dist.GradSync([model._flat[1]]) if world > 1 else None
-    gen = torch.Generator().manual_seed(1234 + rank)
-    batches = [torch.randperm(TRIALS, generator=gen)[:B_PER_GPU].to(dev) for _ in range(args.steps + args.warmup)]
-
-    def step(i):
-        data, targets = gather_batch(xs, ys, batches[i])
-        scores = model(data)
-        loss = crit(scores, targets)
-        opt.zero_grad()
-        loss.backward()
-        if sync is not None:
-            sync()
-        opt.step()
-        return loss
-
+    strong = args.scaling == "strong" and world > 1
+    per_gpu = B_PER_GPU // world if strong else B_PER_GPU
+    if strong and B_PER_GPU % world:
+        raise SystemExit("strong scaling splits the global batch of 64 evenly: --gpus must divide 64")
+    run = EEGRun(dev, rank, world, per_gpu, args.steps + args.warmup)
+    model = run.model
     for i in range(args.warmup):
-        step(i)
+        run.step(i)
     timed = ("eav_eegnet_fir_fwd", "eav_eegnet_fir_wgrad")
     model.kernel_events = {k: [] for k in timed}
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        loss = step(args.warmup + i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt, loss = run.timed(args.steps, args.warmup)           # THE timed region: exactly K steps
     kern_ms = {k: sum(a.elapsed_time(b) for a, b in v) / max(len(v), 1) for k, v in model.kernel_events.items()}
     model.kernel_events = None
-    peaks = measured_peaks(dev) if rank == 0 else None
     final_loss = float(loss.item())
-    # the same step with the opt-in split-precision FIR kernels (fp16 matrix cores, two-piece operands, fp32
-    # accumulate: error against float64 below the exact-fp32 kernels', tests/test_eegnet_kernels_gpu.py) - reported
-    # beside the headline number, never as it
+    blocks_ms = [dt / args.steps * 1e3]
+    for _ in range(args.repeats):                            # spread of the same K-step block
+        blocks_ms.append(run.timed(args.steps, args.warmup)[0] / args.steps * 1e3)
+    peaks = measured_peaks(dev) if rank == 0 else None
+
+    # the same step with the opt-in split-precision FIR / separableConv kernels (fp16 matrix cores) - beside the headline
     model.fir_precision = "split"
-    for i in range(min(args.warmup, 3) + 1):
-        step(i)
+    for i in range(3):
+        run.step(i)
     split_names = ("eav_eegnet_fir_fwd_split", "eav_eegnet_fir_wgrad_split")
     model.kernel_events = {k: [] for k in split_names}
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dts = time.perf_counter() - t1
-    if world > 1:
-        t = torch.tensor([dts], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dts = float(t.item())
+    dts, _ = run.timed(args.steps, args.warmup)
     split_ms = {k: sum(a.elapsed_time(b) for a, b in v) / max(len(v), 1) for k, v in model.kernel_events.items()}
     model.kernel_events = None
     model.fir_precision = "fp32"
-    encoders = None
+
+    # eval-mode training step: what 349 of the reference's 350 epochs run (model.train() is called once, validate()
+    # switches to eval mode and nothing switches back: SURVEY Q4, EEGNet_tor.py:97,119) - BatchNorm on running statistics
+    model.eval()
+    for i in range(3):
+        run.step(i)
+    dte, _ = run.timed(args.steps, args.warmup)
+    model.train()
+
+    multi = None
+    if world > 1:
+        multi = {}
+        # ---- the other data-parallel leg (strong when the headline is weak and vice versa)
+        other = B_PER_GPU if strong else (B_PER_GPU // world if B_PER_GPU % world == 0 else None)
+        if other:
+            r2 = EEGRun(dev, rank, world, other, args.steps + args.warmup)
+            for i in range(args.warmup):
+                r2.step(i)
+            d2, _ = r2.timed(args.steps, args.warmup)
+            multi["weak" if strong else "strong"] = {
+                "value": round(args.steps * other * world / d2, 2), "unit": "samples/s",
+                "ms_per_step": round(d2 / args.steps * 1e3, 4), "per_gpu_batch": other, "global_batch": other * world,
+                "note": "data parallel, one RCCL all-reduce of the 0.68 MB flat gradient buffer per step"}
+            del r2
+            torch.cuda.empty_cache()
+        # ---- Mode S: the 42 per-subject trainings are independent - subjects round-robin over ranks, no collective on
+        # the data path, one all_gather of the per-subject results at the end (Dataload_audio.py:82-115 loop structure)
+        ks = max(2, args.steps // 10)
+        subs = eav_dist.subjects_for_rank(rank, world)
+        results = []
+        run.sync = None
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for s in subs:
+            run.reset_model(1000 + s)
+            for i in range(ks):
+                ls = run.step(i)
+            results.append((s, ls))
+        torch.cuda.synchronize()
+        ds = time.perf_counter() - t0
+        mine = torch.zeros(42, device=dev)
+        for s, ls in results:
+            mine[s - 1] = ls.detach()
+        gathered = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        t = torch.tensor([ds], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ds = float(t.item())
+        losses = torch.stack(gathered).sum(0)
+        multi["subject_sharded"] = {
+            "value": round(42 * ks * B_PER_GPU / ds, 2), "unit": "samples/s", "seconds": round(ds, 4),
+            "subjects": 42, "steps_per_subject": ks, "batch": B_PER_GPU, "subjects_on_busiest_rank": len(
+                eav_dist.subjects_for_rank(0, world)),
+            "scaling": "strong (total work fixed: 42 subjects; ideal speed-up 42 / ceil(42/N))",
+            "all_subjects_reported": bool((losses > 0).all().item()),
+            "note": "independent per-subject trainings, no data-path collective; one all_gather of results"}
+
+    encoders = alt = None
     if not args.no_encoders:
-        del xs, model, opt
+        del run.xs
+        del run, model
         torch.cuda.empty_cache()
         mk = (lambda g: eav_dist.GradSync([g])) if world > 1 else (lambda g: None)
         encoders = {k: bench_encoder(k, dev, world, mk) for k in ("ast", "vit")}
-    alt = bench_alt_eeg(dev) if (world == 1 and not args.no_encoders) else None
+        alt = bench_alt_eeg(dev) if world == 1 else None
 
     if rank == 0:
         dom = max(kern_ms, key=kern_ms.get)
@@ -322,50 +489,71 @@ def main():
             traffic_src = os.path.relpath(f, ROOT)
         except Exception:
             pass
-        achieved = FIR_FLOP_PER_LAUNCH / (kern_ms[dom] * 1e-3) / 1e12
+        achieved = FIR_FLOP_PER_LAUNCH * per_gpu / B_PER_GPU / (kern_ms[dom] * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": dom.replace("eav_eegnet_", "") + "_kernel",
+                    "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                    "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc, gfx950-corrected)",
+                    "traffic_source": traffic_src, "flop_per_launch": FIR_FLOP_PER_LAUNCH * per_gpu / B_PER_GPU,
+                    "measured_peaks": peaks,
+                    "frac_of_measured_mfma_peak": round(achieved / peaks["f32_mfma_tflops"], 4),
+                    "avg_kernel_ms": {k.replace("eav_eegnet_", ""): round(v, 4) for k, v in kern_ms.items()}}
+        cpu_eeg = cpu_baseline_eegnet() if (world == 1 and not args.no_cpu_baseline) else None
+        value = round(args.steps * per_gpu * world / dt, 2)
         out = {
             "metric": "EEGNet training samples/sec (fwd+CE+bwd+Adam), whole job",
-            "value": round(args.steps * B_PER_GPU * world / dt, 2),
-            "unit": "samples/s",
+            "value": value, "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "EEGNet_tor(5, Chans=30, Samples=10000, kernLength=300, F1=8, D=8, F2=64) "
-                                   "train step on x[64,1,30,10000] fp32 per GPU (BASELINE.json configs[1])",
-                       "global_batch": B_PER_GPU * world, "per_gpu_batch": B_PER_GPU,
+                                   f"train step on x[{per_gpu},1,30,10000] fp32 per GPU (BASELINE.json configs[1])",
+                       "global_batch": per_gpu * world, "per_gpu_batch": per_gpu,
                        "parallelism": f"dp{world}" + (" (RCCL grad all-reduce)" if world > 1 else ""),
                        "optimizer": "Adam lr=1e-5", "dropout": 0.5, "final_loss": round(final_loss, 5)},
-            "roofline": {"bound": "mfma", "kernel": dom.replace("eav_eegnet_", "") + "_kernel",
-                         "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-                         "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc, gfx950-corrected)",
-                         "traffic_source": traffic_src,
-                         "flop_per_launch": FIR_FLOP_PER_LAUNCH,
-                         "measured_peaks": peaks,
-                         "frac_of_measured_mfma_peak": round(achieved / peaks["f32_mfma_tflops"], 4),
-                         "avg_kernel_ms": {k.replace("eav_eegnet_", ""): round(v, 4) for k, v in kern_ms.items()}},
+            "repeat_blocks": {"ms_per_step": [round(v, 4) for v in blocks_ms],
+                              "median_ms_per_step": round(statistics.median(blocks_ms), 4),
+                              "min_ms_per_step": round(min(blocks_ms), 4),
+                              "note": f"{len(blocks_ms)} blocks of {args.steps} steps; `value` is the first block"},
+            "roofline": roofline,
         }
-        y1_bytes = B_PER_GPU * 8 * CHANS * SAMPLES * 4
+        if cpu_eeg is not None:
+            out["cpu_baseline"] = cpu_eeg
+        y1_bytes = per_gpu * 8 * CHANS * SAMPLES * 4
+        wg_bytes = 2 * y1_bytes + per_gpu * CHANS * SAMPLES * 4
         out["split_precision"] = {
             "note": "opt-in EEGNet_tor.fir_precision='split': the FIR and separableConv products (forward, data and weight "
                     "gradients) on the fp16 matrix cores with two-piece operands (hi + 2^-11 lo, 3 MFMAs per product, fp32 "
                     "accumulate); measured error vs float64 below the exact-fp32 kernels'; same workload, same parity "
                     "bounds; not the headline value",
-            "value": round(args.steps * B_PER_GPU * world / dts, 2), "unit": "samples/s",
+            "value": round(args.steps * per_gpu * world / dts, 2), "unit": "samples/s",
             "ms_per_step": round(dts / args.steps * 1e3, 4),
             "avg_kernel_ms": {k.replace("eav_eegnet_", ""): round(v, 4) for k, v in split_ms.items()},
-            "roofline": {"bound": "hbm", "kernel": "fir_wgrad_split_kernel",
-                         "algorithmic_bytes": 2 * y1_bytes + B_PER_GPU * CHANS * SAMPLES * 4,
-                         "achieved": round((2 * y1_bytes + B_PER_GPU * CHANS * SAMPLES * 4)
-                                           / (split_ms["eav_eegnet_fir_wgrad_split"] * 1e-3) / 1e9, 1),
+            "roofline": {"bound": "hbm", "kernel": "fir_wgrad_split_kernel", "algorithmic_bytes": wg_bytes,
+                         "achieved": round(wg_bytes / (split_ms["eav_eegnet_fir_wgrad_split"] * 1e-3) / 1e9, 1),
                          "peak": 8000.0, "unit": "GB/s",
-                         "frac": round((2 * y1_bytes + B_PER_GPU * CHANS * SAMPLES * 4)
-                                       / (split_ms["eav_eegnet_fir_wgrad_split"] * 1e-3) / 8e12, 4)}}
+                         "frac": round(wg_bytes / (split_ms["eav_eegnet_fir_wgrad_split"] * 1e-3) / 8e12, 4)}}
+        out["eval_mode_training"] = {
+            "note": "the same step with the model in eval mode (BatchNorm on running statistics, no dropout) - what epochs "
+                    "2..N of the reference's Trainer_uni.train() execute (SURVEY Q4)",
+            "value": round(args.steps * per_gpu * world / dte, 2), "unit": "samples/s",
+            "ms_per_step": round(dte / args.steps * 1e3, 4)}
+        modalities = {"eegnet": {"value": value, "unit": "samples/s", "ms_per_step": out["ms_per_step"],
+                                 "batch_per_gpu": per_gpu, "roofline": roofline, "cpu_baseline": cpu_eeg}}
         if encoders is not None:
-            out["encoders"] = {"note": "12-layer AST / ViT-B/16, synthetic input, fp32 MFMA GEMMs (exact fp32: bf16 "
-                                       "operands miss the 1e-3 logit bound, DESIGN.md section 8); whole-job samples/s",
-                               **encoders}
+            for kind in ("ast", "vit"):
+                cpu = cpu_baseline_encoder(kind) if (world == 1 and not args.no_cpu_baseline) else None
+                e = encoders[kind]
+                for phase in ("unfrozen", "frozen"):
+                    e[phase]["cpu_baseline"] = cpu[phase] if cpu else None
+                modalities[kind] = dict(e["unfrozen"], phases=e,
+                                        workload=("12-layer AST, mel [8,1024,128] per GPU (BASELINE.json configs[2])"
+                                                  if kind == "ast" else
+                                                  "ViT-B/16, frames [128,3,224,224] per GPU (BASELINE.json configs[3])"))
+        out["modalities"] = modalities
+        if multi is not None:
+            out["multi_gpu"] = multi
         if alt is not None:
             out["alt_eeg_encoders"] = {"note": "SURVEY 8f row 4: canonical EEGNet (CNN_EEG.py) and ShallowConvNet + "
                                                "12-layer transformer (Transformer_EEG.py); fp32, hipGraph-replayed "
@@ -373,10 +561,9 @@ def main():
             if not args.no_cpu_baseline:
                 for k, v in cpu_alt_eeg().items():
                     out["alt_eeg_encoders"][k]["cpu_oracle"] = v
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

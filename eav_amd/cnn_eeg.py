@@ -286,6 +286,7 @@ class EEGNetTrainer:
                 self.optimizer.step()
                 loss = loss.detach()
             running_loss += loss          # accumulated on the device: one host read per epoch, not per step (:106)
+        self.criterion.check()            # labels outside [0, classes) seen by any step of this epoch raise here
         return running_loss.item() / len(batches)
 
     def validate_epoch(self):

@@ -71,6 +71,7 @@ class FineTuneBase:
             seen += tb.size(0)
             if after_batch is not None:
                 after_batch(k, nb)
+        self.loss_fn.check()            # labels outside [0, classes) seen by any step of this epoch raise here
         return correct, seen
 
     def _evaluate(self):

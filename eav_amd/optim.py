@@ -175,9 +175,10 @@ class CrossEntropyLoss:
     """``nn.CrossEntropyLoss()`` (mean reduction) as one fused HIP kernel that
     produces the loss and its input gradient together.
 
-    Like torch, it rejects class indices outside [0, classes): the kernel records the first offending label in a
-    device flag (an out-of-range label contributes nothing instead of reading out of bounds) and ``check()`` - called
-    automatically from ``__call__`` unless a hipGraph is being captured - raises on it."""
+    Like torch, it rejects class indices outside [0, classes): the kernel never indexes with such a label (it
+    contributes nothing) and records it in a device flag; ``check()`` reads the flag (one host synchronisation) and
+    raises.  The trainers call it once per epoch - a per-step check would serialise host and GPU; code that drives the
+    criterion directly calls ``check()`` whenever it synchronises anyway."""
 
     def __init__(self):
         self._flag = None
@@ -202,7 +203,4 @@ class CrossEntropyLoss:
             targets = targets.long()
         if self._flag is None or self._flag.device != scores.device:
             self._flag = torch.zeros((), dtype=torch.int32, device=scores.device)
-        loss = _CEFn.apply(scores, targets.contiguous(), self._flag)
-        if not torch.cuda.is_current_stream_capturing():
-            self.check()
-        return loss
+        return _CEFn.apply(scores, targets.contiguous(), self._flag)

@@ -362,6 +362,7 @@ class TrainerUni:
                     self.grad_sync()
                 self.optimizer.step()
                 self._max_norm()
+            self.criterion.check()        # labels outside [0, classes) seen by any step of this epoch raise here
             acc = self.validate()
             if epoch == self.epochs - 1:
                 with open("eeg_results_new_shallow_.txt", "a") as f:                             # :203-205

@@ -453,3 +453,31 @@ def test_conv64_split_is_fp32_grade(L, B, T, padl):
         refw += torch.einsum("ot,itk->oik", du[b].double(), xp[b].unfold(-1, 16, 1))
     ea, eb = (da.double() - refw).abs().max().item(), (db.double() - refw).abs().max().item()
     assert eb <= 1.25 * ea + 1e-7 * refw.abs().max().item(), (ea, eb)
+
+
+def test_cross_entropy_rejects_labels_outside_the_class_range():
+    """torch's CrossEntropyLoss asserts on a class index outside [0, classes); here such a label never indexes anything
+    and check() raises - e.g. the reference's raw EEG labels 1,3,5,7,9 fed to a 5-class head."""
+    from eav_amd._lib import EavError
+    from eav_amd.optim import CrossEntropyLoss
+    crit = CrossEntropyLoss()
+    scores = torch.rand(6, 5, device="cuda", requires_grad=True)
+    good = torch.tensor([0, 1, 2, 3, 4, 0], device="cuda")
+    crit(scores, good).backward()
+    crit.check()
+    g_ok = scores.grad.clone()
+    assert torch.isfinite(g_ok).all()
+    for bad_value in (9, -1):
+        bad = good.clone()
+        bad[3] = bad_value
+        scores.grad = None
+        loss = crit(scores, bad)
+        loss.backward()
+        assert torch.isfinite(loss) and torch.isfinite(scores.grad).all()      # nothing read out of bounds
+        with pytest.raises(EavError, match="outside"):
+            crit.check()
+        crit.check()                                                           # the flag is cleared by the raise
+    with pytest.raises(EavError, match="targets for"):
+        crit(scores, good[:4])
+    with torch.no_grad():                                                      # validate(): no gradient buffer needed
+        assert torch.isfinite(crit(scores.detach(), good))

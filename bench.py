@@ -284,7 +284,9 @@ def relaunch_under_torchrun(args):
 
 # ---------------------------------------------------------------------------------------------- EEGNet
 class EEGRun:
-    """EEGNet replica + HBM-resident synthetic subject + the eager training step of Trainer_uni.train()."""
+    """EEGNet replica + HBM-resident synthetic subject + the training step of Trainer_uni.train() as the trainer runs it:
+    full batches replay a captured hipGraph (GraphStep: batch gather, forward, CE, backward[, all-reduce], fused Adam);
+    `eager_step` issues the same launches one by one (used for the per-kernel HIP-event timing)."""
 
     def __init__(self, dev, rank, world, batch, nsteps, seed=0, subject=None):
         import torch
@@ -299,11 +301,12 @@ class EEGRun:
         self.model = EEGNet_tor(nb_classes=5, Chans=CHANS, Samples=SAMPLES, kernLength=KLEN, F1=8, D=8, F2=64,
                                 dropoutRate=0.5).to(dev).train()
         self.crit = CrossEntropyLoss()
-        self.opt = FusedAdam(self.model.parameters(), lr=1e-5)
+        self.opt = FusedAdam(self.model.parameters(), lr=1e-5, capturable=True)      # as Trainer_uni builds it
         self.model._ensure_flat()
         self.sync = eav_dist.GradSync([self.model._flat[1]]) if world > 1 else None
         gen = torch.Generator().manual_seed(1234 + rank)
         self.batches = [torch.randperm(TRIALS, generator=gen)[:batch].to(dev) for _ in range(nsteps)]
+        self.graphs = {}
 
     def reset_model(self, seed):
         """New subject: fresh weights, optimiser state kept allocated (Mode S trains one model per subject)."""
@@ -320,8 +323,17 @@ class EEGRun:
             st["step"] = 0
             st["exp_avg"].zero_()
             st["exp_avg_sq"].zero_()
+        if self.opt._dev_step is not None:
+            self.opt._dev_step.zero_()
 
     def step(self, i):
+        from eav_amd.eegnet import GraphStep
+        key = (bool(self.model.training), self.model.fir_precision, self.sync is not None)
+        if key not in self.graphs:       # one captured graph per BatchNorm mode / kernel set, like Trainer_uni
+            self.graphs[key] = GraphStep(self.model, self.opt, self.crit, self.xs, self.ys, self.batch, self.sync)
+        return self.graphs[key].run(self.batches[i % len(self.batches)])[1]
+
+    def eager_step(self, i):
         from eav_amd.eegnet import gather_batch
         data, targets = gather_batch(self.xs, self.ys, self.batches[i % len(self.batches)])
         scores = self.model(data)
@@ -388,14 +400,18 @@ def main():
         raise SystemExit("strong scaling splits the global batch of 64 evenly: --gpus must divide 64")
     run = EEGRun(dev, rank, world, per_gpu, args.steps + args.warmup)
     model = run.model
-    for i in range(args.warmup):
+    for i in range(max(args.warmup, 3)):                     # (the third call captures the graph)
         run.step(i)
+    dt, loss = run.timed(args.steps, args.warmup)           # THE timed region: exactly K steps
+    final_loss = float(loss.item())
+    # dominant kernels, timed live with HIP events on the launch stream: the same launches issued eagerly
     timed = ("eav_eegnet_fir_fwd", "eav_eegnet_fir_wgrad")
     model.kernel_events = {k: [] for k in timed}
-    dt, loss = run.timed(args.steps, args.warmup)           # THE timed region: exactly K steps
+    for i in range(min(args.steps, 20)):
+        run.eager_step(args.warmup + i)
+    torch.cuda.synchronize()
     kern_ms = {k: sum(a.elapsed_time(b) for a, b in v) / max(len(v), 1) for k, v in model.kernel_events.items()}
     model.kernel_events = None
-    final_loss = float(loss.item())
     blocks_ms = [dt / args.steps * 1e3]
     for _ in range(args.repeats):                            # spread of the same K-step block
         blocks_ms.append(run.timed(args.steps, args.warmup)[0] / args.steps * 1e3)
@@ -405,9 +421,12 @@ def main():
     model.fir_precision = "split"
     for i in range(3):
         run.step(i)
+    dts, _ = run.timed(args.steps, args.warmup)
     split_names = ("eav_eegnet_fir_fwd_split", "eav_eegnet_fir_wgrad_split")
     model.kernel_events = {k: [] for k in split_names}
-    dts, _ = run.timed(args.steps, args.warmup)
+    for i in range(min(args.steps, 20)):
+        run.eager_step(args.warmup + i)
+    torch.cuda.synchronize()
     split_ms = {k: sum(a.elapsed_time(b) for a, b in v) / max(len(v), 1) for k, v in model.kernel_events.items()}
     model.kernel_events = None
     model.fir_precision = "fp32"
@@ -446,11 +465,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        run.graphs.clear()                                  # no all-reduce in this leg: its own captured step
         for s in subs:
             run.reset_model(1000 + s)
             for i in range(ks):
                 ls = run.step(i)
-            results.append((s, ls))
+            results.append((s, ls.clone()))
         torch.cuda.synchronize()
         ds = time.perf_counter() - t0
         mine = torch.zeros(42, device=dev)
@@ -511,7 +531,8 @@ def main():
                                    f"train step on x[{per_gpu},1,30,10000] fp32 per GPU (BASELINE.json configs[1])",
                        "global_batch": per_gpu * world, "per_gpu_batch": per_gpu,
                        "parallelism": f"dp{world}" + (" (RCCL grad all-reduce)" if world > 1 else ""),
-                       "optimizer": "Adam lr=1e-5", "dropout": 0.5, "final_loss": round(final_loss, 5)},
+                       "optimizer": "Adam lr=1e-5", "dropout": 0.5, "final_loss": round(final_loss, 5),
+                       "launch": "hipGraph replay of the whole step (Trainer_uni's own path: GraphStep)"},
             "repeat_blocks": {"ms_per_step": [round(v, 4) for v in blocks_ms],
                               "median_ms_per_step": round(statistics.median(blocks_ms), 4),
                               "min_ms_per_step": round(min(blocks_ms), 4),

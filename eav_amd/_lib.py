@@ -36,6 +36,7 @@ SIGNATURES = {
     "eav_eegnet_fir_wgrad": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "eav_eegnet_dw_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _p],
     "eav_eegnet_dw_bwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
+    "eav_eegnet_dw_bwd_fused": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _u64, _p, _p, _p],
     "eav_bn_elu_pool_fwd": [_p, _p, _p, _i, _i, _i, _i, _f, _u64, _p, _p, _p],
     "eav_bn_elu_pool_bwd_reduce": [_p, _p, _p, _p, _i, _i, _i, _i, _f, _u64, _p, _p, _p],
     "eav_bn_elu_pool_bwd_apply": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _u64, _p, _p, _p],
@@ -112,6 +113,7 @@ SIGNATURES = {
     "eav_bn_rows_bwd": [_p, _p, _p, _p, _i64, _i, _p],
     "eav_peak_mfma_f32": [_p, _i, _i, _p],
     "eav_peak_copy": [_p, _p, _i64, _p],
+    "eav_peak_copy_variant": [_p, _p, _i64, _i, _i, _p],
     "eav_resize_normalize_u8": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _d, _p, _p, _p],
 }
 # helpers that return a plain value (no status)

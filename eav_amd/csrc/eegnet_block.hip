@@ -22,6 +22,26 @@ __device__ __forceinline__ void ld4(const float* p, int i, int n, bool vec, floa
     for (int e = 0; e < 4; ++e) v[e] = (i + e < n) ? p[i + e] : 0.f;
   }
 }
+// streaming forms: the big activation tensors are touched once per kernel - non-temporal loads / stores keep them from
+// evicting the small reused operands (measured on the float4 copy: +10 % at the same geometry)
+__device__ __forceinline__ void ld4s(const float* p, int i, int n, bool vec, float (&v)[4]) {
+  if (vec && i + 3 < n) {
+    const f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + i));
+    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (i + e < n) ? p[i + e] : 0.f;
+  }
+}
+__device__ __forceinline__ void st4s(float* p, int i, int n, bool vec, const float (&v)[4]) {
+  if (vec && i + 3 < n) {
+    __builtin_nontemporal_store((f32x4){v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4*>(p + i));
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (i + e < n) p[i + e] = v[e];
+  }
+}
 __device__ __forceinline__ void st4(float* p, int i, int n, bool vec, const float (&v)[4]) {
   if (vec && i + 3 < n) {
     *reinterpret_cast<float4*>(p + i) = make_float4(v[0], v[1], v[2], v[3]);
@@ -54,9 +74,14 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ y
     for (int e = 0; e < 4; ++e) acc[d][e] = 0.f;
   if (t < S) {
     const float* src = y1 + ((int64_t)b * F1 + f) * C * S;
+    float nx[2][4];                       // two channel rows in flight ahead of the one being consumed
+    ld4s(src, t, S, vec, nx[0]);
+    ld4s(src + (int64_t)min(1, C - 1) * S, t, S, vec, nx[1]);
     for (int c = 0; c < C; ++c) {
       float v[4];
-      ld4(src + (int64_t)c * S, t, S, vec, v);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] = nx[0][e]; nx[0][e] = nx[1][e]; }
+      ld4s(src + (int64_t)min(c + 2, C - 1) * S, t, S, vec, nx[1]);
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = elu_f(sc * v[e] + sh);
 #pragma unroll
@@ -79,7 +104,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ y
     }
     st[d] = s;
     st[8 + d] = q;
-    if (t < S) st4(z + ((int64_t)b * F1 * DD + f * DD + d) * S, t, S, vec, acc[d]);
+    if (t < S) st4s(z + ((int64_t)b * F1 * DD + f * DD + d) * S, t, S, vec, acc[d]);
   }
   block_sum_256<16>(st, red);
   if (threadIdx.x < 16) {
@@ -216,10 +241,19 @@ __global__ __launch_bounds__(256) void pool_bwd_apply_kernel(const float* __rest
 //   v = scale1*y1 + shift1, a1 = ELU(v), da1 = sum_d w2[f*8+d,c]*dz[b,f*8+d,t], g = da1*ELU'(v)
 //   g1[b,f,c,t] = g;  stats: sum g, sum g*yhat;  dW2[f*8+d,c] += sum_t dz[d,t]*a1[c,t]
 // part_st[(b*nchunk+chunk)][2*8] (slot f), part_w[(b*nchunk+chunk)][64*C] (this block's 8*C slice)
+// FUSED: dz is not read from memory but formed in the prologue from z (depthwiseConv output), dp2 (gradient of the pooled
+// block-1 output) and the depthwiseBN backward coefficients - the arithmetic of pool_bwd_apply_kernel<4>, whose launch
+// and whose dz round trip through HBM (2 x 164 MB at the bench shape) disappear.
+struct DwFuse {
+  const float* z; const float* dp2; const float* bn2;   // bn2: mean, invstd, scale, shift, m1, m2 (64 each)
+  float drop_p; uint64_t seed; const uint8_t* mask; const uint64_t* seed_dev;
+};
+
+template <bool FUSED>
 __global__ __launch_bounds__(256) void dw_bwd_kernel(const float* __restrict__ y1, const float* __restrict__ dz,
                                                      const float* __restrict__ bn1, const float* __restrict__ w2,
                                                      float* __restrict__ g1, float* __restrict__ part_st,
-                                                     float* __restrict__ part_w, int C, int S) {
+                                                     float* __restrict__ part_w, int C, int S, DwFuse fu) {
   __shared__ float wsh[DD * CHMAX];
   __shared__ float red[4 * 8];
   __shared__ float wacc[4 * DD * CHMAX];
@@ -231,13 +265,43 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const float* __restrict__ y
   const bool vec = (S & 3) == 0;
   const int t = chunk * 1024 + threadIdx.x * 4;
   float dzv[DD][4];
+  if (FUSED) {
+    const uint64_t seed = dropout_seed(fu.seed, fu.seed_dev);
+    const int To = S / 4, to = t / 4;
 #pragma unroll
-  for (int d = 0; d < DD; ++d) ld4(dz + ((int64_t)b * F1 * DD + f * DD + d) * S, t < S ? t : S, S, vec, dzv[d]);
+    for (int d = 0; d < DD; ++d) {
+      const int ch = f * DD + d, CH = F1 * DD;
+      const int64_t row = (int64_t)b * CH + ch;
+      const float mean2 = fu.bn2[ch], invstd2 = fu.bn2[CH + ch], sc2 = fu.bn2[2 * CH + ch], sh2 = fu.bn2[3 * CH + ch];
+      const float m1 = fu.bn2[4 * CH + ch], m2 = fu.bn2[5 * CH + ch];
+      float go = 0.f;
+      if (to < To) {
+        const uint64_t oi = (uint64_t)row * To + to;
+        go = fu.dp2[oi] * 0.25f * dropout_mult(fu.drop_p, seed, fu.mask, oi);
+      }
+      float v[4];
+      ld4s(fu.z + row * S, t < S ? t : S, S, vec, v);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float pre = sc2 * v[e] + sh2;
+        const float g = go * elu_grad_from_out(pre, elu_f(pre));
+        dzv[d][e] = (t + e < S) ? sc2 * (g - m1 - (v[e] - mean2) * invstd2 * m2) : 0.f;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int d = 0; d < DD; ++d) ld4(dz + ((int64_t)b * F1 * DD + f * DD + d) * S, t < S ? t : S, S, vec, dzv[d]);
+  }
   float st[2] = {0.f, 0.f};
   const int64_t base = ((int64_t)b * F1 + f) * C * S;
+  float nx[2][4];
+  ld4s(y1 + base, t < S ? t : S, S, vec, nx[0]);
+  ld4s(y1 + base + (int64_t)min(1, C - 1) * S, t < S ? t : S, S, vec, nx[1]);
   for (int c = 0; c < C; ++c) {
     float v[4], g[4], a[4];
-    ld4(y1 + base + (int64_t)c * S, t < S ? t : S, S, vec, v);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = nx[0][e]; nx[0][e] = nx[1][e]; }
+    ld4s(y1 + base + (int64_t)min(c + 2, C - 1) * S, t < S ? t : S, S, vec, nx[1]);
     float wd[DD];
 #pragma unroll
     for (int d = 0; d < DD; ++d) wd[d] = wsh[d * C + c];
@@ -252,7 +316,7 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const float* __restrict__ y
       st[0] += g[e];
       st[1] += g[e] * ((v[e] - mean) * invstd);
     }
-    if (t < S) st4(g1 + base + (int64_t)c * S, t, S, vec, g);
+    if (t < S) st4s(g1 + base + (int64_t)c * S, t, S, vec, g);
     // depthwise weight gradient: 8 values per thread -> transposing butterfly over the wave
     float r[DD];
 #pragma unroll
@@ -315,9 +379,26 @@ extern "C" int eav_eegnet_dw_bwd(const float* y1, const float* dz, const float* 
   EAV_REQUIRE(y1 && dz && bn1 && w2 && g1 && stat_part && w_part && B > 0 && C > 0 && C <= CHMAX && S > 0,
               "eav_eegnet_dw_bwd: bad arguments (Chans must be <= %d)", CHMAX);
   dim3 grid(cdiv(S, 1024), F1, B);
-  hipLaunchKernelGGL(dw_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, y1, dz, bn1, w2, g1, stat_part, w_part,
-                     C, S);
+  hipLaunchKernelGGL(dw_bwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, y1, dz, bn1, w2, g1, stat_part,
+                     w_part, C, S, DwFuse{});
   EAV_CHECK_LAUNCH("eav_eegnet_dw_bwd");
+  return EAV_OK;
+}
+
+// dw_bwd with the depthwiseBN -> ELU -> AvgPool(1,4) -> Dropout backward folded into its prologue (see DwFuse): takes z and
+// dp2 [B,64,S/4] instead of dz.  bn2: mean, invstd, scale, shift, m1, m2 (64 floats each, m1/m2 from eav_bn_bwd_finalize).
+extern "C" int eav_eegnet_dw_bwd_fused(const float* y1, const float* z, const float* dp2, const float* bn2,
+                                       const float* bn1, const float* w2, float* g1, float* stat_part, float* w_part,
+                                       int B, int C, int S, float drop_p, uint64_t seed, const uint8_t* mask,
+                                       const uint64_t* seed_dev, void* stream) {
+  EAV_REQUIRE(y1 && z && dp2 && bn2 && bn1 && w2 && g1 && stat_part && w_part && B > 0 && C > 0 && C <= CHMAX && S >= 4,
+              "eav_eegnet_dw_bwd_fused: bad arguments (Chans must be <= %d)", CHMAX);
+  EAV_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "eav_eegnet_dw_bwd_fused: dropout %f outside [0,1)", drop_p);
+  dim3 grid(cdiv(S, 1024), F1, B);
+  DwFuse fu{z, dp2, bn2, drop_p, seed, mask, seed_dev};
+  hipLaunchKernelGGL(dw_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, y1, nullptr, bn1, w2, g1, stat_part,
+                     w_part, C, S, fu);
+  EAV_CHECK_LAUNCH("eav_eegnet_dw_bwd_fused");
   return EAV_OK;
 }
 

@@ -145,7 +145,9 @@ __global__ __launch_bounds__(256, 2) void fir_fwd_kernel(const float* __restrict
 constexpr int WG_CW = 248;                // max u-samples per wave item (62 K-steps of 4; an even number of K-steps)
 constexpr int WG_QS = 260;                // dy row stride: 260 == 4 (mod 32), rows 16-B aligned; >= WG_CW + 4 + 8
 
-template <int WG_NT>
+// PLAIN: BatchNorm in eval mode (running statistics are constants, m1 = m2 = 0): dy = scale * g, y1 is not read at all -
+// the training mode of every epoch after the first in the reference's Trainer_uni.train().
+template <int WG_NT, bool PLAIN>
 __global__ __launch_bounds__(256, 3) void fir_wgrad_kernel(
     const float* __restrict__ x, const float* __restrict__ y1, const float* __restrict__ g1,
     const float* __restrict__ bnp /* mean, invstd, scale, shift, m1, m2 (8 each) */, float* __restrict__ part, int rows,
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(256, 3) void fir_wgrad_kernel(
       if (lane < nq1) {
         const int64_t base = (((int64_t)b * F1 + f) * C + c) * S;
         if (vec && t >= 0 && t + 3 < S) {
-          ry[f] = *reinterpret_cast<const float4*>(y1 + base + t);
+          if (!PLAIN) ry[f] = *reinterpret_cast<const float4*>(y1 + base + t);
           rg[f] = *reinterpret_cast<const float4*>(g1 + base + t);
         } else {
           float yv[4], gv[4];
@@ -189,7 +191,7 @@ __global__ __launch_bounds__(256, 3) void fir_wgrad_kernel(
           for (int e = 0; e < 4; ++e) {
             const int te = t + e;
             const bool ok = te >= 0 && te < S;
-            yv[e] = ok ? y1[base + te] : 0.f;
+            yv[e] = (ok && !PLAIN) ? y1[base + te] : 0.f;
             gv[e] = ok ? g1[base + te] : 0.f;
           }
           ry[f] = make_float4(yv[0], yv[1], yv[2], yv[3]);
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(256, 3) void fir_wgrad_kernel(
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int te = t + e;
-          o[e] = (te >= 0 && te < S) ? sc * (gv[e] - m1 - (yv[e] - mean) * invstd * m2) : 0.f;
+          o[e] = (te >= 0 && te < S) ? (PLAIN ? sc * gv[e] : sc * (gv[e] - m1 - (yv[e] - mean) * invstd * m2)) : 0.f;
         }
         *reinterpret_cast<float4*>(&dyl[f * WG_QS + 4 * lane]) = make_float4(o[0], o[1], o[2], o[3]);
       }
@@ -346,14 +348,21 @@ extern "C" int eav_eegnet_fir_wgrad_nparts(int B, int C, int S) {
 // part: [nparts][8][klen] floats; sum over parts = dL/d(firstConv.weight)
 extern "C" int eav_eegnet_fir_wgrad(const float* x, const float* y1, const float* g1, const float* bn_params,
                                     float* part, int B, int C, int S, int klen, void* stream) {
-  EAV_REQUIRE(x && y1 && g1 && bn_params && part && B > 0 && C > 0 && S > 0, "eav_eegnet_fir_wgrad: bad arguments");
+  EAV_REQUIRE(x && g1 && bn_params && part && B > 0 && C > 0 && S > 0, "eav_eegnet_fir_wgrad: bad arguments");
   EAV_REQUIRE(klen >= 1 && klen <= 300, "eav_eegnet_fir_wgrad: kernLength %d outside [1,300]", klen);
   int nchunk, CH;
   wgrad_geometry(S, &nchunk, &CH);
   const int nwork = B * C * nchunk;
-#define EAV_FIR_WG(NT)                                                                                            \
-  hipLaunchKernelGGL(fir_wgrad_kernel<NT>, dim3(wgrad_grid(nwork)), dim3(256), 0, (hipStream_t)stream, x, y1, g1, \
-                     bn_params, part, B * C, C, S, klen, (klen - 1) / 2, nchunk, CH)
+  // y1 == NULL selects the eval-mode form (dy = scale * g: the BatchNorm-backward means are zero, y1 is not needed)
+#define EAV_FIR_WG(NT)                                                                                                \
+  do {                                                                                                                \
+    if (y1)                                                                                                           \
+      hipLaunchKernelGGL((fir_wgrad_kernel<NT, false>), dim3(wgrad_grid(nwork)), dim3(256), 0, (hipStream_t)stream,   \
+                         x, y1, g1, bn_params, part, B * C, C, S, klen, (klen - 1) / 2, nchunk, CH);                  \
+    else                                                                                                              \
+      hipLaunchKernelGGL((fir_wgrad_kernel<NT, true>), dim3(wgrad_grid(nwork)), dim3(256), 0, (hipStream_t)stream, x, \
+                         y1, g1, bn_params, part, B * C, C, S, klen, (klen - 1) / 2, nchunk, CH);                     \
+  } while (0)
   if (klen <= 64) EAV_FIR_WG(2);
   else if (klen <= 128) EAV_FIR_WG(4);
   else EAV_FIR_WG(10);

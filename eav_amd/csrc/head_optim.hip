@@ -22,11 +22,24 @@ __global__ __launch_bounds__(1024) void dense_softmax_fwd_kernel(const float* __
   float acc[NCMAX];
 #pragma unroll
   for (int j = 0; j < NCMAX; ++j) acc[j] = 0.f;
-  for (int i = threadIdx.x; i < NF; i += 1024) {
-    const float v = src[i];
+  if ((NF & 3) == 0) {      // 16 B per lane: the kernel is pure load latency (one block per sample)
+    const int nq = NF >> 2;
+    for (int i = threadIdx.x; i < nq; i += 1024) {
+      const float4 v = reinterpret_cast<const float4*>(src)[i];
 #pragma unroll
-    for (int j = 0; j < NCMAX; ++j)
-      if (j < NC) acc[j] += w[(int64_t)j * NF + i] * v;
+      for (int j = 0; j < NCMAX; ++j)
+        if (j < NC) {
+          const float4 wv = reinterpret_cast<const float4*>(w + (int64_t)j * NF)[i];
+          acc[j] += (wv.x * v.x + wv.y * v.y) + (wv.z * v.z + wv.w * v.w);
+        }
+    }
+  } else {
+    for (int i = threadIdx.x; i < NF; i += 1024) {
+      const float v = src[i];
+#pragma unroll
+      for (int j = 0; j < NCMAX; ++j)
+        if (j < NC) acc[j] += w[(int64_t)j * NF + i] * v;
+    }
   }
 #pragma unroll
   for (int j = 0; j < NCMAX; ++j)
@@ -64,7 +77,7 @@ __global__ __launch_bounds__(256) void dense_softmax_bwd_kernel(const float* __r
                                                                 float* __restrict__ dbias, float* __restrict__ din,
                                                                 int B, int NF, int NC) {
   extern __shared__ float dl[];  // [B][NC]
-  for (int idx = threadIdx.x; idx < B * NC; idx += 256) {
+  for (int idx = threadIdx.x; idx < B * NC; idx += blockDim.x) {
     const int b = idx / NC;
     float v = dout[idx];
     if (probs) {  // dl = p * (dp - sum_j dp_j p_j)
@@ -80,7 +93,7 @@ __global__ __launch_bounds__(256) void dense_softmax_bwd_kernel(const float* __r
     for (int b = 0; b < B; ++b) s += dl[b * NC + threadIdx.x];
     dbias[threadIdx.x] = s;
   }
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= NF) return;
   float wv[NCMAX], acc[NCMAX];
 #pragma unroll
@@ -190,7 +203,8 @@ extern "C" int eav_dense_softmax_bwd(const float* dout, const float* probs, cons
   EAV_REQUIRE(dout && in && w && dw && dbias && B > 0 && NF > 0 && NC > 0 && NC <= NCMAX,
               "eav_dense_softmax_bwd: bad arguments (classes <= %d)", NCMAX);
   EAV_REQUIRE((size_t)B * NC * sizeof(float) <= 48 * 1024, "eav_dense_softmax_bwd: batch %d too large", B);
-  hipLaunchKernelGGL(dense_softmax_bwd_kernel, dim3(cdiv(NF, 256)), dim3(256), B * NC * sizeof(float),
+  const int bs = cdiv(NF, 256) >= 512 ? 256 : 64;     // one feature per thread: small blocks so that every CU gets one
+  hipLaunchKernelGGL(dense_softmax_bwd_kernel, dim3(cdiv(NF, bs)), dim3(bs), B * NC * sizeof(float),
                      (hipStream_t)stream, dout, probs, in, w, dw, dbias, din, B, NF, NC);
   EAV_CHECK_LAUNCH("eav_dense_softmax_bwd");
   return EAV_OK;

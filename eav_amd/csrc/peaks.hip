@@ -27,7 +27,46 @@ __global__ __launch_bounds__(256) void peak_copy_kernel(const float4* __restrict
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) dst[i] = src[i];
 }
 
+// tuning variants of the streaming copy (eav_peak_copy_variant): U independent 16-byte loads in flight per lane,
+// optionally non-temporal
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void peak_copy_u_kernel(const float4* __restrict__ src, float4* __restrict__ dst,
+                                                          int64_t n4) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + (U - 1) * stride < n4; i += U * stride) {
+    f32x4 v[U];
+    const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
+    f32x4* d4 = reinterpret_cast<f32x4*>(dst);
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = NT ? __builtin_nontemporal_load(s4 + i + u * stride) : s4[i + u * stride];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (NT) __builtin_nontemporal_store(v[u], d4 + i + u * stride);
+      else d4[i + u * stride] = v[u];
+    }
+  }
+  for (; i < n4; i += stride) dst[i] = src[i];
+}
+
 }  // namespace
+
+extern "C" int eav_peak_copy_variant(const float* src, float* dst, int64_t n, int variant, int blocks, void* stream) {
+  EAV_REQUIRE(src && dst && n > 0 && (n & 3) == 0 && blocks > 0, "eav_peak_copy_variant: bad arguments");
+  const float4* s = reinterpret_cast<const float4*>(src);
+  float4* d = reinterpret_cast<float4*>(dst);
+  hipStream_t st = (hipStream_t)stream;
+  switch (variant) {
+    case 1: hipLaunchKernelGGL((peak_copy_u_kernel<4, false>), dim3(blocks), dim3(256), 0, st, s, d, n / 4); break;
+    case 2: hipLaunchKernelGGL((peak_copy_u_kernel<4, true>), dim3(blocks), dim3(256), 0, st, s, d, n / 4); break;
+    case 3: hipLaunchKernelGGL((peak_copy_u_kernel<8, false>), dim3(blocks), dim3(256), 0, st, s, d, n / 4); break;
+    case 4: hipLaunchKernelGGL((peak_copy_u_kernel<8, true>), dim3(blocks), dim3(256), 0, st, s, d, n / 4); break;
+    case 5: hipLaunchKernelGGL((peak_copy_u_kernel<2, false>), dim3(blocks), dim3(256), 0, st, s, d, n / 4); break;
+    default: hipLaunchKernelGGL((peak_copy_u_kernel<1, false>), dim3(blocks), dim3(256), 0, st, s, d, n / 4); break;
+  }
+  EAV_CHECK_LAUNCH("eav_peak_copy_variant");
+  return EAV_OK;
+}
 
 // launches `blocks` x 4 waves, each issuing 4*iters v_mfma_f32_32x32x2_f32: FLOP = blocks*4*iters*4*4096
 extern "C" int eav_peak_mfma_f32(float* sink, int blocks, int iters, void* stream) {

@@ -290,11 +290,15 @@ class EEGNet_tor(nn.Module):
         L("eav_bn_elu_pool_bwd_reduce", P(ws.dp2), P(ws.z), b2, P(ws.part_pb), B, 64, S, 4, drop, seed1, m1, cnt, st)
         L("eav_bn_bwd_finalize", P(ws.part_pb), B, 64, float(B * S), tr, P(g["depthwiseBN.weight"]),
           P(g["depthwiseBN.bias"]), b2 + 4 * 256, b2 + 4 * 320, st)
-        L("eav_bn_elu_pool_bwd_apply_absmax", P(ws.dp2), P(ws.z), b2, b2 + 4 * 256, P(ws.dz),
-          P(ws.rowmax_dz) if split else None, B, 64, S, 4, drop, seed1, m1, cnt, st)
         # depthwiseConv <- ELU <- firstBN (uses the post-renorm depthwise weight, Q2)
         b1 = P(ws.bn1)
-        L("eav_eegnet_dw_bwd", P(ws.y1), P(ws.dz), b1, w2, P(ws.g1), P(ws.part_dst), P(ws.part_dw2), B, C, S, st)
+        if split:     # the split FIR weight gradient needs max |dz| per row: separate apply pass
+            L("eav_bn_elu_pool_bwd_apply_absmax", P(ws.dp2), P(ws.z), b2, b2 + 4 * 256, P(ws.dz), P(ws.rowmax_dz), B, 64,
+              S, 4, drop, seed1, m1, cnt, st)
+            L("eav_eegnet_dw_bwd", P(ws.y1), P(ws.dz), b1, w2, P(ws.g1), P(ws.part_dst), P(ws.part_dw2), B, C, S, st)
+        else:         # dz = backward of BN2 -> ELU -> pool -> dropout is formed inside dw_bwd: no dz tensor in HBM
+            L("eav_eegnet_dw_bwd_fused", P(ws.y1), P(ws.z), P(ws.dp2), b2, b1, w2, P(ws.g1), P(ws.part_dst),
+              P(ws.part_dw2), B, C, S, drop, seed1, m1, cnt, st)
         L("eav_reduce_partials", P(ws.part_dw2), B * ws.nchunk, 64 * C, 64 * C, 1.0, P(g["depthwiseConv.weight"]), st)
         L("eav_bn_bwd_finalize", P(ws.part_dst), B * ws.nchunk, 8, float(B * C * S), tr, P(g["firstBN.weight"]),
           P(g["firstBN.bias"]), b1 + 4 * 32, b1 + 4 * 40, st)
@@ -307,7 +311,9 @@ class EEGNet_tor(nn.Module):
               P(ws.part_fws), B, C, S, K, st)
             L("eav_reduce_partials", P(ws.part_fws), ws.np_fws, 8 * K, 8 * K, 1.0, P(g["firstConv.weight"]), st)
         else:
-            L("eav_eegnet_fir_wgrad", P(x), P(ws.y1), P(ws.g1), b1, P(ws.part_fw), B, C, S, K, st)
+            # eval-mode training (every epoch after the first, Q4): BatchNorm backward is a plain scale, y1 is not needed
+            L("eav_eegnet_fir_wgrad", P(x), P(ws.y1) if training else None, P(ws.g1), b1, P(ws.part_fw), B, C, S, K,
+              st)
             L("eav_reduce_partials", P(ws.part_fw), ws.np_fw, 8 * K, 8 * K, 1.0, P(g["firstConv.weight"]), st)
         named = dict(self.named_parameters())
         return [g[k].view(named[k].shape) if named[k].requires_grad else None for k in _PARAM_ORDER]

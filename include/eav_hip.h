@@ -47,7 +47,8 @@ int eav_eegnet_fir_fwd_nparts(int B, int C, int S);
 int eav_eegnet_fir_fwd(const float* x, const float* w1, float* y1, float* stat_part, int B, int C, int S, int klen,
                        void* stream);
 /* firstConv weight gradient fused with firstBN backward (autograd of EEGNet_tor.py:51-52):
- * bn_params = mean, invstd, scale, shift, m1, m2 (8 floats each); part [nparts][8][klen]. */
+ * bn_params = mean, invstd, scale, shift, m1, m2 (8 floats each); part [nparts][8][klen].
+ * y1 == NULL: BatchNorm in eval mode (m1 = m2 = 0, the gradient through firstBN is scale * g1; y1 is not read). */
 int eav_eegnet_fir_wgrad_nparts(int B, int C, int S);
 int eav_eegnet_fir_wgrad(const float* x, const float* y1, const float* g1, const float* bn_params, float* part,
                          int B, int C, int S, int klen, void* stream);
@@ -76,6 +77,13 @@ int eav_eegnet_dw_fwd(const float* y1, const float* bn1, const float* w2, float*
  * w_part [B*ceil(S/1024)][64*C]. */
 int eav_eegnet_dw_bwd(const float* y1, const float* dz, const float* bn1, const float* w2, float* g1,
                       float* stat_part, float* w_part, int B, int C, int S, void* stream);
+
+/* the same with the backward of depthwiseBN -> ELU -> AvgPool(1,4) -> Dropout (EEGNet_tor.py:55-58) folded in: dz is
+ * formed from z [B,64,S] and dp2 [B,64,S/4] on the fly (no eav_bn_elu_pool_bwd_apply launch, no dz tensor).
+ * bn2 = mean, invstd, scale, shift, m1, m2 of depthwiseBN (64 floats each). */
+int eav_eegnet_dw_bwd_fused(const float* y1, const float* z, const float* dp2, const float* bn2, const float* bn1,
+                            const float* w2, float* g1, float* stat_part, float* w_part, int B, int C, int S,
+                            float drop_p, uint64_t seed, const uint8_t* mask, const uint64_t* seed_dev, void* stream);
 
 /* ---- BN -> ELU -> AvgPool(1,P) -> Dropout (EEGNet_tor.py:55-58, 60-63), P in {4,8} -------- */
 /* bn = mean, invstd, scale, shift (CH each).  mask: optional uint8 keep-mask [B,CH,T/P]
@@ -350,6 +358,7 @@ int eav_sosfilt_f64(const double* x, double* y, const double* sos, const double*
 /* ---- measured peaks (bench.py): register-only fp32 MFMA loop (FLOP = blocks*4 waves*iters*4*4096) and a float4
  *      streaming copy, to quote roofline fractions against what this chip sustains. */
 int eav_peak_mfma_f32(float* sink, int blocks, int iters, void* stream);
+int eav_peak_copy_variant(const float* src, float* dst, int64_t n, int variant, int blocks, void* stream);
 int eav_peak_copy(const float* src, float* dst, int64_t n, void* stream);
 
 #ifdef __cplusplus

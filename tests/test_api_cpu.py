@@ -200,3 +200,31 @@ def test_shallow_convnet_class_surface_and_default_init():
     assert m.fc.weight.shape == (5, 2600) and m.fc.bias is None
     with pytest.raises(_lib.EavError):
         te.TrainerUni(m, data=[torch.zeros(4, 1, 30, 500), torch.zeros(4, dtype=torch.long)] * 2, device="cpu")
+
+
+def test_calculate_accuracy_and_trial_vote():
+    """Transformer_Vision.py:8-11 (argmax == labels, mean) and :174-185 (mean over 25 frames -> argmax)."""
+    import numpy as np
+    import torch
+    from eav_amd.vision import calculate_accuracy, trial_vote
+    from types import SimpleNamespace
+    logits = torch.tensor([[2.0, 1.0, 0.0], [0.0, 3.0, 1.0], [0.1, 0.2, 0.3], [1.0, 0.0, 0.0]])
+    # the reference passes the HF output object (outputs.logits)
+    assert abs(calculate_accuracy(SimpleNamespace(logits=logits), torch.tensor([0, 1, 0, 0])) - 0.75) < 1e-7
+    frames = np.zeros((2 * 25, 5), np.float32)
+    frames[:25, 3] = 1.0
+    frames[25:, 1] = np.linspace(0, 2, 25)
+    frames[25:, 4] = 0.9
+    pred, acc, f1 = trial_vote(frames, np.array([3, 1]))
+    assert list(pred) == [3, 1] and acc == 1.0 and f1 == 1.0
+
+
+def test_unsupported_configurations_raise_not_silently_differ():
+    """The kernels are specialised to the reference's own configuration; anything else must fail loudly at
+    construction (EEGNet_tor.py:16-17,21 accepts any F1/D/F2/dropoutType)."""
+    from eav_amd.eegnet import EEGNet_tor
+    for kw in (dict(F1=4), dict(D=2), dict(F2=32), dict(kernLength=301), dict(Chans=33),
+               dict(dropoutType="Dropout2d", dropoutRate=0.5)):
+        with pytest.raises(NotImplementedError):
+            EEGNet_tor(5, **kw)
+    EEGNet_tor(5, dropoutType="Dropout2d", dropoutRate=0.0)      # no dropout at all: the type is irrelevant

@@ -44,12 +44,7 @@ __device__ __forceinline__ float sigma_from_bits(unsigned bits) {
   se = max(-126, min(126, se));
   return __uint_as_float((unsigned)(se + 127) << 23);
 }
-__device__ __forceinline__ unsigned slot_bits(const float* slot) {
-  unsigned bits = 0u;
-#pragma unroll
-  for (int i = 0; i < 64; ++i) bits = max(bits, __float_as_uint(slot[i]));
-  return bits;
-}
+__device__ __forceinline__ unsigned slot_bits(const float* slot) { return eav_slot_bits(slot); }
 
 // 8 fp32 -> one hi and one lo operand fragment (8 halves each); lo = fp16((t - hi) * lomul)
 __device__ __forceinline__ void split_frag(const float* t, float lomul, f16x8& hi, f16x8& lo) {
@@ -131,7 +126,7 @@ __device__ __forceinline__ void emit_amax(unsigned* slot, float vmax, int lane, 
   if (!slot) return;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
-  if (lane == 0 && vmax == vmax) atomicMax(slot + (salt & 63), __float_as_uint(vmax));
+  if (lane == 0 && vmax == vmax) atomicMax(slot + EAV_SLOT_SHARD(salt), __float_as_uint(vmax));
 }
 
 // ------------------------------------------------------------------------------------------------ forward
@@ -164,7 +159,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_sp_kernel(const u8* __res
       glds_t_chunk(st + 8192, c, vbase + (int64_t)kt * 128, ldt, lane);
     }
   };
-  const float isg = slot[65];
+  const float isg = slot[EAV_SLOT_ISIGMA];
   const float c1 = scale * LOG2E * isg * isg;
   f32x16 o0, o1;
 #pragma unroll
@@ -279,10 +274,10 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_q_sp_kernel(
       glds_t_chunk(st + 16384, c, ktbase + (int64_t)kt * 128, ldt, lane);
     }
   };
-  const float isg = slot[65], isd = slot_do[65];
+  const float isg = slot[EAV_SLOT_ISIGMA], isd = slot_do[EAV_SLOT_ISIGMA];
   const float c1 = scale * LOG2E * isg * isg;
   const float lq = LOG2E * lse[(int64_t)bh * N + q];
-  const float dq_ = delta[(int64_t)bh * N + q] * slot[64] * slot_do[64];   // delta in operand units
+  const float dq_ = delta[(int64_t)bh * N + q] * slot[EAV_SLOT_SIGMA] * slot_do[EAV_SLOT_SIGMA];   // delta in operand units
   f32x16 g0, g1, x0, x1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { g0[r] = 0.f; g1[r] = 0.f; x0[r] = 0.f; x1[r] = 0.f; }
@@ -391,9 +386,9 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_kv_sp_kernel(
       __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(st + 32768), 4, 0, 0);
     }
   };
-  const float isg = slot[65], isd = slot_do[65];
+  const float isg = slot[EAV_SLOT_ISIGMA], isd = slot_do[EAV_SLOT_ISIGMA];
   const float c1 = scale * LOG2E * isg * isg;
-  const float dsc = slot[64] * slot_do[64];
+  const float dsc = slot[EAV_SLOT_SIGMA] * slot_do[EAV_SLOT_SIGMA];
   const float s2 = sigma_from_bits(slot_bits(slot_ds));   // exact scale of t = dS 2^-22 (measured by the dQ kernel)
   f32x16 gk0, gk1, gv0, gv1;
 #pragma unroll
@@ -505,8 +500,8 @@ __global__ __launch_bounds__(256) void attn_sp_prep_kernel(const float* __restri
   __shared__ float tile[64][65];
   const float sigma = sigma_from_bits(slot_bits(slot));
   if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
-    slot[64] = sigma;
-    slot[65] = 1.f / sigma;
+    slot[EAV_SLOT_SIGMA] = sigma;
+    slot[EAV_SLOT_ISIGMA] = 1.f / sigma;
   }
   const int chunk = blockIdx.x, t0 = blockIdx.y * 64, b = blockIdx.z;
   const int c0 = chunk * 64;

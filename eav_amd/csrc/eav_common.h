@@ -61,6 +61,19 @@ __device__ __forceinline__ void block_sum_256(float (&v)[NV], float* red) {
   __syncthreads();
 }
 
+// Operand-scale slot of the split-operand kernels (EAV_SP_SLOT floats, include/eav_hip.h): 64 shards of the bits of
+// max|x|, one per 128-byte line (word 32*i) so that the producers' atomicMax traffic spreads over 64 L2 lines / channels
+// instead of serialising on two; sigma at word EAV_SLOT_SIGMA, 1/sigma at EAV_SLOT_ISIGMA.
+#define EAV_SLOT_SHARD(i) (32 * ((i) & 63))
+#define EAV_SLOT_SIGMA 2048
+#define EAV_SLOT_ISIGMA 2049
+__device__ __forceinline__ unsigned eav_slot_bits(const float* slot) {
+  unsigned bits = 0u;
+#pragma unroll 8
+  for (int i = 0; i < 64; ++i) bits = max(bits, __float_as_uint(slot[32 * i]));
+  return bits;
+}
+
 // counter-based dropout keep decision: pure function of (seed, element index)
 __device__ __forceinline__ uint32_t eav_hash32(uint64_t seed, uint64_t idx) {
   uint64_t z = seed + (idx + 1) * 0x9E3779B97F4A7C15ull;

@@ -42,7 +42,7 @@ struct SpArgs {
   const unsigned char* A;   // planes [M][Kp/8][2][8]
   const unsigned char* B;   // planes [N][Kp/8][2][8]
   float* C;
-  const float* slotA;       // slot: [0..63] shards of the bits of max|x|, [64] sigma, [65] 1/sigma
+  const float* slotA;       // operand-scale slots (eav_common.h: 64 shards of max|x| bits, sigma, 1/sigma)
   const float* slotB;
   const float* bias;        // [N] or null
   const float* resid;       // [M,N] (ldr) or null, added after the activation
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
   }
 
   // ---- epilogue
-  const float alpha = g.alpha * g.slotA[65] * g.slotB[65];
+  const float alpha = g.alpha * g.slotA[EAV_SLOT_ISIGMA] * g.slotB[EAV_SLOT_ISIGMA];
   const int M = g.M, N = g.N;
   float vmax = 0.f;
 #pragma unroll
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
     if (lane == 0 && vmax == vmax)
-      atomicMax(g.amax + ((blockIdx.x * NW + wave + 17 * blockIdx.z) & 63), __float_as_uint(vmax));
+      atomicMax(g.amax + EAV_SLOT_SHARD(blockIdx.x * NW + wave + 17 * blockIdx.z), __float_as_uint(vmax));
   }
 }
 
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256) void sp_absmax_kernel(const float* __restrict_
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
   if ((threadIdx.x & 63) == 0 && m == m)
-    atomicMax(slot + (((blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)) & 63), __float_as_uint(m));
+    atomicMax(slot + EAV_SLOT_SHARD((blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)), __float_as_uint(m));
 }
 
 // sigma = 2^(14 - floor(log2 amax)): max|sigma v| in [2^14, 2^15); 1 for an all-zero / non-finite tensor
@@ -399,13 +399,10 @@ __global__ __launch_bounds__(256) void sp_convert_kernel(const float* __restrict
                                                          int Cp, unsigned char* __restrict__ dstT, int Rp,
                                                          float lomul, float* __restrict__ colsum_part) {
   __shared__ float tile[64][65];
-  unsigned bits = 0u;
-#pragma unroll
-  for (int i = 0; i < 64; ++i) bits = max(bits, __float_as_uint(slot[i]));
-  const float sigma = sigma_from_bits(bits);
+  const float sigma = sigma_from_bits(eav_slot_bits(slot));
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
-    slot[64] = sigma;
-    slot[65] = 1.f / sigma;
+    slot[EAV_SLOT_SIGMA] = sigma;
+    slot[EAV_SLOT_ISIGMA] = 1.f / sigma;
   }
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
   const int t = threadIdx.x;

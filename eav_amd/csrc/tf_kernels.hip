@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
   if (amax) {   // max |y| of the row into one of the 64 shards of the operand-scale slot (gemm_sp.hip)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
-    if (lane == 0 && vmax == vmax) atomicMax(amax + (row & 63), __float_as_uint(vmax));
+    if (lane == 0 && vmax == vmax) atomicMax(amax + EAV_SLOT_SHARD(row), __float_as_uint(vmax));
   }
 }
 
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   if (amax) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
-    if (lane == 0 && vmax == vmax) atomicMax(amax + ((blockIdx.x * 4 + wave) & 63), __float_as_uint(vmax));
+    if (lane == 0 && vmax == vmax) atomicMax(amax + EAV_SLOT_SHARD(blockIdx.x * 4 + wave), __float_as_uint(vmax));
   }
   if (!part) return;
   float4* shw = reinterpret_cast<float4*>(sh + wave * 2 * D);
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(float* __restrict__ dact,
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
     if ((threadIdx.x & 63) == 0 && vmax == vmax)
-      atomicMax(amax + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & 63), __float_as_uint(vmax));
+      atomicMax(amax + EAV_SLOT_SHARD(blockIdx.x * 4 + (threadIdx.x >> 6)), __float_as_uint(vmax));
   }
 }
 

@@ -176,6 +176,8 @@ class Encoder(nn.Module):
         # "bf16" (bf16 MFMA operands everywhere, fp32 accumulate: ~5e-3 logit drift) or "bf16_bwd" (fp32 forward -
         # logits unchanged - and bf16 operands for the backward products only).  EAV_ENCODER_PRECISION overrides.
         self.precision = os.environ.get("EAV_ENCODER_PRECISION", DEFAULT_PRECISION)
+        self.overlap_wgrad = True     # split mode: weight-gradient GEMMs on a side stream (see _wgrad_sp)
+        self._side, self._wgrad_done = None, {}
         self._wplanes = None          # split mode: {weight key: (planes, planes of the transpose, slot index)}
         self._wplanes_key = None
         self._phase = "fwd"
@@ -337,7 +339,7 @@ class Encoder(nn.Module):
         return ws
 
     # ------------------------------------------------------------------ split-operand (fp16 hi/lo planes) plumbing
-    SLOT = 80   # floats per scale slot (include/eav_hip.h EAV_SP_SLOT)
+    SLOT = 2080   # floats per scale slot (include/eav_hip.h EAV_SP_SLOT)
     FS, BS = 5, 6   # slots per layer: forward y1, qkv, ao, y2, act; backward dh(fc2), dact, dh(o), dao, dS, dqkv
 
     def _alloc_split(self, ws, dev, nsave):
@@ -367,6 +369,8 @@ class Encoder(nn.Module):
             ws.actpT = [h(FF, M) for _ in range(nsave)]
             # backward operands: one set, reused by every layer
             ws.dhp, ws.dhpT = h(M, D), h(D, M)
+            ws.dhpT2 = h(D, M)        # the o_proj stage's transposed planes: the weight gradients run on a side stream, so
+                                      # the two uses of dh per layer must not share one buffer
             ws.dactp, ws.dactpT = h(M, FF), h(FF, M)
             ws.dqkvp, ws.dqkvpT = h(M, 3 * D), h(3 * D, M)
             ws.dembpT = h(D, MP)
@@ -440,6 +444,7 @@ class Encoder(nn.Module):
     def _to_planes_bias(self, src, R, C, slot, dst, dstT, bias_grad):
         """Conversion pass that also produces the bias gradient (column sums of src) - src's max|x| is already in slot."""
         ws = self._ws
+        self._before_overwrite(dstT)
         self._call("eav_sp_convert_colsum", src, R, C, C, slot, _lib.ptr(dst), _lib.ptr(dstT), _lib.ptr(ws.part_cs2),
                    self._st)
         self._call("eav_reduce_partials", _lib.ptr(ws.part_cs2), ws.np_cs2, C, C, 1.0, bias_grad, self._st)
@@ -451,9 +456,40 @@ class Encoder(nn.Module):
                    resid, ldr, acc, amax, self._st)
 
     def _wgrad_sp(self, AT, slotA, BT, slotB, C, M, N, K):
-        """C[M,N] = sum over the K tokens: planes of the transposes, A^T [M,K], B^T [N,K]; split-K."""
-        self._call("eav_gemm_sp_splitk", _lib.ptr(AT), _lib.ptr(BT), C, _lib.ptr(self._ws.splitk), slotA, slotB, M, N,
-                   K, 0, self._st)
+        """C[M,N] = sum over the K tokens: planes of the transposes, A^T [M,K], B^T [N,K]; split-K.
+
+        Weight gradients are off the critical path of the backward (nothing downstream reads them before the optimiser),
+        so they run on a side HIP stream: their MFMA work fills the matrix pipe while the main stream is in its
+        HBM- / VALU-bound stretches (operand conversions, LayerNorm / GELU backward, the attention backward) and in the
+        tails of its own GEMMs.  Ordering: the side stream waits for the event recorded after the conversion that
+        produced A^T; the main stream waits for a weight gradient only before it overwrites that gradient's A^T buffer
+        (one layer later) and at the end of the backward."""
+        if not self.overlap_wgrad or (self.kernel_events is not None and "eav_gemm_sp_splitk" in self.kernel_events):
+            self._call("eav_gemm_sp_splitk", _lib.ptr(AT), _lib.ptr(BT), C, _lib.ptr(self._ws.splitk), slotA, slotB, M,
+                       N, K, 0, self._st)
+            return
+        if self._side is None or self._side.device != AT.device:
+            self._side = torch.cuda.Stream(device=AT.device)
+        ready = torch.cuda.Event()
+        ready.record()
+        self._side.wait_event(ready)
+        _lib.call("eav_gemm_sp_splitk", _lib.ptr(AT), _lib.ptr(BT), C, _lib.ptr(self._ws.splitk), slotA, slotB, M, N, K,
+                  0, self._side.cuda_stream)
+        done = torch.cuda.Event()
+        done.record(self._side)
+        self._wgrad_done[AT.data_ptr()] = done
+
+    def _before_overwrite(self, buf):
+        """Main stream: the weight gradient that still reads `buf` (launched a layer ago on the side stream) must be
+        finished before the next conversion overwrites it."""
+        ev = self._wgrad_done.pop(buf.data_ptr(), None) if buf is not None else None
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+
+    def _join_wgrads(self):
+        if self._side is not None and self._wgrad_done:
+            torch.cuda.current_stream().wait_stream(self._side)
+            self._wgrad_done.clear()
 
     def _launch_forward(self, x):
         c = self.cfg
@@ -628,8 +664,8 @@ class Encoder(nn.Module):
         self._reduce(ws.part_ln, ws.np_ln, 2 * D, D, gp(f"{Lk}.layernorm_after.weight"))
         L("eav_reduce_partials", P(ws.part_ln) + 4 * D, ws.np_ln, 2 * D, D, 1.0, gp(f"{Lk}.layernorm_after.bias"), st)
         # o_proj
-        self._to_planes_bias(dh, M, D, b_dh1, ws.dhp, ws.dhpT, gp(f"{Lk}.attention.o_proj.bias"))
-        self._wgrad_sp(ws.dhpT, b_dh1, ws.aopT[i], s_ao, gp(f"{Lk}.attention.o_proj.weight"), D, D, M)
+        self._to_planes_bias(dh, M, D, b_dh1, ws.dhp, ws.dhpT2, gp(f"{Lk}.attention.o_proj.bias"))
+        self._wgrad_sp(ws.dhpT2, b_dh1, ws.aopT[i], s_ao, gp(f"{Lk}.attention.o_proj.weight"), D, D, M)
         wpl, wsl = self._wp(f"o{i}", transposed=True)
         self._gemm_sp(P(ws.dhp), b_dh1, wpl, wsl, dao, M, D, D, D, amax=b_dao if ws.fused else None)
         # attention core
@@ -732,6 +768,7 @@ class Encoder(nn.Module):
                 if sp:
                     self._layer_backward_split(i, Lk, stp, gp, bslot, fslot, scale)
                     if self.grad_ready_hook is not None:
+                        self._join_wgrads()         # the layer's weight gradients must be complete before they travel
                         lo = offs[f"{Lk}.attention.q_proj.weight"][0]
                         hi = offs[f"{Lk}.mlp.fc2.bias"][0] + offs[f"{Lk}.mlp.fc2.bias"][1]
                         self.grad_ready_hook(lo, hi)
@@ -802,6 +839,7 @@ class Encoder(nn.Module):
             self._call("eav_colsum", P(ws.demb), P(ws.part_cs), MP, D, D, st)
             self._call("eav_reduce_partials", P(ws.part_cs), _lib.plain("eav_colsum_nparts", MP), D, D, 1.0,
                        gp(f"{pre}.embeddings.patch_embeddings.projection.bias"), st)
+        self._join_wgrads()          # side-stream weight gradients complete before autograd / the optimiser see them
         out = []
         for k in self._names:
             p = pm[k]

@@ -213,10 +213,10 @@ int eav_gemm_bf16_splitk(const float* A, const float* B, float* C, float* ws, in
  * Transformer_Vision.py:92).  Operands are "sp16 planes": X[R,K] with the contraction index along K stored as
  * uint16 [R][Kp/8][2][8] (8 hi halves, then 8 lo halves; Kp = eav_sp_kpad(K), zero beyond K) of sigma*X, hi =
  * fp16(sigma x), lo = fp16(sigma x - hi).  A device slot of EAV_SP_SLOT floats per tensor holds 64 shards of the bits of
- * max|x| (words 0..63), sigma (word 64) and 1/sigma (word 65): zero it, let producers atomicMax the shards
+ * max|x| (one per 128-byte line), sigma and 1/sigma: zero it, let producers atomicMax the shards
  * (eav_sp_absmax or a GEMM's amax_slot), then eav_sp_convert writes the planes of X (dst: contraction over columns)
  * and / or of X^T (dstT: contraction over rows) and fills sigma. */
-#define EAV_SP_SLOT 80
+#define EAV_SP_SLOT 2080   /* shard i at word 32*i (one 128-byte line each), sigma at word 2048, 1/sigma at 2049 */
 int eav_sp_kpad(int K);
 int eav_sp_absmax(const float* src, int R, int C, int64_t ld, float* slot, void* stream);
 int eav_sp_convert(const float* src, int R, int C, int64_t ld, float* slot, void* dst, void* dstT, void* stream);

@@ -19,7 +19,7 @@ def kpad(k):
 def planes(x, want=True, wantT=False):
     """x [R,C] fp32 device -> (slot, planes [R, 2*Cp] f16 | None, planesT [C, 2*Rp] f16 | None)"""
     R, C = x.shape
-    slot = torch.zeros(80, device="cuda")
+    slot = torch.zeros(2080, device="cuda")
     _lib.call("eav_sp_absmax", P(x), R, C, x.stride(0), P(slot), None)
     d = torch.empty(R, 2 * kpad(C), dtype=torch.float16, device="cuda") if want else None
     dT = torch.empty(C, 2 * kpad(R), dtype=torch.float16, device="cuda") if wantT else None
@@ -113,7 +113,7 @@ def bench_splitk(name, M, N, K):
 
 def bench_convert(R, C):
     x = torch.randn(R, C, device="cuda")
-    slot = torch.zeros(80, device="cuda")
+    slot = torch.zeros(2080, device="cuda")
     d = torch.empty(R, 2 * kpad(C), dtype=torch.float16, device="cuda")
     dT = torch.empty(C, 2 * kpad(R), dtype=torch.float16, device="cuda")
     ms0 = timeit(lambda: _lib.call("eav_sp_absmax", P(x), R, C, C, P(slot), None))

@@ -242,7 +242,7 @@ def measured_peaks(dev):
     from eav_amd import _lib
     sink = torch.zeros(4, device=dev)
     blocks, iters = 256 * 8, 4000
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
     _lib.call("eav_peak_mfma_f32", sink.data_ptr(), blocks, 200, _lib.stream_ptr())
     ev[0].record()
     _lib.call("eav_peak_mfma_f32", sink.data_ptr(), blocks, iters, _lib.stream_ptr())
@@ -255,9 +255,15 @@ def measured_peaks(dev):
         _lib.call("eav_peak_copy", src.data_ptr(), dst.data_ptr(), n, _lib.stream_ptr())
     ev[3].record()
     torch.cuda.synchronize()
+    _lib.call("eav_peak_mfma_f16", sink.data_ptr(), blocks, 200, _lib.stream_ptr())
+    ev[4].record()
+    _lib.call("eav_peak_mfma_f16", sink.data_ptr(), blocks, 4 * iters, _lib.stream_ptr())
+    ev[5].record()
+    torch.cuda.synchronize()
     tf = blocks * 4 * iters * 4 * 4096.0 / (ev[0].elapsed_time(ev[1]) * 1e-3) / 1e12
     tbs = 3 * 2 * 4.0 * n / (ev[2].elapsed_time(ev[3]) * 1e-3) / 1e12
-    return {"f32_mfma_tflops": round(tf, 1), "hbm_copy_tb_per_s": round(tbs, 2)}
+    tf16 = blocks * 4 * 4 * iters * 4 * 32768.0 / (ev[4].elapsed_time(ev[5]) * 1e-3) / 1e12
+    return {"f32_mfma_tflops": round(tf, 1), "f16_mfma_tflops": round(tf16, 1), "hbm_copy_tb_per_s": round(tbs, 2)}
 
 
 # ---------------------------------------------------------------------------------------------- self-launch

@@ -60,13 +60,17 @@ struct SpArgs {
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
-template <int WM, int WN, bool TWOACC, int ABL = 0>
+// WM x WN waves, each a (32 RM) x (32 RN) block of RM x RN MFMA tiles.
+template <int WM, int WN, int RM, int RN, bool TWOACC>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_kernel(SpArgs g) {
-  constexpr int NW = WM * WN, BM = 64 * WM, BN = 64 * WN;
+  constexpr int NW = WM * WN, BM = 32 * RM * WM, BN = 32 * RN * WN;
   constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
   constexpr int NCH = (BM + BN) / 8;      // 1-KB chunks (8 rows x 128 B) per stage
   constexpr int CPW = NCH / NW;           // chunks per wave
-  static_assert(NCH % NW == 0 && NCH / NW <= 8, "chunks must divide over the waves (at most 8 each)");
+  constexpr int NT = RM * RN;             // MFMA tiles per wave
+  constexpr int NMF = 3 * NT;             // MFMAs per K-step of 16
+  constexpr int NRD = 2 * (RM + RN);      // fragment reads per K-step
+  static_assert(NCH % NW == 0 && CPW <= NMF && NRD <= NMF, "stage chunks / fragment reads must fit the MFMA slots");
   __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
 
   const int t = threadIdx.x, lane = t & 63;
@@ -112,13 +116,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
       gp[i] = g.B + (int64_t)gr * g.ldB + (int64_t)kt0 * 128 + p * 16;
     }
   }
+  auto issue1 = [&](int buf, int i) {
+    const int c = wave + NW * i;
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)gp[i], (lds_ptr_t)(smem + buf * STAGE + c * 1024), 16, 0, 0);
+    gp[i] += 128;
+  };
   auto issue = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < CPW; ++i) {
-      const int c = wave + NW * i;
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)gp[i], (lds_ptr_t)(smem + buf * STAGE + c * 1024), 16, 0, 0);
-      gp[i] += 128;
-    }
+    for (int i = 0; i < CPW; ++i) issue1(buf, i);
   };
 
   // ---- fragment addressing
@@ -129,35 +134,48 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
   for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
     for (int hl = 0; hl < 2; ++hl) lowp[ks][hl] = ((2 * (2 * ks + kh) + hl) ^ gq) * 16;
-  const int offA = (wm * 64 + r32) * 128, offB = A_BYTES + (wn * 64 + r32) * 128;
+  const int offA = (wm * 32 * RM + r32) * 128, offB = A_BYTES + (wn * 32 * RN + r32) * 128;
 
-  f32x16 acc[2][2], acx[2][2];
+  f32x16 acc[RM][RN], acx[TWOACC ? RM : 1][TWOACC ? RN : 1];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < RM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < RN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = acx[i][j][r] = 0.f;
+      for (int r = 0; r < 16; ++r) {
+        acc[i][j][r] = 0.f;
+        if (TWOACC) acx[i][j][r] = 0.f;
+      }
 
   // ---- main loop: software-pipelined and explicitly interleaved (sched_barrier pins the order as written).
   // Two fragment register sets: f0 = K-step 0 of a tile, f1 = K-step 1.  Iteration t:
-  //   phase A: 12 MFMAs on f0(t)   || ds_read f1(t) from buffer t&1
+  //   phase A: MFMAs on f0(t)   || ds_read f1(t) from buffer t&1
   //   lgkmcnt(0), vmcnt(0) [stage t+1 landed], barrier
-  //   phase B: 12 MFMAs on f1(t)   || ds_read f0(t+1) from buffer (t+1)&1 || LDS-DMA of stage t+2 into buffer t&1
+  //   phase B: MFMAs on f1(t)   || ds_read f0(t+1) from buffer (t+1)&1 || LDS-DMA of stage t+2 into buffer t&1
   // so LDS reads, the next stage's DMA issue and their address arithmetic all hide behind MFMA issue slots; a stage has
   // a whole tile's MFMA time to land.  Every wave's reads of buffer t&1 are complete (lgkmcnt(0)) before the barrier that
-  // precedes its re-fill.
-  struct Frags { f16x8 ah[2], al[2], bh[2], bl[2]; };
+  // precedes its re-fill.  One MFMA slot = one MFMA, then (pinned behind it) at most one fragment read and one DMA.
+  struct Frags { f16x8 ah[RM], al[RM], bh[RN], bl[RN]; };
   Frags f0, f1;
 #define SB() __builtin_amdgcn_sched_barrier(0)
 #define MM(c, a, b) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
-#define LDA(i, ks, hl) (*reinterpret_cast<const f16x8*>(sa + (i) * 4096 + lowp[ks][hl]))
-#define LDB(i, ks, hl) (*reinterpret_cast<const f16x8*>(sb + (i) * 4096 + lowp[ks][hl]))
-  auto issue1 = [&](int buf, int i) {
-    if (i < CPW) {
-      const int c = wave + NW * i;
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)gp[i], (lds_ptr_t)(smem + buf * STAGE + c * 1024), 16, 0, 0);
-      gp[i] += 128;
+  // fragment read number r of a K-step: ah[0..RM), bh[0..RN), al[0..RM), bl[0..RN)
+  auto read_frag = [&](Frags& f, const unsigned char* sa, const unsigned char* sb, int ks, int r) {
+    if (r < RM) f.ah[r] = *reinterpret_cast<const f16x8*>(sa + r * 4096 + lowp[ks][0]);
+    else if (r < RM + RN) f.bh[r - RM] = *reinterpret_cast<const f16x8*>(sb + (r - RM) * 4096 + lowp[ks][0]);
+    else if (r < 2 * RM + RN) f.al[r - RM - RN] = *reinterpret_cast<const f16x8*>(sa + (r - RM - RN) * 4096 + lowp[ks][1]);
+    else f.bl[r - 2 * RM - RN] = *reinterpret_cast<const f16x8*>(sb + (r - 2 * RM - RN) * 4096 + lowp[ks][1]);
+  };
+  // MFMA number m of a K-step: the hi.hi products of every tile, then lo.hi, then hi.lo
+  auto mfma_slot = [&](const Frags& f, int m) {
+    const int term = m / NT, tt = m - term * NT, i = tt / RN, j = tt - i * RN;
+    if (term == 0) MM(acc[i][j], f.ah[i], f.bh[j]);
+    else if (TWOACC) {
+      if (term == 1) MM(acx[i][j], f.al[i], f.bh[j]);
+      else MM(acx[i][j], f.ah[i], f.bl[j]);
+    } else {
+      if (term == 1) MM(acc[i][j], f.al[i], f.bh[j]);
+      else MM(acc[i][j], f.ah[i], f.bl[j]);
     }
   };
   const int nk = kt1 - kt0;
@@ -166,76 +184,35 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (nk > 1) issue(1);
-    const unsigned char* sa = smem + offA;
-    const unsigned char* sb = smem + offB;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      f0.ah[i] = LDA(i, 0, 0); f0.bh[i] = LDB(i, 0, 0); f0.al[i] = LDA(i, 0, 1); f0.bl[i] = LDB(i, 0, 1);
-    }
+    for (int r = 0; r < NRD; ++r) read_frag(f0, smem + offA, smem + offB, 0, r);
   }
   auto iter = [&](auto more_c, auto more2_c, int t) {
     constexpr bool more = decltype(more_c)::value, more2 = decltype(more2_c)::value;
     const int buf = t & 1;
     const unsigned char* sa = smem + buf * STAGE + offA;
     const unsigned char* sb = smem + buf * STAGE + offB;
-    // ---------------- phase A
+    const unsigned char* sa2 = smem + (buf ^ 1) * STAGE + offA;
+    const unsigned char* sb2 = smem + (buf ^ 1) * STAGE + offB;
     SB();
-    MM(acc[0][0], f0.ah[0], f0.bh[0]); SB(); f1.ah[0] = LDA(0, 1, 0); SB();
-    MM(acc[0][1], f0.ah[0], f0.bh[1]); SB(); f1.bh[0] = LDB(0, 1, 0); SB();
-    MM(acc[1][0], f0.ah[1], f0.bh[0]); SB(); f1.ah[1] = LDA(1, 1, 0); SB();
-    MM(acc[1][1], f0.ah[1], f0.bh[1]); SB(); f1.bh[1] = LDB(1, 1, 0); SB();
-    if (TWOACC) {
-      MM(acx[0][0], f0.al[0], f0.bh[0]); SB(); f1.al[0] = LDA(0, 1, 1); SB();
-      MM(acx[0][1], f0.al[0], f0.bh[1]); SB(); f1.al[1] = LDA(1, 1, 1); SB();
-      MM(acx[1][0], f0.al[1], f0.bh[0]); SB(); f1.bl[0] = LDB(0, 1, 1); SB();
-      MM(acx[1][1], f0.al[1], f0.bh[1]); SB(); f1.bl[1] = LDB(1, 1, 1); SB();
-      MM(acx[0][0], f0.ah[0], f0.bl[0]);
-      MM(acx[0][1], f0.ah[0], f0.bl[1]);
-      MM(acx[1][0], f0.ah[1], f0.bl[0]);
-      MM(acx[1][1], f0.ah[1], f0.bl[1]);
-    } else {
-      MM(acc[0][0], f0.al[0], f0.bh[0]); SB(); f1.al[0] = LDA(0, 1, 1); SB();
-      MM(acc[0][1], f0.al[0], f0.bh[1]); SB(); f1.al[1] = LDA(1, 1, 1); SB();
-      MM(acc[1][0], f0.al[1], f0.bh[0]); SB(); f1.bl[0] = LDB(0, 1, 1); SB();
-      MM(acc[1][1], f0.al[1], f0.bh[1]); SB(); f1.bl[1] = LDB(1, 1, 1); SB();
-      MM(acc[0][0], f0.ah[0], f0.bl[0]);
-      MM(acc[0][1], f0.ah[0], f0.bl[1]);
-      MM(acc[1][0], f0.ah[1], f0.bl[0]);
-      MM(acc[1][1], f0.ah[1], f0.bl[1]);
+#pragma unroll
+    for (int m = 0; m < NMF; ++m) {          // phase A
+      mfma_slot(f0, m);
+      SB();
+      if (m < NRD) read_frag(f1, sa, sb, 1, m);
+      SB();
     }
-    SB();
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     SB();
-    // ---------------- phase B
-    const unsigned char* sa2 = smem + (buf ^ 1) * STAGE + offA;
-    const unsigned char* sb2 = smem + (buf ^ 1) * STAGE + offB;
-#define LDA2(i, hl) (*reinterpret_cast<const f16x8*>(sa2 + (i) * 4096 + lowp[0][hl]))
-#define LDB2(i, hl) (*reinterpret_cast<const f16x8*>(sb2 + (i) * 4096 + lowp[0][hl]))
-    MM(acc[0][0], f1.ah[0], f1.bh[0]); SB(); if (more) f0.ah[0] = LDA2(0, 0); if (more2 && ABL != 1) issue1(buf, 0); SB();
-    MM(acc[0][1], f1.ah[0], f1.bh[1]); SB(); if (more) f0.bh[0] = LDB2(0, 0); if (more2 && ABL != 1) issue1(buf, 1); SB();
-    MM(acc[1][0], f1.ah[1], f1.bh[0]); SB(); if (more) f0.ah[1] = LDA2(1, 0); if (more2 && ABL != 1) issue1(buf, 2); SB();
-    MM(acc[1][1], f1.ah[1], f1.bh[1]); SB(); if (more) f0.bh[1] = LDB2(1, 0); if (more2 && ABL != 1) issue1(buf, 3); SB();
-    if (TWOACC) {
-      MM(acx[0][0], f1.al[0], f1.bh[0]); SB(); if (more) f0.al[0] = LDA2(0, 1); if (more2 && ABL != 1) issue1(buf, 4); SB();
-      MM(acx[0][1], f1.al[0], f1.bh[1]); SB(); if (more) f0.al[1] = LDA2(1, 1); if (more2 && ABL != 1) issue1(buf, 5); SB();
-      MM(acx[1][0], f1.al[1], f1.bh[0]); SB(); if (more) f0.bl[0] = LDB2(0, 1); if (more2 && ABL != 1) issue1(buf, 6); SB();
-      MM(acx[1][1], f1.al[1], f1.bh[1]); SB(); if (more) f0.bl[1] = LDB2(1, 1); if (more2 && ABL != 1) issue1(buf, 7); SB();
-      MM(acx[0][0], f1.ah[0], f1.bl[0]);
-      MM(acx[0][1], f1.ah[0], f1.bl[1]);
-      MM(acx[1][0], f1.ah[1], f1.bl[0]);
-      MM(acx[1][1], f1.ah[1], f1.bl[1]);
-    } else {
-      MM(acc[0][0], f1.al[0], f1.bh[0]); SB(); if (more) f0.al[0] = LDA2(0, 1); if (more2 && ABL != 1) issue1(buf, 4); SB();
-      MM(acc[0][1], f1.al[0], f1.bh[1]); SB(); if (more) f0.al[1] = LDA2(1, 1); if (more2 && ABL != 1) issue1(buf, 5); SB();
-      MM(acc[1][0], f1.al[1], f1.bh[0]); SB(); if (more) f0.bl[0] = LDB2(0, 1); if (more2 && ABL != 1) issue1(buf, 6); SB();
-      MM(acc[1][1], f1.al[1], f1.bh[1]); SB(); if (more) f0.bl[1] = LDB2(1, 1); if (more2 && ABL != 1) issue1(buf, 7); SB();
-      MM(acc[0][0], f1.ah[0], f1.bl[0]);
-      MM(acc[0][1], f1.ah[0], f1.bl[1]);
-      MM(acc[1][0], f1.ah[1], f1.bl[0]);
-      MM(acc[1][1], f1.ah[1], f1.bl[1]);
+#pragma unroll
+    for (int m = 0; m < NMF; ++m) {          // phase B
+      mfma_slot(f1, m);
+      SB();
+      if (more && m < NRD) read_frag(f0, sa2, sb2, 0, m);
+      if (more2 && m < CPW) issue1(buf, m);
+      SB();
     }
-    SB();
   };
   {
     int t = 0;
@@ -243,19 +220,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
     if (t + 1 < nk) { iter(std::true_type{}, std::false_type{}, t); ++t; }
     if (t < nk) iter(std::false_type{}, std::false_type{}, t);
   }
-#undef LDA2
-#undef LDB2
-#undef LDA
-#undef LDB
 #undef MM
 #undef SB
   if (TWOACC) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < RM; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < RN; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] += acx[i][j][r] * (1.f / 2048.f);
+        for (int r = 0; r < 16; ++r) acc[i][j][r] += acx[TWOACC ? i : 0][TWOACC ? j : 0][r] * (1.f / 2048.f);
   }
 
   // ---- epilogue
@@ -263,15 +236,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
   const int M = g.M, N = g.N;
   float vmax = 0.f;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int col = n0 + wn * 64 + 32 * j + r32;
+  for (int j = 0; j < RN; ++j) {
+    const int col = n0 + wn * 32 * RN + 32 * j + r32;
     if (col >= N) continue;
     const float bias = g.bias ? g.bias[col] : 0.f;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < RM; ++i) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        const int row = m0 + wm * 32 * RM + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * kh;
         if (row >= M) continue;
         float v = alpha * acc[i][j][r] + bias;
         const int64_t o = (int64_t)row * g.ldc + col;
@@ -297,31 +270,26 @@ int g_force_tile = 0;   // test / tuning hook: 0 = heuristic, 1 = 128x128, 2 = 2
 // normal fp16 numbers for elements down to 2^-29 of the tensor maximum.  0: lo = fp16(t - hi), one accumulator (64 fewer
 // VGPRs, same speed at 2 waves per SIMD; full precision only down to 2^-15 of the maximum) - kept as a tuning hook.
 int g_loshift = 11;
-int g_abl = 0;          // ablation (tuning only): 1 = no LDS-DMA after the first stage, 2 = LDS-DMA only
 
-template <int WM, int WN>
-void launch(const SpArgs& g, int nz, hipStream_t st) {
-  if (g_abl == 1)
-    hipLaunchKernelGGL((gemm_sp_kernel<WM, WN, true, 1>), dim3(g.tm * g.tn, 1, nz), dim3(64 * WM * WN), 0, st, g);
-  else if (g_abl == 2)
-    hipLaunchKernelGGL((gemm_sp_kernel<WM, WN, true, 2>), dim3(g.tm * g.tn, 1, nz), dim3(64 * WM * WN), 0, st, g);
-  else if (g_loshift)
-    hipLaunchKernelGGL((gemm_sp_kernel<WM, WN, true>), dim3(g.tm * g.tn, 1, nz), dim3(64 * WM * WN), 0, st, g);
-  else
-    hipLaunchKernelGGL((gemm_sp_kernel<WM, WN, false>), dim3(g.tm * g.tn, 1, nz), dim3(64 * WM * WN), 0, st, g);
+template <int WM, int WN, int RM, int RN>
+void launch(SpArgs& g, int nz, hipStream_t st) {
+  g.tm = cdiv(g.M, 32 * RM * WM);
+  g.tn = cdiv(g.N, 32 * RN * WN);
+  if (g_loshift) {
+    if constexpr (RM * RN <= 4)
+      hipLaunchKernelGGL((gemm_sp_kernel<WM, WN, RM, RN, true>), dim3(g.tm * g.tn, 1, nz), dim3(64 * WM * WN), 0, st, g);
+  } else {
+    hipLaunchKernelGGL((gemm_sp_kernel<WM, WN, RM, RN, false>), dim3(g.tm * g.tn, 1, nz), dim3(64 * WM * WN), 0, st, g);
+  }
 }
 
 void dispatch(SpArgs& g, int nz, hipStream_t st) {
   // measured (tools/gemm_sp_bench.py): the 256 x 128 / 8-wave form only wins on huge square problems (8192^3: +2 %) and
-  // loses up to 15 % on the encoder shapes, so the heuristic always takes 128 x 128; the big tile stays as a tuning hook
-  const bool big = g_force_tile == 2;
-  if (big) {
-    g.tm = cdiv(g.M, 256); g.tn = cdiv(g.N, 128);
-    launch<4, 2>(g, nz, st);
-  } else {
-    g.tm = cdiv(g.M, 128); g.tn = cdiv(g.N, 128);
-    launch<2, 2>(g, nz, st);
-  }
+  // loses up to 15 % on the encoder shapes, so the heuristic takes 128 x 128; 256 x 256 (single accumulator only: 128
+  // accumulator registers per lane) is a tuning hook
+  if (g_force_tile == 2) launch<4, 2, 2, 2>(g, nz, st);
+  else if (g_force_tile == 3 && !g_loshift) launch<2, 4, 4, 2>(g, nz, st);
+  else launch<2, 2, 2, 2>(g, nz, st);
 }
 
 __global__ void sp_splitk_reduce_kernel(const float* __restrict__ ws, int nsplit, int64_t n, float* __restrict__ out,
@@ -404,7 +372,8 @@ __global__ __launch_bounds__(256) void sp_convert_kernel(const float* __restrict
     slot[EAV_SLOT_SIGMA] = sigma;
     slot[EAV_SLOT_ISIGMA] = 1.f / sigma;
   }
-  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int by = blockIdx.y;
+  const int r0 = by * 64, c0 = blockIdx.x * 64;
   const int t = threadIdx.x;
   {
     const int cg = t & 7, rr = t >> 3;
@@ -443,7 +412,7 @@ __global__ __launch_bounds__(256) void sp_convert_kernel(const float* __restrict
     for (int r = 0; r < 64; r += 4) {
       a += tile[r][t]; b += tile[r + 1][t]; c += tile[r + 2][t]; d += tile[r + 3][t];
     }
-    colsum_part[(int64_t)blockIdx.y * C + c0 + t] = ((a + b) + (c + d)) * (1.f / sigma);
+    colsum_part[(int64_t)by * C + c0 + t] = ((a + b) + (c + d)) * (1.f / sigma);
   }
   if (!dstT) return;
   {
@@ -485,7 +454,8 @@ extern "C" int eav_sp_convert(const float* src, int R, int C, int64_t ld, float*
   EAV_REQUIRE(src && slot && R > 0 && C > 0 && (dst || dstT), "eav_sp_convert: bad arguments");
   EAV_REQUIRE((ld & 3) == 0 && (((uintptr_t)src | (uintptr_t)dst | (uintptr_t)dstT) & 15) == 0,
               "eav_sp_convert: leading dimension must be a multiple of 4, buffers 16-byte aligned");
-  hipLaunchKernelGGL(sp_convert_kernel, dim3(cdiv(eav_sp_kpad(C), 64), cdiv(eav_sp_kpad(R), 64)), dim3(256), 0,
+  const int gx = cdiv(eav_sp_kpad(C), 64), gy = cdiv(eav_sp_kpad(R), 64);
+  hipLaunchKernelGGL(sp_convert_kernel, dim3(gx, gy), dim3(256), 0,
                      (hipStream_t)stream, src, R, C, ld, slot, (unsigned char*)dst, eav_sp_kpad(C),
                      (unsigned char*)dstT, eav_sp_kpad(R), g_loshift ? 2048.f : 1.f, (float*)nullptr);
   EAV_CHECK_LAUNCH("eav_sp_convert");
@@ -501,7 +471,8 @@ extern "C" int eav_sp_convert_colsum(const float* src, int R, int C, int64_t ld,
   EAV_REQUIRE(src && slot && R > 0 && C > 0 && colsum_part, "eav_sp_convert_colsum: bad arguments");
   EAV_REQUIRE((ld & 3) == 0 && (((uintptr_t)src | (uintptr_t)dst | (uintptr_t)dstT) & 15) == 0,
               "eav_sp_convert_colsum: leading dimension must be a multiple of 4, buffers 16-byte aligned");
-  hipLaunchKernelGGL(sp_convert_kernel, dim3(cdiv(eav_sp_kpad(C), 64), cdiv(eav_sp_kpad(R), 64)), dim3(256), 0,
+  const int gx = cdiv(eav_sp_kpad(C), 64), gy = cdiv(eav_sp_kpad(R), 64);
+  hipLaunchKernelGGL(sp_convert_kernel, dim3(gx, gy), dim3(256), 0,
                      (hipStream_t)stream, src, R, C, ld, slot, (unsigned char*)dst, eav_sp_kpad(C),
                      (unsigned char*)dstT, eav_sp_kpad(R), g_loshift ? 2048.f : 1.f, colsum_part);
   EAV_CHECK_LAUNCH("eav_sp_convert_colsum");
@@ -511,7 +482,6 @@ extern "C" int eav_sp_convert_colsum(const float* src, int R, int C, int64_t ld,
 extern "C" int eav_gemm_sp_set_tile(int which) {
   g_force_tile = which & 3;
   g_loshift = (which & 4) ? 0 : 11;
-  g_abl = (which >> 4) & 3;
   return EAV_OK;
 }
 

@@ -22,6 +22,29 @@ __global__ __launch_bounds__(256) void peak_mfma_f32_kernel(float* __restrict__ 
   if (s == 12345.678f) sink[0] = s;      // keeps the loop alive, never true
 }
 
+typedef _Float16 pk_f16x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void peak_mfma_f16_kernel(float* __restrict__ sink, int iters) {
+  f32x16 a0, a1, a2, a3;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; a2[r] = 0.f; a3[r] = 0.f; }
+  pk_f16x8 x, y;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {        // full-range random-looking operands (zero operands clock higher: DVFS)
+    x[e] = (_Float16)(0.37f * (float)(((threadIdx.x * 7 + e * 13) % 23) - 11));
+    y[e] = (_Float16)(0.11f * (float)(((threadIdx.x * 5 + e * 3) % 19) - 9));
+  }
+  for (int i = 0; i < iters; ++i) {
+    a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, a0, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, a1, 0, 0, 0);
+    a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, a2, 0, 0, 0);
+    a3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, a3, 0, 0, 0);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s += a0[r] + a1[r] + a2[r] + a3[r];
+  if (s == 12345.678f) sink[0] = s;
+}
+
 __global__ __launch_bounds__(256) void peak_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int64_t n4) {
   const int64_t stride = (int64_t)gridDim.x * 256;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) dst[i] = src[i];
@@ -76,9 +99,19 @@ extern "C" int eav_peak_mfma_f32(float* sink, int blocks, int iters, void* strea
   return EAV_OK;
 }
 
+// `blocks` x 4 waves, each issuing 4*iters v_mfma_f32_32x32x16_f16: FLOP = blocks*4*iters*4*32768
+extern "C" int eav_peak_mfma_f16(float* sink, int blocks, int iters, void* stream) {
+  EAV_REQUIRE(sink && blocks > 0 && iters > 0, "eav_peak_mfma_f16: bad arguments");
+  hipLaunchKernelGGL(peak_mfma_f16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, sink, iters);
+  EAV_CHECK_LAUNCH("eav_peak_mfma_f16");
+  return EAV_OK;
+}
+
 extern "C" int eav_peak_copy(const float* src, float* dst, int64_t n, void* stream) {
   EAV_REQUIRE(src && dst && n > 0 && (n & 3) == 0, "eav_peak_copy: bad arguments");
-  hipLaunchKernelGGL(peak_copy_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream,
+  // one block per CU, four non-temporal 16-byte loads in flight per lane: the best of tools/copy_bench.py's sweep
+  // (6.2 TB/s read+write; thousands of blocks in flight spread the accesses over too many DRAM pages: 4.5 TB/s)
+  hipLaunchKernelGGL((peak_copy_u_kernel<4, true>), dim3(256), dim3(256), 0, (hipStream_t)stream,
                      reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(dst), n / 4);
   EAV_CHECK_LAUNCH("eav_peak_copy");
   return EAV_OK;

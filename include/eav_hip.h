@@ -358,6 +358,7 @@ int eav_sosfilt_f64(const double* x, double* y, const double* sos, const double*
 /* ---- measured peaks (bench.py): register-only fp32 MFMA loop (FLOP = blocks*4 waves*iters*4*4096) and a float4
  *      streaming copy, to quote roofline fractions against what this chip sustains. */
 int eav_peak_mfma_f32(float* sink, int blocks, int iters, void* stream);
+int eav_peak_mfma_f16(float* sink, int blocks, int iters, void* stream);
 int eav_peak_copy_variant(const float* src, float* dst, int64_t n, int variant, int blocks, void* stream);
 int eav_peak_copy(const float* src, float* dst, int64_t n, void* stream);
 

@@ -82,19 +82,25 @@ def check_wgrad(Mtok, N, K):
 
 
 def bench(name, M, N, K, epi=False):
+    """tile codes (eav_gemm_sp_set_tile): 1 = 128x128 two-accumulator planes, 5 = 128x128 single-accumulator planes,
+    7 = 256x256 single-accumulator planes (the operand planes are converted in the matching format)."""
     A = torch.randn(M, K, device="cuda")
     B = torch.randn(N, K, device="cuda") * 0.02
-    sa, pa, _ = planes(A)
-    sb, pb, _ = planes(B)
     C = torch.empty(M, N, device="cuda")
     bias = torch.randn(N, device="cuda") if epi else None
     pre = torch.empty(M, N, device="cuda") if epi else None
+    ref = None
     out = []
-    for tile in (1, 2, 17, 18):
+    for tile in (1, 5, 7):
         _lib.call("eav_gemm_sp_set_tile", tile)
+        sa, pa, _ = planes(A)
+        sb, pb, _ = planes(B)
         ms = timeit(lambda: _lib.call("eav_gemm_sp", P(pa), P(pb), P(C), P(sa), P(sb), M, N, K, N, 1, 0, 0, 1.0,
                                       P(bias), 1 if epi else 0, P(pre), None, 0, 0, None, None))
-        out.append(f"tile{tile}: {ms:7.3f} ms {2.0 * M * N * K / ms / 1e9:7.1f} TF")
+        if ref is None:
+            ref = C.clone()
+        err = ((C - ref).abs().max() / ref.abs().max()).item()
+        out.append(f"tile{tile}: {ms:7.3f} ms {2.0 * M * N * K / ms / 1e9:7.1f} TF (d {err:.0e})")
     _lib.call("eav_gemm_sp_set_tile", 0)
     print(f"{name:28s} M={M:6d} N={N:5d} K={K:6d}  " + "   ".join(out))
 
@@ -116,12 +122,14 @@ def bench_convert(R, C):
     slot = torch.zeros(2080, device="cuda")
     d = torch.empty(R, 2 * kpad(C), dtype=torch.float16, device="cuda")
     dT = torch.empty(C, 2 * kpad(R), dtype=torch.float16, device="cuda")
-    ms0 = timeit(lambda: _lib.call("eav_sp_absmax", P(x), R, C, C, P(slot), None))
-    ms1 = timeit(lambda: _lib.call("eav_sp_convert", P(x), R, C, C, P(slot), P(d), None, None))
-    ms2 = timeit(lambda: _lib.call("eav_sp_convert", P(x), R, C, C, P(slot), P(d), P(dT), None))
     gb = R * C * 4 / 1e9
-    print(f"convert [{R},{C}]: absmax {ms0 * 1e3:6.1f} us ({gb / ms0:5.2f} TB/s)  planes {ms1 * 1e3:6.1f} us "
-          f"({2 * gb / ms1:5.2f} TB/s)  planes+T {ms2 * 1e3:6.1f} us ({3 * gb / ms2:5.2f} TB/s)")
+    for swap in (0,):
+        ms0 = timeit(lambda: _lib.call("eav_sp_absmax", P(x), R, C, C, P(slot), None))
+        ms1 = timeit(lambda: _lib.call("eav_sp_convert", P(x), R, C, C, P(slot), P(d), None, None))
+        ms2 = timeit(lambda: _lib.call("eav_sp_convert", P(x), R, C, C, P(slot), P(d), P(dT), None))
+        print(f"convert [{R},{C}]: absmax {ms0 * 1e3:6.1f} us ({gb / ms0:5.2f} TB/s)  planes {ms1 * 1e3:6.1f} us "
+              f"({2 * gb / ms1:5.2f} TB/s)  planes+T {ms2 * 1e3:6.1f} us ({3 * gb / ms2:5.2f} TB/s)")
+    _lib.call("eav_gemm_sp_set_tile", 0)
 
 
 def checks():
@@ -137,7 +145,7 @@ def checks():
 if __name__ == "__main__":
     _lib.load()
     checks()
-    print("-- two-accumulator mode (lo scaled by 2^11)")
+    print("-- single-accumulator mode (lo not lifted by 2^11)")
     _lib.call("eav_gemm_sp_set_tile", 4)
     checks()
     _lib.call("eav_gemm_sp_set_tile", 0)

@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""gpurun_out/prof_<tag>/ (tools/collect_profiles.sh) -> the small files kept under profiles/:
+
+  <tag>_<run>_kernel_stats.csv     rocprofv3 --kernel-trace --stats summary, as emitted
+  <tag>_<run>_pmc.json             per kernel, mean per launch: duration, HBM bytes (FETCH_SIZE / WRITE_SIZE in KiB;
+                                   FETCH doubled: gfx950 tallies 128-B requests at 64 B - MI355X guide), MFMA pipe busy
+                                   (SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x GRBM_GUI_ACTIVE / 8 XCDs)) and the
+                                   wave-cycle split (parked / issue-stalled).
+usage: summarise_profiles.py <tag>"""
+import collections
+import csv
+import json
+import os
+import re
+import shutil
+import sys
+
+tag = sys.argv[1]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", f"prof_{tag}")
+dst = os.path.join(root, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+
+def short(name):
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    return re.sub(r"\(.*", "", name).strip()
+
+
+def counters(path):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    if not os.path.exists(path):
+        return agg
+    for r in csv.DictReader(open(path)):
+        agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return agg
+
+
+def durations(path):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        agg[short(r["Kernel_Name"])].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+    return agg
+
+
+for run in ("eeg", "ast", "vit"):
+    stats = os.path.join(src, f"{run}_trace", f"{run}_kernel_stats.csv")
+    if not os.path.exists(stats):
+        continue
+    shutil.copy(stats, os.path.join(dst, f"{tag}_{run}_kernel_stats.csv"))
+    dur = durations(os.path.join(src, f"{run}_trace", f"{run}_kernel_trace.csv"))
+    fetch = counters(os.path.join(src, f"{run}_fetch", f"{run}_counter_collection.csv"))
+    write = counters(os.path.join(src, f"{run}_write", f"{run}_counter_collection.csv"))
+    mfma = counters(os.path.join(src, f"{run}_mfma", f"{run}_counter_collection.csv"))
+    total = sum(sum(v) for v in dur.values())
+    out = {}
+    for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
+        if sum(v) < 0.002 * total:
+            continue
+        mean = lambda d, c: (sum(d[k][c]) / len(d[k][c])) if d[k].get(c) else None   # noqa: E731
+        e = {"calls": len(v), "avg_us": round(sum(v) / len(v) / 1e3, 2), "share_of_kernel_time": round(sum(v) / total, 4)}
+        f, w = mean(fetch, "FETCH_SIZE"), mean(write, "WRITE_SIZE")
+        if f is not None and w is not None:
+            e["hbm_read_bytes"] = round(2.0 * f * 1024)
+            e["hbm_write_bytes"] = round(w * 1024)
+            e["hbm_gb_per_s"] = round((2.0 * f + w) * 1024 / (sum(v) / len(v)), 1)      # bytes / ns = GB/s
+        busy, gui = mean(mfma, "SQ_VALU_MFMA_BUSY_CYCLES"), mean(mfma, "GRBM_GUI_ACTIVE")
+        if busy is not None and gui:
+            e["mfma_pipe_busy"] = round(busy / (1024.0 * gui / 8.0), 4)
+            wc = mean(mfma, "SQ_WAVE_CYCLES")
+            if wc:
+                e["wave_cycles_parked"] = round(mean(mfma, "SQ_WAIT_ANY") / wc, 3)
+                e["wave_cycles_issue_stalled"] = round(mean(mfma, "SQ_WAIT_INST_ANY") / wc, 3)
+        out[k] = e
+    note = ("mean per launch over the profiled run; hbm_read = 2 x FETCH_SIZE x 1024 (gfx950 correction), hbm_write = "
+            "WRITE_SIZE x 1024; mfma_pipe_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs); "
+            "counters come from separate --pmc passes of the same command (tools/collect_profiles.sh)")
+    json.dump({"note": note, "total_kernel_ms": round(total / 1e6, 3), "kernels": out},
+              open(os.path.join(dst, f"{tag}_{run}_pmc.json"), "w"), indent=1)
+    print(run, "total kernel ms", round(total / 1e6, 2))
+    for k, e in list(out.items())[:14]:
+        print(f"  {k[:44]:44s} {e['calls']:5d} x {e['avg_us']:9.1f} us  share {e['share_of_kernel_time']:.3f}  "
+              f"HBM {e.get('hbm_gb_per_s', '-'):>7} GB/s  MFMA busy {e.get('mfma_pipe_busy', '-')}")
+# bench.py's roofline.traffic reads <tag>_eegnet_hbm_traffic.json: keep that name / shape for the EEGNet run
+p = os.path.join(dst, f"{tag}_eeg_pmc.json")
+if os.path.exists(p):
+    d = json.load(open(p))
+    ker = {k if k.endswith("_kernel") or "<" in k else k: {"read_bytes": e.get("hbm_read_bytes"),
+                                                            "write_bytes": e.get("hbm_write_bytes"),
+                                                            "total_bytes": (e.get("hbm_read_bytes") or 0) + (e.get("hbm_write_bytes") or 0)}
+           for k, e in d["kernels"].items() if "hbm_read_bytes" in e}
+    for k in list(ker):            # bare template names too ("fir_wgrad_kernel<10, false>" -> "fir_wgrad_kernel")
+        b = k.split("<")[0]
+        ker.setdefault(b, ker[k])
+    json.dump({"note": d["note"], "kernels": ker}, open(os.path.join(dst, f"{tag}_eegnet_hbm_traffic.json"), "w"), indent=1)

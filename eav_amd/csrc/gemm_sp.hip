@@ -76,17 +76,18 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
 
-  // ---- workgroup -> tile: XCD-contiguous, then groups of 8 tile-rows
+  // ---- persistent workgroups: tile ids blockIdx.x, blockIdx.x + gridDim.x, ... (gridDim.x is a multiple of 8 whenever a
+  // workgroup gets more than one tile, so a workgroup stays on its XCD).  tile id -> tile: XCD-contiguous, then groups
+  // of 8 tile-rows x all tile-columns, so that each XCD's L2 sees a compact set of operand panels.
   const int nb = g.tm * g.tn;
-  int lin;
-  {
-    const int id = blockIdx.x, q = nb >> 3, r = nb & 7, xcd = id & 7, j = id >> 3;
-    lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-  }
-  const int gsz = 8 * g.tn, grp = lin / gsz, first_m = grp * 8;
-  const int gm = min(8, g.tm - first_m), rem = lin - grp * gsz;
-  const int tile_m = first_m + rem % gm, tile_n = rem / gm;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  auto tile_origin = [&](int id, int& m0, int& n0) {
+    const int q = nb >> 3, r = nb & 7, xcd = id & 7, j = id >> 3;
+    const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    const int gsz = 8 * g.tn, grp = lin / gsz, first_m = grp * 8;
+    const int gm = min(8, g.tm - first_m), rem = lin - grp * gsz;
+    m0 = (first_m + rem % gm) * BM;
+    n0 = (rem / gm) * BN;
+  };
 
   const int z = blockIdx.z;
   const unsigned char* Ab = g.A;
@@ -100,30 +101,30 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
     Ab += z * g.sA;
     C += z * g.sC;
   }
+  const int nk = kt1 - kt0;
+  if (nk <= 0) return;
 
   // ---- per-lane global source pointers of this wave's chunks (row clamped: ragged tiles re-read the last row)
   const unsigned char* gp[CPW];
+  auto set_sources = [&](int m0, int n0) {
 #pragma unroll
-  for (int i = 0; i < CPW; ++i) {
-    const int c = wave + NW * i;                       // wave-uniform chunk id
-    const int row = 8 * c + (lane >> 3);               // row in the combined [A tile; B tile] image
-    const int p = (lane & 7) ^ ((row >> 1) & 7);       // piece held by this lane's slot
-    if (8 * c < BM) {
-      const int gr = min(m0 + row, g.M - 1);
-      gp[i] = Ab + (int64_t)gr * g.ldA + (int64_t)kt0 * 128 + p * 16;
-    } else {
-      const int gr = min(n0 + row - BM, g.N - 1);
-      gp[i] = g.B + (int64_t)gr * g.ldB + (int64_t)kt0 * 128 + p * 16;
+    for (int i = 0; i < CPW; ++i) {
+      const int c = wave + NW * i;                       // wave-uniform chunk id
+      const int row = 8 * c + (lane >> 3);               // row in the combined [A tile; B tile] image
+      const int p = (lane & 7) ^ ((row >> 1) & 7);       // piece held by this lane's slot
+      if (8 * c < BM) {
+        const int gr = min(m0 + row, g.M - 1);
+        gp[i] = Ab + (int64_t)gr * g.ldA + (int64_t)kt0 * 128 + p * 16;
+      } else {
+        const int gr = min(n0 + row - BM, g.N - 1);
+        gp[i] = g.B + (int64_t)gr * g.ldB + (int64_t)kt0 * 128 + p * 16;
+      }
     }
-  }
+  };
   auto issue1 = [&](int buf, int i) {
     const int c = wave + NW * i;
     __builtin_amdgcn_global_load_lds((glb_ptr_t)gp[i], (lds_ptr_t)(smem + buf * STAGE + c * 1024), 16, 0, 0);
     gp[i] += 128;
-  };
-  auto issue = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < CPW; ++i) issue1(buf, i);
   };
 
   // ---- fragment addressing
@@ -136,27 +137,19 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
     for (int hl = 0; hl < 2; ++hl) lowp[ks][hl] = ((2 * (2 * ks + kh) + hl) ^ gq) * 16;
   const int offA = (wm * 32 * RM + r32) * 128, offB = A_BYTES + (wn * 32 * RN + r32) * 128;
 
-  f32x16 acc[RM][RN], acx[TWOACC ? RM : 1][TWOACC ? RN : 1];
-#pragma unroll
-  for (int i = 0; i < RM; ++i)
-#pragma unroll
-    for (int j = 0; j < RN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        acc[i][j][r] = 0.f;
-        if (TWOACC) acx[i][j][r] = 0.f;
-      }
-
   // ---- main loop: software-pipelined and explicitly interleaved (sched_barrier pins the order as written).
-  // Two fragment register sets: f0 = K-step 0 of a tile, f1 = K-step 1.  Iteration t:
+  // Two fragment register sets: f0 = K-step 0 of a K-tile, f1 = K-step 1.  Iteration t:
   //   phase A: MFMAs on f0(t)   || ds_read f1(t) from buffer t&1
   //   lgkmcnt(0), vmcnt(0) [stage t+1 landed], barrier
   //   phase B: MFMAs on f1(t)   || ds_read f0(t+1) from buffer (t+1)&1 || LDS-DMA of stage t+2 into buffer t&1
   // so LDS reads, the next stage's DMA issue and their address arithmetic all hide behind MFMA issue slots; a stage has
-  // a whole tile's MFMA time to land.  Every wave's reads of buffer t&1 are complete (lgkmcnt(0)) before the barrier that
-  // precedes its re-fill.  One MFMA slot = one MFMA, then (pinned behind it) at most one fragment read and one DMA.
+  // a whole K-tile's MFMA time to land.  Every wave's reads of buffer t&1 are complete (lgkmcnt(0)) before the barrier
+  // that precedes its re-fill.  One MFMA slot = one MFMA, then (pinned behind it) at most one fragment read and one DMA.
+  // In the LAST K-tile's phase B both buffers are free: the NEXT output tile's stages 0 and 1 are issued there, so they
+  // land under this tile's epilogue (a K = 768 problem otherwise spends a quarter of its time in cold prologues).
   struct Frags { f16x8 ah[RM], al[RM], bh[RN], bl[RN]; };
   Frags f0, f1;
+  f32x16 acc[RM][RN], acx[TWOACC ? RM : 1][TWOACC ? RN : 1];
 #define SB() __builtin_amdgcn_sched_barrier(0)
 #define MM(c, a, b) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
   // fragment read number r of a K-step: ah[0..RM), bh[0..RN), al[0..RM), bl[0..RN)
@@ -178,16 +171,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
       else MM(acc[i][j], f.ah[i], f.bl[j]);
     }
   };
-  const int nk = kt1 - kt0;
-  if (nk > 0) {
-    issue(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (nk > 1) issue(1);
-#pragma unroll
-    for (int r = 0; r < NRD; ++r) read_frag(f0, smem + offA, smem + offB, 0, r);
-  }
-  auto iter = [&](auto more_c, auto more2_c, int t) {
+  // more: a K-tile t+1 exists (read its first fragments); more2: a K-tile t+2 exists (issue its DMA);
+  // next_m0 >= 0 (last K-tile only): issue the next output tile's first two stages instead
+  auto iter = [&](auto more_c, auto more2_c, int t, int next_m0, int next_n0) {
     constexpr bool more = decltype(more_c)::value, more2 = decltype(more2_c)::value;
     const int buf = t & 1;
     const unsigned char* sa = smem + buf * STAGE + offA;
@@ -205,64 +191,104 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     SB();
+    if (!more && next_m0 >= 0) set_sources(next_m0, next_n0);
 #pragma unroll
     for (int m = 0; m < NMF; ++m) {          // phase B
       mfma_slot(f1, m);
       SB();
       if (more && m < NRD) read_frag(f0, sa2, sb2, 0, m);
       if (more2 && m < CPW) issue1(buf, m);
+      if (!more && next_m0 >= 0) {
+        if (m < CPW) issue1(0, m);
+        else if (m < 2 * CPW && nk > 1) issue1(1, m - CPW);
+      }
       SB();
     }
+    if (!more && next_m0 >= 0 && nk > 1) {       // the rest of the next tile's second stage (2 CPW may exceed the slots)
+#pragma unroll
+      for (int m = NMF; m < 2 * CPW; ++m) issue1(1, m - CPW);
+    }
   };
-  {
-    int t = 0;
-    for (; t + 2 < nk; ++t) iter(std::true_type{}, std::true_type{}, t);
-    if (t + 1 < nk) { iter(std::true_type{}, std::false_type{}, t); ++t; }
-    if (t < nk) iter(std::false_type{}, std::false_type{}, t);
-  }
-#undef MM
-#undef SB
-  if (TWOACC) {
+
+  bool primed = false;
+  for (int tl = blockIdx.x; tl < nb; tl += gridDim.x) {
+    int m0, n0, nm0 = -1, nn0 = -1;
+    tile_origin(tl, m0, n0);
+    if (tl + (int)gridDim.x < nb) tile_origin(tl + gridDim.x, nm0, nn0);
+    if (!primed) {
+      set_sources(m0, n0);
+#pragma unroll
+      for (int i = 0; i < CPW; ++i) issue1(0, i);
+      if (nk > 1) {
+#pragma unroll
+        for (int i = 0; i < CPW; ++i) issue1(1, i);
+      }
+      primed = true;
+    }
 #pragma unroll
     for (int i = 0; i < RM; ++i)
 #pragma unroll
       for (int j = 0; j < RN; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] += acx[TWOACC ? i : 0][TWOACC ? j : 0][r] * (1.f / 2048.f);
-  }
+        for (int r = 0; r < 16; ++r) {
+          acc[i][j][r] = 0.f;
+          if (TWOACC) acx[i][j][r] = 0.f;
+        }
+    // stages 0 and 1 of this tile (issued in the prologue, or under the previous tile's last K-tile and epilogue)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int r = 0; r < NRD; ++r) read_frag(f0, smem + offA, smem + offB, 0, r);
+    {
+      int t = 0;
+      for (; t + 2 < nk; ++t) iter(std::true_type{}, std::true_type{}, t, -1, -1);
+      if (t + 1 < nk) { iter(std::true_type{}, std::false_type{}, t, -1, -1); ++t; }
+      if (t < nk) iter(std::false_type{}, std::false_type{}, t, nm0, nn0);
+    }
 
-  // ---- epilogue
-  const float alpha = g.alpha * g.slotA[EAV_SLOT_ISIGMA] * g.slotB[EAV_SLOT_ISIGMA];
-  const int M = g.M, N = g.N;
-  float vmax = 0.f;
+    // ---- epilogue of this tile (the next tile's first stages are in flight)
+    if (TWOACC) {
 #pragma unroll
-  for (int j = 0; j < RN; ++j) {
-    const int col = n0 + wn * 32 * RN + 32 * j + r32;
-    if (col >= N) continue;
-    const float bias = g.bias ? g.bias[col] : 0.f;
+      for (int i = 0; i < RM; ++i)
 #pragma unroll
-    for (int i = 0; i < RM; ++i) {
+        for (int j = 0; j < RN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 32 * RM + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        if (row >= M) continue;
-        float v = alpha * acc[i][j][r] + bias;
-        const int64_t o = (int64_t)row * g.ldc + col;
-        if (g.pre) g.pre[(g.kt_per_split > 0 ? 0 : z * g.sC) + o] = v;
-        if (g.gelu) v = gelu_erf(v);
-        if (g.resid) v += g.resid[(int64_t)row * g.ldr + col];
-        if (g.accumulate) v += C[o];
-        C[o] = v;
-        vmax = fmaxf(vmax, fabsf(v));
+          for (int r = 0; r < 16; ++r) acc[i][j][r] += acx[TWOACC ? i : 0][TWOACC ? j : 0][r] * (1.f / 2048.f);
+    }
+    const float alpha = g.alpha * g.slotA[EAV_SLOT_ISIGMA] * g.slotB[EAV_SLOT_ISIGMA];
+    const int M = g.M, N = g.N;
+    float vmax = 0.f;
+#pragma unroll
+    for (int j = 0; j < RN; ++j) {
+      const int col = n0 + wn * 32 * RN + 32 * j + r32;
+      if (col >= N) continue;
+      const float bias = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+      for (int i = 0; i < RM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wm * 32 * RM + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * kh;
+          if (row >= M) continue;
+          float v = alpha * acc[i][j][r] + bias;
+          const int64_t o = (int64_t)row * g.ldc + col;
+          if (g.pre) g.pre[(g.kt_per_split > 0 ? 0 : z * g.sC) + o] = v;
+          if (g.gelu) v = gelu_erf(v);
+          if (g.resid) v += g.resid[(int64_t)row * g.ldr + col];
+          if (g.accumulate) v += C[o];
+          C[o] = v;
+          vmax = fmaxf(vmax, fabsf(v));
+        }
       }
     }
-  }
-  if (g.amax) {
+    if (g.amax) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
-    if (lane == 0 && vmax == vmax)
-      atomicMax(g.amax + EAV_SLOT_SHARD(blockIdx.x * NW + wave + 17 * blockIdx.z), __float_as_uint(vmax));
+      for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+      if (lane == 0 && vmax == vmax)
+        atomicMax(g.amax + EAV_SLOT_SHARD(tl * NW + wave + 17 * blockIdx.z), __float_as_uint(vmax));
+    }
   }
+#undef MM
+#undef SB
 }
 
 int g_force_tile = 0;   // test / tuning hook: 0 = heuristic, 1 = 128x128, 2 = 256x128
@@ -270,16 +296,21 @@ int g_force_tile = 0;   // test / tuning hook: 0 = heuristic, 1 = 128x128, 2 = 2
 // normal fp16 numbers for elements down to 2^-29 of the tensor maximum.  0: lo = fp16(t - hi), one accumulator (64 fewer
 // VGPRs, same speed at 2 waves per SIMD; full precision only down to 2^-15 of the maximum) - kept as a tuning hook.
 int g_loshift = 11;
+int g_persist = 1;      // tuning hook: 0 = one workgroup per output tile
 
 template <int WM, int WN, int RM, int RN>
 void launch(SpArgs& g, int nz, hipStream_t st) {
   g.tm = cdiv(g.M, 32 * RM * WM);
   g.tn = cdiv(g.N, 32 * RN * WN);
+  // persistent workgroups: as many as stay resident (2 per CU for 4-wave tiles, 1 for 8-wave tiles), a multiple of 8 so
+  // that every workgroup's tiles stay on one XCD; fewer tiles than that: one workgroup per tile
+  const int resident = (WM * WN <= 4 ? 2 : 1) * 256 * (g_persist ? 1 : 1 << 20);
+  const int nb = g.tm * g.tn, gx = nb <= resident ? nb : resident;
   if (g_loshift) {
     if constexpr (RM * RN <= 4)
-      hipLaunchKernelGGL((gemm_sp_kernel<WM, WN, RM, RN, true>), dim3(g.tm * g.tn, 1, nz), dim3(64 * WM * WN), 0, st, g);
+      hipLaunchKernelGGL((gemm_sp_kernel<WM, WN, RM, RN, true>), dim3(gx, 1, nz), dim3(64 * WM * WN), 0, st, g);
   } else {
-    hipLaunchKernelGGL((gemm_sp_kernel<WM, WN, RM, RN, false>), dim3(g.tm * g.tn, 1, nz), dim3(64 * WM * WN), 0, st, g);
+    hipLaunchKernelGGL((gemm_sp_kernel<WM, WN, RM, RN, false>), dim3(gx, 1, nz), dim3(64 * WM * WN), 0, st, g);
   }
 }
 
@@ -482,6 +513,7 @@ extern "C" int eav_sp_convert_colsum(const float* src, int R, int C, int64_t ld,
 extern "C" int eav_gemm_sp_set_tile(int which) {
   g_force_tile = which & 3;
   g_loshift = (which & 4) ? 0 : 11;
+  g_persist = (which & 8) ? 0 : 1;
   return EAV_OK;
 }
 

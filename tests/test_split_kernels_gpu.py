@@ -70,7 +70,8 @@ def test_planes_encode_the_tensor():
     assert torch.equal(recT[:, :77], rec[:, :100].t())
 
 
-@pytest.mark.parametrize("shape", [(512, 384, 768), (1000, 200, 100), (9712, 768, 3072), (300, 130, 40), (64, 5, 36)])
+@pytest.mark.parametrize("shape", [(512, 384, 768), (1000, 200, 100), (9712, 768, 3072), (300, 130, 40), (64, 5, 36),
+                                   (9712, 2304, 768)])     # the last one: 1368 tiles on 512 persistent workgroups
 @pytest.mark.parametrize("amp", [(1.0, 0.02), (2e-5, 3e4)])
 def test_gemm_sp_is_fp32_grade(shape, amp):
     M, N, K = shape

@@ -82,8 +82,9 @@ def check_wgrad(Mtok, N, K):
 
 
 def bench(name, M, N, K, epi=False):
-    """tile codes (eav_gemm_sp_set_tile): 1 = 128x128 two-accumulator planes, 5 = 128x128 single-accumulator planes,
-    7 = 256x256 single-accumulator planes (the operand planes are converted in the matching format)."""
+    """tile codes (eav_gemm_sp_set_tile): 1 = 128x128 two-accumulator planes, +4 = single-accumulator planes, 3 = 256x256
+    (single-accumulator only), +8 = one workgroup per tile instead of persistent workgroups (the operand planes are
+    converted in the matching format)."""
     A = torch.randn(M, K, device="cuda")
     B = torch.randn(N, K, device="cuda") * 0.02
     C = torch.empty(M, N, device="cuda")
@@ -91,7 +92,7 @@ def bench(name, M, N, K, epi=False):
     pre = torch.empty(M, N, device="cuda") if epi else None
     ref = None
     out = []
-    for tile in (1, 5, 7):
+    for tile in (1, 9):
         _lib.call("eav_gemm_sp_set_tile", tile)
         sa, pa, _ = planes(A)
         sb, pb, _ = planes(B)
@@ -138,6 +139,7 @@ def checks():
     check(9712, 768, 3072)
     check(2048, 768, 768, wide=True)
     check(300, 130, 40, scaleA=1e-6, scaleB=1e4)
+    check(9712, 2304, 768)          # 1368 tiles: persistent workgroups, several tiles each
     check_wgrad(9712, 768, 256)
     check_wgrad(1214, 200, 136)
 

@@ -317,6 +317,26 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int nsplit, i
   *reinterpret_cast<float4*>(out + i) = make_float4((float)a, (float)b, (float)c, (float)d);
 }
 
+// small outputs with many slices (the ShallowConvNet weight gradients: 40 x 160 outputs, up to 64 slices): 8 lanes share
+// one float4 of the output and walk the slices 8 apart - the serial chain of `nsplit` dependent loads was pure latency -
+// then combine in a fixed butterfly order (fp64, deterministic)
+__global__ void splitk_reduce_wide_kernel(const float* __restrict__ ws, int nsplit, int64_t n, float* __restrict__ out) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int sub = (int)(gid & 7);
+  const int64_t i = (gid >> 3) * 4;
+  double a = 0, b = 0, c = 0, d = 0;
+  if (i < n)
+    for (int s = sub; s < nsplit; s += 8) {
+      const float4 v = *reinterpret_cast<const float4*>(ws + (int64_t)s * n + i);
+      a += v.x; b += v.y; c += v.z; d += v.w;
+    }
+#pragma unroll
+  for (int o = 1; o < 8; o <<= 1) {
+    a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); c += __shfl_xor(c, o, 64); d += __shfl_xor(d, o, 64);
+  }
+  if (sub == 0 && i < n) *reinterpret_cast<float4*>(out + i) = make_float4((float)a, (float)b, (float)c, (float)d);
+}
+
 extern "C" int eav_gemm_f32_splitk(const float* A, const float* B, float* C, float* ws, int M, int N, int K, int lda,
                                    int ldb, int transA, int transB, void* stream) {
   EAV_REQUIRE(A && B && C && ws && M > 0 && N > 0 && K > 0, "eav_gemm_f32_splitk: bad arguments");
@@ -345,7 +365,10 @@ extern "C" int eav_gemm_f32_splitk(const float* A, const float* B, float* C, flo
   EAV_CHECK_LAUNCH("eav_gemm_f32_splitk");
   if (nsplit > 1) {
     const int64_t n = (int64_t)M * N;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv64(n, 1024)), dim3(256), 0, st, ws, nz, n, C);
+    if (nz >= 16 && n <= (1 << 18))
+      hipLaunchKernelGGL(splitk_reduce_wide_kernel, dim3((unsigned)cdiv64(n * 2, 256)), dim3(256), 0, st, ws, nz, n, C);
+    else
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv64(n, 1024)), dim3(256), 0, st, ws, nz, n, C);
     EAV_CHECK_LAUNCH("eav_gemm_f32_splitk(reduce)");
   }
   return EAV_OK;

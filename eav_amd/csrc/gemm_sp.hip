@@ -77,6 +77,21 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return x < 0.f ? h : x - h;
 }
 
+// d gelu / dx = Phi(x) + x phi(x) from the same erfc fit: Phi = erfc(z) / 2 for x < 0, 1 - erfc(z) / 2 otherwise
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.55f, z, 1.0f));
+  float p = 0.10732425004243851f;
+  p = fmaf(p, t, -0.5180373191833496f);
+  p = fmaf(p, t, 0.7597128748893738f);
+  p = fmaf(p, t, -0.04142485186457634f);
+  p = fmaf(p, t, 0.3908415734767914f);
+  p = fmaf(p, t, 0.30158352851867676f);
+  const float e = __builtin_amdgcn_exp2f(-(z * z) * 1.4426950408889634f);
+  const float hq = 0.5f * p * t * e;
+  return (x < 0.f ? hq : 1.0f - hq) + x * e * 0.3989422804014327f;
+}
+
 // WM x WN waves, each a (32 RM) x (32 RN) block of RM x RN MFMA tiles.
 template <int WM, int WN, int RM, int RN, bool TWOACC>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_kernel(SpArgs g) {
@@ -315,7 +330,21 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
           f32x16& a = acc[i][j];
 #pragma unroll
           for (int r = 0; r < 16; ++r) a[r] = alpha * a[r] + bv[r];
-          if (pre) {
+          if (g.gelu == 2) {        // backward through GELU: scale by gelu'(pre), pre = the forward's stored pre-activation
+            float pv[16];
+            if constexpr (VEC) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const float4 v4 = *reinterpret_cast<const float4*>(pre + o + 8 * q);
+                pv[4 * q] = v4.x; pv[4 * q + 1] = v4.y; pv[4 * q + 2] = v4.z; pv[4 * q + 3] = v4.w;
+              }
+            } else {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) pv[r] = ok(r) ? pre[o + 8 * (r >> 2) + (r & 3)] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a[r] *= gelu_erf_grad(pv[r]);
+          } else if (pre) {
             if constexpr (VEC) {
 #pragma unroll
               for (int q = 0; q < 4; ++q)
@@ -326,7 +355,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
                 if (ok(r)) pre[o + 8 * (r >> 2) + (r & 3)] = a[r];
             }
           }
-          if (g.gelu) {
+          if (g.gelu == 1) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) a[r] = gelu_erf(a[r]);
           }
@@ -629,6 +658,7 @@ extern "C" int eav_gemm_sp(const void* A, const void* B, float* C, const float* 
   EAV_REQUIRE((((uintptr_t)A | (uintptr_t)B) & 15) == 0 && (sA_bytes & 15) == 0,
               "eav_gemm_sp: operand planes must be 16-byte aligned");
   EAV_REQUIRE(!(resid && batch > 1), "eav_gemm_sp: residual epilogue is not batched");
+  EAV_REQUIRE(gelu >= 0 && gelu <= 2 && (gelu != 2 || pre), "eav_gemm_sp: gelu = 2 (backward) reads the pre-activation from `pre`");
   SpArgs g;
   const int Kp = eav_sp_kpad(K);
   g.A = (const unsigned char*)A; g.B = (const unsigned char*)B; g.C = C; g.slotA = slotA; g.slotB = slotB;

@@ -72,7 +72,55 @@ __global__ __launch_bounds__(256) void peak_copy_u_kernel(const float4* __restri
   for (; i < n4; i += stride) dst[i] = src[i];
 }
 
+// L2 -> CU read ceilings: every wave reads 1-KB chunks (16 B per lane) of an L2-resident footprint, 8 loads in flight.
+// MODE 0: global_load_dwordx4 into VGPRs; MODE 1: global_load_lds_dwordx4 (LDS-DMA, no VGPR round trip)
+template <int MODE>
+__global__ __launch_bounds__(256) void peak_l2_read_kernel(const unsigned char* __restrict__ src, int footprint_kb,
+                                                           int iters, float* __restrict__ sink) {
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[4 * 8 * 1024];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  unsigned chunk = (blockIdx.x * 4 + wave) * 8u;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int it = 0; it < iters; ++it) {
+    if (MODE == 0) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        v[u] = *reinterpret_cast<const f32x4*>(src + (size_t)((chunk + u) % (unsigned)footprint_kb) * 1024 + lane * 16);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v[u];
+    } else {
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(src + (size_t)((chunk + u) % (unsigned)footprint_kb) * 1024 + lane * 16),
+            (__attribute__((address_space(3))) void*)(lds + (wave * 8 + u) * 1024), 16, 0, 0);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    }
+    chunk += gridDim.x * 32u;
+  }
+  if (MODE == 1) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    acc[0] = reinterpret_cast<const float*>(lds)[threadIdx.x];
+  }
+  if (acc[0] + acc[1] + acc[2] + acc[3] == 12345.678f) sink[0] = acc[0];
+}
+
 }  // namespace
+
+// bytes read = blocks * 4 waves * iters * 8 KB
+extern "C" int eav_peak_l2_read(const void* src, int footprint_kb, int mode, int iters, int blocks, float* sink,
+                                void* stream) {
+  EAV_REQUIRE(src && sink && footprint_kb > 0 && iters > 0 && blocks > 0, "eav_peak_l2_read: bad arguments");
+  if (mode == 0)
+    hipLaunchKernelGGL(peak_l2_read_kernel<0>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned char*)src, footprint_kb, iters, sink);
+  else
+    hipLaunchKernelGGL(peak_l2_read_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned char*)src, footprint_kb, iters, sink);
+  EAV_CHECK_LAUNCH("eav_peak_l2_read");
+  return EAV_OK;
+}
 
 extern "C" int eav_peak_copy_variant(const float* src, float* dst, int64_t n, int variant, int blocks, void* stream) {
   EAV_REQUIRE(src && dst && n > 0 && (n & 3) == 0 && blocks > 0, "eav_peak_copy_variant: bad arguments");

@@ -652,8 +652,8 @@ class Encoder(nn.Module):
         self._to_planes_bias(dh, M, D, b_dh2, ws.dhp, ws.dhpT, gp(f"{Lk}.mlp.fc2.bias"))
         self._wgrad_sp(ws.dhpT, b_dh2, ws.actpT[i], s_act, gp(f"{Lk}.mlp.fc2.weight"), D, FF, M)
         wpl, wsl = self._wp(f"fc2{i}", transposed=True)
-        self._gemm_sp(P(ws.dhp), b_dh2, wpl, wsl, dact, M, FF, D, FF)
-        L("eav_gelu_bwd_amax", dact, P(ws.pre[i]), M * FF, b_dact, st)
+        # data gradient through fc2 and the GELU in one pass: the epilogue multiplies by gelu'(pre) and emits max|dact|
+        self._gemm_sp(P(ws.dhp), b_dh2, wpl, wsl, dact, M, FF, D, FF, gelu=2, pre=P(ws.pre[i]), amax=b_dact)
         # fc1
         self._to_planes_bias(dact, M, FF, b_dact, ws.dactp, ws.dactpT, gp(f"{Lk}.mlp.fc1.bias"))
         self._wgrad_sp(ws.dactpT, b_dact, ws.y2pT[i], s_y2, gp(f"{Lk}.mlp.fc1.weight"), FF, D, M)

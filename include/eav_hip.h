@@ -232,7 +232,9 @@ int eav_layernorm_bwd_amax(const float* dy, const float* x, const float* gamma, 
                            float* dx, int accumulate, float* part, int M, int D, float* amax_slot, void* stream);
 int eav_gelu_bwd_amax(float* dact, const float* pre, int64_t n, float* amax_slot, void* stream);
 /* C[z][m,n] = epilogue(alpha * sum_k A[z][m,k] B[n,k]) from planes A [M,Kp], B [N,Kp]; epilogue as eav_gemm_f32
- * (bias, erf-GELU with pre-activation store, residual, accumulate); amax_slot (optional) receives max |C| bits. */
+ * (bias, erf-GELU with pre-activation store, residual, accumulate); amax_slot (optional) receives max |C| bits.
+ * gelu = 2: backward through GELU - the product is multiplied by gelu'(pre[m,n]), `pre` (ldc) is READ (the forward's
+ * stored pre-activation): fc2's data gradient and eav_gelu_bwd in one pass. */
 int eav_gemm_sp(const void* A, const void* B, float* C, const float* slotA, const float* slotB, int M, int N, int K,
                 int ldc, int batch, int64_t sA_bytes, int64_t sC, float alpha, const float* bias, int gelu, float* pre,
                 const float* resid, int ldr, int accumulate, float* amax_slot, void* stream);
@@ -359,6 +361,9 @@ int eav_sosfilt_f64(const double* x, double* y, const double* sos, const double*
  *      streaming copy, to quote roofline fractions against what this chip sustains. */
 int eav_peak_mfma_f32(float* sink, int blocks, int iters, void* stream);
 int eav_peak_mfma_f16(float* sink, int blocks, int iters, void* stream);
+/* L2 -> CU read ceiling probe (bench.py measured_peaks / tuning): mode 0 = 16-byte loads into registers, 1 = LDS-DMA;
+ * every wave reads 1-KB chunks of the first footprint_kb KB of src, 8 in flight; bytes = blocks * 4 * iters * 8192. */
+int eav_peak_l2_read(const void* src, int footprint_kb, int mode, int iters, int blocks, float* sink, void* stream);
 int eav_peak_copy_variant(const float* src, float* dst, int64_t n, int variant, int blocks, void* stream);
 int eav_peak_copy(const float* src, float* dst, int64_t n, void* stream);
 

@@ -116,6 +116,18 @@ def test_gemm_sp_epilogues_and_batch():
     assert float(amax[:2048:32].view(torch.int32).max().view(torch.float32)) == float(got.abs().max())
     acc = gemm_sp(A, B, C=got.clone(), acc=1)
     assert (acc.double() - (want + A.double() @ B.double().t())).abs().max().item() < 3e-5
+    # gelu = 2: the product times gelu'(pre) with `pre` read (fc2 data gradient + GELU backward in one pass); ragged and
+    # full tiles, against autograd in float64
+    for (m2, n2) in ((300, 200), (256, 256)):
+        A2 = torch.randn(m2, K, device="cuda")
+        B2 = torch.randn(n2, K, device="cuda") * 0.1
+        x = (torch.randn(m2, n2, device="cuda") * 2.0)
+        xd = x.double().requires_grad_(True)
+        torch.nn.functional.gelu(xd).backward(A2.double() @ B2.double().t())
+        amax2 = torch.zeros(SLOT, device="cuda")
+        got2 = gemm_sp(A2, B2, gelu=2, pre=x.clone(), amax=amax2)
+        assert (got2.double() - xd.grad).abs().max().item() < 2e-5 * max(1.0, float(xd.grad.abs().max()))
+        assert float(amax2[:2048:32].view(torch.int32).max().view(torch.float32)) == float(got2.abs().max())
     # batched over A and C (the patch-embedding call: per-image row blocks, shared weight)
     nb, m = 3, 100
     sa, pa, _ = planes(A)

@@ -92,7 +92,7 @@ def bench(name, M, N, K, epi=False):
     pre = torch.empty(M, N, device="cuda") if epi else None
     ref = None
     out = []
-    for tile in (1, 9):
+    for tile in [int(v) for v in os.environ.get('TILES', '1,9').split(',')]:
         _lib.call("eav_gemm_sp_set_tile", tile)
         sa, pa, _ = planes(A)
         sb, pb, _ = planes(B)

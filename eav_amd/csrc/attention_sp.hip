@@ -244,9 +244,9 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_sp_kernel(const u8* __res
 template <int NW>
 __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_q_sp_kernel(
     const u8* __restrict__ rowp, const u8* __restrict__ tp, const u8* __restrict__ dorow, const float* __restrict__ slot,
-    const float* __restrict__ slot_do, const float* __restrict__ lse, const float* __restrict__ delta,
-    float* __restrict__ dqkv, unsigned* __restrict__ amax_ds, unsigned* __restrict__ amax_out, int N, int Npad, int H,
-    float scale) {
+    const float* __restrict__ slot_do, const float* __restrict__ lse, const float* __restrict__ ao,
+    const float* __restrict__ dout, float* __restrict__ delta, float* __restrict__ dqkv,
+    unsigned* __restrict__ amax_ds, unsigned* __restrict__ amax_out, int N, int Npad, int H, float scale) {
   constexpr int STAGE = 24576;   // K rows | V rows | K^T
   __shared__ __attribute__((aligned(1024))) u8 smem[2 * STAGE];
   const int D = H * 64;
@@ -277,7 +277,26 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_q_sp_kernel(
   const float isg = slot[EAV_SLOT_ISIGMA], isd = slot_do[EAV_SLOT_ISIGMA];
   const float c1 = scale * LOG2E * isg * isg;
   const float lq = LOG2E * lse[(int64_t)bh * N + q];
-  const float dq_ = delta[(int64_t)bh * N + q] * slot[EAV_SLOT_SIGMA] * slot_do[EAV_SLOT_SIGMA];   // delta in operand units
+  // delta[q] = dO[q, head] . O[q, head] (fp32): this lane's half of the row, the other half from lane ^ 32; published
+  // for the dK,dV kernel, which runs after this one
+  float dsum = 0.f;
+  {
+    const float4* o4 = reinterpret_cast<const float4*>(ao + ((int64_t)b * N + q) * D + h * 64 + 32 * h2);
+    const float4* g4 = reinterpret_cast<const float4*>(dout + ((int64_t)b * N + q) * D + h * 64 + 32 * h2);
+    float4 ov[8], gv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { ov[i] = o4[i]; gv[i] = g4[i]; }
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      a0 = fmaf(ov[i].x, gv[i].x, a0); a1 = fmaf(ov[i].y, gv[i].y, a1);
+      a2 = fmaf(ov[i].z, gv[i].z, a2); a3 = fmaf(ov[i].w, gv[i].w, a3);
+    }
+    dsum = (a0 + a1) + (a2 + a3);
+    dsum += __shfl_xor(dsum, 32, 64);
+    if (h2 == 0 && q0 + j < N) delta[(int64_t)bh * N + q] = dsum;
+  }
+  const float dq_ = dsum * slot[EAV_SLOT_SIGMA] * slot_do[EAV_SLOT_SIGMA];   // delta in operand units
   f32x16 g0, g1, x0, x1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { g0[r] = 0.f; g1[r] = 0.f; x0[r] = 0.f; x1[r] = 0.f; }
@@ -477,20 +496,6 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_kv_sp_kernel(
   emit_amax(amax_out, vmax, lane, (blockIdx.y * gridDim.x + blockIdx.x) * NW + wave);
 }
 
-// delta[bh][q] = sum_d dO[q, h*64+d] * O[q, h*64+d]   (one wave per (row, head))
-__global__ __launch_bounds__(256) void attn_delta_sp_kernel(const float* __restrict__ o, const float* __restrict__ dout,
-                                                            float* __restrict__ delta, int B, int N, int H) {
-  const int lane = threadIdx.x & 63;
-  const int64_t id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);      // (b*N + q)*H + h
-  if (id >= (int64_t)B * N * H) return;
-  const int h = (int)(id % H);
-  const int64_t row = id / H;
-  const int b = (int)(row / N), q = (int)(row - (int64_t)b * N);
-  const int64_t off = row * (H * 64) + h * 64 + lane;
-  const float v = wave_sum(o[off] * dout[off]);
-  if (lane == 0) delta[((int64_t)b * H + h) * N + q] = v;
-}
-
 // ------------------------------------------------------------------------------------------------ operand preparation
 // src [B*N, ncols] fp32 -> row planes and / or T planes (see the header).  One 64-token x 64-column tile per block;
 // grid (ncols/64, ceil(Npad/64), B).  tmask bit s set: write the T planes of column section s (sections of secw columns).
@@ -599,13 +604,11 @@ extern "C" int eav_attn_bwd_sp(const void* rowp, const void* tp, const void* dor
   EAV_REQUIRE(head_dim == 64, "eav_attn_bwd_sp: head_dim %d unsupported (needs 64)", head_dim);
   const int Npad = eav_attn_sp_npad(N);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(attn_delta_sp_kernel, dim3((unsigned)cdiv64((int64_t)B * N * H, 4)), dim3(256), 0, st, ao, dout,
-                     delta, B, N, H);
-  EAV_CHECK_LAUNCH("eav_attn_bwd_sp(delta)");
   if (N > 512) {
     dim3 grid(cdiv(N, 128), B * H);
     hipLaunchKernelGGL(attn_bwd_q_sp_kernel<4>, grid, dim3(256), 0, st, (const u8*)rowp, (const u8*)tp,
-                       (const u8*)dorow, slot, slot_do, lse, delta, dqkv, (unsigned*)slot_ds, (unsigned*)amax_slot, N,
+                       (const u8*)dorow, slot, slot_do, lse, ao, dout, delta, dqkv, (unsigned*)slot_ds,
+                       (unsigned*)amax_slot, N,
                        Npad, H, scale);
     EAV_CHECK_LAUNCH("eav_attn_bwd_sp(dQ)");
     hipLaunchKernelGGL(attn_bwd_kv_sp_kernel<4>, grid, dim3(256), 0, st, (const u8*)rowp, (const u8*)tp,
@@ -614,7 +617,8 @@ extern "C" int eav_attn_bwd_sp(const void* rowp, const void* tp, const void* dor
   } else {
     dim3 grid(cdiv(N, 64), B * H);
     hipLaunchKernelGGL(attn_bwd_q_sp_kernel<2>, grid, dim3(128), 0, st, (const u8*)rowp, (const u8*)tp,
-                       (const u8*)dorow, slot, slot_do, lse, delta, dqkv, (unsigned*)slot_ds, (unsigned*)amax_slot, N,
+                       (const u8*)dorow, slot, slot_do, lse, ao, dout, delta, dqkv, (unsigned*)slot_ds,
+                       (unsigned*)amax_slot, N,
                        Npad, H, scale);
     EAV_CHECK_LAUNCH("eav_attn_bwd_sp(dQ)");
     // the dK,dV kernel holds 66 KB of tiles per block: 4-wave blocks keep 2 waves per SIMD (a wave past the last key

@@ -525,36 +525,54 @@ __device__ __forceinline__ void split8(const float (&tv)[8], uint4& hi, uint4& l
 }
 
 // src [R, C] fp32 (row stride ld) -> dst planes [R][Cp/8][2][8] (contraction over columns) and / or
-// dstT planes [C][Rp/8][2][8] (contraction over rows).  One 64 x 64 tile per block.
+// dstT planes [C][Rp/8][2][8] (contraction over rows).  64 x 64 tiles; persistent blocks walk the tiles (column index
+// fastest) with the next tile's loads in flight while the current one is split, transposed through LDS and stored - a
+// streaming pass keeps its rate with a few hundred resident blocks and drops with tens of thousands (tools/copy_bench.py).
 __global__ __launch_bounds__(256) void sp_convert_kernel(const float* __restrict__ src, int R, int C, int64_t ld,
                                                          float* __restrict__ slot, unsigned char* __restrict__ dst,
                                                          int Cp, unsigned char* __restrict__ dstT, int Rp,
-                                                         float lomul, float* __restrict__ colsum_part) {
+                                                         float lomul, float* __restrict__ colsum_part, int ntx,
+                                                         int ntiles) {
   __shared__ float tile[64][65];
   const float sigma = sigma_from_bits(eav_slot_bits(slot));
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
     slot[EAV_SLOT_SIGMA] = sigma;
     slot[EAV_SLOT_ISIGMA] = 1.f / sigma;
   }
-  const int by = blockIdx.y;
-  const int r0 = by * 64, c0 = blockIdx.x * 64;
   const int t = threadIdx.x;
-  {
-    const int cg = t & 7, rr = t >> 3;
+  const int cg = t & 7, rr = t >> 3;
+  const bool vec = (ld & 3) == 0 && ((uintptr_t)src & 15) == 0;
+  auto load_tile = [&](int id, float (&v)[2][8]) {
+    const int by = id / ntx, bx = id - by * ntx;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int row = by * 64 + rr + 32 * pass, col = bx * 64 + 8 * cg;
+      if (vec && row < R && col + 7 < C) {
+        const float4 a = *reinterpret_cast<const float4*>(src + (int64_t)row * ld + col);
+        const float4 b = *reinterpret_cast<const float4*>(src + (int64_t)row * ld + col + 4);
+        v[pass][0] = a.x; v[pass][1] = a.y; v[pass][2] = a.z; v[pass][3] = a.w;
+        v[pass][4] = b.x; v[pass][5] = b.y; v[pass][6] = b.z; v[pass][7] = b.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[pass][e] = (row < R && col + e < C) ? src[(int64_t)row * ld + col + e] : 0.f;
+      }
+    }
+  };
+  float cur[2][8];
+  int id = blockIdx.x;
+  if (id < ntiles) load_tile(id, cur);
+  for (; id < ntiles; id += gridDim.x) {
+    float nxt[2][8];
+    const int nid = id + gridDim.x;
+    if (nid < ntiles) load_tile(nid, nxt);
+    const int by = id / ntx, bx = id - by * ntx;
+    const int r0 = by * 64, c0 = bx * 64;
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
       const int row = r0 + rr + 32 * pass, col = c0 + 8 * cg;
       float tv[8];
-      if (row < R && col + 7 < C) {
-        const float4 a = *reinterpret_cast<const float4*>(src + (int64_t)row * ld + col);
-        const float4 b = *reinterpret_cast<const float4*>(src + (int64_t)row * ld + col + 4);
-        tv[0] = a.x; tv[1] = a.y; tv[2] = a.z; tv[3] = a.w; tv[4] = b.x; tv[5] = b.y; tv[6] = b.z; tv[7] = b.w;
-      } else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) tv[e] = (row < R && col + e < C) ? src[(int64_t)row * ld + col + e] : 0.f;
-      }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) tv[e] *= sigma;
+      for (int e = 0; e < 8; ++e) tv[e] = cur[pass][e] * sigma;
       if (dst && row < R && col < Cp) {
         uint4 hi, lo;
         split8(tv, hi, lo, lomul);
@@ -567,34 +585,50 @@ __global__ __launch_bounds__(256) void sp_convert_kernel(const float* __restrict
         for (int e = 0; e < 8; ++e) tile[rr + 32 * pass][8 * cg + e] = tv[e];
       }
     }
-  }
-  if (!dstT && !colsum_part) return;
-  __syncthreads();
-  if (colsum_part && t < 64 && c0 + t < C) {   // bias gradient partial: column sums of this 64-row tile (sigma is 2^e: exact)
-    float a = 0.f, b = 0.f, c = 0.f, d = 0.f;
+    if (dstT || colsum_part) {
+      __syncthreads();
+      if (colsum_part && t < 64 && c0 + t < C) {   // bias gradient partial: column sums of this 64-row tile (sigma is 2^e: exact)
+        float a = 0.f, b = 0.f, c = 0.f, d = 0.f;
 #pragma unroll
-    for (int r = 0; r < 64; r += 4) {
-      a += tile[r][t]; b += tile[r + 1][t]; c += tile[r + 2][t]; d += tile[r + 3][t];
+        for (int r = 0; r < 64; r += 4) {
+          a += tile[r][t]; b += tile[r + 1][t]; c += tile[r + 2][t]; d += tile[r + 3][t];
+        }
+        colsum_part[(int64_t)by * C + c0 + t] = ((a + b) + (c + d)) * (1.f / sigma);
+      }
+      if (dstT) {
+        const int rg = t & 7, cc = t >> 3;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+          const int col = c0 + cc + 32 * pass, row = r0 + 8 * rg;
+          if (col >= C || row >= Rp) continue;
+          float tv[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) tv[e] = tile[8 * rg + e][cc + 32 * pass];
+          uint4 hi, lo;
+          split8(tv, hi, lo, lomul);
+          uint4* o = reinterpret_cast<uint4*>(dstT + (int64_t)col * Rp * 4 + (row >> 3) * 32);
+          o[0] = hi;
+          o[1] = lo;
+        }
+      }
+      __syncthreads();
     }
-    colsum_part[(int64_t)by * C + c0 + t] = ((a + b) + (c + d)) * (1.f / sigma);
-  }
-  if (!dstT) return;
-  {
-    const int rg = t & 7, cc = t >> 3;
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-      const int col = c0 + cc + 32 * pass, row = r0 + 8 * rg;
-      if (col >= C || row >= Rp) continue;
-      float tv[8];
+    for (int pass = 0; pass < 2; ++pass)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) tv[e] = tile[8 * rg + e][cc + 32 * pass];
-      uint4 hi, lo;
-      split8(tv, hi, lo, lomul);
-      uint4* o = reinterpret_cast<uint4*>(dstT + (int64_t)col * Rp * 4 + (row >> 3) * 32);
-      o[0] = hi;
-      o[1] = lo;
-    }
+      for (int e = 0; e < 8; ++e) cur[pass][e] = nxt[pass][e];
   }
+}
+
+int g_convert_blocks = 512;   // resident-block cap of the conversion pass (tuning hook: eav_sp_set_convert_blocks)
+
+void launch_convert(const float* src, int R, int C, int64_t ld, float* slot, void* dst, void* dstT, float* colsum_part,
+                    hipStream_t st) {
+  const int ntx = cdiv(eav_sp_kpad(C), 64), nty = cdiv(eav_sp_kpad(R), 64);
+  const int ntiles = ntx * nty;
+  hipLaunchKernelGGL(sp_convert_kernel, dim3(std::min(ntiles, g_convert_blocks)), dim3(256), 0, st, src, R, C, ld, slot,
+                     (unsigned char*)dst, eav_sp_kpad(C), (unsigned char*)dstT, eav_sp_kpad(R),
+                     g_loshift ? 2048.f : 1.f, colsum_part, ntx, ntiles);
 }
 
 }  // namespace
@@ -618,10 +652,7 @@ extern "C" int eav_sp_convert(const float* src, int R, int C, int64_t ld, float*
   EAV_REQUIRE(src && slot && R > 0 && C > 0 && (dst || dstT), "eav_sp_convert: bad arguments");
   EAV_REQUIRE((ld & 3) == 0 && (((uintptr_t)src | (uintptr_t)dst | (uintptr_t)dstT) & 15) == 0,
               "eav_sp_convert: leading dimension must be a multiple of 4, buffers 16-byte aligned");
-  const int gx = cdiv(eav_sp_kpad(C), 64), gy = cdiv(eav_sp_kpad(R), 64);
-  hipLaunchKernelGGL(sp_convert_kernel, dim3(gx, gy), dim3(256), 0,
-                     (hipStream_t)stream, src, R, C, ld, slot, (unsigned char*)dst, eav_sp_kpad(C),
-                     (unsigned char*)dstT, eav_sp_kpad(R), g_loshift ? 2048.f : 1.f, (float*)nullptr);
+  launch_convert(src, R, C, ld, slot, dst, dstT, nullptr, (hipStream_t)stream);
   EAV_CHECK_LAUNCH("eav_sp_convert");
   return EAV_OK;
 }
@@ -635,13 +666,12 @@ extern "C" int eav_sp_convert_colsum(const float* src, int R, int C, int64_t ld,
   EAV_REQUIRE(src && slot && R > 0 && C > 0 && colsum_part, "eav_sp_convert_colsum: bad arguments");
   EAV_REQUIRE((ld & 3) == 0 && (((uintptr_t)src | (uintptr_t)dst | (uintptr_t)dstT) & 15) == 0,
               "eav_sp_convert_colsum: leading dimension must be a multiple of 4, buffers 16-byte aligned");
-  const int gx = cdiv(eav_sp_kpad(C), 64), gy = cdiv(eav_sp_kpad(R), 64);
-  hipLaunchKernelGGL(sp_convert_kernel, dim3(gx, gy), dim3(256), 0,
-                     (hipStream_t)stream, src, R, C, ld, slot, (unsigned char*)dst, eav_sp_kpad(C),
-                     (unsigned char*)dstT, eav_sp_kpad(R), g_loshift ? 2048.f : 1.f, colsum_part);
+  launch_convert(src, R, C, ld, slot, dst, dstT, colsum_part, (hipStream_t)stream);
   EAV_CHECK_LAUNCH("eav_sp_convert_colsum");
   return EAV_OK;
 }
+
+extern "C" int eav_sp_set_convert_blocks(int n) { g_convert_blocks = n > 0 ? n : 1 << 30; return EAV_OK; }
 
 extern "C" int eav_gemm_sp_set_tile(int which) {
   g_force_tile = which & 3;

@@ -244,6 +244,7 @@ int eav_gemm_sp_splitk_plan(int M, int N, int K);
 int eav_gemm_sp_splitk(const void* A, const void* B, float* C, float* ws, const float* slotA, const float* slotB, int M,
                        int N, int K, int accumulate, void* stream);
 int eav_gemm_sp_set_tile(int which);   /* tuning hook: 0 heuristic, 1 = 128x128 tiles, 2 = 256x128 */
+int eav_sp_set_convert_blocks(int n);  /* tuning hook: resident-block cap of eav_sp_convert (default 512; 0 = one block per tile) */
 /* The same fused attention on the fp16 matrix cores with split operands (csrc/attention_sp.hip; fp32-grade, 3 MFMAs per
  * product).  eav_attn_sp_prep converts an fp32 activation src [B*N, ncols] (qkv or dO; slot holds its max|x| shards, see
  * EAV_SP_SLOT) into row planes [B*N][ncols/8][2][8] f16 and, for the column sections (of secw columns) selected by

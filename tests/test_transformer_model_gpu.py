@@ -200,3 +200,29 @@ def test_batch_size_changes_and_eval_mode(precision):
     with torch.no_grad():
         x, _ = synth.frame_batch(99, 5, 64)
         close(model(torch.from_numpy(x).cuda()).logits, vo.forward(P, torch.from_numpy(x), ocfg).numpy(), 1e-4, 1e-4, "eval")
+
+
+@pytest.mark.parametrize("kind", ["vit", "ast"])
+def test_side_stream_work_does_not_change_a_single_bit(kind):
+    """Weight-gradient GEMMs and the transposed-plane conversions run on a side HIP stream (Encoder.overlap_wgrad); every
+    kernel is deterministic, so a step with the overlap and one with everything on the launch stream must agree bit for
+    bit - any ordering hazard between the two streams would show up here."""
+    from eav_amd import transformer as T
+    from eav_amd.optim import CrossEntropyLoss
+    cfg = T.make_config(kind, hidden=128, layers=3, heads=2, ff=256)
+    torch.manual_seed(11)
+    B = 6
+    x, y = (synth.mel_batch(3, B) if kind == "ast" else synth.frame_batch(3, B))
+    x, y = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    model = T.Encoder(cfg).cuda().train()
+    model.precision = "split"
+    grads = []
+    for overlap in (True, False, True):
+        model.overlap_wgrad = overlap
+        for _ in range(2):          # second pass: buffers of the previous step are being overwritten
+            model.zero_grad()
+            CrossEntropyLoss()(model(x).logits, y).backward()
+        torch.cuda.synchronize()
+        grads.append([p.grad.clone() for p in model.parameters()])
+    for a, b, c in zip(*grads):
+        assert torch.equal(a, b) and torch.equal(a, c)

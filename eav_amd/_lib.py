@@ -67,6 +67,7 @@ SIGNATURES = {
     "eav_gemm_sp_splitk": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "eav_gemm_sp_set_tile": [_i],
     "eav_sp_set_convert_blocks": [_i],
+    "eav_attn_sp_set_nw4_above": [_i],
     "eav_attn_sp_prep": [_p, _p, _p, _p, _i, _i, _i, _i, C.c_uint, _p],
     "eav_attn_fwd_sp": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
     "eav_attn_bwd_sp": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],

@@ -131,20 +131,39 @@ __device__ __forceinline__ void emit_amax(unsigned* slot, float vmax, int lane, 
 
 // ------------------------------------------------------------------------------------------------ forward
 // grid (ceil(N / (32 NW)), B*H).  rowp: row planes of qkv [B*N, 3D]; tp: T planes (chunk 2H + h = V of head h).
+// Workgroup -> (row tile, image-head) with all row tiles of one (image, head) on ONE XCD: the tiles of a head stream the
+// same K / V (or Q / dO) planes, and consecutive workgroup ids go round the 8 XCDs - with the plain (x = tile, y = head)
+// grid the tiles of a head sat on different XCDs and every one of them pulled the head's planes through its own L2
+// (ViT forward: 740 MB fetched per launch against 310 MB of planes).  1-D grid of ntile * nbh workgroups.
+__device__ __forceinline__ void attn_block_map(int ntile, int nbh, int& tile, int& bh) {
+  const int L = blockIdx.x, full = (nbh & ~7) * ntile;
+  if (L < full) {
+    const int idx = L >> 3;
+    bh = (idx / ntile) * 8 + (L & 7);
+    tile = idx - (idx / ntile) * ntile;
+  } else {
+    const int r = L - full;
+    bh = (nbh & ~7) + r / ntile;
+    tile = r - (r / ntile) * ntile;
+  }
+}
+
 template <int NW>
 __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_sp_kernel(const u8* __restrict__ rowp, const u8* __restrict__ tp,
                                                                  const float* __restrict__ slot, float* __restrict__ ao,
                                                                  float* __restrict__ lse, unsigned* __restrict__ amax,
-                                                                 int N, int Npad, int H, float scale) {
+                                                                 int N, int Npad, int H, float scale, int ntile, int nbh) {
   constexpr int STAGE = 16384;   // K row tile | V^T tile
   __shared__ __attribute__((aligned(1024))) u8 smem[2 * STAGE > NW * 32 * 33 * 4 ? 2 * STAGE : NW * 32 * 33 * 4];
   const int D = H * 64;
   const int64_t ldrow = (int64_t)3 * D * 4, ldt = (int64_t)Npad * 4;
-  const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+  int tile_, bh;
+  attn_block_map(ntile, nbh, tile_, bh);
+  const int b = bh / H, h = bh - b * H;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 31, h2 = lane >> 5;
-  const int q0 = blockIdx.x * 32 * NW + wave * 32;
+  const int q0 = tile_ * 32 * NW + wave * 32;
   const u8* rows_b = rowp + (int64_t)b * N * ldrow;
   f16x8 qh[4], ql[4];
   load_row_frags(rows_b + (int64_t)min(q0 + j, N - 1) * ldrow + h * 256, h2, qh, ql);
@@ -233,7 +252,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_sp_kernel(const u8* __res
   __syncthreads();   // every wave is done with the tiles before the patch area is reused
   const float vmax = store_rows_T(reinterpret_cast<float*>(smem) + wave * (32 * 33), o0, o1, inv,
                                   ao + (int64_t)b * N * D + h * 64, D, q0, N, lane);
-  emit_amax(amax, vmax, lane, (blockIdx.y * gridDim.x + blockIdx.x) * NW + wave);
+  emit_amax(amax, vmax, lane, (int)blockIdx.x * NW + wave);
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dQ
@@ -246,16 +265,18 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_q_sp_kernel(
     const u8* __restrict__ rowp, const u8* __restrict__ tp, const u8* __restrict__ dorow, const float* __restrict__ slot,
     const float* __restrict__ slot_do, const float* __restrict__ lse, const float* __restrict__ ao,
     const float* __restrict__ dout, float* __restrict__ delta, float* __restrict__ dqkv,
-    unsigned* __restrict__ amax_ds, unsigned* __restrict__ amax_out, int N, int Npad, int H, float scale) {
+    unsigned* __restrict__ amax_ds, unsigned* __restrict__ amax_out, int N, int Npad, int H, float scale, int ntile, int nbh) {
   constexpr int STAGE = 24576;   // K rows | V rows | K^T
   __shared__ __attribute__((aligned(1024))) u8 smem[2 * STAGE];
   const int D = H * 64;
   const int64_t ldrow = (int64_t)3 * D * 4, lddo = (int64_t)D * 4, ldt = (int64_t)Npad * 4;
-  const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+  int tile_, bh;
+  attn_block_map(ntile, nbh, tile_, bh);
+  const int b = bh / H, h = bh - b * H;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 31, h2 = lane >> 5;
-  const int q0 = blockIdx.x * 32 * NW + wave * 32;
+  const int q0 = tile_ * 32 * NW + wave * 32;
   const int q = min(q0 + j, N - 1);
   const u8* rows_b = rowp + (int64_t)b * N * ldrow;
   f16x8 qh[4], ql[4], gh[4], gl[4];
@@ -353,12 +374,12 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_q_sp_kernel(
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) { g0[r] += x0[r] * (1.f / 2048.f); g1[r] += x1[r] * (1.f / 2048.f); }
-  emit_amax(amax_ds, tmax, lane, (blockIdx.y * gridDim.x + blockIdx.x) * NW + wave);
+  emit_amax(amax_ds, tmax, lane, (int)blockIdx.x * NW + wave);
   __syncthreads();
   const float mul = scale * (1.f / DS_DOWN) * isd * isg * isg;
   const float vmax = store_rows_T(reinterpret_cast<float*>(smem) + wave * (32 * 33), g0, g1, mul,
                                   dqkv + (int64_t)b * N * 3 * D + h * 64, 3 * D, q0, N, lane);
-  emit_amax(amax_out, vmax, lane, (blockIdx.y * gridDim.x + blockIdx.x) * NW + wave);
+  emit_amax(amax_out, vmax, lane, (int)blockIdx.x * NW + wave);
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
@@ -369,16 +390,18 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_kv_sp_kernel(
     const u8* __restrict__ rowp, const u8* __restrict__ tp, const u8* __restrict__ dorow, const u8* __restrict__ dotp,
     const float* __restrict__ slot, const float* __restrict__ slot_do, const float* __restrict__ slot_ds,
     const float* __restrict__ lse, const float* __restrict__ delta, float* __restrict__ dqkv,
-    unsigned* __restrict__ amax_out, int N, int Npad, int H, float scale) {
+    unsigned* __restrict__ amax_out, int N, int Npad, int H, float scale, int ntile, int nbh) {
   constexpr int STAGE = 32768 + 256;   // Q rows | dO rows | Q^T | dO^T | lse[32], delta[32] of the query tile
   __shared__ __attribute__((aligned(1024))) u8 smem[2 * STAGE];
   const int D = H * 64;
   const int64_t ldrow = (int64_t)3 * D * 4, lddo = (int64_t)D * 4, ldt = (int64_t)Npad * 4;
-  const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+  int tile_, bh;
+  attn_block_map(ntile, nbh, tile_, bh);
+  const int b = bh / H, h = bh - b * H;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 31, h2 = lane >> 5;
-  const int k0 = blockIdx.x * 32 * NW + wave * 32;
+  const int k0 = tile_ * 32 * NW + wave * 32;
   const int key = min(k0 + j, N - 1);
   const u8* rows_b = rowp + (int64_t)b * N * ldrow;
   f16x8 kh[4], kl[4], vh[4], vl[4];
@@ -493,7 +516,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_kv_sp_kernel(
   const float mv = isd / SP;
   float vmax = store_rows_T(patch, gk0, gk1, mk, base + D, 3 * D, k0, N, lane);
   vmax = fmaxf(vmax, store_rows_T(patch, gv0, gv1, mv, base + 2 * D, 3 * D, k0, N, lane));
-  emit_amax(amax_out, vmax, lane, (blockIdx.y * gridDim.x + blockIdx.x) * NW + wave);
+  emit_amax(amax_out, vmax, lane, (int)blockIdx.x * NW + wave);
 }
 
 // ------------------------------------------------------------------------------------------------ operand preparation
@@ -577,18 +600,24 @@ extern "C" int eav_attn_sp_prep(const float* src, float* slot, void* rowp, void*
   return EAV_OK;
 }
 
+// 4-wave (128-row) workgroups above this sequence length, 2-wave ones below: measured on ViT (N = 197) forward 106 -> 86 us,
+// backward 418 -> 379 us with 4 waves (half as many re-reads of a head's K / V planes, one idle wave instead of one idle
+// half-block); tuning hook
+int g_nw4_above = 128;
+extern "C" int eav_attn_sp_set_nw4_above(int n) { g_nw4_above = n; return 0; }
+
 extern "C" int eav_attn_fwd_sp(const void* rowp, const void* tp, const float* slot, float* ao, float* lse,
                                float* amax_slot, int B, int H, int N, int head_dim, float scale, void* stream) {
   EAV_REQUIRE(rowp && tp && slot && ao && lse && B > 0 && H > 0 && N > 0, "eav_attn_fwd_sp: bad arguments");
   EAV_REQUIRE(head_dim == 64, "eav_attn_fwd_sp: head_dim %d unsupported (needs 64)", head_dim);
   const int Npad = eav_attn_sp_npad(N);
   hipStream_t st = (hipStream_t)stream;
-  if (N > 512) {
-    hipLaunchKernelGGL(attn_fwd_sp_kernel<4>, dim3(cdiv(N, 128), B * H), dim3(256), 0, st, (const u8*)rowp,
-                       (const u8*)tp, slot, ao, lse, (unsigned*)amax_slot, N, Npad, H, scale);
+  if (N > g_nw4_above) {
+    hipLaunchKernelGGL(attn_fwd_sp_kernel<4>, dim3(cdiv(N, 128) * B * H), dim3(256), 0, st, (const u8*)rowp,
+                       (const u8*)tp, slot, ao, lse, (unsigned*)amax_slot, N, Npad, H, scale, cdiv(N, 128), B * H);
   } else {
-    hipLaunchKernelGGL(attn_fwd_sp_kernel<2>, dim3(cdiv(N, 64), B * H), dim3(128), 0, st, (const u8*)rowp,
-                       (const u8*)tp, slot, ao, lse, (unsigned*)amax_slot, N, Npad, H, scale);
+    hipLaunchKernelGGL(attn_fwd_sp_kernel<2>, dim3(cdiv(N, 64) * B * H), dim3(128), 0, st, (const u8*)rowp,
+                       (const u8*)tp, slot, ao, lse, (unsigned*)amax_slot, N, Npad, H, scale, cdiv(N, 64), B * H);
   }
   EAV_CHECK_LAUNCH("eav_attn_fwd_sp");
   return EAV_OK;
@@ -604,29 +633,23 @@ extern "C" int eav_attn_bwd_sp(const void* rowp, const void* tp, const void* dor
   EAV_REQUIRE(head_dim == 64, "eav_attn_bwd_sp: head_dim %d unsupported (needs 64)", head_dim);
   const int Npad = eav_attn_sp_npad(N);
   hipStream_t st = (hipStream_t)stream;
-  if (N > 512) {
-    dim3 grid(cdiv(N, 128), B * H);
-    hipLaunchKernelGGL(attn_bwd_q_sp_kernel<4>, grid, dim3(256), 0, st, (const u8*)rowp, (const u8*)tp,
+  const int nbh = B * H, nt128 = cdiv(N, 128), nt64 = cdiv(N, 64);
+  if (N > g_nw4_above) {
+    hipLaunchKernelGGL(attn_bwd_q_sp_kernel<4>, dim3(nt128 * nbh), dim3(256), 0, st, (const u8*)rowp, (const u8*)tp,
                        (const u8*)dorow, slot, slot_do, lse, ao, dout, delta, dqkv, (unsigned*)slot_ds,
-                       (unsigned*)amax_slot, N,
-                       Npad, H, scale);
+                       (unsigned*)amax_slot, N, Npad, H, scale, nt128, nbh);
     EAV_CHECK_LAUNCH("eav_attn_bwd_sp(dQ)");
-    hipLaunchKernelGGL(attn_bwd_kv_sp_kernel<4>, grid, dim3(256), 0, st, (const u8*)rowp, (const u8*)tp,
-                       (const u8*)dorow, (const u8*)dotp, slot, slot_do, slot_ds, lse, delta, dqkv,
-                       (unsigned*)amax_slot, N, Npad, H, scale);
   } else {
-    dim3 grid(cdiv(N, 64), B * H);
-    hipLaunchKernelGGL(attn_bwd_q_sp_kernel<2>, grid, dim3(128), 0, st, (const u8*)rowp, (const u8*)tp,
+    hipLaunchKernelGGL(attn_bwd_q_sp_kernel<2>, dim3(nt64 * nbh), dim3(128), 0, st, (const u8*)rowp, (const u8*)tp,
                        (const u8*)dorow, slot, slot_do, lse, ao, dout, delta, dqkv, (unsigned*)slot_ds,
-                       (unsigned*)amax_slot, N,
-                       Npad, H, scale);
+                       (unsigned*)amax_slot, N, Npad, H, scale, nt64, nbh);
     EAV_CHECK_LAUNCH("eav_attn_bwd_sp(dQ)");
-    // the dK,dV kernel holds 66 KB of tiles per block: 4-wave blocks keep 2 waves per SIMD (a wave past the last key
-    // only stages tiles)
-    hipLaunchKernelGGL(attn_bwd_kv_sp_kernel<4>, dim3(cdiv(N, 128), B * H), dim3(256), 0, st, (const u8*)rowp,
-                       (const u8*)tp, (const u8*)dorow, (const u8*)dotp, slot, slot_do, slot_ds, lse, delta, dqkv,
-                       (unsigned*)amax_slot, N, Npad, H, scale);
   }
+  // the dK,dV kernel holds 66 KB of tiles per block: 4-wave blocks keep 2 waves per SIMD at every N (a wave past the last
+  // key only stages tiles)
+  hipLaunchKernelGGL(attn_bwd_kv_sp_kernel<4>, dim3(nt128 * nbh), dim3(256), 0, st, (const u8*)rowp, (const u8*)tp,
+                     (const u8*)dorow, (const u8*)dotp, slot, slot_do, slot_ds, lse, delta, dqkv, (unsigned*)amax_slot, N,
+                     Npad, H, scale, nt128, nbh);
   EAV_CHECK_LAUNCH("eav_attn_bwd_sp(dK,dV)");
   return EAV_OK;
 }

@@ -135,3 +135,7 @@ if __name__ == "__main__":
         sys.exit(0)
     bench("ast B=8 ", 8, 1214)
     bench("vit B=128", 128, 197)
+    _lib.call("eav_attn_sp_set_nw4_above", 512)
+    bench("vit B=128 (2-wave blocks)", 128, 197)
+    _lib.call("eav_attn_sp_set_nw4_above", 128)
+    bench("shallow B=32", 32, 488, H=1)

@@ -8,17 +8,17 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 EEG="python3 $R/bench.py --no-encoders --no-cpu-baseline --steps 20 --warmup 3 --repeats 0"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/eeg_trace -o eeg -- $EEG > $OUT/eeg_trace.log 2>&1
-rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/eeg_fetch -o eeg -- $EEG > $OUT/eeg_fetch.log 2>&1
-rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/eeg_write -o eeg -- $EEG > $OUT/eeg_write.log 2>&1
-rocprofv3 --kernel-trace --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY -d $OUT/eeg_mfma -o eeg -- $EEG > $OUT/eeg_mfma.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/eeg_trace -o eeg -- $EEG > $OUT/eeg_trace.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/eeg_fetch -o eeg -- $EEG > $OUT/eeg_fetch.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/eeg_write -o eeg -- $EEG > $OUT/eeg_write.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY -d $OUT/eeg_mfma -o eeg -- $EEG > $OUT/eeg_mfma.log 2>&1
 for K in "ast 8" "vit 128"; do
   N=${K%% *}
   ENC="python3 $R/tools/encoder_step_bench.py $K split"
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${N}_trace -o $N -- $ENC > $OUT/${N}_trace.log 2>&1
-  rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/${N}_fetch -o $N -- $ENC > $OUT/${N}_fetch.log 2>&1
-  rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/${N}_write -o $N -- $ENC > $OUT/${N}_write.log 2>&1
-  rocprofv3 --kernel-trace --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY -d $OUT/${N}_mfma -o $N -- $ENC > $OUT/${N}_mfma.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${N}_trace -o $N -- $ENC > $OUT/${N}_trace.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/${N}_fetch -o $N -- $ENC > $OUT/${N}_fetch.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/${N}_write -o $N -- $ENC > $OUT/${N}_write.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY -d $OUT/${N}_mfma -o $N -- $ENC > $OUT/${N}_mfma.log 2>&1
 done
 # keep the merge-back small: counter / stats csv only
 find $OUT -name "*.csv" -size +40M -delete

@@ -87,17 +87,39 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     ab[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   float vmax = 0.f;
-  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
-    const float mean = mean_i[row], rstd = rstd_i[row];
+  // the rows of a wave are independent: the NEXT row's x, dy (and dx when accumulating) are loaded before the current
+  // row's reductions, so a wave always has a row in flight (in the encoder step this kernel runs beside a weight-gradient
+  // GEMM on the side stream, where an un-prefetched row costs a fully loaded memory system's latency each time)
+  float4 xn[LN_MAXQ], dn[LN_MAXQ], pn[LN_MAXQ];
+  float mean_n = 0.f, rstd_n = 0.f;
+  auto fetch = [&](int row) {
     const float4* xs = reinterpret_cast<const float4*>(x + (int64_t)row * D);
     const float4* ds = reinterpret_cast<const float4*>(dy + (int64_t)row * D);
-    float4 xh[LN_MAXQ], gd[LN_MAXQ];
+    const float4* ps = reinterpret_cast<const float4*>(dx + (int64_t)row * D);
+#pragma unroll
+    for (int i = 0; i < LN_MAXQ; ++i) {
+      const int q = lane + 64 * i;
+      if (q < nq) {
+        xn[i] = xs[q];
+        dn[i] = ds[q];
+        if (accumulate) pn[i] = ps[q];
+      }
+    }
+    mean_n = mean_i[row];
+    rstd_n = rstd_i[row];
+  };
+  int row = blockIdx.x * 4 + wave;
+  if (row < M) fetch(row);
+  for (; row < M; row += gridDim.x * 4) {
+    const float mean = mean_n, rstd = rstd_n;
+    float4 xh[LN_MAXQ], gd[LN_MAXQ], pv[LN_MAXQ];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < LN_MAXQ; ++i) {
       const int q = lane + 64 * i;
       if (q < nq) {
-        const float4 xv = xs[q], dv = ds[q];
+        const float4 xv = xn[i], dv = dn[i];
+        pv[i] = pn[i];
         xh[i] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
         gd[i] = make_float4(dv.x * gm[i].x, dv.y * gm[i].y, dv.z * gm[i].z, dv.w * gm[i].w);
         ag[i].x += dv.x * xh[i].x; ag[i].y += dv.y * xh[i].y; ag[i].z += dv.z * xh[i].z; ag[i].w += dv.w * xh[i].w;
@@ -105,9 +127,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         s1 += (gd[i].x + gd[i].y) + (gd[i].z + gd[i].w);
         s2 += (gd[i].x * xh[i].x + gd[i].y * xh[i].y) + (gd[i].z * xh[i].z + gd[i].w * xh[i].w);
       } else {
-        xh[i] = gd[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        xh[i] = gd[i] = pv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
+    const int next = row + gridDim.x * 4;
+    if (next < M) fetch(next);
     const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
     float4* dst = reinterpret_cast<float4*>(dx + (int64_t)row * D);
 #pragma unroll
@@ -117,8 +141,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         float4 o = make_float4(rstd * (gd[i].x - m1 - xh[i].x * m2), rstd * (gd[i].y - m1 - xh[i].y * m2),
                                rstd * (gd[i].z - m1 - xh[i].z * m2), rstd * (gd[i].w - m1 - xh[i].w * m2));
         if (accumulate) {
-          const float4 p = dst[q];
-          o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
+          o.x += pv[i].x; o.y += pv[i].y; o.z += pv[i].z; o.w += pv[i].w;
         }
         dst[q] = o;
         vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));

@@ -17,3 +17,9 @@ for M in (9712, 25216):
     t0 = t(lambda: _lib.call("eav_layernorm_fwd", P(x), P(g), P(b), P(y), P(mean), P(rstd), M, D, 1e-12, None))
     t1 = t(lambda: _lib.call("eav_layernorm_fwd_amax", P(x), P(g), P(b), P(y), P(mean), P(rstd), M, D, 1e-12, P(slot), None))
     print(f"M={M}: layernorm_fwd {t0:.1f} us, with amax {t1:.1f} us")
+    dy = torch.randn(M, D, device="cuda"); dx = torch.zeros(M, D, device="cuda")
+    npart = _lib.plain("eav_layernorm_bwd_nparts", M)
+    part = torch.empty(npart, 2 * D, device="cuda")
+    _lib.call("eav_layernorm_fwd", P(x), P(g), P(b), P(y), P(mean), P(rstd), M, D, 1e-12, None)
+    t2 = t(lambda: _lib.call("eav_layernorm_bwd_amax", P(dy), P(x), P(g), P(mean), P(rstd), P(dx), 1, P(part), M, D, P(slot), None))
+    print(f"M={M}: layernorm_bwd (accumulate, amax) {t2:.1f} us = {4 * M * D * 4 / t2 / 1e6:.2f} TB/s")

@@ -252,11 +252,12 @@ int launch_bm(const GemmArgs& g, int batch, hipStream_t st) {
 }
 
 // 128-row tiles by default; 64-row tiles when the 128-row grid would leave the chip under-filled (e.g. the
-// N = 768 projections at M = 9712: 456 blocks for 768 resident slots)
+// N = 768 projections at M = 9712: 456 blocks for 768 resident slots) and for outputs of at most 64 rows (the 40 x 160
+// weight gradients of the ShallowConvNet transformer)
 template <int BN, bool TA, bool TB>
 int launch(const GemmArgs& g, int batch, hipStream_t st) {
   const int64_t blocks128 = (int64_t)cdiv(g.M, 128) * cdiv(g.N, BN) * batch;
-  if (blocks128 < 640 && g.M > 64) return launch_bm<64, BN, TA, TB>(g, batch, st);
+  if (blocks128 < 640 || g.M <= 64) return launch_bm<64, BN, TA, TB>(g, batch, st);
   return launch_bm<128, BN, TA, TB>(g, batch, st);
 }
 

@@ -661,8 +661,7 @@ class Encoder(nn.Module):
         self._gemm_sp(P(ws.dactp), b_dact, wpl, wsl, dy, M, D, FF, D)
         L("eav_layernorm_bwd_amax", dy, P(ws.hmid[i]), w(f"{Lk}.layernorm_after.weight"), stp + 8 * M, stp + 12 * M, dh,
           1, P(ws.part_ln), M, D, b_dh1, st)
-        self._reduce(ws.part_ln, ws.np_ln, 2 * D, D, gp(f"{Lk}.layernorm_after.weight"))
-        L("eav_reduce_partials", P(ws.part_ln) + 4 * D, ws.np_ln, 2 * D, D, 1.0, gp(f"{Lk}.layernorm_after.bias"), st)
+        self._reduce_ln(gp(f"{Lk}.layernorm_after.weight"), gp(f"{Lk}.layernorm_after.bias"))
         # o_proj
         self._to_planes_bias(dh, M, D, b_dh1, ws.dhp, ws.dhpT2, gp(f"{Lk}.attention.o_proj.bias"))
         self._wgrad_sp(ws.dhpT2, b_dh1, ws.aopT[i], s_ao, gp(f"{Lk}.attention.o_proj.weight"), D, D, M)
@@ -696,12 +695,21 @@ class Encoder(nn.Module):
         # the gradient w.r.t. this layer's input is the next (lower) layer's dh: leave its max in that layer's slot
         L("eav_layernorm_bwd_amax", dy, P(ws.hs[i]), w(f"{Lk}.layernorm_before.weight"), stp, stp + 4 * M, dh, 1,
           P(ws.part_ln), M, D, bslot(1 + self.BS * (i - 1)) if i > 0 else bslot(0), st)
-        self._reduce(ws.part_ln, ws.np_ln, 2 * D, D, gp(f"{Lk}.layernorm_before.weight"))
-        L("eav_reduce_partials", P(ws.part_ln) + 4 * D, ws.np_ln, 2 * D, D, 1.0, gp(f"{Lk}.layernorm_before.bias"), st)
+        self._reduce_ln(gp(f"{Lk}.layernorm_before.weight"), gp(f"{Lk}.layernorm_before.bias"))
 
     def _wgrad(self, A, B, C, M, N, K, lda, ldb):
         """C[M,N] = A^T.B for A stored [K,M], B stored [K,N] (weight gradient: contraction over tokens)."""
         self._call(self._gemm_name() + "_splitk", A, B, C, _lib.ptr(self._ws.splitk), M, N, K, lda, ldb, 1, 1, self._st)
+
+    def _reduce_ln(self, gw, gb):
+        """LayerNorm weight / bias gradients from ws.part_ln ([np_ln][2 D]: dgamma | dbeta partials): one launch when the
+        two gradients are neighbours in the flat buffer (they are: weight, then bias, D floats each)."""
+        ws, D = self._ws, self.cfg.hidden
+        if gb == gw + 4 * D:
+            self._reduce(ws.part_ln, ws.np_ln, 2 * D, 2 * D, gw)
+        else:
+            self._reduce(ws.part_ln, ws.np_ln, 2 * D, D, gw)
+            self._call("eav_reduce_partials", _lib.ptr(ws.part_ln) + 4 * D, ws.np_ln, 2 * D, D, 1.0, gb, self._st)
 
     def _reduce(self, part, nparts, stride, n, out):
         self._call("eav_reduce_partials", _lib.ptr(part), nparts, stride, n, 1.0, out, self._st)

@@ -301,8 +301,11 @@ class ShallowConvNet(nn.Module):
 
         def ln_bwd(dyp, xin, gk, bk, mean, rstd, dx):
             L("eav_layernorm_bwd", dyp, xin, w(gk), mean, rstd, dx, 0, P(ws.part_ln), M, NF, st)
-            reduce(P(ws.part_ln), ws.np_ln, 2 * NF, NF, gp(gk))
-            reduce(P(ws.part_ln) + 4 * NF, ws.np_ln, 2 * NF, NF, gp(bk))
+            if gp(bk) == gp(gk) + 4 * NF:      # weight and bias gradients are neighbours in the flat buffer: one launch
+                reduce(P(ws.part_ln), ws.np_ln, 2 * NF, 2 * NF, gp(gk))
+            else:
+                reduce(P(ws.part_ln), ws.np_ln, 2 * NF, NF, gp(gk))
+                reduce(P(ws.part_ln) + 4 * NF, ws.np_ln, 2 * NF, NF, gp(bk))
 
         # fc + softmax, then log <- pool <- square <- BatchNorm
         L("eav_dense_softmax_bwd", P(dprobs), P(ws.probs), P(ws.feat), w("fc.weight"), gp("fc.weight"), P(ws.dbias),

@@ -93,3 +93,12 @@ __device__ __forceinline__ float dropout_mult(float drop_p, uint64_t seed, const
   bool keep = mask ? (mask[idx] != 0) : ((float)eav_hash32(seed, idx) * (1.0f / 16777216.0f) >= drop_p);
   return keep ? 1.f / (1.f - drop_p) : 0.f;
 }
+// drop_p < 0 selects nn.Dropout2d semantics with probability -drop_p: ONE draw per (sample, channel) row (the keep
+// decision hashes the row index instead of the element index; an explicit mask stays per element)
+__device__ __forceinline__ float dropout_mult_row(float drop_p, uint64_t seed, const uint8_t* mask, uint64_t idx,
+                                                  uint64_t row) {
+  if (drop_p >= 0.f) return dropout_mult(drop_p, seed, mask, idx);
+  const float p = -drop_p;
+  const bool keep = mask ? (mask[idx] != 0) : ((float)eav_hash32(seed, row) * (1.0f / 16777216.0f) >= p);
+  return keep ? 1.f / (1.f - p) : 0.f;
+}

@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__
       for (int e = 0; e < 4; ++e) s += elu_f(sc * v[e] + sh);
     }
     const uint64_t oi = (uint64_t)row * To + to;
-    const float r = s * (1.0f / P) * dropout_mult(drop_p, seed, mask, oi);
+    const float r = s * (1.0f / P) * dropout_mult_row(drop_p, seed, mask, oi, (uint64_t)row);
     out[oi] = r;
     amax = fmaxf(amax, fabsf(r));
   }
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void pool_bwd_reduce_kernel(const float* __res
   float st[2] = {0.f, 0.f};
   for (int to = threadIdx.x; to < To; to += 256) {
     const uint64_t oi = (uint64_t)row * To + to;
-    const float go = dp[oi] * (1.0f / P) * dropout_mult(drop_p, seed, mask, oi);
+    const float go = dp[oi] * (1.0f / P) * dropout_mult_row(drop_p, seed, mask, oi, (uint64_t)row);
 #pragma unroll
     for (int j = 0; j < P; j += 4) {
       float v[4];
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void pool_bwd_apply_kernel(const float* __rest
     float go = 0.f;
     if (to < To) {
       const uint64_t oi = (uint64_t)row * To + to;
-      go = dp[oi] * (1.0f / P) * dropout_mult(drop_p, seed, mask, oi);
+      go = dp[oi] * (1.0f / P) * dropout_mult_row(drop_p, seed, mask, oi, (uint64_t)row);
     }
     float v[4], o[4];
     ld4(src, t, T, vec, v);
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const float* __restrict__ y
       float go = 0.f;
       if (to < To) {
         const uint64_t oi = (uint64_t)row * To + to;
-        go = fu.dp2[oi] * 0.25f * dropout_mult(fu.drop_p, seed, fu.mask, oi);
+        go = fu.dp2[oi] * 0.25f * dropout_mult_row(fu.drop_p, seed, fu.mask, oi, (uint64_t)row);
       }
       float v[4];
       ld4s(fu.z + row * S, t < S ? t : S, S, vec, v);
@@ -393,7 +393,7 @@ extern "C" int eav_eegnet_dw_bwd_fused(const float* y1, const float* z, const fl
                                        const uint64_t* seed_dev, void* stream) {
   EAV_REQUIRE(y1 && z && dp2 && bn2 && bn1 && w2 && g1 && stat_part && w_part && B > 0 && C > 0 && C <= CHMAX && S >= 4,
               "eav_eegnet_dw_bwd_fused: bad arguments (Chans must be <= %d)", CHMAX);
-  EAV_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "eav_eegnet_dw_bwd_fused: dropout %f outside [0,1)", drop_p);
+  EAV_REQUIRE(drop_p > -1.f && drop_p < 1.f, "eav_eegnet_dw_bwd_fused: dropout %f outside (-1,1)", drop_p);
   dim3 grid(cdiv(S, 1024), F1, B);
   DwFuse fu{z, dp2, bn2, drop_p, seed, mask, seed_dev};
   hipLaunchKernelGGL(dw_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, y1, nullptr, bn1, w2, g1, stat_part,
@@ -412,7 +412,7 @@ extern "C" int eav_bn_elu_pool_fwd_absmax(const float* in, const float* bn, floa
                                           const uint64_t* seed_dev, void* stream) {
   EAV_REQUIRE(in && bn && out && B > 0 && CH > 0 && T >= P, "eav_bn_elu_pool_fwd: bad arguments");
   EAV_REQUIRE(P == 4 || P == 8, "eav_bn_elu_pool_fwd: pool %d not in {4,8}", P);
-  EAV_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "eav_bn_elu_pool_fwd: dropout %f outside [0,1)", drop_p);
+  EAV_REQUIRE(drop_p > -1.f && drop_p < 1.f, "eav_bn_elu_pool_fwd: dropout %f outside (-1,1)", drop_p);
   if (P == 4)
     hipLaunchKernelGGL(pool_fwd_kernel<4>, dim3(B * CH), dim3(256), 0, (hipStream_t)stream, in, bn, out, CH, T,
                        drop_p, seed, mask, seed_dev, absmax_part);

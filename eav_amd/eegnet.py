@@ -113,8 +113,9 @@ class EEGNet_tor(nn.Module):
 
         self.nb_classes, self.Chans, self.Samples, self.kernLength = nb_classes, Chans, Samples, kernLength
         self.norm_rate, self.dropoutRate = float(norm_rate), float(dropoutRate)
-        if dropoutType != 'Dropout' and dropoutRate > 0:
-            raise NotImplementedError("eav_amd.EEGNet_tor: only element-wise Dropout is implemented")
+        # any other dropoutType is nn.Dropout2d in the reference (:21): one keep decision per (sample, channel) map - the
+        # kernels take it as a negative probability (eav_hip.h)
+        self.spatial_dropout = dropoutType != 'Dropout'
         self._ws = None
         self._wss = {}                         # workspaces by (B, Chans, Samples, device): see _workspace()
         self._flat = None
@@ -194,13 +195,15 @@ class EEGNet_tor(nn.Module):
         w1, g1w, g1b, w2, g2w, g2b, w3, g3w, g3b, wd, bd = [P(p) for p in self._params()]
         bn1, bn2, bn3 = self.firstBN, self.depthwiseBN, self.separableBN
         drop = self.dropoutRate if training else 0.0
+        if self.spatial_dropout:
+            drop = -drop
         masks = self._dropout_masks if training else None
         self._token += 1
         # dropout stream: effective seed = base + 2 * (device-resident count of training forwards) - no host
         # argument changes from step to step, so the whole step can be replayed from a hipGraph
         seed1, seed2 = self.dropout_seed, self.dropout_seed + 1
         cnt = None
-        if drop > 0.0 and masks is None:
+        if drop != 0.0 and masks is None:
             if self._fwd_counter is None or self._fwd_counter.device != x.device:
                 self._fwd_counter = torch.zeros((), dtype=torch.int64, device=x.device)
             L("eav_counter_inc", P(self._fwd_counter), st)

@@ -87,7 +87,9 @@ int eav_eegnet_dw_bwd_fused(const float* y1, const float* z, const float* dp2, c
 
 /* ---- BN -> ELU -> AvgPool(1,P) -> Dropout (EEGNet_tor.py:55-58, 60-63), P in {4,8} -------- */
 /* bn = mean, invstd, scale, shift (CH each).  mask: optional uint8 keep-mask [B,CH,T/P]
- * (NULL = counter-based generator keyed by seed); drop_p = 0 disables dropout. */
+ * (NULL = counter-based generator keyed by seed); drop_p = 0 disables dropout; drop_p < 0 = nn.Dropout2d with
+ * probability -drop_p: one keep decision per (sample, channel) row (the reference's dropoutType != 'Dropout',
+ * EEGNet_tor.py:21) - eav_bn_elu_pool_* and eav_eegnet_dw_bwd_fused. */
 /* seed_dev (optional, device uint64): effective seed = seed + 2 * (*seed_dev) - a device-resident step counter,
  * so that a captured hipGraph draws a fresh mask on every replay. */
 int eav_bn_elu_pool_fwd(const float* in, const float* bn, float* out, int B, int CH, int T, int P, float drop_p,

@@ -72,13 +72,15 @@ BNAMES = ["firstBN.running_mean", "firstBN.running_var", "depthwiseBN.running_me
           "depthwiseBN.running_var", "separableBN.running_mean", "separableBN.running_var"]
 
 
-def eegnet_case(mod, name, B, S, wseed, xseed, train_mode, wscale=1.0, masks=False, lr=1e-3, steps=2):
+def eegnet_case(mod, name, B, S, wseed, xseed, train_mode, wscale=1.0, masks=False, lr=1e-3, steps=2,
+                dropout_type="Dropout"):
     """Run `steps` reference training steps (Trainer_uni.train body, :104-110)
     and record everything the parity tests compare."""
     torch.manual_seed(0)
     torch.set_num_threads(8)
     drop = 0.5 if masks else 0.0
-    model = mod.EEGNet_tor(nb_classes=5, Chans=30, Samples=S, kernLength=300, F1=8, D=8, F2=64, dropoutRate=drop)
+    model = mod.EEGNet_tor(nb_classes=5, Chans=30, Samples=S, kernLength=300, F1=8, D=8, F2=64, dropoutRate=drop,
+                           dropoutType=dropout_type)
     fix_hooks(model)
     sd = eegnet_weights(wseed, S, scale=wscale)
     load_eegnet_state(model, sd)
@@ -100,6 +102,15 @@ def eegnet_case(mod, name, B, S, wseed, xseed, train_mode, wscale=1.0, masks=Fal
             captured.append(keep.numpy().astype(np.uint8))
             return inp * keep / (1.0 - p)
         F.dropout = cap
+        orig2d = F.dropout2d
+
+        def cap2d(inp, p=0.5, training=True, inplace=False):      # nn.Dropout2d: one draw per (sample, channel) map
+            if not training or p == 0.0:
+                return inp
+            keep = (torch.rand(inp.shape[0], inp.shape[1], *([1] * (inp.dim() - 2))) >= p).to(inp.dtype).expand_as(inp)
+            captured.append(keep.numpy().astype(np.uint8))
+            return inp * keep / (1.0 - p)
+        F.dropout2d = cap2d
     try:
         for s in range(steps):
             x, y = synth.eeg_batch(xseed + s, B, 30, S)
@@ -121,6 +132,7 @@ def eegnet_case(mod, name, B, S, wseed, xseed, train_mode, wscale=1.0, masks=Fal
         if masks:
             import torch.nn.functional as F
             F.dropout = orig
+            F.dropout2d = orig2d
     for i, m in enumerate(captured):
         out[f"mask{i}"] = m
     # keep the big S=10000 fixture small: grads of dense.weight / firstConv kept, rest summarised
@@ -143,6 +155,8 @@ def make_eegnet():
     eegnet_case(mod, "s500_maxnorm", B=4, S=500, wseed=12, xseed=102, train_mode=True, wscale=3.0)
     eegnet_case(mod, "s500_dropout", B=4, S=500, wseed=13, xseed=103, train_mode=True, masks=True)
     eegnet_case(mod, "s10000_train", B=2, S=10000, wseed=14, xseed=104, train_mode=True, steps=1)
+    eegnet_case(mod, "s500_dropout2d", B=6, S=500, wseed=15, xseed=105, train_mode=True, masks=True,
+                dropout_type="SpatialDropout2D")
     make_eegnet_loop(mod)
 
 

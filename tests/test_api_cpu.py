@@ -223,8 +223,10 @@ def test_unsupported_configurations_raise_not_silently_differ():
     """The kernels are specialised to the reference's own configuration; anything else must fail loudly at
     construction (EEGNet_tor.py:16-17,21 accepts any F1/D/F2/dropoutType)."""
     from eav_amd.eegnet import EEGNet_tor
-    for kw in (dict(F1=4), dict(D=2), dict(F2=32), dict(kernLength=301), dict(Chans=33),
-               dict(dropoutType="Dropout2d", dropoutRate=0.5)):
+    for kw in (dict(F1=4), dict(D=2), dict(F2=32), dict(kernLength=301), dict(Chans=33)):
         with pytest.raises(NotImplementedError):
             EEGNet_tor(5, **kw)
-    EEGNet_tor(5, dropoutType="Dropout2d", dropoutRate=0.0)      # no dropout at all: the type is irrelevant
+    # every dropoutType other than 'Dropout' is nn.Dropout2d in the reference (:21) - supported (per-map masks)
+    m = EEGNet_tor(5, dropoutType="SpatialDropout2D", dropoutRate=0.5)
+    assert m.spatial_dropout and isinstance(m.dropout, torch.nn.Dropout2d)
+    assert not EEGNet_tor(5).spatial_dropout

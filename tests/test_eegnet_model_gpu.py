@@ -29,9 +29,10 @@ def close(got, ref, rtol, atol, what):
     assert (err <= atol + rtol * np.abs(ref)).all(), f"{what}: max err {err.max():.3e}, ref max {np.abs(ref).max():.3e}"
 
 
-def build(S, sd, drop=0.0):
+def build(S, sd, drop=0.0, dropout_type="Dropout"):
     from eav_amd.eegnet import EEGNet_tor
-    m = EEGNet_tor(nb_classes=5, Chans=30, Samples=S, kernLength=300, F1=8, D=8, F2=64, dropoutRate=drop)
+    m = EEGNet_tor(nb_classes=5, Chans=30, Samples=S, kernLength=300, F1=8, D=8, F2=64, dropoutRate=drop,
+                   dropoutType=dropout_type)
     full = m.state_dict()
     for k, v in sd.items():
         full[k] = torch.from_numpy(np.ascontiguousarray(v))
@@ -40,14 +41,15 @@ def build(S, sd, drop=0.0):
 
 
 @pytest.mark.parametrize("fir_precision", ["fp32", "split"])
-@pytest.mark.parametrize("case", ["s500_train", "s500_eval", "s500_maxnorm", "s500_dropout"])
+@pytest.mark.parametrize("case", ["s500_train", "s500_eval", "s500_maxnorm", "s500_dropout", "s500_dropout2d"])
 def test_steps_match_reference_golden(golden_dir, case, fir_precision):
     """fir_precision="split" (the FIR products on the fp16 matrix cores with two-piece operands) is held to exactly the
     same bounds as the exact-fp32 kernels."""
     from eav_amd.optim import CrossEntropyLoss, FusedAdam
     g = np.load(os.path.join(golden_dir, f"eegnet_{case}.npz"))
     B, S, lr = int(g["B"]), int(g["S"]), float(g["lr"])
-    model = build(S, eegnet_weights(int(g["wseed"]), S, scale=float(g["wscale"])), float(g["drop_p"]))
+    model = build(S, eegnet_weights(int(g["wseed"]), S, scale=float(g["wscale"])), float(g["drop_p"]),
+                  "SpatialDropout2D" if case.endswith("2d") else "Dropout")   # the reference's nn.Dropout2d branch (:21)
     model.fir_precision = fir_precision
     model.train(bool(int(g["train_mode"])))
     crit, opt = CrossEntropyLoss(), FusedAdam(model.parameters(), lr=lr)
@@ -329,3 +331,43 @@ def test_trainer_graph_replay_survives_other_batch_sizes(capsys):
     assert finals[0][1] == finals[1][1]                  # identical printed losses / accuracies
     for k in finals[0][0]:
         assert torch.equal(finals[0][0][k], finals[1][0][k]), k
+
+
+@pytest.mark.parametrize("fir_precision", ["fp32", "split"])
+def test_generated_spatial_dropout_is_per_feature_map(fir_precision):
+    """dropoutType != 'Dropout' is nn.Dropout2d in the reference (EEGNet_tor.py:21): the generated masks drop whole
+    (sample, channel) maps, about half of them, differently on every step, and the backward regenerates the same masks
+    (probabilities and gradients equal the oracle's when it is handed the masks read back from the workspace)."""
+    from eav_amd.optim import CrossEntropyLoss
+    from oracle import eegnet_oracle as orc
+    S, B = 500, 16
+    sd = eegnet_weights(21, S)
+    model = build(S, sd, 0.5, "SpatialDropout2D").train()
+    model.fir_precision = fir_precision
+    x, y = synth.eeg_batch(211, B, 30, S)
+    seen = []
+    for step in range(2):
+        scores = model(torch.from_numpy(x).cuda())
+        loss = CrossEntropyLoss()(scores, torch.from_numpy(y).cuda())
+        model.zero_grad()
+        loss.backward()
+        torch.cuda.synchronize()
+        ws = model._ws
+        keep1 = (ws.p2.view(B, 64, -1) != 0)
+        keep2 = (ws.p3.view(B, 64, -1) != 0)
+        for keep in (keep1, keep2):
+            rows = keep.any(dim=2)
+            assert torch.equal(keep, rows.unsqueeze(2).expand_as(keep) & keep) and bool((keep.all(dim=2) == rows).all())
+            assert 0.35 < rows.float().mean().item() < 0.65
+        seen.append(keep1.any(dim=2).clone())
+        masks = (keep1.float().cpu().view(B, 64, 1, -1), keep2.float().cpu().view(B, 64, 1, -1))
+        st = orc.Stepper({k: torch.from_numpy(sd[k].copy()) for k in orc.PARAM_NAMES},
+                         {k: torch.from_numpy(sd[k].copy()) for k in orc.BUFFER_NAMES}, lr=1e-3, drop_p=0.5)
+        if step == 0:
+            probs, lref, gref = st.step(torch.from_numpy(x), torch.from_numpy(y), True, masks)
+            close(scores, probs.numpy(), 1e-4, 2e-5, "probs")
+            named = dict(model.named_parameters())
+            for k in orc.PARAM_NAMES:
+                ref = gref[k].numpy()
+                close(named[k].grad, ref, 1e-3, 1e-3 * np.abs(ref).max(), f"grad.{k}")
+    assert not torch.equal(seen[0], seen[1])

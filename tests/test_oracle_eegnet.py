@@ -33,7 +33,7 @@ def _close_params(a, b, lr, what, frac=0.995):
     assert err.max() <= 0.25 * lr, f"{what}: max err {err.max():.3e} vs lr {lr}"
 
 
-@pytest.mark.parametrize("case", ["s500_train", "s500_eval", "s500_maxnorm", "s500_dropout"])
+@pytest.mark.parametrize("case", ["s500_train", "s500_eval", "s500_maxnorm", "s500_dropout", "s500_dropout2d"])
 def test_oracle_matches_reference_steps(golden_dir, case):
     g = np.load(os.path.join(golden_dir, f"eegnet_{case}.npz"))
     B, S = int(g["B"]), int(g["S"])

@@ -15,6 +15,11 @@ kind, B = sys.argv[1], int(sys.argv[2])
 prec = sys.argv[3] if len(sys.argv) > 3 else "fp32"
 model = T.Encoder(T.make_config(kind)).cuda().train()
 model.precision = prec
+if os.environ.get("NO_OVERLAP"):
+    model.overlap_wgrad = False
+if os.environ.get("SP_TILE"):
+    from eav_amd import _lib
+    _lib.call("eav_gemm_sp_set_tile", int(os.environ["SP_TILE"]))
 x, y = (synth.mel_batch(5, B) if kind == "ast" else synth.frame_batch(5, B))
 x, y = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
 opt, crit = FusedAdam(model.parameters(), lr=5e-6, weight_decay=0.01, decoupled=True), CrossEntropyLoss()

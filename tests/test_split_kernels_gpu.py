@@ -211,8 +211,11 @@ def _attn_prep(x, B, N, ncols, secw, tmask):
     return slot, rowp, tp
 
 
+# (3, 4, .) / (3, 3, .): 12 / 9 image-heads = one full group of 8 on the XCD-aware workgroup map plus a remainder;
+# N = 128 / 129: either side of the 64-row / 128-row workgroup switch
 @pytest.mark.parametrize("cfg", [(1, 2, 64, 1.0, False), (2, 3, 197, 1.0, False), (1, 2, 1214, 1.0, False),
-                                 (2, 2, 300, 3.0, True), (1, 1, 33, 1.0, False)])
+                                 (2, 2, 300, 3.0, True), (1, 1, 33, 1.0, False), (3, 4, 129, 1.0, False),
+                                 (3, 3, 128, 1.0, False), (4, 4, 70, 1.0, False)])
 def test_attention_sp_is_fp32_grade(cfg):
     B, H, N, qs, spike = cfg
     D = H * 64
@@ -246,3 +249,51 @@ def test_attention_sp_is_fp32_grade(cfg):
     for i in range(3):
         sl = slice(i * D, (i + 1) * D)
         assert rel(dqkv[:, sl], rg[:, sl]) <= 1.5 * rel(dq32[:, sl], rg[:, sl]) + 3e-7, i
+
+
+@pytest.mark.parametrize("shape", [(256, 256, 64), (300, 200, 96), (128, 130, 40)])
+@pytest.mark.parametrize("opts", [dict(bias=True), dict(bias=True, gelu=1, pre=True), dict(bias=True, resid=True),
+                                  dict(gelu=1, resid=True, acc=True, pre=True), dict(acc=True), dict(gelu=2),
+                                  dict(bias=True, gelu=2, resid=True)])
+def test_gemm_sp_epilogue_option_matrix(shape, opts):
+    """Every epilogue option combination on tiles inside the matrix (16-byte path) and ragged ones (element path),
+    against float64: C = [accumulate C0 +] [resid +] act(alpha A.B^T + bias), act = GELU or . x gelu'(pre)."""
+    M, N, K = shape
+    torch.manual_seed(M + N + len(opts))
+    A = torch.randn(M, K, device="cuda")
+    B = torch.randn(N, K, device="cuda") * 0.2
+    bias = torch.randn(N, device="cuda") if opts.get("bias") else None
+    resid = torch.randn(M, N, device="cuda") if opts.get("resid") else None
+    C0 = torch.randn(M, N, device="cuda")
+    gelu = opts.get("gelu", 0)
+    xin = torch.randn(M, N, device="cuda") * 1.5
+    pre = xin.clone() if gelu == 2 else (torch.empty(M, N, device="cuda") if opts.get("pre") else None)
+    lin = 0.75 * (A.double() @ B.double().t()) + (bias.double() if bias is not None else 0.0)
+    if gelu == 1:
+        want = torch.nn.functional.gelu(lin)
+    elif gelu == 2:
+        xd = xin.double().requires_grad_(True)
+        torch.nn.functional.gelu(xd).backward(torch.ones_like(xd))
+        want = lin * xd.grad
+    else:
+        want = lin
+    if resid is not None:
+        want = want + resid.double()
+    if opts.get("acc"):
+        want = want + C0.double()
+    kw = dict(alpha=0.75, gelu=gelu, C=C0.clone(), acc=1 if opts.get("acc") else 0)
+    if bias is not None:
+        kw["bias"] = bias
+    if resid is not None:
+        kw["resid"] = resid
+    if pre is not None:
+        kw["pre"] = pre
+    amax = torch.zeros(SLOT, device="cuda")
+    got = gemm_sp(A, B, amax=amax, **kw)
+    tol = 3e-5 * max(1.0, float(want.abs().max()))
+    assert (got.double() - want).abs().max().item() < tol
+    if gelu == 1 and pre is not None:
+        assert (pre.double() - lin).abs().max().item() < tol
+    if gelu == 2:
+        assert torch.equal(pre, xin)             # read-only in the backward mode
+    assert float(amax[:2048:32].view(torch.int32).max().view(torch.float32)) == float(got.abs().max())

@@ -59,6 +59,7 @@ SIGNATURES = {
     "eav_gemm_f32_splitk": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "eav_sp_absmax": [_p, _i, _i, _i64, _p, _p],
     "eav_sp_convert": [_p, _i, _i, _i64, _p, _p, _p, _p],
+    "eav_sp_convert_gelu": [_p, _i, _i, _i64, _p, _p, _p, _p],
     "eav_sp_convert_colsum": [_p, _i, _i, _i64, _p, _p, _p, _p, _p],
     "eav_layernorm_fwd_amax": [_p, _p, _p, _p, _p, _p, _i, _i, _f, _p, _p],
     "eav_layernorm_bwd_amax": [_p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _p, _p],

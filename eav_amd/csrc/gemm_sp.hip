@@ -64,6 +64,7 @@ struct SpArgs {
 // Measured over [-6, 6] against float64: max |error| 2.5e-7 (0.5 x (1 + erff(x / sqrt 2)) in fp32: 4.5e-7), max
 // |error| / |x| 1.7e-7.  One v_rcp_f32, one v_exp_f32, 12 other VALU instructions.
 __device__ __forceinline__ float gelu_erf(float x) {
+#pragma clang fp contract(off)   // one rounding sequence wherever this is inlined (GEMM epilogue and conversion pass agree bit for bit)
   const float z = fabsf(x) * 0.70710678118654752f;
   const float t = __builtin_amdgcn_rcpf(fmaf(0.55f, z, 1.0f));
   float p = 0.10732425004243851f;
@@ -79,6 +80,7 @@ __device__ __forceinline__ float gelu_erf(float x) {
 
 // d gelu / dx = Phi(x) + x phi(x) from the same erfc fit: Phi = erfc(z) / 2 for x < 0, 1 - erfc(z) / 2 otherwise
 __device__ __forceinline__ float gelu_erf_grad(float x) {
+#pragma clang fp contract(off)
   const float z = fabsf(x) * 0.70710678118654752f;
   const float t = __builtin_amdgcn_rcpf(fmaf(0.55f, z, 1.0f));
   float p = 0.10732425004243851f;
@@ -359,6 +361,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
 #pragma unroll
             for (int r = 0; r < 16; ++r) a[r] = gelu_erf(a[r]);
           }
+          if (g.gelu == 3) {          // C receives the PRE-activation; only max|GELU| is published (eav_sp_convert_gelu
+                                      // applies the activation while it splits - the activation tensor never exists in fp32)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float gv = fabsf(gelu_erf(a[r]));
+              vmax = fmaxf(vmax, ok(r) ? gv : 0.f);
+            }
+          }
           if (g.resid) {
             const float* rp = g.resid + (int64_t)row * g.ldr + col;
             float rv[16];
@@ -394,14 +404,16 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
 #pragma unroll
             for (int q = 0; q < 4; ++q)
               *reinterpret_cast<float4*>(C + o + 8 * q) = make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
+            if (g.gelu != 3) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) vmax = fmaxf(vmax, fabsf(a[r]));
+              for (int r = 0; r < 16; ++r) vmax = fmaxf(vmax, fabsf(a[r]));
+            }
           } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               if (ok(r)) {
                 C[o + 8 * (r >> 2) + (r & 3)] = a[r];
-                vmax = fmaxf(vmax, fabsf(a[r]));
+                if (g.gelu != 3) vmax = fmaxf(vmax, fabsf(a[r]));
               }
             }
           }
@@ -449,10 +461,9 @@ void launch(SpArgs& g, int nz, hipStream_t st) {
 
 void dispatch(SpArgs& g, int nz, hipStream_t st) {
   // measured (tools/gemm_sp_bench.py): the 256 x 128 / 8-wave form only wins on huge square problems (8192^3: +2 %) and
-  // loses up to 15 % on the encoder shapes, so the heuristic takes 128 x 128; 256 x 256 (single accumulator only: 128
-  // accumulator registers per lane) is a tuning hook
+  // loses up to 15 % on the encoder shapes, so the heuristic takes 128 x 128 (a 256 x 256 single-accumulator form gained
+  // 7-13 % only at >= 4096^3 and was dropped)
   if (g_force_tile == 2) launch<4, 2, 2, 2>(g, nz, st);
-  else if (g_force_tile == 3 && !g_loshift) launch<2, 4, 4, 2>(g, nz, st);
   else launch<2, 2, 2, 2>(g, nz, st);
 }
 
@@ -532,7 +543,7 @@ __global__ __launch_bounds__(256) void sp_convert_kernel(const float* __restrict
                                                          float* __restrict__ slot, unsigned char* __restrict__ dst,
                                                          int Cp, unsigned char* __restrict__ dstT, int Rp,
                                                          float lomul, float* __restrict__ colsum_part, int ntx,
-                                                         int ntiles) {
+                                                         int ntiles, int gelu) {
   __shared__ float tile[64][65];
   const float sigma = sigma_from_bits(eav_slot_bits(slot));
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -572,7 +583,7 @@ __global__ __launch_bounds__(256) void sp_convert_kernel(const float* __restrict
       const int row = r0 + rr + 32 * pass, col = c0 + 8 * cg;
       float tv[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) tv[e] = cur[pass][e] * sigma;
+      for (int e = 0; e < 8; ++e) tv[e] = (gelu ? gelu_erf(cur[pass][e]) : cur[pass][e]) * sigma;
       if (dst && row < R && col < Cp) {
         uint4 hi, lo;
         split8(tv, hi, lo, lomul);
@@ -623,12 +634,12 @@ __global__ __launch_bounds__(256) void sp_convert_kernel(const float* __restrict
 int g_convert_blocks = 512;   // resident-block cap of the conversion pass (tuning hook: eav_sp_set_convert_blocks)
 
 void launch_convert(const float* src, int R, int C, int64_t ld, float* slot, void* dst, void* dstT, float* colsum_part,
-                    hipStream_t st) {
+                    hipStream_t st, int gelu = 0) {
   const int ntx = cdiv(eav_sp_kpad(C), 64), nty = cdiv(eav_sp_kpad(R), 64);
   const int ntiles = ntx * nty;
   hipLaunchKernelGGL(sp_convert_kernel, dim3(std::min(ntiles, g_convert_blocks)), dim3(256), 0, st, src, R, C, ld, slot,
                      (unsigned char*)dst, eav_sp_kpad(C), (unsigned char*)dstT, eav_sp_kpad(R),
-                     g_loshift ? 2048.f : 1.f, colsum_part, ntx, ntiles);
+                     g_loshift ? 2048.f : 1.f, colsum_part, ntx, ntiles, gelu);
 }
 
 }  // namespace
@@ -654,6 +665,17 @@ extern "C" int eav_sp_convert(const float* src, int R, int C, int64_t ld, float*
               "eav_sp_convert: leading dimension must be a multiple of 4, buffers 16-byte aligned");
   launch_convert(src, R, C, ld, slot, dst, dstT, nullptr, (hipStream_t)stream);
   EAV_CHECK_LAUNCH("eav_sp_convert");
+  return EAV_OK;
+}
+
+// planes of GELU(src): src holds pre-activations (eav_gemm_sp with gelu = 3), slot the maximum of |GELU(src)|
+extern "C" int eav_sp_convert_gelu(const float* src, int R, int C, int64_t ld, float* slot, void* dst, void* dstT,
+                                   void* stream) {
+  EAV_REQUIRE(src && slot && R > 0 && C > 0 && (dst || dstT), "eav_sp_convert_gelu: bad arguments");
+  EAV_REQUIRE((ld & 3) == 0 && (((uintptr_t)src | (uintptr_t)dst | (uintptr_t)dstT) & 15) == 0,
+              "eav_sp_convert_gelu: leading dimension must be a multiple of 4, buffers 16-byte aligned");
+  launch_convert(src, R, C, ld, slot, dst, dstT, nullptr, (hipStream_t)stream, 1);
+  EAV_CHECK_LAUNCH("eav_sp_convert_gelu");
   return EAV_OK;
 }
 
@@ -688,7 +710,8 @@ extern "C" int eav_gemm_sp(const void* A, const void* B, float* C, const float* 
   EAV_REQUIRE((((uintptr_t)A | (uintptr_t)B) & 15) == 0 && (sA_bytes & 15) == 0,
               "eav_gemm_sp: operand planes must be 16-byte aligned");
   EAV_REQUIRE(!(resid && batch > 1), "eav_gemm_sp: residual epilogue is not batched");
-  EAV_REQUIRE(gelu >= 0 && gelu <= 2 && (gelu != 2 || pre), "eav_gemm_sp: gelu = 2 (backward) reads the pre-activation from `pre`");
+  EAV_REQUIRE(gelu >= 0 && gelu <= 3 && (gelu != 2 || pre), "eav_gemm_sp: gelu = 2 (backward) reads the pre-activation from `pre`");
+  EAV_REQUIRE(gelu != 3 || (!pre && !resid && !accumulate), "eav_gemm_sp: gelu = 3 stores the pre-activation only");
   SpArgs g;
   const int Kp = eav_sp_kpad(K);
   g.A = (const unsigned char*)A; g.B = (const unsigned char*)B; g.C = C; g.slotA = slotA; g.slotB = slotB;

@@ -623,9 +623,12 @@ class Encoder(nn.Module):
           w(f"{Lk}.layernorm_after.bias"), P(y), stp + 8 * M, stp + 12 * M, M, D, c.eps, s_y2, st)
         self._to_planes(P(y), M, D, D, s_y2, ws.y2p[j], T(ws.y2pT) if ws.full else None, amax_done=True)
         wpl, wsl = self._wp(f"fc1{i}")
-        self._gemm_sp(P(ws.y2p[j]), s_y2, wpl, wsl, P(act), M, FF, D, FF, bias=w(f"{Lk}.mlp.fc1.bias"), gelu=1,
-                      pre=P(ws.pre[j]) if ws.full else None, amax=s_act)
-        self._to_planes(P(act), M, FF, FF, s_act, ws.actp[j], T(ws.actpT) if ws.full else None, amax_done=True)
+        # fc1 stores the PRE-activation only (kept per layer for the backward; a scratch buffer in the frozen phase) and
+        # max|GELU|; the conversion applies the GELU while it splits - the activation never exists in fp32
+        pre = P(ws.pre[j]) if ws.full else P(act)
+        self._gemm_sp(P(ws.y2p[j]), s_y2, wpl, wsl, pre, M, FF, D, FF, bias=w(f"{Lk}.mlp.fc1.bias"), gelu=3, amax=s_act)
+        self._call("eav_sp_convert_gelu", pre, M, FF, FF, s_act, P(ws.actp[j]),
+                   P(ws.actpT[j]) if ws.full else None, self._st)
         wpl, wsl = self._wp(f"fc2{i}")
         self._gemm_sp(P(ws.actp[j]), s_act, wpl, wsl, P(hout), M, D, FF, D, bias=w(f"{Lk}.mlp.fc2.bias"),
                       resid=P(ws.hmid[j]), ldr=D)

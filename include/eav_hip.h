@@ -222,6 +222,8 @@ int eav_gemm_bf16_splitk(const float* A, const float* B, float* C, float* ws, in
 int eav_sp_kpad(int K);
 int eav_sp_absmax(const float* src, int R, int C, int64_t ld, float* slot, void* stream);
 int eav_sp_convert(const float* src, int R, int C, int64_t ld, float* slot, void* dst, void* dstT, void* stream);
+/* planes of GELU(src): src = pre-activations written by eav_gemm_sp with gelu = 3, slot = max |GELU(src)| */
+int eav_sp_convert_gelu(const float* src, int R, int C, int64_t ld, float* slot, void* dst, void* dstT, void* stream);
 /* the same pass also emitting bias-gradient partials: colsum_part [eav_sp_convert_colsum_nparts(R)][C] (column sums of
  * 64-row tiles; finish with eav_reduce_partials) */
 int eav_sp_convert_colsum_nparts(int R);
@@ -236,7 +238,9 @@ int eav_gelu_bwd_amax(float* dact, const float* pre, int64_t n, float* amax_slot
 /* C[z][m,n] = epilogue(alpha * sum_k A[z][m,k] B[n,k]) from planes A [M,Kp], B [N,Kp]; epilogue as eav_gemm_f32
  * (bias, erf-GELU with pre-activation store, residual, accumulate); amax_slot (optional) receives max |C| bits.
  * gelu = 2: backward through GELU - the product is multiplied by gelu'(pre[m,n]), `pre` (ldc) is READ (the forward's
- * stored pre-activation): fc2's data gradient and eav_gelu_bwd in one pass. */
+ * stored pre-activation): fc2's data gradient and eav_gelu_bwd in one pass.
+ * gelu = 3: C receives the pre-activation itself and amax_slot max |GELU(C)| - the activation is formed by
+ * eav_sp_convert_gelu while it splits (no fp32 activation tensor); pre / resid / accumulate must be unset. */
 int eav_gemm_sp(const void* A, const void* B, float* C, const float* slotA, const float* slotB, int M, int N, int K,
                 int ldc, int batch, int64_t sA_bytes, int64_t sC, float alpha, const float* bias, int gelu, float* pre,
                 const float* resid, int ldr, int accumulate, float* amax_slot, void* stream);

@@ -297,3 +297,26 @@ def test_gemm_sp_epilogue_option_matrix(shape, opts):
     if gelu == 2:
         assert torch.equal(pre, xin)             # read-only in the backward mode
     assert float(amax[:2048:32].view(torch.int32).max().view(torch.float32)) == float(got.abs().max())
+
+
+def test_pre_activation_only_epilogue_and_gelu_conversion():
+    """gelu = 3 + eav_sp_convert_gelu (fc1 of the encoder: no fp32 activation tensor) give the same planes, bit for bit,
+    as gelu = 1 followed by eav_sp_convert of the stored activation."""
+    torch.manual_seed(9)
+    M, N, K = 300, 256, 96
+    A = torch.randn(M, K, device="cuda")
+    B = torch.randn(N, K, device="cuda") * 0.3
+    bias = torch.randn(N, device="cuda")
+    pre1 = torch.empty(M, N, device="cuda")
+    s1 = torch.zeros(SLOT, device="cuda")
+    act = gemm_sp(A, B, bias=bias, gelu=1, pre=pre1, amax=s1)
+    p1 = torch.zeros(M, 2 * kpad(N), dtype=torch.float16, device="cuda")
+    p1T = torch.zeros(N, 2 * kpad(M), dtype=torch.float16, device="cuda")
+    _lib.call("eav_sp_convert", P(act), M, N, N, P(s1), P(p1), P(p1T), None)
+    s3 = torch.zeros(SLOT, device="cuda")
+    pre3 = gemm_sp(A, B, bias=bias, gelu=3, amax=s3)
+    p3, p3T = torch.zeros_like(p1), torch.zeros_like(p1T)
+    _lib.call("eav_sp_convert_gelu", P(pre3), M, N, N, P(s3), P(p3), P(p3T), None)
+    assert torch.equal(pre3, pre1)
+    assert float(s3[:2048:32].view(torch.int32).max()) == float(s1[:2048:32].view(torch.int32).max())
+    assert torch.equal(p3.view(torch.int16), p1.view(torch.int16)) and torch.equal(p3T.view(torch.int16), p1T.view(torch.int16))

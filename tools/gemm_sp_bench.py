@@ -82,8 +82,7 @@ def check_wgrad(Mtok, N, K):
 
 
 def bench(name, M, N, K, epi=False):
-    """tile codes (eav_gemm_sp_set_tile): 1 = 128x128 two-accumulator planes, +4 = single-accumulator planes, 3 = 256x256
-    (single-accumulator only), +8 = one workgroup per tile instead of persistent workgroups (the operand planes are
+    """tile codes (eav_gemm_sp_set_tile): 1 = 128x128 two-accumulator planes, 2 = 256x128, +4 = single-accumulator planes, +8 = one workgroup per tile instead of persistent workgroups (the operand planes are
     converted in the matching format)."""
     A = torch.randn(M, K, device="cuda")
     B = torch.randn(N, K, device="cuda") * 0.02

@@ -14,6 +14,7 @@ recomputed; attention probabilities are materialised per layer ([B*H, N, N] fp32
 """
 from __future__ import annotations
 
+import contextlib
 import json
 import os
 from types import SimpleNamespace
@@ -177,7 +178,7 @@ class Encoder(nn.Module):
         # logits unchanged - and bf16 operands for the backward products only).  EAV_ENCODER_PRECISION overrides.
         self.precision = os.environ.get("EAV_ENCODER_PRECISION", DEFAULT_PRECISION)
         self.overlap_wgrad = True     # split mode: weight-gradient GEMMs on a side stream (see _wgrad_sp)
-        self._side, self._wgrad_done = None, {}
+        self._side, self._wgrad_done, self._wready = None, {}, {}
         self._wplanes = None          # split mode: {weight key: (planes, planes of the transpose, slot index)}
         self._wplanes_key = None
         self._phase = "fwd"
@@ -414,24 +415,42 @@ class Encoder(nn.Module):
                          torch.empty(inn, 2 * kp(out), dtype=torch.float16, device=dev) if need_T else None, n)
             self._wplanes = wp
         wp = self._wplanes
-        st = _lib.stream_ptr()
         stale = []
         for k, pname, out, inn in keys:
             src = _lib.ptr(self._pmap[pname])
             if everything or any(lo < src + 4 * out * inn and src < hi for lo, hi in dirty):
                 stale.append((k, src, out, inn))
-        if len(stale) == len(keys):
-            wp["_slots"].zero_()
-        for k, src, out, inn in stale:
-            pl, plT, n = wp[k]
-            if len(stale) != len(keys):
-                wp["_slots"][n].zero_()
-            slot = wp["_slots"].data_ptr() + 4 * self.SLOT * n
-            _lib.call("eav_sp_absmax", src, out, inn, inn, slot, st)
-            _lib.call("eav_sp_convert", src, out, inn, inn, slot, _lib.ptr(pl), _lib.ptr(plT), st)
+        # After an optimiser step every matrix is stale: ~100 small launches (max|w| + conversion per matrix).  They go to
+        # the side stream - idle during the forward - in layer order, one event per matrix; the main stream waits for a
+        # matrix's event right before the first GEMM that reads its planes (_wp), so only the patch projection's
+        # conversion is ever on the critical path.
+        side = self._side_stream(dev) if (stale and self.overlap_wgrad and self.kernel_events is None) else None
+        self._wready = {}
+        if side is not None:
+            start = torch.cuda.Event()
+            start.record()                      # the weights are final (the optimiser ran on this stream)
+            side.wait_event(start)
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            st = _lib.stream_ptr()
+            if len(stale) == len(keys):
+                wp["_slots"].zero_()
+            for k, src, out, inn in stale:
+                pl, plT, n = wp[k]
+                if len(stale) != len(keys):
+                    wp["_slots"][n].zero_()
+                slot = wp["_slots"].data_ptr() + 4 * self.SLOT * n
+                _lib.call("eav_sp_absmax", src, out, inn, inn, slot, st)
+                _lib.call("eav_sp_convert", src, out, inn, inn, slot, _lib.ptr(pl), _lib.ptr(plT), st)
+                if side is not None:
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    self._wready[k] = ev
         self._wplanes_key = key
 
     def _wp(self, key, transposed=False):
+        ev = self._wready.pop(key, None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
         pl, plT, n = self._wplanes[key]
         return _lib.ptr(plT if transposed else pl), self._wplanes["_slots"].data_ptr() + 4 * self.SLOT * n
 
@@ -468,8 +487,7 @@ class Encoder(nn.Module):
             self._call("eav_gemm_sp_splitk", _lib.ptr(AT), _lib.ptr(BT), C, _lib.ptr(self._ws.splitk), slotA, slotB, M,
                        N, K, 0, self._st)
             return
-        if self._side is None or self._side.device != AT.device:
-            self._side = torch.cuda.Stream(device=AT.device)
+        self._side_stream(AT.device)
         ready = torch.cuda.Event()
         ready.record()
         self._side.wait_event(ready)
@@ -478,6 +496,11 @@ class Encoder(nn.Module):
         done = torch.cuda.Event()
         done.record(self._side)
         self._wgrad_done[AT.data_ptr()] = done
+
+    def _side_stream(self, dev):
+        if self._side is None or self._side.device != dev:
+            self._side = torch.cuda.Stream(device=dev)
+        return self._side
 
     def _before_overwrite(self, buf):
         """Main stream: the weight gradient that still reads `buf` (launched a layer ago on the side stream) must be

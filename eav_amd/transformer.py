@@ -179,6 +179,7 @@ class Encoder(nn.Module):
         self.precision = os.environ.get("EAV_ENCODER_PRECISION", DEFAULT_PRECISION)
         self.overlap_wgrad = True     # split mode: weight-gradient GEMMs on a side stream (see _wgrad_sp)
         self._side, self._wgrad_done, self._wready = None, {}, {}
+        self._part_busy, self._ring_pos = {}, {}
         self._wplanes = None          # split mode: {weight key: (planes, planes of the transpose, slot index)}
         self._wplanes_key = None
         self._phase = "fwd"
@@ -328,6 +329,7 @@ class Encoder(nn.Module):
             ws.demb = f(B * c.npatch, D)
             ws.np_ln = _lib.plain("eav_layernorm_bwd_nparts", M)
             ws.part_ln = f(ws.np_ln, 2 * D)
+            ws.part_ln_pool = [ws.part_ln, f(ws.np_ln, 2 * D)]     # split path: see _part_buf
             ws.np_cs = _lib.plain("eav_colsum_nparts", M)
             ws.part_cs = f(ws.np_cs, max(FF, 3 * D))
             shapes = [(D, FF, M), (FF, D, M), (3 * D, D, M), (D, D, M), (D, c.kp, B * c.npatch)]
@@ -377,6 +379,7 @@ class Encoder(nn.Module):
             ws.dembpT = h(D, MP)
             ws.np_cs2 = _lib.plain("eav_sp_convert_colsum_nparts", M)
             ws.part_cs2 = torch.empty(ws.np_cs2, max(FF, 3 * D), dtype=torch.float32, device=dev)
+            ws.part_cs2_pool = [ws.part_cs2] + [torch.empty_like(ws.part_cs2) for _ in range(3)]
             ws.bslots = torch.zeros(1 + self.BS * Lr, self.SLOT, dtype=torch.float32, device=dev)
             if ws.fused:
                 ws.dorow = torch.empty(M, 2 * D, dtype=torch.float16, device=dev)
@@ -460,13 +463,39 @@ class Encoder(nn.Module):
             self._call("eav_sp_absmax", src, R, C, ld, slot, self._st)
         self._call("eav_sp_convert", src, R, C, ld, slot, _lib.ptr(dst), _lib.ptr(dstT), self._st)
 
+    def _part_buf(self, pool):
+        """Next buffer of a small ring of partial-sum buffers.  The final reductions of bias / LayerNorm parameter gradients
+        are gradient OUTPUTS nothing downstream reads, so they run on the side stream (_reduce_async); the main stream
+        waits for the reduction that last read a buffer only when the ring comes round to it (a layer later)."""
+        ws = self._ws
+        ring = getattr(ws, pool)
+        i = self._ring_pos.get(pool, -1) + 1
+        self._ring_pos[pool] = i = i % len(ring)
+        ev = self._part_busy.pop(ring[i].data_ptr(), None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+        return ring[i]
+
+    def _reduce_async(self, buf, off_bytes, nparts, stride, n, out):
+        if not (self.overlap_wgrad and self.kernel_events is None):
+            self._call("eav_reduce_partials", _lib.ptr(buf) + off_bytes, nparts, stride, n, 1.0, out, self._st)
+            return
+        side = self._side_stream(buf.device)
+        ready = torch.cuda.Event()
+        ready.record()
+        side.wait_event(ready)
+        _lib.call("eav_reduce_partials", _lib.ptr(buf) + off_bytes, nparts, stride, n, 1.0, out, side.cuda_stream)
+        done = torch.cuda.Event()
+        done.record(side)
+        self._part_busy[buf.data_ptr()] = done
+
     def _to_planes_bias(self, src, R, C, slot, dst, dstT, bias_grad):
         """Conversion pass that also produces the bias gradient (column sums of src) - src's max|x| is already in slot."""
         ws = self._ws
         self._before_overwrite(dstT)
-        self._call("eav_sp_convert_colsum", src, R, C, C, slot, _lib.ptr(dst), _lib.ptr(dstT), _lib.ptr(ws.part_cs2),
-                   self._st)
-        self._call("eav_reduce_partials", _lib.ptr(ws.part_cs2), ws.np_cs2, C, C, 1.0, bias_grad, self._st)
+        part = self._part_buf("part_cs2_pool")
+        self._call("eav_sp_convert_colsum", src, R, C, C, slot, _lib.ptr(dst), _lib.ptr(dstT), _lib.ptr(part), self._st)
+        self._reduce_async(part, 0, ws.np_cs2, C, C, bias_grad)
 
     def _gemm_sp(self, A, slotA, B, slotB, C, M, N, K, ldc, batch=1, sA=0, sC=0, alpha=1.0, bias=None, gelu=0,
                  pre=None, resid=None, ldr=0, acc=0, amax=None):
@@ -510,9 +539,10 @@ class Encoder(nn.Module):
             torch.cuda.current_stream().wait_event(ev)
 
     def _join_wgrads(self):
-        if self._side is not None and self._wgrad_done:
+        if self._side is not None and (self._wgrad_done or self._part_busy):
             torch.cuda.current_stream().wait_stream(self._side)
             self._wgrad_done.clear()
+            self._part_busy.clear()
 
     def _launch_forward(self, x):
         c = self.cfg
@@ -685,9 +715,10 @@ class Encoder(nn.Module):
         self._wgrad_sp(ws.dactpT, b_dact, ws.y2pT[i], s_y2, gp(f"{Lk}.mlp.fc1.weight"), FF, D, M)
         wpl, wsl = self._wp(f"fc1{i}", transposed=True)
         self._gemm_sp(P(ws.dactp), b_dact, wpl, wsl, dy, M, D, FF, D)
+        part = self._part_buf("part_ln_pool")
         L("eav_layernorm_bwd_amax", dy, P(ws.hmid[i]), w(f"{Lk}.layernorm_after.weight"), stp + 8 * M, stp + 12 * M, dh,
-          1, P(ws.part_ln), M, D, b_dh1, st)
-        self._reduce_ln(gp(f"{Lk}.layernorm_after.weight"), gp(f"{Lk}.layernorm_after.bias"))
+          1, P(part), M, D, b_dh1, st)
+        self._reduce_ln(part, gp(f"{Lk}.layernorm_after.weight"), gp(f"{Lk}.layernorm_after.bias"))
         # o_proj
         self._to_planes_bias(dh, M, D, b_dh1, ws.dhp, ws.dhpT2, gp(f"{Lk}.attention.o_proj.bias"))
         self._wgrad_sp(ws.dhpT2, b_dh1, ws.aopT[i], s_ao, gp(f"{Lk}.attention.o_proj.weight"), D, D, M)
@@ -719,23 +750,24 @@ class Encoder(nn.Module):
         wpl, wsl = self._wp(f"qkv{i}", transposed=True)
         self._gemm_sp(P(ws.dqkvp), b_dqkv, wpl, wsl, dy, M, D, 3 * D, D)
         # the gradient w.r.t. this layer's input is the next (lower) layer's dh: leave its max in that layer's slot
+        part = self._part_buf("part_ln_pool")
         L("eav_layernorm_bwd_amax", dy, P(ws.hs[i]), w(f"{Lk}.layernorm_before.weight"), stp, stp + 4 * M, dh, 1,
-          P(ws.part_ln), M, D, bslot(1 + self.BS * (i - 1)) if i > 0 else bslot(0), st)
-        self._reduce_ln(gp(f"{Lk}.layernorm_before.weight"), gp(f"{Lk}.layernorm_before.bias"))
+          P(part), M, D, bslot(1 + self.BS * (i - 1)) if i > 0 else bslot(0), st)
+        self._reduce_ln(part, gp(f"{Lk}.layernorm_before.weight"), gp(f"{Lk}.layernorm_before.bias"))
 
     def _wgrad(self, A, B, C, M, N, K, lda, ldb):
         """C[M,N] = A^T.B for A stored [K,M], B stored [K,N] (weight gradient: contraction over tokens)."""
         self._call(self._gemm_name() + "_splitk", A, B, C, _lib.ptr(self._ws.splitk), M, N, K, lda, ldb, 1, 1, self._st)
 
-    def _reduce_ln(self, gw, gb):
-        """LayerNorm weight / bias gradients from ws.part_ln ([np_ln][2 D]: dgamma | dbeta partials): one launch when the
+    def _reduce_ln(self, part, gw, gb):
+        """LayerNorm weight / bias gradients from `part` ([np_ln][2 D]: dgamma | dbeta partials): one launch when the
         two gradients are neighbours in the flat buffer (they are: weight, then bias, D floats each)."""
         ws, D = self._ws, self.cfg.hidden
         if gb == gw + 4 * D:
-            self._reduce(ws.part_ln, ws.np_ln, 2 * D, 2 * D, gw)
+            self._reduce_async(part, 0, ws.np_ln, 2 * D, 2 * D, gw)
         else:
-            self._reduce(ws.part_ln, ws.np_ln, 2 * D, D, gw)
-            self._call("eav_reduce_partials", _lib.ptr(ws.part_ln) + 4 * D, ws.np_ln, 2 * D, D, 1.0, gb, self._st)
+            self._reduce(part, ws.np_ln, 2 * D, D, gw)
+            self._call("eav_reduce_partials", _lib.ptr(part) + 4 * D, ws.np_ln, 2 * D, D, 1.0, gb, self._st)
 
     def _reduce(self, part, nparts, stride, n, out):
         self._call("eav_reduce_partials", _lib.ptr(part), nparts, stride, n, 1.0, out, self._st)

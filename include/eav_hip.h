@@ -9,6 +9,8 @@
  * eav_last_error(), thread-local).  All pointers are caller-owned DEVICE pointers unless said
  * otherwise; nothing is allocated inside; `stream` is a hipStream_t (NULL = default stream);
  * launches are asynchronous.  Tensors are dense, row-major, fp32 unless noted.
+ * The only process-wide state are the eav_*_set_* tuning hooks (tile shape, resident-block caps): plain globals read at
+ * launch time, meant to be set once before work is issued (benchmarks / experiments), not synchronised across threads.
  */
 #ifndef EAV_HIP_H
 #define EAV_HIP_H

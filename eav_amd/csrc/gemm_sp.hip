@@ -544,7 +544,13 @@ __global__ __launch_bounds__(256) void sp_convert_kernel(const float* __restrict
                                                          int Cp, unsigned char* __restrict__ dstT, int Rp,
                                                          float lomul, float* __restrict__ colsum_part, int ntx,
                                                          int ntiles, int gelu) {
+  // A thread's natural output - the hi and the lo piece of 8 values - is 32 contiguous bytes but a store carries 16: stored
+  // directly, every store instruction writes 16-byte chunks with 16-byte holes (measured: 4.4 TB/s; with 32-byte holes
+  // 2.5-3).  The pieces go through an LDS image of the tile's planes instead and leave in linear order: each store
+  // instruction then writes whole 256-byte row segments.
   __shared__ float tile[64][65];
+  __shared__ uint4 pimg[64 * 16 + 64];     // planes image: row r = 16 pieces (8 groups x hi, lo), one piece of padding per row
+  __shared__ uint4 timg[64 * 16 + 64];     // the same for the transposed planes (row = tile column)
   const float sigma = sigma_from_bits(eav_slot_bits(slot));
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     slot[EAV_SLOT_SIGMA] = sigma;
@@ -569,6 +575,15 @@ __global__ __launch_bounds__(256) void sp_convert_kernel(const float* __restrict
       }
     }
   };
+  // linear copy-out of an image: piece p = t + 256 k -> image row p >> 4, piece p & 15 (a wave = 4 rows x 256 bytes)
+  auto copy_out = [&](const uint4* img, unsigned char* base, int64_t pitch, int row0, int nrows, int grp0, int ngrp) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int p = t + 256 * k, r = p >> 4, pc = p & 15;
+      if (row0 + r < nrows && grp0 + (pc >> 1) < ngrp)
+        *reinterpret_cast<uint4*>(base + (int64_t)(row0 + r) * pitch + (int64_t)grp0 * 32 + pc * 16) = img[r * 17 + pc];
+    }
+  };
   float cur[2][8];
   int id = blockIdx.x;
   if (id < ntiles) load_tile(id, cur);
@@ -580,50 +595,46 @@ __global__ __launch_bounds__(256) void sp_convert_kernel(const float* __restrict
     const int r0 = by * 64, c0 = bx * 64;
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
-      const int row = r0 + rr + 32 * pass, col = c0 + 8 * cg;
       float tv[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) tv[e] = (gelu ? gelu_erf(cur[pass][e]) : cur[pass][e]) * sigma;
-      if (dst && row < R && col < Cp) {
+      if (dst) {
         uint4 hi, lo;
         split8(tv, hi, lo, lomul);
-        uint4* o = reinterpret_cast<uint4*>(dst + (int64_t)row * Cp * 4 + (col >> 3) * 32);
-        o[0] = hi;
-        o[1] = lo;
+        pimg[(rr + 32 * pass) * 17 + 2 * cg] = hi;
+        pimg[(rr + 32 * pass) * 17 + 2 * cg + 1] = lo;
       }
       if (dstT || colsum_part) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) tile[rr + 32 * pass][8 * cg + e] = tv[e];
       }
     }
-    if (dstT || colsum_part) {
-      __syncthreads();
-      if (colsum_part && t < 64 && c0 + t < C) {   // bias gradient partial: column sums of this 64-row tile (sigma is 2^e: exact)
-        float a = 0.f, b = 0.f, c = 0.f, d = 0.f;
+    __syncthreads();
+    if (dst) copy_out(pimg, dst, (int64_t)Cp * 4, r0, R, c0 >> 3, Cp >> 3);
+    if (colsum_part && t < 64 && c0 + t < C) {   // bias gradient partial: column sums of this 64-row tile (sigma is 2^e: exact)
+      float a = 0.f, b = 0.f, c = 0.f, d = 0.f;
 #pragma unroll
-        for (int r = 0; r < 64; r += 4) {
-          a += tile[r][t]; b += tile[r + 1][t]; c += tile[r + 2][t]; d += tile[r + 3][t];
-        }
-        colsum_part[(int64_t)by * C + c0 + t] = ((a + b) + (c + d)) * (1.f / sigma);
+      for (int r = 0; r < 64; r += 4) {
+        a += tile[r][t]; b += tile[r + 1][t]; c += tile[r + 2][t]; d += tile[r + 3][t];
       }
-      if (dstT) {
-        const int rg = t & 7, cc = t >> 3;
-#pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-          const int col = c0 + cc + 32 * pass, row = r0 + 8 * rg;
-          if (col >= C || row >= Rp) continue;
-          float tv[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) tv[e] = tile[8 * rg + e][cc + 32 * pass];
-          uint4 hi, lo;
-          split8(tv, hi, lo, lomul);
-          uint4* o = reinterpret_cast<uint4*>(dstT + (int64_t)col * Rp * 4 + (row >> 3) * 32);
-          o[0] = hi;
-          o[1] = lo;
-        }
-      }
-      __syncthreads();
+      colsum_part[(int64_t)by * C + c0 + t] = ((a + b) + (c + d)) * (1.f / sigma);
     }
+    if (dstT) {
+      const int rg = t & 7, cc = t >> 3;
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        float tv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) tv[e] = tile[8 * rg + e][cc + 32 * pass];
+        uint4 hi, lo;
+        split8(tv, hi, lo, lomul);
+        timg[(cc + 32 * pass) * 17 + 2 * rg] = hi;
+        timg[(cc + 32 * pass) * 17 + 2 * rg + 1] = lo;
+      }
+      __syncthreads();
+      copy_out(timg, dstT, (int64_t)Rp * 4, c0, C, r0 >> 3, Rp >> 3);
+    }
+    __syncthreads();     // tile / pimg / timg are rewritten by the next iteration
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass)
 #pragma unroll

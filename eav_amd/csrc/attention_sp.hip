@@ -525,7 +525,10 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_kv_sp_kernel(
 __global__ __launch_bounds__(256) void attn_sp_prep_kernel(const float* __restrict__ src, float* __restrict__ slot,
                                                            u8* __restrict__ rowp, u8* __restrict__ tp, int N, int Npad,
                                                            int ncols, int secw, unsigned tmask) {
+  // hi / lo pieces leave through LDS images in linear order: whole 256-byte row segments per store instruction instead of
+  // 16-byte chunks with 16-byte holes (the same change took eav_sp_convert from 4.3 to 5.4 TB/s)
   __shared__ float tile[64][65];
+  __shared__ uint4 pimg[64 * 17];
   const float sigma = sigma_from_bits(slot_bits(slot));
   if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
     slot[EAV_SLOT_SIGMA] = sigma;
@@ -547,16 +550,15 @@ __global__ __launch_bounds__(256) void attn_sp_prep_kernel(const float* __restri
         tv[0] = a.x; tv[1] = a.y; tv[2] = a.z; tv[3] = a.w; tv[4] = c.x; tv[5] = c.y; tv[6] = c.z; tv[7] = c.w;
 #pragma unroll
         for (int e = 0; e < 8; ++e) tv[e] *= sigma;
-        if (rowp) {
-          f16x8 hi, lo;
-          split_frag(tv, 1.f, hi, lo);
-          uint4* o = reinterpret_cast<uint4*>(rowp + ((int64_t)b * N + tok) * ncols * 4 + (col >> 3) * 32);
-          o[0] = *reinterpret_cast<const uint4*>(&hi);
-          o[1] = *reinterpret_cast<const uint4*>(&lo);
-        }
       } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e) tv[e] = 0.f;
+      }
+      if (rowp) {
+        f16x8 hi, lo;
+        split_frag(tv, 1.f, hi, lo);
+        pimg[(rr + 32 * pass) * 17 + 2 * cg] = *reinterpret_cast<const uint4*>(&hi);
+        pimg[(rr + 32 * pass) * 17 + 2 * cg + 1] = *reinterpret_cast<const uint4*>(&lo);
       }
       if (wantT) {
 #pragma unroll
@@ -564,23 +566,38 @@ __global__ __launch_bounds__(256) void attn_sp_prep_kernel(const float* __restri
       }
     }
   }
-  if (!wantT) return;
   __syncthreads();
+  if (rowp) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int p = t + 256 * k, r = p >> 4, pc = p & 15;
+      if (t0 + r < N)
+        *reinterpret_cast<uint4*>(rowp + ((int64_t)b * N + t0 + r) * ncols * 4 + (c0 >> 3) * 32 + pc * 16) = pimg[r * 17 + pc];
+    }
+  }
+  if (!wantT) return;
+  __syncthreads();          // pimg is reused for the transposed image
   {
     const int rg = t & 7, cc = t >> 3;
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
-      const int d = cc + 32 * pass, tok = t0 + 8 * rg;
-      if (tok >= Npad) continue;
+      const int d = cc + 32 * pass;
       float tv[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) tv[e] = tile[8 * rg + e][d];
       f16x8 hi, lo;
       split_frag(tv, 1.f, hi, lo);
-      uint4* o = reinterpret_cast<uint4*>(tp + (((int64_t)b * (ncols / 64) + chunk) * 64 + d) * Npad * 4 + (tok >> 3) * 32);
-      o[0] = *reinterpret_cast<const uint4*>(&hi);
-      o[1] = *reinterpret_cast<const uint4*>(&lo);
+      pimg[d * 17 + 2 * rg] = *reinterpret_cast<const uint4*>(&hi);
+      pimg[d * 17 + 2 * rg + 1] = *reinterpret_cast<const uint4*>(&lo);
     }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int p = t + 256 * k, d = p >> 4, pc = p & 15;
+    if (t0 + 8 * (pc >> 1) < Npad)
+      *reinterpret_cast<uint4*>(tp + (((int64_t)b * (ncols / 64) + chunk) * 64 + d) * Npad * 4 + (t0 >> 3) * 32 + pc * 16) =
+          pimg[d * 17 + pc];
   }
 }
 

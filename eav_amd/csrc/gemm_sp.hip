@@ -105,7 +105,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
   constexpr int NMF = 3 * NT;             // MFMAs per K-step of 16
   constexpr int NRD = 2 * (RM + RN);      // fragment reads per K-step
   static_assert(NCH % NW == 0 && CPW <= NMF && NRD <= NMF, "stage chunks / fragment reads must fit the MFMA slots");
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
+  // + one 32 x 32 fp32 patch per wave: the epilogue turns accumulator blocks into row-linear order through it
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE + NW * 4096];
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -297,65 +298,33 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
     float* pre = g.pre ? g.pre + (g.kt_per_split > 0 ? 0 : z * g.sC) : nullptr;
     // Accumulator block (i, j) holds output rows rowb + (lane & 31), columns colb + 4 kh + 8 q + e in register 4 q + e.
     // Every run-time option (pre-activation store, GELU, residual, accumulate) is tested once per block, all loads of a
-    // block are issued before its arithmetic.  Vector form (tile inside the matrix, 16-byte aligned rows): 4 float4
-    // stores per block instead of 16 dword stores - a wave's 64 + stores would otherwise run into the 63-entry vmcnt
-    // limit behind the next tile's in-flight stages.
-    auto epilogue = [&](auto vec_c) {
-      constexpr bool VEC = decltype(vec_c)::value;
+    // block are issued before its arithmetic.  Element form: ragged tiles and unaligned operands.
+    auto epilogue_elements = [&]() {
 #pragma unroll
       for (int j = 0; j < RN; ++j) {
         const int col = n0 + wn * 32 * RN + 32 * j + 4 * kh;
         float bv[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) bv[r] = 0.f;
-        if (g.bias) {
-          if constexpr (VEC) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const float4 b4 = *reinterpret_cast<const float4*>(g.bias + col + 8 * q);
-              bv[4 * q] = b4.x; bv[4 * q + 1] = b4.y; bv[4 * q + 2] = b4.z; bv[4 * q + 3] = b4.w;
-            }
-          } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int c = col + 8 * (r >> 2) + (r & 3);
-              bv[r] = c < N ? g.bias[c] : 0.f;
-            }
-          }
+        for (int r = 0; r < 16; ++r) {
+          const int c = col + 8 * (r >> 2) + (r & 3);
+          bv[r] = (g.bias && c < N) ? g.bias[c] : 0.f;
         }
 #pragma unroll
         for (int i = 0; i < RM; ++i) {
           const int row = m0 + wm * 32 * RM + 32 * i + r32;
-          const bool rowok = VEC || row < M;
-          auto ok = [&](int r) { return VEC || (rowok && col + 8 * (r >> 2) + (r & 3) < N); };
+          const bool rowok = row < M;
+          auto ok = [&](int r) { return rowok && col + 8 * (r >> 2) + (r & 3) < N; };
           const int64_t o = (int64_t)row * g.ldc + col;
           f32x16& a = acc[i][j];
 #pragma unroll
           for (int r = 0; r < 16; ++r) a[r] = alpha * a[r] + bv[r];
           if (g.gelu == 2) {        // backward through GELU: scale by gelu'(pre), pre = the forward's stored pre-activation
-            float pv[16];
-            if constexpr (VEC) {
 #pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                const float4 v4 = *reinterpret_cast<const float4*>(pre + o + 8 * q);
-                pv[4 * q] = v4.x; pv[4 * q + 1] = v4.y; pv[4 * q + 2] = v4.z; pv[4 * q + 3] = v4.w;
-              }
-            } else {
-#pragma unroll
-              for (int r = 0; r < 16; ++r) pv[r] = ok(r) ? pre[o + 8 * (r >> 2) + (r & 3)] : 0.f;
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) a[r] *= gelu_erf_grad(pv[r]);
+            for (int r = 0; r < 16; ++r) a[r] *= gelu_erf_grad(ok(r) ? pre[o + 8 * (r >> 2) + (r & 3)] : 0.f);
           } else if (pre) {
-            if constexpr (VEC) {
 #pragma unroll
-              for (int q = 0; q < 4; ++q)
-                *reinterpret_cast<float4*>(pre + o + 8 * q) = make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
-            } else {
-#pragma unroll
-              for (int r = 0; r < 16; ++r)
-                if (ok(r)) pre[o + 8 * (r >> 2) + (r & 3)] = a[r];
-            }
+            for (int r = 0; r < 16; ++r)
+              if (ok(r)) pre[o + 8 * (r >> 2) + (r & 3)] = a[r];
           }
           if (g.gelu == 1) {
 #pragma unroll
@@ -372,59 +341,117 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
           if (g.resid) {
             const float* rp = g.resid + (int64_t)row * g.ldr + col;
             float rv[16];
-            if constexpr (VEC) {
 #pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                const float4 v4 = *reinterpret_cast<const float4*>(rp + 8 * q);
-                rv[4 * q] = v4.x; rv[4 * q + 1] = v4.y; rv[4 * q + 2] = v4.z; rv[4 * q + 3] = v4.w;
-              }
-            } else {
-#pragma unroll
-              for (int r = 0; r < 16; ++r) rv[r] = ok(r) ? rp[8 * (r >> 2) + (r & 3)] : 0.f;
-            }
+            for (int r = 0; r < 16; ++r) rv[r] = ok(r) ? rp[8 * (r >> 2) + (r & 3)] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) a[r] += rv[r];
           }
           if (g.accumulate) {
             float cv[16];
-            if constexpr (VEC) {
 #pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                const float4 v4 = *reinterpret_cast<const float4*>(C + o + 8 * q);
-                cv[4 * q] = v4.x; cv[4 * q + 1] = v4.y; cv[4 * q + 2] = v4.z; cv[4 * q + 3] = v4.w;
-              }
-            } else {
-#pragma unroll
-              for (int r = 0; r < 16; ++r) cv[r] = ok(r) ? C[o + 8 * (r >> 2) + (r & 3)] : 0.f;
-            }
+            for (int r = 0; r < 16; ++r) cv[r] = ok(r) ? C[o + 8 * (r >> 2) + (r & 3)] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) a[r] += cv[r];
           }
-          if constexpr (VEC) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-              *reinterpret_cast<float4*>(C + o + 8 * q) = make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
-            if (g.gelu != 3) {
-#pragma unroll
-              for (int r = 0; r < 16; ++r) vmax = fmaxf(vmax, fabsf(a[r]));
-            }
-          } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              if (ok(r)) {
-                C[o + 8 * (r >> 2) + (r & 3)] = a[r];
-                if (g.gelu != 3) vmax = fmaxf(vmax, fabsf(a[r]));
-              }
+          for (int r = 0; r < 16; ++r) {
+            if (ok(r)) {
+              C[o + 8 * (r >> 2) + (r & 3)] = a[r];
+              if (g.gelu != 3) vmax = fmaxf(vmax, fabsf(a[r]));
             }
           }
           __builtin_amdgcn_sched_barrier(0);   // keep the next block's loads behind this block's stores (register pressure)
         }
       }
     };
+    // Row-linear form (tile inside the matrix, aligned rows): the B-tile fragment is the MFMA's first operand, so a lane
+    // holds one output row x 16 columns; an accumulator block goes through the
+    // wave's LDS patch (16-byte slots XOR-swizzled by row: conflict-free both ways) and comes back with lane l owning
+    // columns 4 (l & 7) .. + 3 of rows (l >> 3) + 8 k - every global access of a wave instruction is then 8 whole
+    // 128-byte row segments instead of 32 rows x 32 bytes (the planes conversion gained 25 % from the same change).
+    auto epilogue_linear = [&]() {
+      float* patch = reinterpret_cast<float*>(smem + 2 * STAGE + wave * 4096);
+      const int prow = lane >> 3, pc4 = lane & 7;
+#pragma unroll
+      for (int j = 0; j < RN; ++j) {
+        const int colb = n0 + wn * 32 * RN + 32 * j;
+        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g.bias) b4 = *reinterpret_cast<const float4*>(g.bias + colb + 4 * pc4);
+#pragma unroll
+        for (int i = 0; i < RM; ++i) {
+          const int rowb = m0 + wm * 32 * RM + 32 * i;
+          f32x16& a = acc[i][j];
+#pragma unroll
+          for (int q = 0; q < 4; ++q)     // lane (row r32, kh) holds columns 4 kh + 8 q .. + 3: 16-byte slot kh + 2 q
+            *reinterpret_cast<float4*>(patch + r32 * 32 + (((kh + 2 * q) ^ (r32 & 7)) << 2)) =
+                make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          float v[16];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int r = prow + 8 * k;
+            const float4 x = *reinterpret_cast<const float4*>(patch + r * 32 + ((pc4 ^ (r & 7)) << 2));
+            v[4 * k] = alpha * x.x + b4.x; v[4 * k + 1] = alpha * x.y + b4.y;
+            v[4 * k + 2] = alpha * x.z + b4.z; v[4 * k + 3] = alpha * x.w + b4.w;
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the patch is free for the next block
+          const int64_t o = (int64_t)(rowb + prow) * g.ldc + colb + 4 * pc4;     // + 8 k ldc per k
+          if (g.gelu == 2) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const float4 p4 = *reinterpret_cast<const float4*>(pre + o + (int64_t)8 * k * g.ldc);
+              v[4 * k] *= gelu_erf_grad(p4.x); v[4 * k + 1] *= gelu_erf_grad(p4.y);
+              v[4 * k + 2] *= gelu_erf_grad(p4.z); v[4 * k + 3] *= gelu_erf_grad(p4.w);
+            }
+          } else if (pre) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              *reinterpret_cast<float4*>(pre + o + (int64_t)8 * k * g.ldc) =
+                  make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+          }
+          if (g.gelu == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = gelu_erf(v[r]);
+          }
+          if (g.gelu == 3) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) vmax = fmaxf(vmax, fabsf(gelu_erf(v[r])));
+          }
+          if (g.resid) {
+            const float* rp = g.resid + (int64_t)(rowb + prow) * g.ldr + colb + 4 * pc4;
+            float4 r4[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) r4[k] = *reinterpret_cast<const float4*>(rp + (int64_t)8 * k * g.ldr);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              v[4 * k] += r4[k].x; v[4 * k + 1] += r4[k].y; v[4 * k + 2] += r4[k].z; v[4 * k + 3] += r4[k].w;
+            }
+          }
+          if (g.accumulate) {
+            float4 c4[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) c4[k] = *reinterpret_cast<const float4*>(C + o + (int64_t)8 * k * g.ldc);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              v[4 * k] += c4[k].x; v[4 * k + 1] += c4[k].y; v[4 * k + 2] += c4[k].z; v[4 * k + 3] += c4[k].w;
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            *reinterpret_cast<float4*>(C + o + (int64_t)8 * k * g.ldc) =
+                make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+          if (g.gelu != 3) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) vmax = fmaxf(vmax, fabsf(v[r]));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    };
     const bool aligned = (((uintptr_t)C | (uintptr_t)pre | (uintptr_t)g.resid | (uintptr_t)g.bias) & 15) == 0 &&
                          ((g.ldc | g.ldr | (int)(g.sC & 3)) & 3) == 0;
-    if (aligned && m0 + BM <= M && n0 + BN <= N) epilogue(std::true_type{});
-    else epilogue(std::false_type{});
+    if (aligned && m0 + BM <= M && n0 + BN <= N) epilogue_linear();
+    else epilogue_elements();
     if (g.amax) {
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));

@@ -212,26 +212,47 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmArgs g) {
     __syncthreads();
   }
 
-  // epilogue: C layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  // epilogue: C layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).  Per 32 x 32 block every run-time option
+  // is tested once and all residual / accumulate loads are issued before the arithmetic (element by element, each load
+  // was followed by its own s_waitcnt vmcnt(0): 16 serial memory round trips per block)
+  float* prep = g.pre ? g.pre + zb * g.sCb + zh * g.sCh : nullptr;
 #pragma unroll
   for (int b = 0; b < NT; ++b) {
     const int col = n0 + wn * WN + 32 * b + n;
-    if (col >= N) continue;
-    const float bias = g.bias ? g.bias[col] : 0.f;
+    const bool colok = col < N;
+    const float bias = (g.bias && colok) ? g.bias[col] : 0.f;
 #pragma unroll
     for (int a = 0; a < MT; ++a) {
+      const int row0 = m0 + wm * WM + 32 * a + 4 * kk;
+      auto rowof = [&](int r) { return row0 + (r & 3) + 8 * (r >> 2); };
+      float v[16], rv[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * WM + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * kk;
-        if (row >= M) continue;
-        float v = g.alpha * acc[a][b][r] + bias;
-        const int64_t o = (int64_t)row * g.ldc + col;
-        if (g.pre) g.pre[zb * g.sCb + zh * g.sCh + o] = v;
-        if (g.gelu) v = gelu_erf(v);
-        if (g.resid) v += g.resid[(int64_t)row * g.ldr + col];
-        if (g.accumulate) v += C[o];
-        C[o] = v;
+        v[r] = g.alpha * acc[a][b][r] + bias;
+        rv[r] = 0.f;
       }
+      if (g.resid) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (colok && rowof(r) < M) rv[r] = g.resid[(int64_t)rowof(r) * g.ldr + col];
+      }
+      if (g.accumulate) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (colok && rowof(r) < M) rv[r] += C[(int64_t)rowof(r) * g.ldc + col];
+      }
+      if (prep) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (colok && rowof(r) < M) prep[(int64_t)rowof(r) * g.ldc + col] = v[r];
+      }
+      if (g.gelu) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = gelu_erf(v[r]);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (colok && rowof(r) < M) C[(int64_t)rowof(r) * g.ldc + col] = v[r] + rv[r];
     }
   }
 }

@@ -1,13 +1,14 @@
 // fp32-grade GEMM on the gfx950 fp16 matrix cores with split operands ("sp16" planes).
 //
 // Every dense contraction of the AST / ViT training step (nn.Linear forward, data gradient, weight gradient, the
-// patch-embedding projection: Transformer_Audio.py:72, Transformer_Vision.py:92 through the HF modelling code) can
-// run here instead of on the exact-fp32 MFMA (gemm_f32.hip, 157 TFLOP/s peak).  An fp32 operand v is held as
-//     hi = fp16(sigma v),  lo = fp16(sigma v - hi)            sigma = 2^e with max|sigma v| in [2^14, 2^15)
-// and a product is three v_mfma_f32_32x32x16_f16 into ONE fp32 accumulator: hi.hi + lo.hi + hi.lo (fp16 x fp16
-// products are exact in fp32; the dropped lo.lo term is <= 2^-22 of the product).  The result is fp32-grade
-// (measured against float64 beside the exact-fp32 kernel: tests/test_gemm_sp_gpu.py) at a third of the 2.5 PFLOP/s
-// fp16 peak instead of 1/16.
+// patch-embedding projection: Transformer_Audio.py:72, Transformer_Vision.py:92 through the HF modelling code) runs
+// here by default instead of on the exact-fp32 MFMA (gemm_f32.hip, 157 TFLOP/s peak).  An fp32 operand v is held as
+//     hi = fp16(sigma v),  lo = fp16((sigma v - hi) 2^11)      sigma = 2^e with max|sigma v| in [2^14, 2^15)
+// and a product is three v_mfma_f32_32x32x16_f16: hi.hi into one fp32 accumulator, lo.hi + hi.lo into a second one that
+// is folded in with 2^-11 at the end (fp16 x fp16 products are exact in fp32; the dropped lo.lo term is <= 2^-22 of the
+// product; the lift keeps lo a normal fp16 number for elements down to 2^-29 of the tensor maximum).  The result is
+// fp32-grade (measured against float64 beside the exact-fp32 kernel: tests/test_split_kernels_gpu.py) at a third of the
+// 2.5 PFLOP/s fp16 peak instead of 1/16.
 //
 // Operand format ("planes"): a matrix X[R, K] whose CONTRACTION index is the column index is stored as
 //     uint16 planes[R][Kp/8][2][8]      Kp = K rounded up to 32, zero beyond K
@@ -15,17 +16,19 @@
 // lane's MFMA operand fragment, and a 32-deep K-tile of a row is one 128-byte line.  There is ONE GEMM layout
 // (C[m,n] = sum_k A[m,k] B[n,k]); the data / weight gradient products use planes of the transposed tensors, which
 // eav_sp_convert writes in the same pass (the tensor is converted once per step where it is produced, not re-rounded
-// per tile).  sigma lives in a device "slot" of EAV_SP_SLOT floats: words 0..63 are shards of the bits of
-// max|v| (producers atomicMax one shard each - integer max of non-negative floats is order-independent, hence
-// deterministic, and 64 shards keep the L2 atomics off one address), eav_sp_convert reduces them to sigma (word 64)
-// and 1/sigma (word 65), the GEMM folds 1/(sigma_A sigma_B) into alpha.  Nothing crosses to the host.
+// per tile).  sigma lives in a device "slot" of EAV_SP_SLOT floats (eav_common.h): 64 shards of the bits of max|v|, one
+// per 128-byte line (producers atomicMax one shard each - integer max of non-negative floats is order-independent, hence
+// deterministic; separate lines keep the L2 atomics from serialising), then sigma and 1/sigma, which eav_sp_convert
+// writes; the GEMM folds 1/(sigma_A sigma_B) into alpha.  Nothing crosses to the host.
 //
-// Kernel: BM x BN x 32 tiles (128 x 128 with 4 waves, 2 blocks per CU; 256 x 128 with 8 waves), each wave a 64 x 64
-// block of 2 x 2 MFMA tiles = 24 MFMAs per K-tile.  Operands go HBM/L2 -> LDS with global_load_lds_dwordx4 (no
-// VGPR round trip, no ds_write), double-buffered, ONE barrier per K-tile.  LDS image: row r, piece p (0..7) at
+// Kernel: 128 x 128 x 32 tiles, 4 waves, 2 workgroups per CU (a 256 x 128 / 8-wave form stays as a tuning hook), each
+// wave a 64 x 64 block of 2 x 2 MFMA tiles = 24 MFMAs per K-tile.  Operands go HBM/L2 -> LDS with global_load_lds_dwordx4
+// (no VGPR round trip, no ds_write), double-buffered, ONE barrier per K-tile.  LDS image: row r, piece p (0..7) at
 // 16-byte slot r*8 + (p ^ ((r>>1)&7)); the XOR is applied to the per-lane SOURCE address (the LDS-DMA destination is
-// lane-linear) and again on the fragment read, which makes every ds_read_b128 conflict-free.  Workgroup ids are
-// remapped so that each XCD's L2 sees a compact group of tiles (8 tile-rows x all tile-columns at a time).
+// lane-linear) and again on the fragment read, which makes every ds_read_b128 conflict-free.  Workgroups are persistent:
+// tile ids are remapped so that each XCD's L2 sees a compact group of tiles (8 tile-rows x all tile-columns at a time),
+// and the next tile's first two stages are in flight under the current tile's epilogue.  The epilogue turns each
+// accumulator block row-linear through a per-wave LDS patch (whole 128-byte row segments per global access).
 #include <algorithm>
 #include <type_traits>
 

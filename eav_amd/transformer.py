@@ -4,13 +4,23 @@ The reference never defines these models - it instantiates Hugging Face classes
 (`AutoModelForAudioClassification.from_pretrained`, Transformer_Audio.py:22;
 `AutoModelForImageClassification.from_pretrained`, Transformer_Vision.py:29) and trains them
 with `loss.backward()`.  This module restates that arithmetic as an explicit schedule of
-libeav_hip.so kernels (fp32 MFMA GEMMs + row kernels), keeps the HF 5.x parameter names so
-`state_dict()` / safetensors checkpoints interchange (HF 4.x names are accepted on load), and
-exposes the pieces the reference trainers touch: `model(x).logits`, `model.classifier`,
-`model.parameters()`, `train()/eval()`, `.to(device)`.
+libeav_hip.so kernels, keeps the HF 5.x parameter names so `state_dict()` / safetensors
+checkpoints interchange (HF 4.x names are accepted on load), and exposes the pieces the
+reference trainers touch: `model(x).logits`, `model.classifier`, `model.parameters()`,
+`train()/eval()`, `.to(device)`.
 
-Everything is kept resident (288 GB HBM): all activations a backward needs are saved, nothing is
-recomputed; attention probabilities are materialised per layer ([B*H, N, N] fp32).
+Two arithmetic paths behind `Encoder.precision` (env EAV_ENCODER_PRECISION), same parity bounds:
+  "split" (default)  every dense projection and the fused attention on the fp16 matrix cores with
+                     fp16 hi + lo operand planes, three MFMAs per product, fp32 accumulation -
+                     fp32-grade (gemm_sp.hip, attention_sp.hip).  Weight-gradient
+                     GEMMs, the final bias / LayerNorm gradient reductions and the refresh of the
+                     weight planes run on a side HIP stream.
+  "fp32"             the same schedule on the exact-fp32 MFMA (gemm_f32.hip, attention.hip).
+
+Everything is kept resident (288 GB HBM): what a backward needs is saved, nothing is recomputed
+(split: the fp16 planes of the layer inputs of every GEMM and of q | k | v, the pre-activations of
+the MLP and the attention outputs / log-sum-exps; the fused attention never materialises the
+[B*H, N, N] probabilities - only the reduced test configurations with head_dim != 64 do).
 """
 from __future__ import annotations
 

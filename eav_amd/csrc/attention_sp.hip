@@ -130,7 +130,8 @@ __device__ __forceinline__ void emit_amax(unsigned* slot, float vmax, int lane, 
 }
 
 // ------------------------------------------------------------------------------------------------ forward
-// grid (ceil(N / (32 NW)), B*H).  rowp: row planes of qkv [B*N, 3D]; tp: T planes (chunk 2H + h = V of head h).
+// 1-D grid of ceil(N / (32 NW)) * B*H workgroups (attn_block_map: the row tiles of a head share an XCD).  rowp: row planes
+// of qkv [B*N, 3D]; tp: T planes (chunk 2H + h = V of head h).
 // Workgroup -> (row tile, image-head) with all row tiles of one (image, head) on ONE XCD: the tiles of a head stream the
 // same K / V (or Q / dO) planes, and consecutive workgroup ids go round the 8 XCDs - with the plain (x = tile, y = head)
 // grid the tiles of a head sat on different XCDs and every one of them pulled the head's planes through its own L2

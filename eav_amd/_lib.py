@@ -49,6 +49,7 @@ SIGNATURES = {
     "eav_scale_by_scalar": [_p, _p, _i64, _p],
     "eav_adam_step": [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _i64, _i, _p, _p],
     "eav_counter_inc": [_p, _p],
+    "eav_counter_inc4": [_p, _p, _p, _p, _p],
     "eav_gather_rows": [_p, _p, _p, _i, _i64, _p],
     "eav_gather_i64": [_p, _p, _p, _i, _p],
     "eav_gemm_f32": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64, _f, _p,

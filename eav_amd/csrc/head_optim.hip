@@ -253,6 +253,19 @@ extern "C" int eav_adam_step(float* p, const float* g, float* m, float* v, int64
 
 __global__ void counter_inc_kernel(int64_t* p) { *p += 1; }
 
+__global__ void counter_inc4_kernel(int64_t* a, int64_t* b, int64_t* c, int64_t* d) {
+  int64_t* p = threadIdx.x == 0 ? a : threadIdx.x == 1 ? b : threadIdx.x == 2 ? c : d;
+  if (p) *p += 1;
+}
+
+// up to four distinct counters in one launch (NULL entries are skipped)
+extern "C" int eav_counter_inc4(int64_t* c0, int64_t* c1, int64_t* c2, int64_t* c3, void* stream) {
+  EAV_REQUIRE(c0 || c1 || c2 || c3, "eav_counter_inc4: no counter");
+  hipLaunchKernelGGL(counter_inc4_kernel, dim3(1), dim3(4), 0, (hipStream_t)stream, c0, c1, c2, c3);
+  EAV_CHECK_LAUNCH("eav_counter_inc4");
+  return EAV_OK;
+}
+
 extern "C" int eav_counter_inc(int64_t* counter, void* stream) {
   EAV_REQUIRE(counter, "eav_counter_inc: null counter");
   hipLaunchKernelGGL(counter_inc_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, counter);

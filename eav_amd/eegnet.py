@@ -206,8 +206,12 @@ class EEGNet_tor(nn.Module):
         if drop != 0.0 and masks is None:
             if self._fwd_counter is None or self._fwd_counter.device != x.device:
                 self._fwd_counter = torch.zeros((), dtype=torch.int64, device=x.device)
-            L("eav_counter_inc", P(self._fwd_counter), st)
             cnt = P(self._fwd_counter)
+        if cnt is not None or training:
+            # one launch for the dropout step counter and the three BatchNorm step counters (nn.BatchNorm2d's
+            # num_batches_tracked): library kernels, no torch op inside a captured step
+            L("eav_counter_inc4", cnt, *([P(bn.num_batches_tracked) for bn in (bn1, bn2, bn3)] if training else [None] * 3),
+              st)
         m1 = P(masks[0]) if masks is not None else None
         m2 = P(masks[1]) if masks is not None else None
 
@@ -215,8 +219,6 @@ class EEGNet_tor(nn.Module):
             b0 = P(buf)
             L("eav_bn_finalize", P(part), nparts, nch, float(count), gw, gb, P(bn.running_mean), P(bn.running_var),
               int(training), float(bn.momentum), float(bn.eps), b0, b0 + 4 * nch, b0 + 8 * nch, b0 + 12 * nch, st)
-            if training:       # nn.BatchNorm2d's step counter, bumped by a library kernel (no torch op in a captured step)
-                L("eav_counter_inc", P(bn.num_batches_tracked), st)
 
         if self.fir_precision not in ("fp32", "split"):
             raise ValueError(f"fir_precision {self.fir_precision!r}: expected 'fp32' or 'split'")

@@ -186,6 +186,7 @@ int eav_gather_rows(const float* src, const int64_t* idx, float* out, int nrows,
 int eav_gather_i64(const int64_t* src, const int64_t* idx, int64_t* out, int n, void* stream);
 /* *counter += 1 on the stream (device-resident step counters for hipGraph replay). */
 int eav_counter_inc(int64_t* counter, void* stream);
+int eav_counter_inc4(int64_t* c0, int64_t* c1, int64_t* c2, int64_t* c3, void* stream);   /* distinct counters; NULL = skip */
 
 /* ---- AST / ViT encoders (HF ASTForAudioClassification / ViTForImageClassification as called at
  *      Transformer_Audio.py:22,72 and Transformer_Vision.py:29,92) ------------------------------ */

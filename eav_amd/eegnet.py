@@ -23,7 +23,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .optim import CrossEntropyLoss, FusedAdam, flatten_parameters
+from .optim import CrossEntropyLoss, FusedAdam, flatten_parameters, unit_gradient
 
 _PARAM_ORDER = [
     "firstConv.weight", "firstBN.weight", "firstBN.bias",
@@ -355,7 +355,7 @@ class GraphStep:
             scores = model(data)
             loss = criterion(scores, targets)
             optimizer.zero_grad(set_to_none=True)
-            loss.backward()
+            loss.backward(gradient=unit_gradient(loss.device))      # no ones_like fill, no scaling launch
             return scores, loss
 
         def update():        # fused Adam (+ e.g. the max-norm projection of Transformer_EEG.py:195-199)

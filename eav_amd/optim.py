@@ -165,10 +165,25 @@ class _CEFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         # d loss / d scores was produced by the forward launch; the incoming gradient (1.0 for loss.backward()) is
-        # applied in place by the library - no torch kernel inside a captured step
-        _lib.call("eav_scale_by_scalar", ctx.dsc.data_ptr(), gout.contiguous().data_ptr(), ctx.dsc.numel(),
-                  _lib.stream_ptr())
+        # applied in place by the library - no torch kernel inside a captured step.  `unit_gradient(device)` is a constant
+        # 1.0 that callers may pass as the seed (loss.backward(gradient=...)): recognised here, nothing is launched
+        if gout.data_ptr() != _UNIT.get(gout.device, (None, 0))[1]:
+            _lib.call("eav_scale_by_scalar", ctx.dsc.data_ptr(), gout.contiguous().data_ptr(), ctx.dsc.numel(),
+                      _lib.stream_ptr())
         return ctx.dsc, None, None
+
+
+_UNIT = {}
+
+
+def unit_gradient(device):
+    """A device-resident constant 1.0 to seed ``loss.backward(gradient=unit_gradient(dev))`` with: autograd then needs no
+    fill kernel for the implicit ones_like(loss), and the CE backward recognises it and skips its scaling launch."""
+    device = torch.device(device)
+    if device not in _UNIT:
+        t = torch.ones((), dtype=torch.float32, device=device)
+        _UNIT[device] = (t, t.data_ptr())
+    return _UNIT[device][0]
 
 
 class CrossEntropyLoss:

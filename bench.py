@@ -156,7 +156,9 @@ def bench_encoder(kind, dev, world, sync_factory, steps=4, warmup=2, blocks=3):
             "step_tflops": round(gflop / dt / 1e3, 2),
             "roofline": {"bound": "mfma", "kernel": "gemm_sp_kernel" if prec == "split" else "gemm_f32_kernel",
                          "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                         "traffic": None,
+                         "traffic": _pmc_traffic(kind, prec, freeze),
+                         "traffic_unit": "mean HBM bytes per GEMM launch of the unfrozen split step (rocprofv3 --pmc "
+                                         "FETCH_SIZE / WRITE_SIZE passes, gfx950-corrected; profiles/*_pmc.json)",
                          "note": "algorithmic 2MNK flops of every dense projection of the step / summed kernel time "
                                  "(HIP events around each launch, separate pass)" +
                                  ("; the split kernel issues 3x these flops on the fp16 matrix cores: issue rate "
@@ -167,6 +169,20 @@ def bench_encoder(kind, dev, world, sync_factory, steps=4, warmup=2, blocks=3):
     del model, opt
     torch.cuda.empty_cache()
     return res
+
+
+def _pmc_traffic(kind, prec, freeze):
+    """HBM bytes per launch of the dominant GEMM kernel from the committed PMC summaries (profiled: unfrozen split step)."""
+    if prec != "split" or freeze:
+        return None
+    try:
+        import glob
+        f = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{kind}_pmc.json")))[-1]
+        k = json.load(open(f))["kernels"]
+        e = next(v for name, v in k.items() if name.startswith("gemm_sp_kernel"))
+        return int(e["hbm_read_bytes"] + e["hbm_write_bytes"])
+    except Exception:
+        return None
 
 
 # ---------------------------------------------------------------------------------------------- alternative EEG encoders

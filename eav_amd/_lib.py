@@ -34,6 +34,8 @@ SIGNATURES = {
     "eav_renorm_rows": [_p, _i, _i, _f, _p],
     "eav_eegnet_fir_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
     "eav_eegnet_fir_wgrad": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "eav_eegnet_fir_fwd_indexed": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "eav_eegnet_fir_wgrad_indexed": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "eav_eegnet_dw_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _p],
     "eav_eegnet_dw_bwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     "eav_eegnet_dw_bwd_fused": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _u64, _p, _p, _p],

@@ -35,7 +35,8 @@ constexpr int TPS = 16;           // tiles per LDS segment
 template <int NSTEP>
 __global__ __launch_bounds__(256, 2) void fir_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w1,
                                                          float* __restrict__ y1, float* __restrict__ part, int rows,
-                                                         int C, int S, int klen, int padl, int nseg, int ntiles) {
+                                                         int C, int S, int klen, int padl, int nseg, int ntiles,
+                                                         const int64_t* __restrict__ xidx) {
   constexpr int HALO = 2 * NSTEP;                 // taps + shifts covered by one tile's window
   constexpr int SEG_M4 = TPS * 32 + NSTEP / 2;    // floats per polyphase plane
   __shared__ __attribute__((aligned(16))) float xs[4 * SEG_M4];
@@ -65,7 +66,8 @@ __global__ __launch_bounds__(256, 2) void fir_fwd_kernel(const float* __restrict
     const int tile0 = seg * TPS;
     const int nt = min(TPS, ntiles - tile0);
     const int useg0 = tile0 * TILE;
-    const float* xrow = x + (int64_t)row * S;
+    // xidx: the batch is rows xidx[0..B) of a larger resident array (the trainer's data set) - no gathered copy
+    const float* xrow = x + (xidx ? (xidx[row / C] * C + row % C) : (int64_t)row) * S;
     const int nload = nt * TILE + HALO;
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
@@ -151,7 +153,7 @@ template <int WG_NT, bool PLAIN>
 __global__ __launch_bounds__(256, 3) void fir_wgrad_kernel(
     const float* __restrict__ x, const float* __restrict__ y1, const float* __restrict__ g1,
     const float* __restrict__ bnp /* mean, invstd, scale, shift, m1, m2 (8 each) */, float* __restrict__ part, int rows,
-    int C, int S, int klen, int padl, int nchunk, int CH) {
+    int C, int S, int klen, int padl, int nchunk, int CH, const int64_t* __restrict__ xidx) {
   constexpr int LAGS = 32 * WG_NT;                    // lags covered (>= klen)
   constexpr int WG_XW = WG_CW + 8 + LAGS;             // x window per item (incl. the look-ahead K-step)
   constexpr int WG_WAVE_LDS = F1 * WG_QS + WG_XW;     // floats per wave
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(256, 3) void fir_wgrad_kernel(
         }
       }
     }
-    const float* xrow = x + (int64_t)row * S;
+    const float* xrow = x + (xidx ? (xidx[b] * C + c) : (int64_t)row) * S;
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
       const int idx = lane + 64 * i;
@@ -315,15 +317,24 @@ extern "C" int eav_eegnet_fir_fwd_nparts(int B, int C, int S) {
   return fir_grid(B * C * nseg);
 }
 
+extern "C" int eav_eegnet_fir_fwd_indexed(const float* x, const int64_t* xidx, const float* w1, float* y1,
+                                          float* stat_part, int B, int C, int S, int klen, void* stream);
+
 extern "C" int eav_eegnet_fir_fwd(const float* x, const float* w1, float* y1, float* stat_part, int B, int C, int S,
                                   int klen, void* stream) {
+  return eav_eegnet_fir_fwd_indexed(x, nullptr, w1, y1, stat_part, B, C, S, klen, stream);
+}
+
+// the batch = samples xidx[0..B) of x [*, C, S] (xidx == NULL: x is the batch itself)
+extern "C" int eav_eegnet_fir_fwd_indexed(const float* x, const int64_t* xidx, const float* w1, float* y1,
+                                          float* stat_part, int B, int C, int S, int klen, void* stream) {
   EAV_REQUIRE(x && w1 && y1 && stat_part && B > 0 && C > 0 && S > 0, "eav_eegnet_fir_fwd: bad arguments");
   EAV_REQUIRE(klen >= 1 && klen <= 300, "eav_eegnet_fir_fwd: kernLength %d outside [1,300]", klen);
   const int ntiles = cdiv(S, TILE), nseg = cdiv(ntiles, TPS);
   const int nwork = B * C * nseg;
 #define EAV_FIR_FWD(NS)                                                                                         \
   hipLaunchKernelGGL(fir_fwd_kernel<NS>, dim3(fir_grid(nwork)), dim3(256), 0, (hipStream_t)stream, x, w1, y1,  \
-                     stat_part, B * C, C, S, klen, (klen - 1) / 2, nseg, ntiles)
+                     stat_part, B * C, C, S, klen, (klen - 1) / 2, nseg, ntiles, xidx)
   if (klen <= 65) EAV_FIR_FWD(34);
   else if (klen <= 129) EAV_FIR_FWD(66);
   else EAV_FIR_FWD(152);
@@ -346,8 +357,18 @@ extern "C" int eav_eegnet_fir_wgrad_nparts(int B, int C, int S) {
 }
 
 // part: [nparts][8][klen] floats; sum over parts = dL/d(firstConv.weight)
+extern "C" int eav_eegnet_fir_wgrad_indexed(const float* x, const int64_t* xidx, const float* y1, const float* g1,
+                                            const float* bn_params, float* part, int B, int C, int S, int klen,
+                                            void* stream);
+
 extern "C" int eav_eegnet_fir_wgrad(const float* x, const float* y1, const float* g1, const float* bn_params,
                                     float* part, int B, int C, int S, int klen, void* stream) {
+  return eav_eegnet_fir_wgrad_indexed(x, nullptr, y1, g1, bn_params, part, B, C, S, klen, stream);
+}
+
+extern "C" int eav_eegnet_fir_wgrad_indexed(const float* x, const int64_t* xidx, const float* y1, const float* g1,
+                                            const float* bn_params, float* part, int B, int C, int S, int klen,
+                                            void* stream) {
   EAV_REQUIRE(x && g1 && bn_params && part && B > 0 && C > 0 && S > 0, "eav_eegnet_fir_wgrad: bad arguments");
   EAV_REQUIRE(klen >= 1 && klen <= 300, "eav_eegnet_fir_wgrad: kernLength %d outside [1,300]", klen);
   int nchunk, CH;
@@ -358,10 +379,10 @@ extern "C" int eav_eegnet_fir_wgrad(const float* x, const float* y1, const float
   do {                                                                                                                \
     if (y1)                                                                                                           \
       hipLaunchKernelGGL((fir_wgrad_kernel<NT, false>), dim3(wgrad_grid(nwork)), dim3(256), 0, (hipStream_t)stream,   \
-                         x, y1, g1, bn_params, part, B * C, C, S, klen, (klen - 1) / 2, nchunk, CH);                  \
+                         x, y1, g1, bn_params, part, B * C, C, S, klen, (klen - 1) / 2, nchunk, CH, xidx);            \
     else                                                                                                              \
       hipLaunchKernelGGL((fir_wgrad_kernel<NT, true>), dim3(wgrad_grid(nwork)), dim3(256), 0, (hipStream_t)stream, x, \
-                         y1, g1, bn_params, part, B * C, C, S, klen, (klen - 1) / 2, nchunk, CH);                     \
+                         y1, g1, bn_params, part, B * C, C, S, klen, (klen - 1) / 2, nchunk, CH, xidx);               \
   } while (0)
   if (klen <= 64) EAV_FIR_WG(2);
   else if (klen <= 128) EAV_FIR_WG(4);

@@ -71,6 +71,16 @@ class _Workspace:
         self.part_fws = None       # allocated on first use of the split mode ([np_fws, 8*klen])
 
 
+class IndexedBatch:
+    """A batch addressed in place: samples `idx` (device int64 [B]) of an HBM-resident data set `data` [N,1,C,S].  The FIR
+    kernels - the only readers of the network input - take the index vector, so no gathered copy of the batch is made."""
+
+    def __init__(self, data, idx):
+        self.data, self.idx = data, idx
+        self.shape = (idx.numel(),) + tuple(data.shape[1:])
+        self.device = data.device
+
+
 class _EEGNetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, model, *params):
@@ -163,6 +173,25 @@ class EEGNet_tor(nn.Module):
         self._ensure_flat()
         return _EEGNetFn.apply(x, self, *self._params())
 
+    def forward_indexed(self, data, idx):
+        """forward(data[idx]) without materialising data[idx] (Trainer_uni's per-step batch assembly,
+        EEGNet_tor.py:100-101): `data` [N,1,Chans,Samples] fp32 contiguous on the device, `idx` device int64 [B].  The
+        split-precision FIR path needs the batch's own maximum first and keeps the gathered copy."""
+        if data.dim() != 4 or data.shape[1] != 1 or data.shape[2] != self.Chans or data.shape[3] != self.Samples or \
+                not data.is_cuda or data.dtype != torch.float32 or not data.is_contiguous():
+            raise ValueError(f"expected a contiguous fp32 device array [N,1,{self.Chans},{self.Samples}]")
+        if idx.dtype != torch.int64 or idx.device != data.device or idx.dim() != 1:
+            raise ValueError("idx must be a 1-D int64 tensor on the data's device")
+        if self.fir_precision != "fp32":
+            out = torch.empty((idx.numel(),) + tuple(data.shape[1:]), dtype=torch.float32, device=data.device)
+            _lib.call("eav_gather_rows", data.data_ptr(), idx.data_ptr(), out.data_ptr(), idx.numel(), data[0].numel(),
+                      _lib.stream_ptr())
+            return self.forward(out)
+        if self.firstConv.weight.device != data.device:
+            raise _lib.EavError("model and input are on different devices")
+        self._ensure_flat()
+        return _EEGNetFn.apply(IndexedBatch(data, idx), self, *self._params())
+
     # ------------------------------------------------------------------ kernels
     def _call(self, name, *args):
         """_lib.call, optionally bracketed by HIP events on the launch stream (bench.py's live
@@ -229,7 +258,10 @@ class EEGNet_tor(nn.Module):
             L("eav_eegnet_fir_fwd_split", P(x), w1, P(ws.scale_x), P(ws.scale_w), P(ws.y1), P(ws.part_fir), B, C, S, K,
               st)
         else:
-            L("eav_eegnet_fir_fwd", P(x), w1, P(ws.y1), P(ws.part_fir), B, C, S, K, st)
+            if isinstance(x, IndexedBatch):
+                L("eav_eegnet_fir_fwd_indexed", P(x.data), P(x.idx), w1, P(ws.y1), P(ws.part_fir), B, C, S, K, st)
+            else:
+                L("eav_eegnet_fir_fwd", P(x), w1, P(ws.y1), P(ws.part_fir), B, C, S, K, st)
         bnfin(ws.part_fir, ws.np_fir, 8, B * C * S, g1w, g1b, bn1, ws.bn1)
         L("eav_eegnet_dw_fwd", P(ws.y1), P(ws.bn1), w2, P(ws.z), P(ws.part_dw), B, C, S, st)
         bnfin(ws.part_dw, B * ws.nchunk, 64, B * S, g2w, g2b, bn2, ws.bn2)
@@ -317,8 +349,12 @@ class EEGNet_tor(nn.Module):
             L("eav_reduce_partials", P(ws.part_fws), ws.np_fws, 8 * K, 8 * K, 1.0, P(g["firstConv.weight"]), st)
         else:
             # eval-mode training (every epoch after the first, Q4): BatchNorm backward is a plain scale, y1 is not needed
-            L("eav_eegnet_fir_wgrad", P(x), P(ws.y1) if training else None, P(ws.g1), b1, P(ws.part_fw), B, C, S, K,
-              st)
+            if isinstance(x, IndexedBatch):
+                L("eav_eegnet_fir_wgrad_indexed", P(x.data), P(x.idx), P(ws.y1) if training else None, P(ws.g1), b1,
+                  P(ws.part_fw), B, C, S, K, st)
+            else:
+                L("eav_eegnet_fir_wgrad", P(x), P(ws.y1) if training else None, P(ws.g1), b1, P(ws.part_fw), B, C, S, K,
+                  st)
             L("eav_reduce_partials", P(ws.part_fw), ws.np_fw, 8 * K, 8 * K, 1.0, P(g["firstConv.weight"]), st)
         named = dict(self.named_parameters())
         return [g[k].view(named[k].shape) if named[k].requires_grad else None for k in _PARAM_ORDER]
@@ -351,8 +387,14 @@ class GraphStep:
         self.idx = torch.zeros(batch, dtype=torch.long, device=dev)
 
         def compute():       # batch gather + forward + loss + backward
-            data, targets = gather_batch(xs, ys, self.idx)
-            scores = model(data)
+            if hasattr(model, "forward_indexed") and xs.is_cuda and xs.dim() == 4 and xs.is_contiguous():
+                # EEGNet_tor reads the batch in place through the index vector: only the labels are gathered
+                targets = torch.empty(batch, dtype=torch.long, device=dev)
+                _lib.call("eav_gather_i64", ys.data_ptr(), self.idx.data_ptr(), targets.data_ptr(), batch, _lib.stream_ptr())
+                scores = model.forward_indexed(xs, self.idx)
+            else:
+                data, targets = gather_batch(xs, ys, self.idx)
+                scores = model(data)
             loss = criterion(scores, targets)
             optimizer.zero_grad(set_to_none=True)
             loss.backward(gradient=unit_gradient(loss.device))      # no ones_like fill, no scaling launch

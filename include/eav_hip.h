@@ -54,6 +54,13 @@ int eav_eegnet_fir_fwd(const float* x, const float* w1, float* y1, float* stat_p
 int eav_eegnet_fir_wgrad_nparts(int B, int C, int S);
 int eav_eegnet_fir_wgrad(const float* x, const float* y1, const float* g1, const float* bn_params, float* part,
                          int B, int C, int S, int klen, void* stream);
+/* The same two kernels with the batch addressed in place: sample b of the batch = row xidx[b] of x [*,C,S] (the
+ * trainer's HBM-resident data set) - the per-step batch copy (EEGNet_tor.py:100-101: a host->device copy in the
+ * reference, a device gather otherwise) disappears.  xidx: device int64 [B]; NULL = x is the batch. */
+int eav_eegnet_fir_fwd_indexed(const float* x, const int64_t* xidx, const float* w1, float* y1, float* stat_part, int B,
+                               int C, int S, int klen, void* stream);
+int eav_eegnet_fir_wgrad_indexed(const float* x, const int64_t* xidx, const float* y1, const float* g1,
+                                 const float* bn_params, float* part, int B, int C, int S, int klen, void* stream);
 /* Opt-in fp32-grade fast path of the same two products on the fp16 matrix cores with split operands
  * (v = hi + 2^-11 lo, three MFMAs per product, fp32 accumulate; csrc/eegnet_fir_split.hip).  scale_x / scale_w: device
  * float[3] = {sigma, 1/sigma, max|v|} from eav_absmax_scale (power-of-two pre-scales keeping the pieces in fp16 range). */

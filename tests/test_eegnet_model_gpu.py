@@ -371,3 +371,26 @@ def test_generated_spatial_dropout_is_per_feature_map(fir_precision):
                 ref = gref[k].numpy()
                 close(named[k].grad, ref, 1e-3, 1e-3 * np.abs(ref).max(), f"grad.{k}")
     assert not torch.equal(seen[0], seen[1])
+
+
+@pytest.mark.parametrize("training", [True, False])
+def test_indexed_batch_equals_gathered_batch(training):
+    """forward_indexed(data, idx) - the FIR kernels read the batch in place through the index vector, as Trainer_uni's
+    captured step does - equals forward(data[idx]) bit for bit, probabilities and every gradient."""
+    S, N, B = 500, 12, 5
+    sd = eegnet_weights(31, S)
+    x, _ = synth.eeg_batch(310, N, 30, S)
+    data = torch.from_numpy(x).cuda().reshape(N, 1, 30, S).contiguous()
+    idx = torch.tensor([7, 0, 11, 3, 7], dtype=torch.long, device="cuda")
+    outs = []
+    for indexed in (True, False):
+        model = build(S, sd, 0.0).train(training)
+        scores = model.forward_indexed(data, idx) if indexed else model(data[idx].contiguous())
+        scores.square().sum().backward()
+        torch.cuda.synchronize()
+        outs.append((scores.detach().clone(), [p.grad.clone() for p in model.parameters()]))
+    assert torch.equal(outs[0][0], outs[1][0])
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert torch.equal(a, b)
+    with pytest.raises(ValueError):
+        build(S, sd, 0.0).forward_indexed(data, idx.int())

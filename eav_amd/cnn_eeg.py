@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .eegnet import DeviceLoader, GraphStep
+from .eegnet import DeviceLoader, GraphStep, cached_workspace
 from .optim import CrossEntropyLoss, FusedAdam, flatten_parameters
 
 _PARAM_ORDER = [
@@ -158,9 +158,7 @@ class EEGNet(nn.Module):
         wkey = (B, C, S, str(x.device))
         if not hasattr(self, "_wss"):
             self._wss = {}
-        if wkey not in self._wss:
-            self._wss[wkey] = _Workspace(self, B, x.device)
-        ws = self._ws = self._wss[wkey]
+        ws = self._ws = cached_workspace(self._wss, wkey, lambda: _Workspace(self, B, x.device))
         training = bool(self.training)
         w1, g1w, g1b, wd, g2w, g2b, wdw, wp, g3w, g3b, wc, bc = [P(p) for p in self._params()]
         drop = self.dropoutRate if training else 0.0

@@ -133,7 +133,19 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ in, c
                                                  float* __restrict__ loss, float* __restrict__ din,
                                                  int* __restrict__ ncorrect, int* __restrict__ bad_label, int B,
                                                  int NC) {
-  __shared__ float red[8];
+  // nn.CrossEntropyLoss semantics: targets equal to -100 (torch's default ignore_index) are excluded from the mean and
+  // receive a zero gradient; any other index outside [0, NC) is an error - reported through `bad_label`, and the row is
+  // treated like an ignored one (zero gradient: a bad label never pushes a wrong update into the weights).
+  __shared__ float red[12];
+  float nv[1] = {0.f};
+  for (int b = threadIdx.x; b < B; b += 256) {
+    const int64_t yl = y[b];
+    nv[0] += (yl >= 0 && yl < NC) ? 1.f : 0.f;
+  }
+  block_sum_256<1>(nv, red);
+  if (threadIdx.x == 0) red[8] = nv[0];
+  __syncthreads();
+  const float nvalid = red[8];
   float st[2] = {0.f, 0.f};
   for (int b = threadIdx.x; b < B; b += 256) {
     const float* r = in + (int64_t)b * NC;
@@ -146,15 +158,18 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ in, c
     const float lse = mx + logf(s);
     const int64_t yl = y[b];
     const bool ok = yl >= 0 && yl < NC;        // torch asserts on class indices outside [0, NC); never index with one
-    if (!ok && bad_label) *bad_label = yl >= 0 ? (int)min(yl, (int64_t)0x7ffffffe) + 1 : (int)max(yl, (int64_t)-0x7fffffff);
+    if (!ok && yl != -100 && bad_label)
+      *bad_label = yl >= 0 ? (int)min(yl, (int64_t)0x7ffffffe) + 1 : (int)max(yl, (int64_t)-0x7fffffff);
     const int yy = ok ? (int)yl : -1;
     st[0] += ok ? lse - r[yy] : 0.f;
     st[1] += (am == yy) ? 1.f : 0.f;
     if (din)
-      for (int j = 0; j < NC; ++j) din[(int64_t)b * NC + j] = (expf(r[j] - lse) - (j == yy ? 1.f : 0.f)) / (float)B;
+      for (int j = 0; j < NC; ++j)
+        din[(int64_t)b * NC + j] = ok ? (expf(r[j] - lse) - (j == yy ? 1.f : 0.f)) / nvalid : 0.f;
   }
   block_sum_256<2>(st, red);
-  if (threadIdx.x == 0 && loss) *loss = st[0] / (float)B;
+  // all targets ignored: torch returns nan (0 / 0)
+  if (threadIdx.x == 0 && loss) *loss = nvalid > 0.f ? st[0] / nvalid : __builtin_nanf("");
   if (threadIdx.x == 1 && ncorrect) *ncorrect += (int)(st[0] + 0.5f);
 }
 

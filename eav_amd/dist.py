@@ -20,13 +20,15 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None):
+def init_from_env(backend=None, force=False):
     """Initialise the default process group from torchrun's environment.
-    Returns (rank, world_size, local_rank).  backend: 'nccl' (= RCCL) on GPUs, 'gloo' for CPU tests."""
+    Returns (rank, world_size, local_rank).  backend: 'nccl' (= RCCL) on GPUs, 'gloo' for CPU tests.
+    force: create the group even for WORLD_SIZE = 1 (a one-rank RCCL communicator: every collective of the N > 1 path runs
+    through the real backend on a single GPU - tests/test_rccl_gpu.py)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -56,10 +58,14 @@ class GradSync:
     final (last layer first), so the RCCL transfers of ~28 MB buckets run on the communicator's stream under the
     remaining backward kernels; `sync()` then only waits for the outstanding work and reduces what is left."""
 
-    def __init__(self, flat_grads, group=None):
+    def __init__(self, flat_grads, group=None, force=False):
+        """force: issue the collectives even in a one-rank group (exercises the backend; the sum over one rank is the
+        identity, so results must be bit-equal to the unsynchronised run)."""
         self.flat_grads = list(flat_grads)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.enabled = self.world > 1 or (force and dist.is_initialized())
+        self.collectives = 0     # all-reduce calls issued (bookkeeping, like bytes_reduced)
         self.weight = 1.0 / self.world
         self._pending = []
         self._done = []          # (buffer index, lo, hi) ranges already submitted during this backward
@@ -75,17 +81,18 @@ class GradSync:
         if self.weight != 1.0:
             view.mul_(self.weight)
         self.bytes_reduced += 4 * view.numel()
+        self.collectives += 1
         return dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
 
     def bucket(self, lo, hi, buffer=0):
         """Asynchronously all-reduce flat_grads[buffer][lo:hi] (elements)."""
-        if self.world == 1 or hi <= lo:
+        if not self.enabled or hi <= lo:
             return
         self._pending.append(self._reduce(self.flat_grads[buffer][lo:hi], True))
         self._done.append((buffer, lo, hi))
 
     def __call__(self):
-        if self.world == 1:
+        if not self.enabled:
             return
         for work in self._pending:
             work.wait()
@@ -115,14 +122,20 @@ class GradSync:
             self.active[buffer] = [(int(a), int(b)) for a, b in ranges]
 
 
-def attach(trainer):
+def backend_name():
+    """'nccl' (= RCCL on ROCm), 'gloo', or 'none' when no process group exists - what reports must print instead of
+    assuming RCCL."""
+    return dist.get_backend() if dist.is_initialized() else "none"
+
+
+def attach(trainer, force=False):
     """Give a Trainer_uni (or any trainer exposing .model with a flat gradient buffer) a gradient
-    all-reduce when running under torchrun with WORLD_SIZE > 1."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    all-reduce when running under torchrun with WORLD_SIZE > 1 (force: also in a one-rank group)."""
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return trainer
     model = trainer.model
     model._ensure_flat()
-    trainer.grad_sync = GradSync([model._flat[1]])
+    trainer.grad_sync = GradSync([model._flat[1]], force=force)
     if hasattr(model, "grad_ready_hook"):
         model.grad_ready_hook = trainer.grad_sync.bucket     # overlap the all-reduce with the backward
     # hipGraph replay stays on (Trainer_uni / GraphStep): with a grad_sync the step is captured as TWO graphs - batch

@@ -71,6 +71,24 @@ class _Workspace:
         self.part_fws = None       # allocated on first use of the split mode ([np_fws, 8*klen])
 
 
+def cached_workspace(cache, key, make, keep_unpinned=2):
+    """Workspace cache shared by the EEG models.  A captured hipGraph (GraphStep) has the raw device pointers of the
+    workspace it was captured with baked in, so THOSE workspaces (marked `pinned` by GraphStep after capture) live as long
+    as the model; eager sizes - ragged last batches, validation, user-chosen inference batches - share `keep_unpinned`
+    replaceable slots (most recently used first), so varying batch sizes do not accumulate multi-GB workspaces."""
+    ws = cache.get(key)
+    if ws is None:
+        if not torch.cuda.is_current_stream_capturing():
+            loose = [k for k, w in cache.items() if not getattr(w, "pinned", False)]
+            for k in loose[:max(0, len(loose) - (keep_unpinned - 1))]:     # dict order = insertion / last-use order
+                del cache[k]
+        ws = make()
+    else:
+        del cache[key]          # re-insert: most recently used last
+    cache[key] = ws
+    return ws
+
+
 class IndexedBatch:
     """A batch addressed in place: samples `idx` (device int64 [B]) of an HBM-resident data set `data` [N,1,C,S].  The FIR
     kernels - the only readers of the network input - take the index vector, so no gathered copy of the batch is made."""
@@ -88,10 +106,17 @@ class _EEGNetFn(torch.autograd.Function):
         ctx.token = model._launch_forward(x)
         # the probabilities tensor this forward wrote: no copy kernel.  (A detached alias, not the saved object itself:
         # returning the very tensor that the model also keeps for its backward crashes hipGraph capture in torch 2.10.)
+        # The alias shares its version counter with the saved tensor: an in-place edit of the returned scores before
+        # backward (clamp_, += eps ...) would silently corrupt dense_softmax_bwd's input - checked in backward.
+        ctx.probs_version = model._saved[-1]._version
         return model._saved[-1].detach()
 
     @staticmethod
     def backward(ctx, dprobs):
+        saved = ctx.model._saved
+        if saved is not None and saved[0] == ctx.token and saved[-1]._version != ctx.probs_version:
+            raise _lib.EavError("EEGNet_tor: the scores returned by forward() were modified in place before backward(); "
+                                "they alias the probabilities the backward reads - clone() them first")
         grads = ctx.model._launch_backward(dprobs.contiguous(), ctx.token)
         return (None, None, *grads)
 
@@ -207,14 +232,11 @@ class EEGNet_tor(nn.Module):
             _lib.call(name, *args)
 
     def _workspace(self, B, dev):
-        """One workspace per problem size, kept for the life of the model: a captured hipGraph (GraphStep) has the
-        raw device pointers of the workspace it was captured with baked in, so a workspace must never be freed or
-        re-allocated when another batch size (the partial last batch, validation) comes through."""
+        """One workspace per problem size; the ones a hipGraph was captured with are pinned for the life of the model,
+        the others share a small replaceable set (cached_workspace)."""
         key = (B, self.Chans, self.Samples, str(dev))
-        ws = self._wss.get(key)
-        if ws is None:
-            ws = self._wss[key] = _Workspace(B, self.Chans, self.Samples, self.kernLength, self.nb_classes, dev)
-        return ws
+        return cached_workspace(self._wss, key, lambda: _Workspace(B, self.Chans, self.Samples, self.kernLength,
+                                                                   self.nb_classes, dev))
 
     def _launch_forward(self, x):
         L, P, st = self._call, _lib.ptr, _lib.stream_ptr()
@@ -435,6 +457,8 @@ class GraphStep:
                 if self.grad_sync is None:
                     self._update()
             del scores, loss
+            if getattr(self.model, "_ws", None) is not None:
+                self.model._ws.pinned = True       # the graph holds this workspace's raw pointers (cached_workspace)
             if self.grad_sync is not None:
                 # the gradients the update graph reads live in the model's flat buffer (static address); capture the
                 # update on its own (its launches are recorded, not executed)

@@ -143,10 +143,16 @@ class FusedAdam(torch.optim.Optimizer):
                 self._launch(r[0], r[1], r[2], r[3], r[4], group, r[5])
                 # tell whoever caches derived copies of these parameters (transformer.Encoder's fp16 operand
                 # planes) which byte ranges of the flat buffer just changed
+                # (only flat buffers whose owner registered interest - `_eav_track_dirty` - are tracked, and the list
+                # collapses to its hull beyond a few entries: an eager loop that nobody drains must not grow it)
                 for fl in touched.values():
                     lo = fl.data_ptr()
-                    if lo <= r[0] < lo + 4 * fl.numel():
-                        fl._eav_dirty = getattr(fl, "_eav_dirty", []) + [(r[0], r[0] + 4 * r[4])]
+                    if getattr(fl, "_eav_track_dirty", False) and lo <= r[0] < lo + 4 * fl.numel():
+                        d = getattr(fl, "_eav_dirty", [])
+                        d.append((r[0], r[0] + 4 * r[4]))
+                        if len(d) > 64:
+                            d = [(min(a for a, _ in d), max(b for _, b in d))]
+                        fl._eav_dirty = d
         return loss
 
 
@@ -168,8 +174,12 @@ class _CEFn(torch.autograd.Function):
         # applied in place by the library - no torch kernel inside a captured step.  `unit_gradient(device)` is a constant
         # 1.0 that callers may pass as the seed (loss.backward(gradient=...)): recognised here, nothing is launched
         if gout.data_ptr() != _UNIT.get(gout.device, (None, 0))[1]:
-            _lib.call("eav_scale_by_scalar", ctx.dsc.data_ptr(), gout.contiguous().data_ptr(), ctx.dsc.numel(),
+            # any other upstream gradient scales a COPY: ctx.dsc stays the unit-gradient result, so a second backward
+            # (retain_graph=True) or a re-used graph never scales twice
+            out = ctx.dsc.clone()
+            _lib.call("eav_scale_by_scalar", out.data_ptr(), gout.contiguous().data_ptr(), out.numel(),
                       _lib.stream_ptr())
+            return out, None, None
         return ctx.dsc, None, None
 
 
@@ -190,8 +200,9 @@ class CrossEntropyLoss:
     """``nn.CrossEntropyLoss()`` (mean reduction) as one fused HIP kernel that
     produces the loss and its input gradient together.
 
-    Like torch, it rejects class indices outside [0, classes): the kernel never indexes with such a label (it
-    contributes nothing) and records it in a device flag; ``check()`` reads the flag (one host synchronisation) and
+    Like torch, targets equal to -100 (the default ignore_index) are excluded from the mean and get a zero gradient, and
+    any other class index outside [0, classes) is rejected: the kernel never indexes with such a label (the row
+    contributes nothing to the loss and receives a zero gradient) and records it in a device flag; ``check()`` reads the flag (one host synchronisation) and
     raises.  The trainers call it once per epoch - a per-step check would serialise host and GPU; code that drives the
     criterion directly calls ``check()`` whenever it synchronises anyway."""
 

@@ -234,6 +234,22 @@ class Encoder(nn.Module):
     def head_parameters(self):
         return list(self.classifier.parameters())
 
+    # Anything that rewrites parameters wholesale drops the cached fp16 weight planes of the split path (the version key
+    # in _refresh_weight_planes would catch these too; this makes it independent of how torch implements them).
+    def invalidate_weight_planes(self):
+        """Call after writing parameters in a way torch cannot see (`p.data.mul_(...)`, raw-pointer kernels): `.data`
+        writes move neither the parameter's nor the flat buffer's version counter."""
+        self._wplanes_key = None
+
+    def load_state_dict(self, *args, **kwargs):
+        self._wplanes_key = None
+        return super().load_state_dict(*args, **kwargs)
+
+    def _apply(self, fn, *args, **kwargs):
+        self._wplanes_key = None
+        self._wplanes = None
+        return super()._apply(fn, *args, **kwargs)
+
     def head_grad_ranges(self):
         """[(lo, hi)] element ranges of the classifier's gradients in the flat gradient buffer."""
         self._ensure_flat()
@@ -412,7 +428,15 @@ class Encoder(nn.Module):
         products) that changed: FusedAdam records the byte ranges it updated (`_eav_dirty`), any torch in-place write
         to the flat buffer (load_state_dict, .copy_) bumps its version and invalidates everything."""
         flat = self._flat[0]
-        key = (flat.data_ptr(), flat._version)
+        # Invalidation key: flatten_parameters rebinds p.data to views of the flat buffer, and a rebound .data has its
+        # OWN version counter - load_state_dict, p.copy_/add_ under no_grad and torch.optim optimisers bump the
+        # parameters' versions, never the flat buffer's.  So the key is the sum of the GEMM weights' versions (host-side,
+        # ~50 attribute reads) plus the flat buffer's own version (flat.copy_ / flat.zero_ style writes);
+        # load_state_dict / _apply also drop the cache outright.  FusedAdam writes through raw pointers (no version
+        # moves): it reports the byte ranges it updated instead (`_eav_dirty`, recorded only because this model asked
+        # for it through `_eav_track_dirty`).
+        flat._eav_track_dirty = True
+        key = (flat.data_ptr(), flat._version, sum(self._pmap[pn]._version for _, pn, _, _ in self._weight_keys()))
         dirty = getattr(flat, "_eav_dirty", [])
         flat._eav_dirty = []
         have_T = self._wplanes is not None and self._wplanes["_T"]

@@ -29,7 +29,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .eegnet import DeviceLoader, GraphStep
+from .eegnet import DeviceLoader, GraphStep, cached_workspace
 from .optim import CrossEntropyLoss, FusedAdam, flatten_parameters
 
 NF, KC, POOL, STRIDE, HD = 40, 13, 35, 7, 64     # filters / conv taps / pool window / pool stride / attention tile
@@ -208,9 +208,7 @@ class ShallowConvNet(nn.Module):
         wkey = (B, S, str(x.device))
         if not hasattr(self, "_wss"):
             self._wss = {}
-        if wkey not in self._wss:
-            self._wss[wkey] = self._alloc(B, S, x.device)
-        ws = self._ws = self._wss[wkey]
+        ws = self._ws = cached_workspace(self._wss, wkey, lambda: self._alloc(B, S, x.device))
         T, M = ws.T, ws.M
         n = dict(self.named_parameters())
         w = lambda k: P(n[k])  # noqa: E731

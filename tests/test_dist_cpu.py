@@ -96,3 +96,38 @@ def test_grad_allreduce_gloo_world2(tmp_path):
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert (tmp_path / "ok_0").exists() and (tmp_path / "ok_1").exists(), r.stdout + r.stderr
+
+
+def test_forced_one_rank_group_gloo(tmp_path):
+    """The world-1 forced mode tests/test_rccl_gpu.py relies on (there with backend nccl): init_from_env(force=True)
+    creates a one-rank group, GradSync(force=True) really issues its collectives, results are unchanged."""
+    script = tmp_path / "w1.py"
+    script.write_text(textwrap.dedent(f"""
+        import sys
+        sys.path.insert(0, {ROOT!r})
+        import torch, torch.distributed as dist
+        from eav_amd import dist as ed
+        assert ed.backend_name() == "none"
+        rank, world, local = ed.init_from_env("gloo", force=True)
+        assert (rank, world) == (0, 1) and dist.is_initialized() and ed.backend_name() == "gloo"
+        g = torch.arange(100, dtype=torch.float32)
+        off = ed.GradSync([g])                       # default: a one-rank group needs no exchange
+        off.bucket(0, 50); off()
+        assert not off.enabled and off.collectives == 0 and off.bytes_reduced == 0
+        s = ed.GradSync([g], force=True)
+        s.bucket(10, 30)
+        s()
+        assert s.enabled and s.collectives == 3 and s.bytes_reduced == 400       # [10,30) + [0,10) + [30,100)
+        assert torch.equal(g, torch.arange(100, dtype=torch.float32))
+        dist.destroy_process_group()
+        open({str(tmp_path)!r} + "/ok", "w").write("ok")
+    """))
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert (tmp_path / "ok").exists()

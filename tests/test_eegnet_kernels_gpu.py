@@ -481,3 +481,73 @@ def test_cross_entropy_rejects_labels_outside_the_class_range():
         crit(scores, good[:4])
     with torch.no_grad():                                                      # validate(): no gradient buffer needed
         assert torch.isfinite(crit(scores.detach(), good))
+
+
+def test_cross_entropy_matches_torch_semantics_for_ignored_rows_and_repeated_backward():
+    """nn.CrossEntropyLoss (EEGNet_tor.py:81, Transformer_Audio.py:31): targets equal to ignore_index = -100 are left out
+    of the mean and get a zero gradient; a bad label contributes a ZERO gradient row (never a wrong update); a second
+    backward through the same graph (retain_graph) or a non-unit upstream gradient scales a copy, not the stored
+    gradient."""
+    from eav_amd._lib import EavError
+    from eav_amd.optim import CrossEntropyLoss
+    torch.manual_seed(3)
+    scores = torch.randn(7, 5, device="cuda", requires_grad=True)
+    y = torch.tensor([0, -100, 2, 3, -100, 1, 4], device="cuda")
+    ref_s = scores.detach().cpu().clone().requires_grad_(True)
+    ref = torch.nn.CrossEntropyLoss()(ref_s, y.cpu())
+    ref.backward()
+    crit = CrossEntropyLoss()
+    loss = crit(scores, y)
+    loss.backward(retain_graph=True)
+    crit.check()                                                    # -100 is not an error
+    assert abs(float(loss) - float(ref)) < 1e-6
+    assert torch.allclose(scores.grad.cpu(), ref_s.grad, atol=1e-7)
+    assert (scores.grad[1] == 0).all() and (scores.grad[4] == 0).all()
+    # second backward with an upstream gradient of 3: exactly 3x the unit result, and a third one with 1 again is not
+    # contaminated by the scaling
+    g1 = scores.grad.clone()
+    scores.grad = None
+    loss.backward(gradient=torch.tensor(3.0, device="cuda"), retain_graph=True)
+    assert torch.allclose(scores.grad, 3 * g1, rtol=1e-6, atol=0)
+    scores.grad = None
+    loss.backward()
+    assert torch.equal(scores.grad, g1)
+    # a bad label: zero gradient row, the other rows as if it were ignored, flag raised
+    bad = y.clone()
+    bad[0] = 7
+    scores.grad = None
+    crit(scores, bad).backward()
+    assert (scores.grad[0] == 0).all()
+    y2 = y.clone()
+    y2[0] = -100
+    ref_s.grad = None
+    torch.nn.CrossEntropyLoss()(ref_s, y2.cpu()).backward()
+    assert torch.allclose(scores.grad.cpu(), ref_s.grad, atol=1e-7)
+    with pytest.raises(EavError, match="outside"):
+        crit.check()
+
+
+def test_scores_returned_by_eegnet_must_not_be_edited_in_place_before_backward():
+    from eav_amd._lib import EavError
+    from eav_amd.eegnet import EEGNet_tor
+    from eav_amd.optim import CrossEntropyLoss
+    torch.manual_seed(0)
+    m = EEGNet_tor(5, Chans=30, Samples=500, dropoutRate=0.0).cuda().train()
+    x = torch.randn(4, 1, 30, 500, device="cuda")
+    y = torch.tensor([0, 1, 2, 3], device="cuda")
+    s = m(x)
+    loss = CrossEntropyLoss()(s, y)
+    with torch.no_grad():
+        s.clamp_(min=1e-3)                      # aliases the probabilities the backward reads
+    with pytest.raises(EavError, match="modified in place"):
+        loss.backward()
+
+
+def test_workspace_cache_is_bounded_for_eager_batch_sizes():
+    from eav_amd.eegnet import EEGNet_tor
+    torch.manual_seed(0)
+    m = EEGNet_tor(5, Chans=30, Samples=500).cuda().eval()
+    with torch.no_grad():
+        for B in (1, 2, 3, 5, 7, 2, 9):
+            m(torch.randn(B, 1, 30, 500, device="cuda"))
+    assert len(m._wss) <= 2, list(m._wss)

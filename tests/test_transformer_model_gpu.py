@@ -226,3 +226,68 @@ def test_side_stream_work_does_not_change_a_single_bit(kind):
         grads.append([p.grad.clone() for p in model.parameters()])
     for a, b, c in zip(*grads):
         assert torch.equal(a, b) and torch.equal(a, c)
+
+
+@pytest.mark.parametrize("kind", ["vit", "ast"])
+def test_split_weight_planes_follow_every_kind_of_weight_update(kind):
+    """The split path caches fp16 hi/lo planes of the GEMM weights.  They must be rebuilt whenever the weights change,
+    however they change: load_state_dict (restoring a checkpoint), a torch.optim optimiser (the reference trainers use
+    optim.AdamW on model.parameters(), Transformer_Audio.py:30), an in-place edit under no_grad, FusedAdam (raw
+    pointer writes).  Each time the logits must equal those of a FRESH model built from the same weights, bit for bit
+    (same kernels, same planes), and differ from the stale ones."""
+    from eav_amd import transformer as T
+    from eav_amd.optim import CrossEntropyLoss, FusedAdam
+    cfg = T.make_config(kind, hidden=128, layers=2, heads=2, ff=256)
+    Wa = _weights(kind, 11, 0.08, hidden=128, layers=2, heads=2, ff=256)
+    Wb = _weights(kind, 12, 0.08, hidden=128, layers=2, heads=2, ff=256)
+    x, y = _batch(kind, cfg, 5, 2)
+    xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+
+    def fresh_logits(state):
+        m = T.Encoder(cfg, {k: v.detach().cpu().numpy() for k, v in state.items()}).cuda().eval()
+        m.precision = "split"
+        with torch.no_grad():
+            return m(xd).logits.clone()
+
+    model = T.Encoder(cfg, Wa).cuda().eval()
+    model.precision = "split"
+    with torch.no_grad():
+        la = model(xd).logits.clone()                       # planes of Wa are cached now
+    # (1) load_state_dict
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in Wb.items()})
+    with torch.no_grad():
+        lb = model(xd).logits.clone()
+    assert not torch.equal(la, lb)
+    assert torch.equal(lb, fresh_logits(model.state_dict())), "stale planes after load_state_dict"
+    # (2) torch.optim.AdamW over model.parameters() (versions of the parameters move, not of the flat buffer)
+    model.train()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-2)
+    CrossEntropyLoss()(model(xd).logits, yd).backward()
+    opt.step()
+    model.eval()
+    with torch.no_grad():
+        lc = model(xd).logits.clone()
+    assert not torch.equal(lb, lc)
+    assert torch.equal(lc, fresh_logits(model.state_dict())), "stale planes after torch.optim.AdamW"
+    # (3) in-place edit under no_grad
+    with torch.no_grad():
+        dict(model.named_parameters())[f"{cfg.prefix}.layers.0.mlp.fc1.weight"].mul_(1.5)
+        ld = model(xd).logits.clone()
+    assert not torch.equal(lc, ld)
+    assert torch.equal(ld, fresh_logits(model.state_dict())), "stale planes after p.mul_()"
+    # (4) FusedAdam (raw-pointer writes: the dirty-range fast path)
+    model.train()
+    fopt = FusedAdam(model.parameters(), lr=1e-2, weight_decay=0.01, decoupled=True)
+    fopt.zero_grad()
+    CrossEntropyLoss()(model(xd).logits, yd).backward()
+    fopt.step()
+    model.eval()
+    with torch.no_grad():
+        le = model(xd).logits.clone()
+    assert not torch.equal(ld, le)
+    assert torch.equal(le, fresh_logits(model.state_dict())), "stale planes after FusedAdam"
+    # eager FusedAdam loops that nobody drains must not grow the dirty list without bound
+    flat = model._flat[0]
+    for _ in range(40):
+        fopt.step()
+    assert len(getattr(flat, "_eav_dirty", [])) <= 65

@@ -102,8 +102,10 @@ SIGNATURES = {
     "eav_eegnet_fir_wgrad_split": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "eav_tconv_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "eav_tconv_wgrad": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
-    "eav_spatial_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
-    "eav_spatial_bwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "eav_spatial_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "eav_spatial_bwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "eav_dconv_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "eav_dconv_wgrad": [_p, _p, _p, _i, _i, _i, _i, _i, _p],
     "eav_sepconv_fwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "eav_pointwise_bwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "eav_dwt_bwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
@@ -138,6 +140,7 @@ PLAIN = {
     "eav_eegnet_fir_wgrad_split_nparts": ([_i, _i, _i], _i),
     "eav_tconv_wgrad_nparts": ([_i, _i, _i, _i, _i], _i),
     "eav_spatial_nparts": ([_i, _i], _i),
+    "eav_dconv_fwd_nparts": ([_i, _i], _i),
     "eav_sepconv_fwd_nparts": ([_i, _i], _i),
     "eav_pointwise_bwd_nparts": ([_i, _i], _i),
     "eav_conv64_fwd_nparts": ([_i, _i], _i),

@@ -183,7 +183,7 @@ class EEGNet(nn.Module):
 
         L("eav_tconv_fwd", P(x), w1, P(ws.y1), P(ws.part_t), B, C, S, F1, K, st)
         bnfin(ws.part_t, ws.np_t, F1, B * C * S, g1w, g1b, self.block1[1], ws.bn1)
-        L("eav_spatial_fwd", P(ws.y1), P(ws.bn1), wd, P(ws.z2), P(ws.part_s), B, C, S, F1, D, st)
+        L("eav_spatial_fwd", P(ws.y1), P(ws.bn1), wd, P(ws.z2), P(ws.part_s), B, C, S, F1, D, 0, st)
         bnfin(ws.part_s, ws.np_s, C2, B * S, g2w, g2b, self.block1[3], ws.bn2)
         L("eav_bn_elu_pool_fwd", P(ws.z2), P(ws.bn2), P(ws.a2), B, C2, S, 4, drop, seed1, m1, cnt, st)
         L("eav_sepconv_fwd", P(ws.a2), wdw, wp, P(ws.d3), P(ws.z3), P(ws.part_c), B, C2, F2, ws.T2, K2, st)
@@ -233,7 +233,7 @@ class EEGNet(nn.Module):
           cnt, st)
         # depthwise spatial conv <- BatchNorm <- temporal conv
         b1 = P(ws.bn1)
-        L("eav_spatial_bwd", P(ws.y1), P(ws.dz2), b1, wd, P(ws.g1), P(ws.part_sst), P(ws.part_sw), B, C, S, F1, D, st)
+        L("eav_spatial_bwd", P(ws.y1), P(ws.dz2), b1, wd, P(ws.g1), P(ws.part_sst), P(ws.part_sw), B, C, S, F1, D, 0, st)
         L("eav_reduce_partials", P(ws.part_sw), ws.np_s, C2 * C, C2 * C, 1.0, P(g["block1.2.weight"]), st)
         L("eav_bn_bwd_finalize", P(ws.part_sst), ws.np_s, F1, float(B * C * S), tr, P(g["block1.1.weight"]),
           P(g["block1.1.bias"]), b1 + 16 * F1, b1 + 20 * F1, st)

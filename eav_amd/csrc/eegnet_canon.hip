@@ -196,7 +196,8 @@ __device__ __forceinline__ void st4(float* p, int i, int n, bool vec, const floa
 
 __global__ __launch_bounds__(256) void spatial_fwd_kernel(const float* __restrict__ y1, const float* __restrict__ bn1,
                                                           const float* __restrict__ wd, float* __restrict__ z,
-                                                          float* __restrict__ part, int C, int S, int F1, int D) {
+                                                          float* __restrict__ part, int C, int S, int F1, int D,
+                                                          int elu) {
   __shared__ float wl[8][128];
   __shared__ float red[4 * 16];
   const int tile = blockIdx.x, f = blockIdx.y, b = blockIdx.z, tid = threadIdx.x, C2 = F1 * D;
@@ -219,7 +220,10 @@ __global__ __launch_bounds__(256) void spatial_fwd_kernel(const float* __restric
       float v[4];
       ld4(src + (int64_t)c * S, t, S, vec, v);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = (t + e < S) ? fmaf(sc, v[e], sh) : 0.f;
+      for (int e = 0; e < 4; ++e) {
+        const float o = fmaf(sc, v[e], sh);
+        v[e] = (t + e < S) ? (elu ? elu_f(o) : o) : 0.f;      // elu: EEGNet_tor.py:53 (BN -> ELU -> depthwise)
+      }
 #pragma unroll
       for (int d = 0; d < 8; ++d) {
         const float w = wl[d][c];
@@ -247,7 +251,8 @@ __global__ __launch_bounds__(256) void spatial_fwd_kernel(const float* __restric
 __global__ __launch_bounds__(256) void spatial_bwd_kernel(const float* __restrict__ y1, const float* __restrict__ dz,
                                                           const float* __restrict__ bn1, const float* __restrict__ wd,
                                                           float* __restrict__ g1, float* __restrict__ stat_part,
-                                                          float* __restrict__ w_part, int C, int S, int F1, int D) {
+                                                          float* __restrict__ w_part, int C, int S, int F1, int D,
+                                                          int elu) {
   __shared__ float wl[8][128];
   __shared__ float wred[4][8][128];
   __shared__ float red[4 * 2];
@@ -280,6 +285,14 @@ __global__ __launch_bounds__(256) void spatial_bwd_kernel(const float* __restric
       const float w = wl[d][c];
 #pragma unroll
       for (int e = 0; e < 4; ++e) g[e] = fmaf(w, dzv[d][e], g[e]);
+    }
+    if (elu) {      // the conv saw a = ELU(o): the weight gradient pairs dz with a, and g passes back through ELU'
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float a = elu_f(o[e]);
+        g[e] *= elu_grad_from_out(o[e], a);
+        o[e] = a;
+      }
     }
     if (live) st4(g1 + base + (int64_t)c * S, t, S, vec, g);
 #pragma unroll
@@ -445,6 +458,124 @@ __global__ __launch_bounds__(256) void dwt_bwd_kernel(const float* __restrict__ 
   if (tid < K2) part[((int64_t)b * C2 + ch) * K2 + tid] = acc[0];
 }
 
+// ------------------------------------------------------------------------------------ dense temporal conv (generic)
+// EEGNet_tor's "separableConv" is a DENSE Conv2d(F1*D -> F2, (1,16), groups=1, padding='same') (EEGNet_tor.py:37,59).
+// The reference configuration (64 -> 64) runs on the fp32 matrix cores (eegnet_conv64.hip); any other width takes
+// these direct kernels.  out[b,o,t] = sum_ci sum_k W(o,ci,k) in[b,ci,t+k-padl] with W(o,ci,k) = w[o so + ci si + k'],
+// k' = kflip ? K-1-k : k - the data gradient is the same kernel on the transposed, tap-flipped weights (so = K,
+// si = Cout K, kflip = 1, padl' = K-1-padl).  part[(b,tile)][o] = sum out, [Cout+o] = sum out^2 (BatchNorm statistics).
+constexpr int DT = 64;    // output samples per block
+
+__global__ __launch_bounds__(256) void dconv_fwd_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                        float* __restrict__ out, float* __restrict__ part, int Cin,
+                                                        int Cout, int T, int K, int padl, int so, int si, int kflip) {
+  __shared__ float in_s[64][DT + 16];
+  __shared__ float w_s[64][8][17];
+  const int tile = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, t0 = tile * DT;
+  const int o = tid >> 2, q = tid & 3;
+  for (int i = tid; i < Cin * (DT + 16); i += 256) {
+    const int ci = i / (DT + 16), tl = i - ci * (DT + 16), u = t0 + tl - padl;
+    in_s[ci][tl] = (u >= 0 && u < T) ? in[((int64_t)b * Cin + ci) * T + u] : 0.f;
+  }
+  float acc[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  for (int c0 = 0; c0 < Cin; c0 += 8) {
+    __syncthreads();      // in_s complete (first pass) / previous weight chunk consumed
+    for (int i = tid; i < 64 * 8 * 16; i += 256) {
+      const int oo = i >> 7, cc = (i >> 4) & 7, k = i & 15;
+      w_s[oo][cc][k] = (oo < Cout && c0 + cc < Cin && k < K)
+                           ? w[(int64_t)oo * so + (int64_t)(c0 + cc) * si + (kflip ? K - 1 - k : k)] : 0.f;
+    }
+    __syncthreads();
+    for (int cc = 0; cc < 8 && c0 + cc < Cin; ++cc) {
+      float win[31], wv[16];
+#pragma unroll
+      for (int e = 0; e < 31; ++e) win[e] = in_s[c0 + cc][16 * q + e];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) wv[k] = w_s[o][cc][k];
+#pragma unroll
+      for (int k = 0; k < 16; ++k)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = fmaf(wv[k], win[e + k], acc[e]);
+    }
+  }
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int t = t0 + 16 * q + e;
+    if (o < Cout && t < T) {
+      out[((int64_t)b * Cout + o) * T + t] = acc[e];
+      s1 += acc[e];
+      s2 += acc[e] * acc[e];
+    }
+  }
+  if (part) {
+    s1 += __shfl_xor(s1, 1, 64); s1 += __shfl_xor(s1, 2, 64);
+    s2 += __shfl_xor(s2, 1, 64); s2 += __shfl_xor(s2, 2, 64);
+    if (q == 0 && o < Cout) {
+      float* pr = part + ((int64_t)b * gridDim.x + tile) * 2 * Cout;
+      pr[o] = s1;
+      pr[Cout + o] = s2;
+    }
+  }
+}
+
+// weight gradient: part[b][o][ci][k] = sum_t dy[b,o,t] x[b,ci,t+k-padl]; a block owns (b, 4 output channels), a thread
+// (ci, 4 taps); time is walked in tiles of 128 samples staged in LDS.
+constexpr int DWT = 128;
+
+__global__ __launch_bounds__(256) void dconv_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                          float* __restrict__ part, int Cin, int Cout, int T, int K,
+                                                          int padl) {
+  __shared__ float x_s[64][DWT + 16];
+  __shared__ float dy_s[4][DWT];
+  const int og = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int ci = tid >> 2, kq = tid & 3;
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  for (int t0 = 0; t0 < T; t0 += DWT) {
+    __syncthreads();
+    for (int i = tid; i < Cin * (DWT + 16); i += 256) {
+      const int c = i / (DWT + 16), tl = i - c * (DWT + 16), u = t0 + tl - padl;
+      x_s[c][tl] = (u >= 0 && u < T) ? x[((int64_t)b * Cin + c) * T + u] : 0.f;
+    }
+    for (int i = tid; i < 4 * DWT; i += 256) {
+      const int oo = i / DWT, tl = i - oo * DWT, o = 4 * og + oo;
+      dy_s[oo][tl] = (o < Cout && t0 + tl < T) ? dy[((int64_t)b * Cout + o) * T + t0 + tl] : 0.f;
+    }
+    __syncthreads();
+    if (ci < Cin) {
+      float xw[4];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) xw[j + 1] = x_s[ci][4 * kq + j];
+      for (int tl = 0; tl < DWT; ++tl) {
+        xw[0] = xw[1]; xw[1] = xw[2]; xw[2] = xw[3];
+        xw[3] = x_s[ci][tl + 4 * kq + 3];
+#pragma unroll
+        for (int oo = 0; oo < 4; ++oo) {
+          const float g = dy_s[oo][tl];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[oo][j] = fmaf(g, xw[j], acc[oo][j]);
+        }
+      }
+    }
+  }
+  if (ci < Cin)
+#pragma unroll
+    for (int oo = 0; oo < 4; ++oo) {
+      const int o = 4 * og + oo;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = 4 * kq + j;
+        if (o < Cout && k < K) part[(((int64_t)b * Cout + o) * Cin + ci) * K + k] = acc[oo][j];
+      }
+    }
+}
+
 }  // namespace
 
 // =============================================================================================== C ABI
@@ -516,21 +647,22 @@ static int spatial_ok(const char* who, int B, int C, int S, int F1, int D) {
 extern "C" int eav_spatial_nparts(int B, int S) { return B * cdiv(S, SPT); }
 
 extern "C" int eav_spatial_fwd(const float* y1, const float* bn1, const float* wd, float* z, float* stat_part, int B,
-                               int C, int S, int F1, int D, void* stream) {
+                               int C, int S, int F1, int D, int elu, void* stream) {
   EAV_REQUIRE(y1 && bn1 && wd && z && stat_part, "eav_spatial_fwd: null pointer");
   if (int rc = spatial_ok("eav_spatial_fwd", B, C, S, F1, D)) return rc;
   hipLaunchKernelGGL(spatial_fwd_kernel, dim3(cdiv(S, SPT), F1, B), dim3(256), 0, (hipStream_t)stream, y1, bn1, wd, z,
-                     stat_part, C, S, F1, D);
+                     stat_part, C, S, F1, D, elu);
   EAV_CHECK_LAUNCH("eav_spatial_fwd");
   return EAV_OK;
 }
 
 extern "C" int eav_spatial_bwd(const float* y1, const float* dz, const float* bn1, const float* wd, float* g1,
-                               float* stat_part, float* w_part, int B, int C, int S, int F1, int D, void* stream) {
+                               float* stat_part, float* w_part, int B, int C, int S, int F1, int D, int elu,
+                               void* stream) {
   EAV_REQUIRE(y1 && dz && bn1 && wd && g1 && stat_part && w_part, "eav_spatial_bwd: null pointer");
   if (int rc = spatial_ok("eav_spatial_bwd", B, C, S, F1, D)) return rc;
   hipLaunchKernelGGL(spatial_bwd_kernel, dim3(cdiv(S, SPT), F1, B), dim3(256), 0, (hipStream_t)stream, y1, dz, bn1, wd,
-                     g1, stat_part, w_part, C, S, F1, D);
+                     g1, stat_part, w_part, C, S, F1, D, elu);
   EAV_CHECK_LAUNCH("eav_spatial_bwd");
   return EAV_OK;
 }
@@ -576,5 +708,43 @@ extern "C" int eav_dwt_bwd(const float* dd3, const float* a, const float* wdw, f
   hipLaunchKernelGGL(dwt_bwd_kernel, dim3(B * C2), dim3(256), 0, (hipStream_t)stream, dd3, a, wdw, da, w_part, C2, T,
                      K2, (K2 - 1) / 2);
   EAV_CHECK_LAUNCH("eav_dwt_bwd");
+  return EAV_OK;
+}
+
+static int dconv_ok(const char* who, int B, int Cin, int Cout, int T, int K) {
+  if (!(B > 0 && B <= 65535 && Cin >= 1 && Cin <= 64 && Cout >= 1 && Cout <= 64 && T > 0 && K >= 1 && K <= 16))
+    return eav_set_error(EAV_EINVAL, "%s: need channels<=64, taps<=16 (got B=%d Cin=%d Cout=%d T=%d K=%d)", who, B, Cin,
+                         Cout, T, K);
+  return EAV_OK;
+}
+
+extern "C" int eav_dconv_fwd_nparts(int B, int T) { return B * cdiv(T, DT); }
+
+extern "C" int eav_dconv_fwd(const float* in, const float* w, float* out, float* stat_part, int B, int Cin, int Cout,
+                             int T, int K, int transposed, void* stream) {
+  EAV_REQUIRE(in && w && out, "eav_dconv_fwd: null pointer");
+  if (int rc = dconv_ok("eav_dconv_fwd", B, Cin, Cout, T, K)) return rc;
+  // forward: w [Cout][Cin][K], left pad (K-1)/2 (torch 'same').  transposed (data gradient): `in` = dL/dout with Cin :=
+  // the conv's output channels, `out` = dL/din with Cout := its input channels; w is still the FORWARD weight
+  // [Cin][Cout][K] read transposed with flipped taps, left pad K-1-(K-1)/2
+  const int padl = (K - 1) / 2;
+  if (transposed)
+    hipLaunchKernelGGL(dconv_fwd_kernel, dim3(cdiv(T, DT), B), dim3(256), 0, (hipStream_t)stream, in, w, out, stat_part,
+                       Cin, Cout, T, K, K - 1 - padl, K, Cout * K, 1);
+  else
+    hipLaunchKernelGGL(dconv_fwd_kernel, dim3(cdiv(T, DT), B), dim3(256), 0, (hipStream_t)stream, in, w, out, stat_part,
+                       Cin, Cout, T, K, padl, Cin * K, K, 0);
+  EAV_CHECK_LAUNCH("eav_dconv_fwd");
+  return EAV_OK;
+}
+
+// part [B][Cout*Cin*K]: finish with eav_reduce_partials(part, B, Cout*Cin*K, Cout*Cin*K, ...)
+extern "C" int eav_dconv_wgrad(const float* dy, const float* x, float* part, int B, int Cin, int Cout, int T, int K,
+                               void* stream) {
+  EAV_REQUIRE(dy && x && part, "eav_dconv_wgrad: null pointer");
+  if (int rc = dconv_ok("eav_dconv_wgrad", B, Cin, Cout, T, K)) return rc;
+  hipLaunchKernelGGL(dconv_wgrad_kernel, dim3(cdiv(Cout, 4), B), dim3(256), 0, (hipStream_t)stream, dy, x, part, Cin, Cout,
+                     T, K, (K - 1) / 2);
+  EAV_CHECK_LAUNCH("eav_dconv_wgrad");
   return EAV_OK;
 }

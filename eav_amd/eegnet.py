@@ -71,6 +71,34 @@ class _Workspace:
         self.part_fws = None       # allocated on first use of the split mode ([np_fws, 8*klen])
 
 
+class _GenericWorkspace:
+    """Device buffers of the run-time-parametrised path (EEGNet_tor._generic)."""
+
+    def __init__(self, m, B, dev):
+        f = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)  # noqa: E731
+        C, S, F1, C2, F2, K = m.Chans, m.Samples, m.F1, m.F1 * m.D, m.F2, m.kernLength
+        T2, T3 = S // 4, S // 4 // 8
+        self.T2, self.T3, self.NF = T2, T3, F2 * T3
+        self.y1, self.g1 = f(B, F1, C, S), f(B, F1, C, S)
+        self.z, self.dz = f(B, C2, S), f(B, C2, S)
+        self.p2, self.dp2 = f(B, C2, T2), f(B, C2, T2)
+        self.u3, self.du3 = f(B, F2, T2), f(B, F2, T2)
+        self.p3, self.dp3 = f(B, F2 * T3), f(B, F2 * T3)
+        self.bn1, self.bn2, self.bn3 = f(6 * F1), f(6 * C2), f(6 * F2)
+        self.np_t = _lib.plain("eav_tconv_fwd_nparts", B, C, S, F1, K)
+        self.part_t = f(self.np_t, 2 * F1)
+        self.np_s = _lib.plain("eav_spatial_nparts", B, S)
+        self.part_s = f(self.np_s, 2 * C2)
+        self.np_c = _lib.plain("eav_dconv_fwd_nparts", B, T2)
+        self.part_c = f(self.np_c, 2 * F2)
+        self.part_pb = f(B, 2 * max(C2, F2))
+        self.part_sst = f(self.np_s, 2 * F1)
+        self.part_sw = f(self.np_s, C2 * C)
+        self.np_tw = _lib.plain("eav_tconv_wgrad_nparts", B, C, S, F1, K)
+        self.part_tw = f(self.np_tw, F1 * K)
+        self.part_cw = f(B, F2 * C2 * 16)
+
+
 def cached_workspace(cache, key, make, keep_unpinned=2):
     """Workspace cache shared by the EEG models.  A captured hipGraph (GraphStep) has the raw device pointers of the
     workspace it was captured with baked in, so THOSE workspaces (marked `pinned` by GraphStep after capture) live as long
@@ -125,11 +153,14 @@ class EEGNet_tor(nn.Module):
     def __init__(self, nb_classes, Chans=30, Samples=500, dropoutRate=0.5, kernLength=300, F1=8, D=8, F2=64,
                  norm_rate=1.0, dropoutType='Dropout'):
         super().__init__()
-        if F1 != 8 or D != 8 or F2 != 64:
-            raise NotImplementedError("eav_amd.EEGNet_tor: the gfx950 kernels are built for F1=8, D=8, F2=64 "
-                                      "(the reference configuration, EEGNet_tor.py:159)")
-        if not (1 <= kernLength <= 300) or not (1 <= Chans <= 32) or not (1 <= nb_classes <= 16) or Samples < 32:
-            raise NotImplementedError("eav_amd.EEGNet_tor: need kernLength<=300, Chans<=32, nb_classes<=16, Samples>=32")
+        # The reference configuration (F1=8, D=8, F2=64, kernLength<=300, Chans<=32: EEGNet_tor.py:159) runs the specialised
+        # fp32-MFMA kernels; every other width the reference constructor accepts (:16-17) takes the run-time-parametrised
+        # kernels of csrc/eegnet_canon.hip (`_generic`), whose LDS tiles bound it at the sizes below.
+        self._generic = not (F1 == 8 and D == 8 and F2 == 64 and 1 <= kernLength <= 300 and 1 <= Chans <= 32)
+        if not (1 <= F1 <= 16 and 1 <= D <= 8 and F1 * D <= 64 and 1 <= F2 <= 64 and 1 <= kernLength <= 512
+                and 1 <= Chans <= 128 and 1 <= nb_classes <= 16 and Samples >= 32):
+            raise NotImplementedError("eav_amd.EEGNet_tor: the gfx950 kernels cover F1<=16, D<=8, F1*D<=64, F2<=64, "
+                                      "kernLength<=512, Chans<=128, nb_classes<=16, Samples>=32")
         # same sub-modules in the same construction order as the reference (:21-48): identical
         # state_dict keys and identical consumption of the torch RNG by the default initialisers
         self.dropout = nn.Dropout(dropoutRate) if dropoutType == 'Dropout' else nn.Dropout2d(dropoutRate)
@@ -147,6 +178,7 @@ class EEGNet_tor(nn.Module):
         self.softmax = nn.Softmax(dim=1)
 
         self.nb_classes, self.Chans, self.Samples, self.kernLength = nb_classes, Chans, Samples, kernLength
+        self.F1, self.D, self.F2 = F1, D, F2
         self.norm_rate, self.dropoutRate = float(norm_rate), float(dropoutRate)
         # any other dropoutType is nn.Dropout2d in the reference (:21): one keep decision per (sample, channel) map - the
         # kernels take it as a negative probability (eav_hip.h)
@@ -207,7 +239,7 @@ class EEGNet_tor(nn.Module):
             raise ValueError(f"expected a contiguous fp32 device array [N,1,{self.Chans},{self.Samples}]")
         if idx.dtype != torch.int64 or idx.device != data.device or idx.dim() != 1:
             raise ValueError("idx must be a 1-D int64 tensor on the data's device")
-        if self.fir_precision != "fp32":
+        if self.fir_precision != "fp32" or self._generic:
             out = torch.empty((idx.numel(),) + tuple(data.shape[1:]), dtype=torch.float32, device=data.device)
             _lib.call("eav_gather_rows", data.data_ptr(), idx.data_ptr(), out.data_ptr(), idx.numel(), data[0].numel(),
                       _lib.stream_ptr())
@@ -239,6 +271,8 @@ class EEGNet_tor(nn.Module):
                                                                    self.nb_classes, dev))
 
     def _launch_forward(self, x):
+        if self._generic:
+            return self._launch_forward_generic(x)
         L, P, st = self._call, _lib.ptr, _lib.stream_ptr()
         B, C, S, K, nb = x.shape[0], self.Chans, self.Samples, self.kernLength, self.nb_classes
         ws = self._ws = self._workspace(B, x.device)
@@ -307,10 +341,109 @@ class EEGNet_tor(nn.Module):
         self._saved = (self._token, x, training, drop, seed1, seed2, masks, cnt, split, ws, probs)
         return self._token
 
+    # ------------------------------------------------------------------ generic widths (csrc/eegnet_canon.hip)
+    def _launch_forward_generic(self, x):
+        """EEGNet_tor.forward (:50-67) for any F1 / D / F2 / kernLength / Chans the reference constructor accepts, on the
+        run-time-parametrised kernels: eav_tconv_* (firstConv), eav_spatial_* with the ELU flag (firstBN -> ELU ->
+        depthwiseConv), eav_dconv_* (the dense "separableConv"), the shared BN -> ELU -> pool -> dropout and classifier
+        kernels.  Same quirks as the specialised path: max-norm after the forward (Q1/Q2), softmax output (Q3)."""
+        L, P, st = self._call, _lib.ptr, _lib.stream_ptr()
+        B, C, S, K, nb = x.shape[0], self.Chans, self.Samples, self.kernLength, self.nb_classes
+        F1, D, F2 = self.F1, self.D, self.F2
+        C2 = F1 * D
+        if self.fir_precision != "fp32":
+            raise ValueError("fir_precision='split' exists for the reference configuration (F1=8, D=8, F2=64) only")
+        key = ("generic", B, C, S, str(x.device))
+        ws = self._ws = cached_workspace(self._wss, key, lambda: _GenericWorkspace(self, B, x.device))
+        training = bool(self.training)
+        w1, g1w, g1b, w2, g2w, g2b, w3, g3w, g3b, wd, bd = [P(p) for p in self._params()]
+        bn1, bn2, bn3 = self.firstBN, self.depthwiseBN, self.separableBN
+        drop = self.dropoutRate if training else 0.0
+        if self.spatial_dropout:
+            drop = -drop
+        masks = self._dropout_masks if training else None
+        self._token += 1
+        seed1, seed2 = self.dropout_seed, self.dropout_seed + 1
+        cnt = None
+        if drop != 0.0 and masks is None:
+            if self._fwd_counter is None or self._fwd_counter.device != x.device:
+                self._fwd_counter = torch.zeros((), dtype=torch.int64, device=x.device)
+            cnt = P(self._fwd_counter)
+        if cnt is not None or training:
+            L("eav_counter_inc4", cnt, *([P(bn.num_batches_tracked) for bn in (bn1, bn2, bn3)] if training else [None] * 3),
+              st)
+        m1 = P(masks[0]) if masks is not None else None
+        m2 = P(masks[1]) if masks is not None else None
+
+        def bnfin(part, nparts, nch, count, gw, gb, bn, buf):
+            b0 = P(buf)
+            L("eav_bn_finalize", P(part), nparts, nch, float(count), gw, gb, P(bn.running_mean), P(bn.running_var),
+              int(training), float(bn.momentum), float(bn.eps), b0, b0 + 4 * nch, b0 + 8 * nch, b0 + 12 * nch, st)
+
+        L("eav_tconv_fwd", P(x), w1, P(ws.y1), P(ws.part_t), B, C, S, F1, K, st)                       # :51
+        bnfin(ws.part_t, ws.np_t, F1, B * C * S, g1w, g1b, bn1, ws.bn1)                                 # :52
+        L("eav_spatial_fwd", P(ws.y1), P(ws.bn1), w2, P(ws.z), P(ws.part_s), B, C, S, F1, D, 1, st)     # :53-54
+        bnfin(ws.part_s, ws.np_s, C2, B * S, g2w, g2b, bn2, ws.bn2)                                     # :55
+        L("eav_bn_elu_pool_fwd", P(ws.z), P(ws.bn2), P(ws.p2), B, C2, S, 4, drop, seed1, m1, cnt, st)   # :56-58
+        L("eav_dconv_fwd", P(ws.p2), w3, P(ws.u3), P(ws.part_c), B, C2, F2, ws.T2, 16, 0, st)           # :59
+        bnfin(ws.part_c, ws.np_c, F2, B * ws.T2, g3w, g3b, bn3, ws.bn3)                                 # :60
+        L("eav_bn_elu_pool_fwd", P(ws.u3), P(ws.bn3), P(ws.p3), B, F2, ws.T2, 8, drop, seed2, m2, cnt, st)   # :61-63
+        probs = torch.empty(B, nb, dtype=torch.float32, device=x.device)
+        L("eav_dense_softmax_fwd", P(ws.p3), wd, bd, None, P(probs), B, ws.NF, nb, st)                  # :64-66
+        if self.apply_max_norm:
+            L("eav_renorm_rows", w2, C2, C, self.norm_rate, st)
+            L("eav_renorm_rows", wd, nb, ws.NF, self.norm_rate, st)
+        self._saved = (self._token, x, training, drop, seed1, seed2, masks, cnt, False, ws, probs)
+        return self._token
+
+    def _launch_backward_generic(self, dprobs):
+        L, P, st = self._call, _lib.ptr, _lib.stream_ptr()
+        _, x, training, drop, seed1, seed2, masks, cnt, _, ws, probs = self._saved
+        B, C, S, K, nb = x.shape[0], self.Chans, self.Samples, self.kernLength, self.nb_classes
+        F1, D, F2 = self.F1, self.D, self.F2
+        C2, T2, NF = F1 * D, ws.T2, ws.NF
+        flat, gflat, offs = self._flat
+        g = {k: gflat[offs[k][0]:offs[k][0] + offs[k][1]] for k in _PARAM_ORDER}
+        w2, w3, wd = P(self.depthwiseConv.weight), P(self.separableConv.weight), P(self.dense.weight)
+        m1 = P(masks[0]) if masks is not None else None
+        m2 = P(masks[1]) if masks is not None else None
+        tr = int(training)
+        L("eav_dense_softmax_bwd", P(dprobs), P(probs), P(ws.p3), wd, P(g["dense.weight"]), P(g["dense.bias"]),
+          P(ws.dp3), B, NF, nb, st)
+        b3 = P(ws.bn3)
+        L("eav_bn_elu_pool_bwd_reduce", P(ws.dp3), P(ws.u3), b3, P(ws.part_pb), B, F2, T2, 8, drop, seed2, m2, cnt, st)
+        L("eav_bn_bwd_finalize", P(ws.part_pb), B, F2, float(B * T2), tr, P(g["separableBN.weight"]),
+          P(g["separableBN.bias"]), b3 + 16 * F2, b3 + 20 * F2, st)
+        L("eav_bn_elu_pool_bwd_apply", P(ws.dp3), P(ws.u3), b3, b3 + 16 * F2, P(ws.du3), B, F2, T2, 8, drop, seed2, m2,
+          cnt, st)
+        # the dense temporal conv: data gradient = the same kernel on the transposed, tap-flipped weights
+        L("eav_dconv_fwd", P(ws.du3), w3, P(ws.dp2), None, B, F2, C2, T2, 16, 1, st)
+        L("eav_dconv_wgrad", P(ws.du3), P(ws.p2), P(ws.part_cw), B, C2, F2, T2, 16, st)
+        n3 = F2 * C2 * 16
+        L("eav_reduce_partials", P(ws.part_cw), B, n3, n3, 1.0, P(g["separableConv.weight"]), st)
+        b2 = P(ws.bn2)
+        L("eav_bn_elu_pool_bwd_reduce", P(ws.dp2), P(ws.z), b2, P(ws.part_pb), B, C2, S, 4, drop, seed1, m1, cnt, st)
+        L("eav_bn_bwd_finalize", P(ws.part_pb), B, C2, float(B * S), tr, P(g["depthwiseBN.weight"]),
+          P(g["depthwiseBN.bias"]), b2 + 16 * C2, b2 + 20 * C2, st)
+        L("eav_bn_elu_pool_bwd_apply", P(ws.dp2), P(ws.z), b2, b2 + 16 * C2, P(ws.dz), B, C2, S, 4, drop, seed1, m1,
+          cnt, st)
+        # depthwiseConv <- ELU <- firstBN (post-renorm depthwise weight, Q2), then the firstConv weight gradient
+        b1 = P(ws.bn1)
+        L("eav_spatial_bwd", P(ws.y1), P(ws.dz), b1, w2, P(ws.g1), P(ws.part_sst), P(ws.part_sw), B, C, S, F1, D, 1, st)
+        L("eav_reduce_partials", P(ws.part_sw), ws.np_s, C2 * C, C2 * C, 1.0, P(g["depthwiseConv.weight"]), st)
+        L("eav_bn_bwd_finalize", P(ws.part_sst), ws.np_s, F1, float(B * C * S), tr, P(g["firstBN.weight"]),
+          P(g["firstBN.bias"]), b1 + 16 * F1, b1 + 20 * F1, st)
+        L("eav_tconv_wgrad", P(x), P(ws.y1), P(ws.g1), b1, P(ws.part_tw), B, C, S, F1, K, st)
+        L("eav_reduce_partials", P(ws.part_tw), ws.np_tw, F1 * K, F1 * K, 1.0, P(g["firstConv.weight"]), st)
+        named = dict(self.named_parameters())
+        return [g[k].view(named[k].shape) if named[k].requires_grad else None for k in _PARAM_ORDER]
+
     def _launch_backward(self, dprobs, token):
         if self._saved is None or self._saved[0] != token:
             raise _lib.EavError("EEGNet_tor.backward: the activations of this forward were overwritten by a later "
                                 "forward (one outstanding forward per backward)")
+        if self._generic:
+            return self._launch_backward_generic(dprobs)
         L, P, st = self._call, _lib.ptr, _lib.stream_ptr()
         _, x, training, drop, seed1, seed2, masks, cnt, split, ws, probs = self._saved
         B, C, S, K, nb = x.shape[0], self.Chans, self.Samples, self.kernLength, self.nb_classes

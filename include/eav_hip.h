@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define EAV_ABI_VERSION 2
+#define EAV_ABI_VERSION 3
 
 const char* eav_last_error(void);
 int eav_abi_version(void);
@@ -149,13 +149,25 @@ int eav_tconv_wgrad_nparts(int B, int C, int S, int F1, int K);
 int eav_tconv_wgrad(const float* x, const float* y1, const float* g1, const float* bn_params, float* part, int B,
                     int C, int S, int F1, int K, void* stream);
 /* block1[1..2]: BatchNorm affine -> depthwise nn.Conv2d(F1,D*F1,(Chans,1),groups=F1) (CNN_EEG.py:23-25):
- * y1 -> z [B,D*F1,S]; stat_part [eav_spatial_nparts()][2*D*F1]. */
+ * y1 -> z [B,D*F1,S]; stat_part [eav_spatial_nparts()][2*D*F1].  elu != 0 puts an ELU between the BatchNorm and the
+ * conv: firstBN -> ELU -> depthwiseConv of EEGNet_tor (EEGNet_tor.py:52-54) for widths the specialised
+ * eav_eegnet_dw_* kernels do not cover. */
 int eav_spatial_nparts(int B, int S);
 int eav_spatial_fwd(const float* y1, const float* bn1, const float* wd, float* z, float* stat_part, int B, int C,
-                    int S, int F1, int D, void* stream);
+                    int S, int F1, int D, int elu, void* stream);
 /* backward: g1 [B,F1,C,S] = dL/d(BN output); stat_part [nparts][2*F1]; w_part [nparts][D*F1*C]. */
 int eav_spatial_bwd(const float* y1, const float* dz, const float* bn1, const float* wd, float* g1, float* stat_part,
-                    float* w_part, int B, int C, int S, int F1, int D, void* stream);
+                    float* w_part, int B, int C, int S, int F1, int D, int elu, void* stream);
+/* Dense temporal conv nn.Conv2d(Cin,Cout,(1,K),padding='same',bias=False), K <= 16, channels <= 64: the
+ * "separableConv" of EEGNet_tor (EEGNet_tor.py:37,59) at widths other than 64 -> 64 (those run eav_conv64_*).
+ * in [B,Cin,T], w [Cout,Cin,K] -> out [B,Cout,T]; stat_part (or NULL) [eav_dconv_fwd_nparts()][2*Cout] = per-channel
+ * sum / sum of squares.  transposed != 0: the data gradient - in = dL/dout [B,Cin,T] (Cin = the conv's OUTPUT
+ * channels), out = dL/din [B,Cout,T], w = the forward weight [Cin,Cout,K]. */
+int eav_dconv_fwd_nparts(int B, int T);
+int eav_dconv_fwd(const float* in, const float* w, float* out, float* stat_part, int B, int Cin, int Cout, int T,
+                  int K, int transposed, void* stream);
+/* its weight gradient: part [B][Cout*Cin*K] (finish with eav_reduce_partials over the B rows). */
+int eav_dconv_wgrad(const float* dy, const float* x, float* part, int B, int Cin, int Cout, int T, int K, void* stream);
 /* block2[0..1]: depthwise (1,K2) 'same' conv then pointwise 1x1 conv (CNN_EEG.py:35-37): a [B,C2,T] ->
  * d3 [B,C2,T] (kept for the backward) and z [B,F2,T]; stat_part [eav_sepconv_fwd_nparts()][2*F2]. */
 int eav_sepconv_fwd_nparts(int B, int T);

@@ -73,22 +73,27 @@ BNAMES = ["firstBN.running_mean", "firstBN.running_var", "depthwiseBN.running_me
 
 
 def eegnet_case(mod, name, B, S, wseed, xseed, train_mode, wscale=1.0, masks=False, lr=1e-3, steps=2,
-                dropout_type="Dropout"):
+                dropout_type="Dropout", arch=None):
     """Run `steps` reference training steps (Trainer_uni.train body, :104-110)
     and record everything the parity tests compare."""
     torch.manual_seed(0)
     torch.set_num_threads(8)
     drop = 0.5 if masks else 0.0
-    model = mod.EEGNet_tor(nb_classes=5, Chans=30, Samples=S, kernLength=300, F1=8, D=8, F2=64, dropoutRate=drop,
-                           dropoutType=dropout_type)
+    # arch: a non-default network shape (the reference constructor takes any F1 / D / F2 / kernLength / Chans, :16-17)
+    a = dict(nb=5, chans=30, klen=300, F1=8, D=8, F2=64)
+    a.update(arch or {})
+    model = mod.EEGNet_tor(nb_classes=a["nb"], Chans=a["chans"], Samples=S, kernLength=a["klen"], F1=a["F1"], D=a["D"],
+                           F2=a["F2"], dropoutRate=drop, dropoutType=dropout_type)
     fix_hooks(model)
-    sd = eegnet_weights(wseed, S, scale=wscale)
+    sd = eegnet_weights(wseed, S, scale=wscale, **a)
     load_eegnet_state(model, sd)
     model.train(train_mode)
     crit = torch.nn.CrossEntropyLoss()
     opt = torch.optim.Adam(model.parameters(), lr=lr)
     out = {"B": B, "S": S, "wseed": wseed, "xseed": xseed, "train_mode": int(train_mode),
            "wscale": wscale, "lr": lr, "steps": steps, "drop_p": drop}
+    if arch:
+        out.update({"arch." + k: v for k, v in a.items()})
     captured = []
     if masks:
         # capture the Bernoulli keep-masks the reference draws: wrap F.dropout
@@ -113,7 +118,7 @@ def eegnet_case(mod, name, B, S, wseed, xseed, train_mode, wscale=1.0, masks=Fal
         F.dropout2d = cap2d
     try:
         for s in range(steps):
-            x, y = synth.eeg_batch(xseed + s, B, 30, S)
+            x, y = synth.eeg_batch(xseed + s, B, a["chans"], S, a["nb"])
             xt, yt = torch.from_numpy(x), torch.from_numpy(y)
             scores = model(xt)
             loss = crit(scores, yt)
@@ -157,7 +162,22 @@ def make_eegnet():
     eegnet_case(mod, "s10000_train", B=2, S=10000, wseed=14, xseed=104, train_mode=True, steps=1)
     eegnet_case(mod, "s500_dropout2d", B=6, S=500, wseed=15, xseed=105, train_mode=True, masks=True,
                 dropout_type="SpatialDropout2D")
+    make_eegnet_generic(mod)
     make_eegnet_loop(mod)
+
+
+def make_eegnet_generic(mod=None):
+    """Widths other than the reference driver's (EEGNet_tor.py:16-17 accepts any): the canonical EEGNet shape (train
+    mode with max-norm active, eval mode), an odd shape with captured dropout masks, and an F1 = 8 shape whose
+    firstConv takes the MFMA kernels while the rest is generic."""
+    mod = mod or import_reference_eegnet()
+    canon = dict(nb=4, chans=64, klen=64, F1=4, D=2, F2=16)
+    eegnet_case(mod, "generic_train", B=4, S=256, wseed=31, xseed=131, train_mode=True, arch=canon, wscale=2.0)
+    eegnet_case(mod, "generic_eval", B=4, S=256, wseed=31, xseed=131, train_mode=False, arch=canon)
+    eegnet_case(mod, "generic_odd", B=3, S=352, wseed=32, xseed=132, train_mode=True, masks=True,
+                arch=dict(nb=5, chans=19, klen=37, F1=6, D=3, F2=24))
+    eegnet_case(mod, "generic_f8", B=3, S=320, wseed=33, xseed=133, train_mode=True,
+                arch=dict(nb=5, chans=30, klen=128, F1=8, D=2, F2=32))
 
 
 def make_eegnet_loop(mod):
@@ -239,6 +259,8 @@ if __name__ == "__main__":
         make_datasplit()
     if what in ("eegnet", "all"):
         make_eegnet()
+    if what == "eegnet_generic":
+        make_eegnet_generic()
     if what in ("ast", "vit", "all"):
         from make_goldens_tf import make_ast, make_vit  # noqa
         if what in ("ast", "all"):

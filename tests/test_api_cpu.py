@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/eav_hip.h but not exported"
     assert sorted(_lib.EXPORTS) == names, set(_lib.EXPORTS) ^ set(names)
-    assert lib.eav_abi_version() == 2
+    assert lib.eav_abi_version() == 3
 
 
 def test_argument_validation_without_gpu():
@@ -91,7 +91,7 @@ def test_no_cpu_fallback():
         with pytest.raises(_lib.EavError):
             Trainer_uni(m, [np.zeros((4, 1, 30, 500), np.float32), np.zeros(4, np.int64)] * 2)
     with pytest.raises(NotImplementedError):
-        EEGNet_tor(nb_classes=5, F1=4)
+        EEGNet_tor(nb_classes=5, F1=32)          # beyond the LDS tiles of the generic kernels
 
 
 def test_device_loader_visits_batches_like_dataloader():
@@ -220,10 +220,24 @@ def test_calculate_accuracy_and_trial_vote():
 
 
 def test_unsupported_configurations_raise_not_silently_differ():
-    """The kernels are specialised to the reference's own configuration; anything else must fail loudly at
-    construction (EEGNet_tor.py:16-17,21 accepts any F1/D/F2/dropoutType)."""
+    """EEGNet_tor.py:16-17,21 accepts any F1 / D / F2 / kernLength / Chans / dropoutType.  The reference configuration
+    runs the specialised fp32-MFMA kernels, other widths the run-time-parametrised kernels (`_generic`) with the same
+    sub-modules / state_dict; only sizes beyond those kernels' LDS tiles fail - loudly, at construction."""
     from eav_amd.eegnet import EEGNet_tor
-    for kw in (dict(F1=4), dict(D=2), dict(F2=32), dict(kernLength=301), dict(Chans=33)):
+    ref = __import__("torch").nn
+    assert not EEGNet_tor(5)._generic
+    for kw in (dict(F1=4), dict(D=2), dict(F2=32), dict(kernLength=301), dict(Chans=33),
+               dict(F1=4, D=2, F2=16, kernLength=64, Chans=64, Samples=256)):
+        m = EEGNet_tor(5, **kw)
+        assert m._generic
+        full = dict(F1=8, D=8, F2=64, kernLength=300, Chans=30, Samples=500)
+        full.update(kw)
+        assert tuple(m.firstConv.weight.shape) == (full["F1"], 1, 1, full["kernLength"])
+        assert tuple(m.depthwiseConv.weight.shape) == (full["F1"] * full["D"], 1, full["Chans"], 1)
+        assert tuple(m.separableConv.weight.shape) == (full["F2"], full["F1"] * full["D"], 1, 16)
+        assert tuple(m.dense.weight.shape) == (5, full["F2"] * (full["Samples"] // 32))
+        assert isinstance(m.separableBN, ref.BatchNorm2d)
+    for kw in (dict(F1=32), dict(D=16), dict(F1=16, D=8), dict(F2=128), dict(kernLength=513), dict(Chans=129)):
         with pytest.raises(NotImplementedError):
             EEGNet_tor(5, **kw)
     # every dropoutType other than 'Dropout' is nn.Dropout2d in the reference (:21) - supported (per-map masks)

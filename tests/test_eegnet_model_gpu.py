@@ -29,10 +29,17 @@ def close(got, ref, rtol, atol, what):
     assert (err <= atol + rtol * np.abs(ref)).all(), f"{what}: max err {err.max():.3e}, ref max {np.abs(ref).max():.3e}"
 
 
-def build(S, sd, drop=0.0, dropout_type="Dropout"):
+def arch_of(g):
+    a = dict(nb=5, chans=30, klen=300, F1=8, D=8, F2=64)
+    a.update({k[5:]: int(g[k]) for k in g.files if k.startswith("arch.")})
+    return a
+
+
+def build(S, sd, drop=0.0, dropout_type="Dropout", arch=None):
     from eav_amd.eegnet import EEGNet_tor
-    m = EEGNet_tor(nb_classes=5, Chans=30, Samples=S, kernLength=300, F1=8, D=8, F2=64, dropoutRate=drop,
-                   dropoutType=dropout_type)
+    a = arch or dict(nb=5, chans=30, klen=300, F1=8, D=8, F2=64)
+    m = EEGNet_tor(nb_classes=a["nb"], Chans=a["chans"], Samples=S, kernLength=a["klen"], F1=a["F1"], D=a["D"], F2=a["F2"],
+                   dropoutRate=drop, dropoutType=dropout_type)
     full = m.state_dict()
     for k, v in sd.items():
         full[k] = torch.from_numpy(np.ascontiguousarray(v))
@@ -81,6 +88,85 @@ def test_steps_match_reference_golden(golden_dir, case, fir_precision):
         for k in BN:
             close(full[k], g[f"post{s}.{k}"], 1e-4, 1e-5, f"post{s}.{k}")
         assert int(full["firstBN.num_batches_tracked"]) == (s + 1 if int(g["train_mode"]) else 0)
+
+
+@pytest.mark.parametrize("case", ["generic_train", "generic_eval", "generic_odd", "generic_f8"])
+def test_generic_widths_match_reference_golden(golden_dir, case):
+    """EEGNet_tor.py:16-17 accepts any F1 / D / F2 / kernLength / Chans: widths other than the reference driver's run the
+    run-time-parametrised kernels (eav_tconv_*, eav_spatial_* with ELU, eav_dconv_*).  Goldens captured from the imported
+    reference at the canonical EEGNet shape (F1=4, D=2, F2=16, kernLength=64, Chans=64; max-norm active), in eval mode,
+    at an odd shape with the reference's own dropout draws, and at F1=8 (MFMA firstConv + generic rest); same bounds as
+    the specialised path."""
+    from eav_amd.optim import CrossEntropyLoss, FusedAdam
+    g = np.load(os.path.join(golden_dir, f"eegnet_{case}.npz"))
+    a = arch_of(g)
+    B, S, lr = int(g["B"]), int(g["S"]), float(g["lr"])
+    model = build(S, eegnet_weights(int(g["wseed"]), S, scale=float(g["wscale"]), **a), float(g["drop_p"]), arch=a)
+    assert model._generic
+    model.train(bool(int(g["train_mode"])))
+    crit, opt = CrossEntropyLoss(), FusedAdam(model.parameters(), lr=lr)
+    for s in range(int(g["steps"])):
+        x, y = synth.eeg_batch(int(g["xseed"]) + s, B, a["chans"], S, a["nb"])
+        if float(g["drop_p"]) > 0:
+            model.set_dropout_masks((torch.from_numpy(g[f"mask{2 * s}"]).cuda().contiguous(),
+                                     torch.from_numpy(g[f"mask{2 * s + 1}"]).cuda().contiguous()))
+        scores = model(torch.from_numpy(x).cuda())
+        loss = crit(scores, torch.from_numpy(y).cuda())
+        opt.zero_grad()
+        loss.backward()
+        loose = s > 0
+        close(scores, g[f"probs{s}"], 1e-4, 2e-5 if not loose else 1e-4, f"probs{s}")
+        close(loss, g[f"loss{s}"], 1e-5, 1e-5 if not loose else 1e-4, f"loss{s}")
+        named = dict(model.named_parameters())
+        for k in PN:
+            ref = g[f"grad{s}.{k}"]
+            close(named[k].grad, ref, 1e-3, (1e-3 if not loose else 5e-3) * np.abs(ref).max(), f"grad{s}.{k}")
+        opt.step()
+        torch.cuda.synchronize()
+        full = model.state_dict()
+        for k in PN:
+            err = np.abs(full[k].cpu().double().numpy() - g[f"post{s}.{k}"].astype(np.float64))
+            assert err.max() <= 0.5 * lr + 1e-6, f"post{s}.{k}: {err.max():.3e}"
+            assert (err <= 2e-5 + 1e-4 * np.abs(g[f"post{s}.{k}"])).mean() > 0.98, f"post{s}.{k}: tight fraction"
+        for k in BN:
+            close(full[k], g[f"post{s}.{k}"], 1e-4, 1e-5, f"post{s}.{k}")
+    crit.check()
+
+
+def test_generic_widths_train_through_trainer_uni_like_the_oracle():
+    """Trainer_uni (hipGraph replay, indexed batches fall back to a gather) on a generic-width model: two epochs against
+    the CPU oracle stepping through the same batches."""
+    from eav_amd.eegnet import EEGNet_tor, Trainer_uni
+    from oracle import eegnet_oracle as orc
+    a = dict(nb=5, chans=22, klen=50, F1=5, D=3, F2=20)
+    S, n = 288, 24
+    sd = eegnet_weights(41, S, **a)
+    x, y = synth.eeg_batch(410, n, a["chans"], S, a["nb"])
+    m = EEGNet_tor(a["nb"], Chans=a["chans"], Samples=S, kernLength=a["klen"], F1=a["F1"], D=a["D"], F2=a["F2"],
+                   dropoutRate=0.0)
+    full = m.state_dict()
+    full.update({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+    m.load_state_dict(full)
+    tr = Trainer_uni(m, [x, y, x[:8], y[:8]], lr=1e-3, batch_size=8, num_epochs=2, device="cuda")
+    order = [np.arange(n), np.arange(n)[::-1].copy()]
+    tr.train_dataloader.order_override = [o.copy() for o in order]
+    with redirect_stdout(io.StringIO()):
+        tr.train()
+    torch.cuda.synchronize()
+    st = orc.Stepper({k: torch.from_numpy(sd[k].copy()) for k in orc.PARAM_NAMES},
+                     {k: torch.from_numpy(sd[k].copy()) for k in orc.BUFFER_NAMES}, lr=1e-3, drop_p=0.0)
+    for e, o in enumerate(order):
+        for i in range(0, n, 8):
+            idx = o[i:i + 8]
+            st.step(torch.from_numpy(x[idx]), torch.from_numpy(y[idx]), e == 0, None)     # Q4: eval mode from epoch 2
+    got = m.state_dict()
+    for k in orc.PARAM_NAMES:
+        ref = st.P[k].detach().numpy()
+        err = np.abs(got[k].cpu().numpy() - ref)
+        assert err.max() <= 6 * 1e-3 * 0.5 + 1e-6, (k, err.max())          # six Adam steps of lr 1e-3, half a step each at most
+        assert (err <= 5e-5 + 1e-3 * np.abs(ref)).mean() > 0.97, (k, "tight fraction")
+    for k in orc.BUFFER_NAMES:
+        close(got[k], st.Bf[k].numpy(), 1e-3, 1e-4, k)
 
 
 def test_s10000_matches_reference_golden_and_oracle(golden_dir):

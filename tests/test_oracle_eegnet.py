@@ -33,17 +33,26 @@ def _close_params(a, b, lr, what, frac=0.995):
     assert err.max() <= 0.25 * lr, f"{what}: max err {err.max():.3e} vs lr {lr}"
 
 
-@pytest.mark.parametrize("case", ["s500_train", "s500_eval", "s500_maxnorm", "s500_dropout", "s500_dropout2d"])
+def _arch(g):
+    """Network shape of a golden: the reference driver's unless the fixture records another (`arch.*`, generic cases)."""
+    a = dict(nb=5, chans=30, klen=300, F1=8, D=8, F2=64)
+    a.update({k[5:]: int(g[k]) for k in g.files if k.startswith("arch.")})
+    return a
+
+
+@pytest.mark.parametrize("case", ["s500_train", "s500_eval", "s500_maxnorm", "s500_dropout", "s500_dropout2d",
+                                  "generic_train", "generic_eval", "generic_odd", "generic_f8"])
 def test_oracle_matches_reference_steps(golden_dir, case):
     g = np.load(os.path.join(golden_dir, f"eegnet_{case}.npz"))
     B, S = int(g["B"]), int(g["S"])
-    sd = eegnet_weights(int(g["wseed"]), S, scale=float(g["wscale"]))
+    a = _arch(g)
+    sd = eegnet_weights(int(g["wseed"]), S, scale=float(g["wscale"]), **a)
     P = {k: torch.from_numpy(sd[k].copy()) for k in orc.PARAM_NAMES}
     Bf = {k: torch.from_numpy(sd[k].copy()) for k in orc.BUFFER_NAMES}
     st = orc.Stepper(P, Bf, lr=float(g["lr"]), drop_p=float(g["drop_p"]))
     training = bool(int(g["train_mode"]))
     for s in range(int(g["steps"])):
-        x, y = synth.eeg_batch(int(g["xseed"]) + s, B, 30, S)
+        x, y = synth.eeg_batch(int(g["xseed"]) + s, B, a["chans"], S, a["nb"])
         masks = None
         if float(g["drop_p"]) > 0:
             masks = (torch.from_numpy(g[f"mask{2 * s}"].astype(np.float32)),

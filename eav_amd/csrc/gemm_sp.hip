@@ -38,7 +38,19 @@
 namespace {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+// ds_read_b64_tr_b16: within each group of 16 lanes the sixteen 8-byte reads form a [4][16] fp16 block - lane 4r + q
+// supplies row r, columns 4q .. 4q+3 - and lane j receives column j of the four rows (measured on gfx950 with
+// tools/probes/tr16_probe.hip).  With rows = contraction index (tokens) and columns = features, two such reads give a
+// lane the eight consecutive-k values of an MFMA operand fragment from a TOKEN-major image: the weight-gradient products
+// contract over tokens directly from the row planes, no transposed copy of any activation / gradient tensor exists.
+__device__ __forceinline__ f16x4 lds_read_tr16(const unsigned char* p) {
+  return __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)p));
+}
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
 struct SpArgs {
@@ -98,16 +110,27 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
 }
 
 // WM x WN waves, each a (32 RM) x (32 RN) block of RM x RN MFMA tiles.
-template <int WM, int WN, int RM, int RN, bool TWOACC>
+//
+// TR = false: C[m,n] = sum_k A[m,k] B[n,k] - both operands are row planes whose COLUMN index is contracted (forward and
+// data-gradient products).  TR = true: C[m,n] = sum_t A[t,m] B[t,n] - the ROW index (token) of both row planes is
+// contracted (weight-gradient products).  A K-tile is then 32 tokens x 128 features of each operand (512 B of every
+// token row: 16 hi/lo piece pairs), staged token-major: piece (t, w = 2 fg + hl) at 16-byte slot t 32 + (w ^ s(t)),
+// s(t) = (t & 1) | ((t & 2) << 2), applied to the per-lane SOURCE address of the LDS-DMA as in the other mode.  A
+// fragment is two ds_read_b64_tr_b16 (tokens 4h .. 4h+3, h = 0, 1); the 32 lanes of a half-wave then touch the 16
+// distinct 16-byte slots {row r = t & 3} x {4 feature groups} in both 8-byte halves: conflict-free.  Rows of the planes
+// beyond the token count (up to the next multiple of 32) must be ZERO - they are contracted like real tokens.
+template <int WM, int WN, int RM, int RN, bool TWOACC, bool TR>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_kernel(SpArgs g) {
   constexpr int NW = WM * WN, BM = 32 * RM * WM, BN = 32 * RN * WN;
   constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
-  constexpr int NCH = (BM + BN) / 8;      // 1-KB chunks (8 rows x 128 B) per stage
+  constexpr int NCH = (BM + BN) / 8;      // 1-KB chunks (8 rows x 128 B; TR: 2 tokens x 512 B) per stage
   constexpr int CPW = NCH / NW;           // chunks per wave
   constexpr int NT = RM * RN;             // MFMA tiles per wave
   constexpr int NMF = 3 * NT;             // MFMAs per K-step of 16
-  constexpr int NRD = 2 * (RM + RN);      // fragment reads per K-step
-  static_assert(NCH % NW == 0 && CPW <= NMF && NRD <= NMF, "stage chunks / fragment reads must fit the MFMA slots");
+  constexpr int NRD = (TR ? 4 : 2) * (RM + RN);      // fragment reads per K-step
+  static_assert(NCH % NW == 0 && CPW <= NMF && NRD <= (TR ? 2 : 1) * NMF,
+                "stage chunks / fragment reads must fit the MFMA slots");
+  static_assert(!TR || (BM == 128 && BN == 128 && RM == 2 && RN == 2), "the token-major image is laid out for 128 x 128");
   // + one 32 x 32 fp32 patch per wave: the epilogue turns accumulator blocks into row-linear order through it
   __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE + NW * 4096];
 
@@ -144,25 +167,65 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
 
   // ---- per-lane global source pointers of this wave's chunks (row clamped: ragged tiles re-read the last row)
   const unsigned char* gp[CPW];
+  int64_t gstep[TR ? CPW : 1];                           // TR: bytes from one K-tile (32 tokens) to the next
+  // TR: L2 prefetch.  A token tile is fresh HBM data for every workgroup (the operands are streamed once along the
+  // contraction; nothing of the next tile is in L2 yet, unlike the other mode where the next K-tile of a row is the
+  // neighbouring line of a panel its XCD is already streaming), and one K-tile of cover (1.3 us) is less than an HBM miss
+  // (2.3 us per K-tile measured with one workgroup per CU and nothing else running).  One extra load per wave and
+  // K-tile - lane l touches 128-byte line l & 7 of the wave's chunk l >> 3 of the tile THREE ahead, destination a
+  // register nobody reads - pulls that tile into L2 two tiles before its LDS-DMA is issued; the mid-tile wait becomes
+  // vmcnt(1) so that only the DMAs, not the newest prefetch, are waited for.
+  const unsigned char* pf = nullptr;
+  int64_t pfstep = 0;
+  constexpr int PFD = 3;
+  constexpr bool PF = TR;   // (in the other mode the same prefetch costs 7-16 %: its next K-tile is mostly L2-resident already)
   auto set_sources = [&](int m0, int n0) {
+    if constexpr (TR) {
+      const int c = wave + NW * (lane >> 3), j = lane & 7;
+      const bool isA = 8 * c < BM;
+      const int tk = 2 * (isA ? c : c - BM / 8) + (j >> 2);
+      const int64_t ld = isA ? g.ldA : g.ldB;
+      const int64_t colb = min((int64_t)(isA ? m0 : n0) * 4 + (j & 3) * 128, ld - 128);
+      pf = (isA ? Ab : g.B) + ((int64_t)(kt0 + PFD) * 32 + tk) * ld + colb;
+      pfstep = 32 * ld;
+    }
 #pragma unroll
     for (int i = 0; i < CPW; ++i) {
       const int c = wave + NW * i;                       // wave-uniform chunk id
-      const int row = 8 * c + (lane >> 3);               // row in the combined [A tile; B tile] image
-      const int p = (lane & 7) ^ ((row >> 1) & 7);       // piece held by this lane's slot
-      if (8 * c < BM) {
-        const int gr = min(m0 + row, g.M - 1);
-        gp[i] = Ab + (int64_t)gr * g.ldA + (int64_t)kt0 * 128 + p * 16;
+      if constexpr (TR) {
+        const bool isA = 8 * c < BM;
+        const int tk = 2 * (isA ? c : c - BM / 8) + (lane >> 5);          // token within the K-tile
+        const int w = (lane & 31) ^ ((tk & 1) | ((tk & 2) << 2));          // piece held by this lane's slot
+        const int fg = w >> 1, hl = w & 1;
+        const int64_t ld = isA ? g.ldA : g.ldB;
+        const int grp = min((isA ? m0 : n0) / 8 + fg, (int)(ld >> 5) - 1);  // ragged feature tiles re-read the last group
+        gp[i] = (isA ? Ab : g.B) + ((int64_t)kt0 * 32 + tk) * ld + (int64_t)grp * 32 + hl * 16;
+        gstep[i] = 32 * ld;
       } else {
-        const int gr = min(n0 + row - BM, g.N - 1);
-        gp[i] = g.B + (int64_t)gr * g.ldB + (int64_t)kt0 * 128 + p * 16;
+        const int row = 8 * c + (lane >> 3);               // row in the combined [A tile; B tile] image
+        const int p = (lane & 7) ^ ((row >> 1) & 7);       // piece held by this lane's slot
+        if (8 * c < BM) {
+          const int gr = min(m0 + row, g.M - 1);
+          gp[i] = Ab + (int64_t)gr * g.ldA + (int64_t)kt0 * 128 + p * 16;
+        } else {
+          const int gr = min(n0 + row - BM, g.N - 1);
+          gp[i] = g.B + (int64_t)gr * g.ldB + (int64_t)kt0 * 128 + p * 16;
+        }
       }
     }
   };
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)smem;
+  // The LDS-DMA is issued from inline asm, not through __builtin_amdgcn_global_load_lds: hipcc orders every LDS access
+  // it cannot disambiguate behind the outstanding DMA builtins with an `s_waitcnt vmcnt(0)` - the transposing reads of the
+  // TR loop (each DMA was waited for right after its issue) and the epilogue's patch reads (the next tile's first stages
+  // were drained before the epilogue could start).  An asm DMA is invisible to that pass; the waits that order DMA and
+  // fragment reads are the explicit ones of this kernel (mid-tile vmcnt + barrier, tile start).
   auto issue1 = [&](int buf, int i) {
     const int c = wave + NW * i;
-    __builtin_amdgcn_global_load_lds((glb_ptr_t)gp[i], (lds_ptr_t)(smem + buf * STAGE + c * 1024), 16, 0, 0);
-    gp[i] += 128;
+    const unsigned dst = lds0 + buf * STAGE + c * 1024;
+    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gp[i]), "s"(dst) : "memory", "m0");
+    if constexpr (TR) gp[i] += gstep[i];
+    else gp[i] += 128;
   };
 
   // ---- fragment addressing
@@ -174,6 +237,19 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
 #pragma unroll
     for (int hl = 0; hl < 2; ++hl) lowp[ks][hl] = ((2 * (2 * ks + kh) + hl) ^ gq) * 16;
   const int offA = (wm * 32 * RM + r32) * 128, offB = A_BYTES + (wn * 32 * RN + r32) * 128;
+  // TR: lane = 16 g4 + 4 kk + c supplies token 8 (g4 >> 1) + kk (+ 4 h + 16 ks), features 16 (g4 & 1) + 4 c .. + 3 of tile i
+  int trA[RM][2], trB[RN][2];
+  if constexpr (TR) {
+    const int g4 = lane >> 4, kk = (lane >> 2) & 3, c = lane & 3;
+    const int lb = (8 * (g4 >> 1) + kk) * 512 + (g4 & 1) * 64 + (c >> 1) * 32 + (c & 1) * 8;
+#pragma unroll
+    for (int hl = 0; hl < 2; ++hl) {
+#pragma unroll
+      for (int i = 0; i < RM; ++i) trA[i][hl] = lb + wm * 256 + ((i ^ (kk >> 1)) << 7) + ((hl ^ (kk & 1)) << 4);
+#pragma unroll
+      for (int j = 0; j < RN; ++j) trB[j][hl] = A_BYTES + lb + wn * 256 + ((j ^ (kk >> 1)) << 7) + ((hl ^ (kk & 1)) << 4);
+    }
+  }
 
   // ---- main loop: software-pipelined and explicitly interleaved (sched_barrier pins the order as written).
   // Two fragment register sets: f0 = K-step 0 of a K-tile, f1 = K-step 1.  Iteration t:
@@ -187,10 +263,22 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
   // land under this tile's epilogue (a K = 768 problem otherwise spends a quarter of its time in cold prologues).
   struct Frags { f16x8 ah[RM], al[RM], bh[RN], bl[RN]; };
   Frags f0, f1;
+  float pfsink = 0.f;       // destination of the TR prefetch loads: live to the end of the kernel, never read
   f32x16 acc[RM][RN], acx[TWOACC ? RM : 1][TWOACC ? RN : 1];
 #define SB() __builtin_amdgcn_sched_barrier(0)
 #define MM(c, a, b) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
   // fragment read number r of a K-step: ah[0..RM), bh[0..RN), al[0..RM), bl[0..RN)
+  // TR: read r of a K-step (0 .. 4 (RM + RN)): fragment r >> 1 in the order ah[], bh[], al[], bl[], token half r & 1
+  auto read_frag_tr = [&](Frags& f, const unsigned char* stage, int ks, int r) {
+    const int fi = r >> 1, h = r & 1;
+    const unsigned char* p = stage + ks * 8192 + h * 2048;
+#define EAV_TRRD(dst, off) { const f16x4 v = lds_read_tr16(p + (off)); if (h) dst.hi = v; else dst.lo = v; }
+    if (fi < RM) EAV_TRRD(f.ah[fi], trA[fi][0])
+    else if (fi < RM + RN) EAV_TRRD(f.bh[fi - RM], trB[fi - RM][0])
+    else if (fi < 2 * RM + RN) EAV_TRRD(f.al[fi - RM - RN], trA[fi - RM - RN][1])
+    else EAV_TRRD(f.bl[fi - 2 * RM - RN], trB[fi - 2 * RM - RN][1])
+#undef EAV_TRRD
+  };
   auto read_frag = [&](Frags& f, const unsigned char* sa, const unsigned char* sb, int ks, int r) {
     if (r < RM) f.ah[r] = *reinterpret_cast<const f16x8*>(sa + r * 4096 + lowp[ks][0]);
     else if (r < RM + RN) f.bh[r - RM] = *reinterpret_cast<const f16x8*>(sb + (r - RM) * 4096 + lowp[ks][0]);
@@ -225,10 +313,16 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
     for (int m = 0; m < NMF; ++m) {          // phase A
       mfma_slot(f0, m);
       SB();
-      if (m < NRD) read_frag(f1, sa, sb, 1, m);
+      if constexpr (TR) {
+        read_frag_tr(f1, smem + buf * STAGE, 1, m);
+        if (m + NMF < NRD) read_frag_tr(f1, smem + buf * STAGE, 1, m + NMF);
+      } else {
+        if (m < NRD) read_frag(f1, sa, sb, 1, m);
+      }
       SB();
     }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (PF && t >= 1 && t + PFD - 1 < nk) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");   // newest = the prefetch of t - 1
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     SB();
     if (!more && next_m0 >= 0) set_sources(next_m0, next_n0);
@@ -236,7 +330,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
     for (int m = 0; m < NMF; ++m) {          // phase B
       mfma_slot(f1, m);
       SB();
-      if (more && m < NRD) read_frag(f0, sa2, sb2, 0, m);
+      if constexpr (TR) {
+        if (more) {
+          read_frag_tr(f0, smem + (buf ^ 1) * STAGE, 0, m);
+          if (m + NMF < NRD) read_frag_tr(f0, smem + (buf ^ 1) * STAGE, 0, m + NMF);
+        }
+      } else {
+        if (more && m < NRD) read_frag(f0, sa2, sb2, 0, m);
+      }
       if (more2 && m < CPW) issue1(buf, m);
       if (!more && next_m0 >= 0) {
         if (m < CPW) issue1(0, m);
@@ -247,6 +348,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
     if (!more && next_m0 >= 0 && nk > 1) {       // the rest of the next tile's second stage (2 CPW may exceed the slots)
 #pragma unroll
       for (int m = NMF; m < 2 * CPW; ++m) issue1(1, m - CPW);
+    }
+    if constexpr (PF && more2) {
+      if (t + PFD < nk) {                          // after this iteration's DMAs: the newest VMEM operation in flight
+        asm volatile("global_load_dword %0, %1, off" : "+v"(pfsink) : "v"(pf) : "memory");
+        pf += pfstep;
+      }
     }
   };
 
@@ -278,7 +385,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 #pragma unroll
-    for (int r = 0; r < NRD; ++r) read_frag(f0, smem + offA, smem + offB, 0, r);
+    for (int r = 0; r < NRD; ++r) {
+      if constexpr (TR) read_frag_tr(f0, smem, 0, r);
+      else read_frag(f0, smem + offA, smem + offB, 0, r);
+    }
     {
       int t = 0;
       for (; t + 2 < nk; ++t) iter(std::true_type{}, std::true_type{}, t, -1, -1);
@@ -462,6 +572,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
         atomicMax(g.amax + EAV_SLOT_SHARD(tl * NW + wave + 17 * blockIdx.z), __float_as_uint(vmax));
     }
   }
+  if constexpr (PF) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" ::"v"(pfsink));
+  }
 #undef MM
 #undef SB
 }
@@ -473,7 +587,7 @@ int g_force_tile = 0;   // test / tuning hook: 0 = heuristic, 1 = 128x128, 2 = 2
 int g_loshift = 11;
 int g_persist = 1;      // tuning hook: 0 = one workgroup per output tile
 
-template <int WM, int WN, int RM, int RN>
+template <int WM, int WN, int RM, int RN, bool TR = false>
 void launch(SpArgs& g, int nz, hipStream_t st) {
   g.tm = cdiv(g.M, 32 * RM * WM);
   g.tn = cdiv(g.N, 32 * RN * WN);
@@ -483,9 +597,10 @@ void launch(SpArgs& g, int nz, hipStream_t st) {
   const int nb = g.tm * g.tn, gx = nb <= resident ? nb : resident;
   if (g_loshift) {
     if constexpr (RM * RN <= 4)
-      hipLaunchKernelGGL((gemm_sp_kernel<WM, WN, RM, RN, true>), dim3(gx, 1, nz), dim3(64 * WM * WN), 0, st, g);
+      hipLaunchKernelGGL((gemm_sp_kernel<WM, WN, RM, RN, true, TR>), dim3(gx, 1, nz), dim3(64 * WM * WN), 0, st, g);
   } else {
-    hipLaunchKernelGGL((gemm_sp_kernel<WM, WN, RM, RN, false>), dim3(gx, 1, nz), dim3(64 * WM * WN), 0, st, g);
+    if constexpr (!TR)
+      hipLaunchKernelGGL((gemm_sp_kernel<WM, WN, RM, RN, false, false>), dim3(gx, 1, nz), dim3(64 * WM * WN), 0, st, g);
   }
 }
 
@@ -496,6 +611,8 @@ void dispatch(SpArgs& g, int nz, hipStream_t st) {
   if (g_force_tile == 2) launch<4, 2, 2, 2>(g, nz, st);
   else launch<2, 2, 2, 2>(g, nz, st);
 }
+
+void dispatch_tr(SpArgs& g, int nz, hipStream_t st) { launch<2, 2, 2, 2, true>(g, nz, st); }
 
 __global__ void sp_splitk_reduce_kernel(const float* __restrict__ ws, int nsplit, int64_t n, float* __restrict__ out,
                                         int accumulate) {
@@ -775,29 +892,32 @@ extern "C" int eav_gemm_sp_splitk_plan(int M, int N, int K) {
   return ns < 1 ? 1 : ns;
 }
 
+// Weight-gradient product C[M,N] = sum_t A[t,m] B[t,n] over ROW planes (contraction over the rows = tokens): A planes
+// [Tp][Mp/8][2][8], B planes [Tp][Np/8][2][8] with Tp = T rounded up to 32 and the rows >= T ZERO (the conversion never
+// writes them; allocate zero-filled).  Split-K over the token tiles with a fixed-order fp64 reduction of the slabs.
 extern "C" int eav_gemm_sp_splitk(const void* A, const void* B, float* C, float* ws, const float* slotA,
-                                  const float* slotB, int M, int N, int K, int accumulate, void* stream) {
-  EAV_REQUIRE(A && B && C && ws && slotA && slotB && M > 0 && N > 0 && K > 0, "eav_gemm_sp_splitk: bad arguments");
+                                  const float* slotB, int M, int N, int T, int accumulate, void* stream) {
+  EAV_REQUIRE(A && B && C && ws && slotA && slotB && M > 0 && N > 0 && T > 0, "eav_gemm_sp_splitk: bad arguments");
   EAV_REQUIRE((N & 3) == 0 && (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)ws) & 15) == 0,
               "eav_gemm_sp_splitk: N must be a multiple of 4, buffers 16-byte aligned");
-  const int nsplit = eav_gemm_sp_splitk_plan(M, N, K);
+  EAV_REQUIRE(g_loshift != 0, "eav_gemm_sp_splitk: the single-accumulator tuning mode has no token-contracting kernel");
+  const int nsplit = eav_gemm_sp_splitk_plan(M, N, T);
   SpArgs g;
-  const int Kp = eav_sp_kpad(K);
   g.A = (const unsigned char*)A; g.B = (const unsigned char*)B; g.slotA = slotA; g.slotB = slotB;
   g.bias = nullptr; g.resid = nullptr; g.pre = nullptr; g.amax = nullptr;
-  g.M = M; g.N = N; g.nkt = Kp / 32; g.ldA = (int64_t)Kp * 4; g.ldB = (int64_t)Kp * 4; g.ldc = N; g.ldr = 0;
-  g.sA = 0; g.sC = 0; g.alpha = 1.f; g.gelu = 0;
+  g.M = M; g.N = N; g.nkt = cdiv(T, 32); g.ldA = (int64_t)eav_sp_kpad(M) * 4; g.ldB = (int64_t)eav_sp_kpad(N) * 4;
+  g.ldc = N; g.ldr = 0; g.sA = 0; g.sC = 0; g.alpha = 1.f; g.gelu = 0;
   hipStream_t st = (hipStream_t)stream;
   if (nsplit <= 1) {
     g.C = C; g.accumulate = accumulate; g.kt_per_split = 0;
-    dispatch(g, 1, st);
+    dispatch_tr(g, 1, st);
     EAV_CHECK_LAUNCH("eav_gemm_sp_splitk");
     return EAV_OK;
   }
   g.C = ws; g.accumulate = 0;
   g.kt_per_split = cdiv(g.nkt, nsplit);
   const int nz = cdiv(g.nkt, g.kt_per_split);
-  dispatch(g, nz, st);
+  dispatch_tr(g, nz, st);
   EAV_CHECK_LAUNCH("eav_gemm_sp_splitk");
   const int64_t n = (int64_t)M * N;
   hipLaunchKernelGGL(sp_splitk_reduce_kernel, dim3((unsigned)cdiv64(n, 1024)), dim3(256), 0, st, ws, nz, n, C,

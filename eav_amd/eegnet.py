@@ -708,15 +708,20 @@ class Trainer_uni:
 
     def validate(self):
         self.model.eval()
-        total_loss = 0
-        total_correct = 0
+        # EEGNet_tor.py:118-135 reads loss.item() and the hit count back after every batch; here both stay on the device
+        # (one slot per batch, one hit counter) and are read once - the sums are formed in the reference's order
+        nb = len(self.test_dataloader)
+        losses = torch.zeros(max(nb, 1), dtype=torch.float32, device=self.device)
+        correct = torch.zeros((), dtype=torch.int32, device=self.device)
         with torch.no_grad():
-            for data, targets in self.test_dataloader:
+            for k, (data, targets) in enumerate(self.test_dataloader):
                 scores = self.model(data)
-                loss = self.criterion(scores, targets)
-                total_loss += loss.item()
-                predictions = scores.argmax(dim=1)
-                total_correct += (predictions == targets).sum().item()
+                self.criterion.accumulate(scores, targets, losses[k], correct)
+        total_loss = 0
+        for v in losses[:nb].cpu().tolist():
+            total_loss += v
+        total_correct = int(correct.item())
+        self.criterion.check()
         avg_loss = total_loss / len(self.test_dataloader)
         accuracy = total_correct / len(self.test_dataloader.dataset)
         print(f"Validation - Loss: {avg_loss:.4f}, Accuracy: {accuracy:.4f}")

@@ -217,6 +217,19 @@ class CrossEntropyLoss:
                 raise _lib.EavError(f"CrossEntropyLoss: target {bad - 1 if bad > 0 else bad} is outside [0, classes) "
                                     "(the reference's labels 1,3,5,7,9 must be mapped to 0..4 first)")
 
+    def accumulate(self, scores, targets, loss_out, ncorrect):
+        """Evaluation form (no gradient, nothing read back): writes the mean loss of this batch into the 0-dim device
+        tensor `loss_out` and adds the number of argmax hits to the device int32 `ncorrect` - a validation loop reads
+        both once per epoch instead of synchronising twice per batch (EEGNet_tor.py:126-130 calls .item() per batch)."""
+        if not scores.is_cuda or scores.dim() != 2 or scores.dtype != torch.float32 or not scores.is_contiguous():
+            raise _lib.EavError("CrossEntropyLoss.accumulate: scores must be a contiguous fp32 [batch, classes] device tensor")
+        if targets.dtype != torch.int64:
+            targets = targets.long()
+        if self._flag is None or self._flag.device != scores.device:
+            self._flag = torch.zeros((), dtype=torch.int32, device=scores.device)
+        _lib.call("eav_ce_fwd_bwd", scores.data_ptr(), targets.contiguous().data_ptr(), loss_out.data_ptr(), None,
+                  ncorrect.data_ptr(), self._flag.data_ptr(), scores.shape[0], scores.shape[1], _lib.stream_ptr())
+
     def __call__(self, scores, targets):
         if not isinstance(scores, torch.Tensor) or not scores.is_cuda or not targets.is_cuda:
             raise _lib.EavError("CrossEntropyLoss needs device tensors (no CPU fallback)")

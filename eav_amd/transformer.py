@@ -376,9 +376,12 @@ class Encoder(nn.Module):
         D, FF, Lr, M = c.hidden, c.ff, c.layers, ws.M
         MP = ws.B * c.npatch
         kp = lambda k: _lib.plain("eav_sp_kpad", k)  # noqa: E731
-        h = lambda r, k: torch.empty(r, 2 * kp(k), dtype=torch.float16, device=dev)  # noqa: E731
+        # Row planes only: the weight-gradient products contract over the ROWS (tokens) of the same planes the forward /
+        # data-gradient products read (transposing LDS reads in gemm_sp.hip), so no transposed copy of any activation or
+        # gradient exists.  Rows are padded to a multiple of 32 with zeros (contracted like real tokens; the conversion
+        # never writes them).
+        h = lambda r, k: torch.zeros((r + 31) // 32 * 32, 2 * kp(k), dtype=torch.float16, device=dev)  # noqa: E731
         full = ws.full
-        # forward operands (planes; the transposes feed the weight-gradient products)
         ws.colp = h(MP, c.kp)
         ws.y1p = [h(M, D) for _ in range(nsave)]
         ws.aop = [h(M, D) for _ in range(nsave)]
@@ -391,18 +394,11 @@ class Encoder(nn.Module):
             ws.qkvrow = [torch.empty(M, 6 * D, dtype=torch.float16, device=dev) for _ in range(nsave)]
             ws.qkvT = [torch.empty(ws.B, 3 * H, 64, 2 * Npad, dtype=torch.float16, device=dev) for _ in range(nsave)]
         if full:
-            ws.colpT = h(c.kp, MP)
-            ws.y1pT = [h(D, M) for _ in range(nsave)]
-            ws.aopT = [h(D, M) for _ in range(nsave)]
-            ws.y2pT = [h(D, M) for _ in range(nsave)]
-            ws.actpT = [h(FF, M) for _ in range(nsave)]
-            # backward operands: one set, reused by every layer
-            ws.dhp, ws.dhpT = h(M, D), h(D, M)
-            ws.dhpT2 = h(D, M)        # the o_proj stage's transposed planes: the weight gradients run on a side stream, so
-                                      # the two uses of dh per layer must not share one buffer
-            ws.dactp, ws.dactpT = h(M, FF), h(FF, M)
-            ws.dqkvp, ws.dqkvpT = h(M, 3 * D), h(3 * D, M)
-            ws.dembpT = h(D, MP)
+            # backward operands: one set, reused by every layer.  dh is converted twice per layer (fc2 and o_proj stage)
+            # and its weight gradients run on the side stream, so the two uses must not share one buffer
+            ws.dhp, ws.dhp2 = h(M, D), h(M, D)
+            ws.dactp, ws.dqkvp = h(M, FF), h(M, 3 * D)
+            ws.dembp = h(MP, D)
             ws.np_cs2 = _lib.plain("eav_sp_convert_colsum_nparts", M)
             ws.part_cs2 = torch.empty(ws.np_cs2, max(FF, 3 * D), dtype=torch.float32, device=dev)
             ws.part_cs2_pool = [ws.part_cs2] + [torch.empty_like(ws.part_cs2) for _ in range(3)]
@@ -491,11 +487,11 @@ class Encoder(nn.Module):
         pl, plT, n = self._wplanes[key]
         return _lib.ptr(plT if transposed else pl), self._wplanes["_slots"].data_ptr() + 4 * self.SLOT * n
 
-    def _to_planes(self, src, R, C, ld, slot, dst, dstT, amax_done=False):
-        """fp32 [R, C] -> planes (contraction over columns) and / or planes of the transpose (contraction over rows)."""
+    def _to_planes(self, src, R, C, ld, slot, dst, amax_done=False):
+        """fp32 [R, C] -> row planes (one set serves the products that contract over columns AND those over rows)."""
         if not amax_done:
             self._call("eav_sp_absmax", src, R, C, ld, slot, self._st)
-        self._call("eav_sp_convert", src, R, C, ld, slot, _lib.ptr(dst), _lib.ptr(dstT), self._st)
+        self._call("eav_sp_convert", src, R, C, ld, slot, _lib.ptr(dst), None, self._st)
 
     def _part_buf(self, pool):
         """Next buffer of a small ring of partial-sum buffers.  The final reductions of bias / LayerNorm parameter gradients
@@ -523,12 +519,12 @@ class Encoder(nn.Module):
         done.record(side)
         self._part_busy[buf.data_ptr()] = done
 
-    def _to_planes_bias(self, src, R, C, slot, dst, dstT, bias_grad):
+    def _to_planes_bias(self, src, R, C, slot, dst, bias_grad):
         """Conversion pass that also produces the bias gradient (column sums of src) - src's max|x| is already in slot."""
         ws = self._ws
-        self._before_overwrite(dstT)
+        self._before_overwrite(dst)
         part = self._part_buf("part_cs2_pool")
-        self._call("eav_sp_convert_colsum", src, R, C, C, slot, _lib.ptr(dst), _lib.ptr(dstT), _lib.ptr(part), self._st)
+        self._call("eav_sp_convert_colsum", src, R, C, C, slot, _lib.ptr(dst), None, _lib.ptr(part), self._st)
         self._reduce_async(part, 0, ws.np_cs2, C, C, bias_grad)
 
     def _gemm_sp(self, A, slotA, B, slotB, C, M, N, K, ldc, batch=1, sA=0, sC=0, alpha=1.0, bias=None, gelu=0,
@@ -538,13 +534,14 @@ class Encoder(nn.Module):
                    resid, ldr, acc, amax, self._st)
 
     def _wgrad_sp(self, AT, slotA, BT, slotB, C, M, N, K):
-        """C[M,N] = sum over the K tokens: planes of the transposes, A^T [M,K], B^T [N,K]; split-K.
+        """C[M,N] = sum over the K tokens of A[t,m] B[t,n]: ROW planes of A [K,M] and B [K,N] (the contraction runs over the
+        rows: eav_gemm_sp_splitk reads the fragments with transposing LDS loads); split-K.
 
         Weight gradients are off the critical path of the backward (nothing downstream reads them before the optimiser),
         so they run on a side HIP stream: their MFMA work fills the matrix pipe while the main stream is in its
         HBM- / VALU-bound stretches (operand conversions, LayerNorm / GELU backward, the attention backward) and in the
         tails of its own GEMMs.  Ordering: the side stream waits for the event recorded after the conversion that
-        produced A^T; the main stream waits for a weight gradient only before it overwrites that gradient's A^T buffer
+        produced A; the main stream waits for a weight gradient only before it overwrites that gradient's A planes
         (one layer later) and at the end of the backward."""
         if not self.overlap_wgrad or (self.kernel_events is not None and "eav_gemm_sp_splitk" in self.kernel_events):
             self._call("eav_gemm_sp_splitk", _lib.ptr(AT), _lib.ptr(BT), C, _lib.ptr(self._ws.splitk), slotA, slotB, M,
@@ -605,7 +602,7 @@ class Encoder(nn.Module):
         L("eav_im2col", P(x), P(ws.col), B, c.C, c.H, c.W, c.patch, c.sy, c.sx, c.transposed, st)
         h0 = ws.hs[0]
         if sp:
-            self._to_planes(P(ws.col), B * c.npatch, c.kp, c.kp, fslot(0), ws.colp, ws.colpT if ws.full else None)
+            self._to_planes(P(ws.col), B * c.npatch, c.kp, c.kp, fslot(0), ws.colp)
             wpl, wsl = self._wp("patch")
             self._gemm_sp(P(ws.colp), fslot(0), wpl, wsl, P(h0) + 4 * c.nextra * D, c.npatch, D, c.kp, D, batch=B,
                           sA=c.npatch * kpb(c.kp), sC=N * D,
@@ -679,12 +676,11 @@ class Encoder(nn.Module):
         D, FF, N, H, M = c.hidden, c.ff, c.ntok, c.heads, ws.M
         hd = D // H
         w = lambda k: P(self._pmap[k])  # noqa: E731
-        T = (lambda lst: lst[j]) if ws.full else (lambda lst: None)  # noqa: E731
         s_y1, s_qkv, s_ao, s_y2, s_act = (fslot(1 + self.FS * i + k) for k in range(5))
         y, ao, act = ws.y1[0], ws.ao[j], ws.act[0]
         L("eav_layernorm_fwd_amax", P(hin), w(f"{Lk}.layernorm_before.weight"), w(f"{Lk}.layernorm_before.bias"), P(y),
           stp, stp + 4 * M, M, D, c.eps, s_y1, st)
-        self._to_planes(P(y), M, D, D, s_y1, ws.y1p[j], T(ws.y1pT) if ws.full else None, amax_done=True)
+        self._to_planes(P(y), M, D, D, s_y1, ws.y1p[j], amax_done=True)
         qkv = P(ws.qkv[0 if ws.fused else j])
         wpl, wsl = self._wp(f"qkv{i}")
         self._gemm_sp(P(ws.y1p[j]), s_y1, wpl, wsl, qkv, M, 3 * D, D, 3 * D, bias=w(f"{Lk}.attention.q_proj.bias"),
@@ -702,20 +698,19 @@ class Encoder(nn.Module):
             L("eav_softmax_fwd", Pm, ws.B * H * N, N, ldn, st)
             self._gemm_f32(Pm, qkv + 8 * D, P(ao), N, hd, N, ldn, 3 * D, D, tB=1, batch=ws.B * H, heads=H,
                            sA=(H * N * ldn, N * ldn), sB=(N * 3 * D, hd), sC=(N * D, hd))
-        self._to_planes(P(ao), M, D, D, s_ao, ws.aop[j], T(ws.aopT) if ws.full else None, amax_done=ws.fused)
+        self._to_planes(P(ao), M, D, D, s_ao, ws.aop[j], amax_done=ws.fused)
         wpl, wsl = self._wp(f"o{i}")
         self._gemm_sp(P(ws.aop[j]), s_ao, wpl, wsl, P(ws.hmid[j]), M, D, D, D, bias=w(f"{Lk}.attention.o_proj.bias"),
                       resid=P(hin), ldr=D)
         L("eav_layernorm_fwd_amax", P(ws.hmid[j]), w(f"{Lk}.layernorm_after.weight"),
           w(f"{Lk}.layernorm_after.bias"), P(y), stp + 8 * M, stp + 12 * M, M, D, c.eps, s_y2, st)
-        self._to_planes(P(y), M, D, D, s_y2, ws.y2p[j], T(ws.y2pT) if ws.full else None, amax_done=True)
+        self._to_planes(P(y), M, D, D, s_y2, ws.y2p[j], amax_done=True)
         wpl, wsl = self._wp(f"fc1{i}")
         # fc1 stores the PRE-activation only (kept per layer for the backward; a scratch buffer in the frozen phase) and
         # max|GELU|; the conversion applies the GELU while it splits - the activation never exists in fp32
         pre = P(ws.pre[j]) if ws.full else P(act)
         self._gemm_sp(P(ws.y2p[j]), s_y2, wpl, wsl, pre, M, FF, D, FF, bias=w(f"{Lk}.mlp.fc1.bias"), gelu=3, amax=s_act)
-        self._call("eav_sp_convert_gelu", pre, M, FF, FF, s_act, P(ws.actp[j]),
-                   P(ws.actpT[j]) if ws.full else None, self._st)
+        self._call("eav_sp_convert_gelu", pre, M, FF, FF, s_act, P(ws.actp[j]), None, self._st)
         wpl, wsl = self._wp(f"fc2{i}")
         self._gemm_sp(P(ws.actp[j]), s_act, wpl, wsl, P(hout), M, D, FF, D, bias=w(f"{Lk}.mlp.fc2.bias"),
                       resid=P(ws.hmid[j]), ldr=D)
@@ -739,14 +734,14 @@ class Encoder(nn.Module):
         b_dh2, b_dact, b_dh1, b_dao, b_ds, b_dqkv = (bslot(1 + self.BS * i + k) for k in range(6))
         # fc2: h_out = h_mid + act.W2^T + b2.  max|dh| is already in b_dh2 (left there by the producer of dh); every
         # conversion pass also yields the bias gradient of its tensor
-        self._to_planes_bias(dh, M, D, b_dh2, ws.dhp, ws.dhpT, gp(f"{Lk}.mlp.fc2.bias"))
-        self._wgrad_sp(ws.dhpT, b_dh2, ws.actpT[i], s_act, gp(f"{Lk}.mlp.fc2.weight"), D, FF, M)
+        self._to_planes_bias(dh, M, D, b_dh2, ws.dhp, gp(f"{Lk}.mlp.fc2.bias"))
+        self._wgrad_sp(ws.dhp, b_dh2, ws.actp[i], s_act, gp(f"{Lk}.mlp.fc2.weight"), D, FF, M)
         wpl, wsl = self._wp(f"fc2{i}", transposed=True)
         # data gradient through fc2 and the GELU in one pass: the epilogue multiplies by gelu'(pre) and emits max|dact|
         self._gemm_sp(P(ws.dhp), b_dh2, wpl, wsl, dact, M, FF, D, FF, gelu=2, pre=P(ws.pre[i]), amax=b_dact)
         # fc1
-        self._to_planes_bias(dact, M, FF, b_dact, ws.dactp, ws.dactpT, gp(f"{Lk}.mlp.fc1.bias"))
-        self._wgrad_sp(ws.dactpT, b_dact, ws.y2pT[i], s_y2, gp(f"{Lk}.mlp.fc1.weight"), FF, D, M)
+        self._to_planes_bias(dact, M, FF, b_dact, ws.dactp, gp(f"{Lk}.mlp.fc1.bias"))
+        self._wgrad_sp(ws.dactp, b_dact, ws.y2p[i], s_y2, gp(f"{Lk}.mlp.fc1.weight"), FF, D, M)
         wpl, wsl = self._wp(f"fc1{i}", transposed=True)
         self._gemm_sp(P(ws.dactp), b_dact, wpl, wsl, dy, M, D, FF, D)
         part = self._part_buf("part_ln_pool")
@@ -754,10 +749,10 @@ class Encoder(nn.Module):
           1, P(part), M, D, b_dh1, st)
         self._reduce_ln(part, gp(f"{Lk}.layernorm_after.weight"), gp(f"{Lk}.layernorm_after.bias"))
         # o_proj
-        self._to_planes_bias(dh, M, D, b_dh1, ws.dhp, ws.dhpT2, gp(f"{Lk}.attention.o_proj.bias"))
-        self._wgrad_sp(ws.dhpT2, b_dh1, ws.aopT[i], s_ao, gp(f"{Lk}.attention.o_proj.weight"), D, D, M)
+        self._to_planes_bias(dh, M, D, b_dh1, ws.dhp2, gp(f"{Lk}.attention.o_proj.bias"))
+        self._wgrad_sp(ws.dhp2, b_dh1, ws.aop[i], s_ao, gp(f"{Lk}.attention.o_proj.weight"), D, D, M)
         wpl, wsl = self._wp(f"o{i}", transposed=True)
-        self._gemm_sp(P(ws.dhp), b_dh1, wpl, wsl, dao, M, D, D, D, amax=b_dao if ws.fused else None)
+        self._gemm_sp(P(ws.dhp2), b_dh1, wpl, wsl, dao, M, D, D, D, amax=b_dao if ws.fused else None)
         # attention core
         if ws.fused:
             L("eav_attn_sp_prep", dao, b_dao, P(ws.dorow), P(ws.doT), ws.B, N, D, D, 1, st)
@@ -779,8 +774,8 @@ class Encoder(nn.Module):
         # fused q/k/v projection
         if not ws.fused:
             self._call("eav_sp_absmax", dqkv, M, 3 * D, 3 * D, b_dqkv, st)
-        self._to_planes_bias(dqkv, M, 3 * D, b_dqkv, ws.dqkvp, ws.dqkvpT, gp(f"{Lk}.attention.q_proj.bias"))
-        self._wgrad_sp(ws.dqkvpT, b_dqkv, ws.y1pT[i], s_y1, gp(f"{Lk}.attention.q_proj.weight"), 3 * D, D, M)
+        self._to_planes_bias(dqkv, M, 3 * D, b_dqkv, ws.dqkvp, gp(f"{Lk}.attention.q_proj.bias"))
+        self._wgrad_sp(ws.dqkvp, b_dqkv, ws.y1p[i], s_y1, gp(f"{Lk}.attention.q_proj.weight"), 3 * D, D, M)
         wpl, wsl = self._wp(f"qkv{i}", transposed=True)
         self._gemm_sp(P(ws.dqkvp), b_dqkv, wpl, wsl, dy, M, D, 3 * D, D)
         # the gradient w.r.t. this layer's input is the next (lower) layer's dh: leave its max in that layer's slot
@@ -930,8 +925,8 @@ class Encoder(nn.Module):
             MP = B * c.npatch
             if sp:
                 # demb is a row subset of dh, whose maximum layer 0's LayerNorm backward left in bslot(0)
-                self._to_planes(P(ws.demb), MP, D, D, bslot(0), None, ws.dembpT, amax_done=True)
-                self._wgrad_sp(ws.dembpT, bslot(0), ws.colpT, fslot(0),
+                self._to_planes(P(ws.demb), MP, D, D, bslot(0), ws.dembp, amax_done=True)
+                self._wgrad_sp(ws.dembp, bslot(0), ws.colp, fslot(0),
                                gp(f"{pre}.embeddings.patch_embeddings.projection.weight"), D, c.kp, MP)
             else:
                 self._wgrad(P(ws.demb), P(ws.col), gp(f"{pre}.embeddings.patch_embeddings.projection.weight"), D, c.kp,

@@ -139,26 +139,42 @@ def test_gemm_sp_epilogues_and_batch():
     assert (C[:, 2:].double() - ref).abs().max().item() < 2e-5 and (C[:, :2] == 0).all()
 
 
-@pytest.mark.parametrize("shape", [(9712, 768, 256), (1214, 200, 136), (50, 64, 64)])
-def test_weight_gradient_through_transposed_planes(shape):
+def row_planes(x):
+    """Row planes with the rows padded to a multiple of 32 with zeros (what the token-contracting GEMM requires)."""
+    R, C = x.shape
+    slot = torch.zeros(SLOT, device="cuda")
+    _lib.call("eav_sp_absmax", P(x), R, C, x.stride(0), P(slot), None)
+    d = torch.zeros((R + 31) // 32 * 32, 2 * kpad(C), dtype=torch.float16, device="cuda")
+    _lib.call("eav_sp_convert", P(x), R, C, x.stride(0), P(slot), P(d), None, None)
+    return slot, d
+
+
+@pytest.mark.parametrize("shape", [(9712, 768, 256), (1214, 200, 136), (50, 64, 64), (4096, 3072, 768), (197, 40, 2304),
+                                   (33, 128, 128)])
+def test_weight_gradient_contracts_over_the_rows_of_row_planes(shape):
+    """dW[N,K] = dY^T X straight from the ROW planes of dY [tokens,N] and X [tokens,K]: the kernel contracts over the rows
+    (tokens) with transposing LDS reads (ds_read_b64_tr_b16) - no transposed planes exist.  Asymmetric operands (a
+    transposed or mis-swizzled fragment cannot pass), ragged token counts (zero pad rows), ragged and sub-tile feature
+    counts, split-K accumulate mode, bit-reproducibility."""
     tokens, N, K = shape
     torch.manual_seed(7)
-    dY = torch.randn(tokens, N, device="cuda") * 1e-3
-    X = torch.randn(tokens, K, device="cuda")
-    sa, _, aT = planes(dY, False, True)
-    sb, _, bT = planes(X, False, True)
+    dY = torch.randn(tokens, N, device="cuda") * 1e-3 * (1 + torch.arange(N, device="cuda") % 7)
+    X = torch.randn(tokens, K, device="cuda") * (1 + 0.25 * (torch.arange(tokens, device="cuda") % 5))[:, None]
+    sa, pa = row_planes(dY)
+    sb, pb = row_planes(X)
     C = torch.empty(N, K, device="cuda")
     ns = _lib.plain("eav_gemm_sp_splitk_plan", N, K, tokens)
     ws = torch.empty(max(ns, 1) * N * K, device="cuda")
-    _lib.call("eav_gemm_sp_splitk", P(aT), P(bT), P(C), P(ws), P(sa), P(sb), N, K, tokens, 0, None)
+    _lib.call("eav_gemm_sp_splitk", P(pa), P(pb), P(C), P(ws), P(sa), P(sb), N, K, tokens, 0, None)
     ref = dY.double().t() @ X.double()
     den = dY.double().abs().t() @ X.double().abs()
-    assert ((C.double() - ref).abs() / den).max().item() < 2e-7
+    err = ((C.double() - ref).abs() / den).max().item()
+    assert err < 2e-7, err
     C2 = C.clone()
-    _lib.call("eav_gemm_sp_splitk", P(aT), P(bT), P(C2), P(ws), P(sa), P(sb), N, K, tokens, 1, None)
+    _lib.call("eav_gemm_sp_splitk", P(pa), P(pb), P(C2), P(ws), P(sa), P(sb), N, K, tokens, 1, None)
     assert torch.allclose(C2, 2 * C, rtol=1e-6, atol=0)
     C3 = torch.empty_like(C)   # bit-reproducible (fixed-order split-K reduction)
-    _lib.call("eav_gemm_sp_splitk", P(aT), P(bT), P(C3), P(ws), P(sa), P(sb), N, K, tokens, 0, None)
+    _lib.call("eav_gemm_sp_splitk", P(pa), P(pb), P(C3), P(ws), P(sa), P(sb), N, K, tokens, 0, None)
     assert torch.equal(C3, C)
 
 

@@ -27,6 +27,16 @@ def planes(x, want=True, wantT=False):
     return slot, d, dT
 
 
+def row_planes(x):
+    """row planes with the rows zero-padded to a multiple of 32 (operands of the token-contracting eav_gemm_sp_splitk)"""
+    R, C = x.shape
+    slot = torch.zeros(2080, device="cuda")
+    _lib.call("eav_sp_absmax", P(x), R, C, x.stride(0), P(slot), None)
+    d = torch.zeros((R + 31) // 32 * 32, 2 * kpad(C), dtype=torch.float16, device="cuda")
+    _lib.call("eav_sp_convert", P(x), R, C, x.stride(0), P(slot), P(d), None, None)
+    return slot, d
+
+
 def timeit(f, reps=10):
     for _ in range(3):
         f()
@@ -70,8 +80,8 @@ def check_wgrad(Mtok, N, K):
     dY = torch.randn(Mtok, N, device="cuda") * 1e-3
     X = torch.randn(Mtok, K, device="cuda")
     ref = dY.double().t() @ X.double()
-    sa, _, paT = planes(dY, want=False, wantT=True)
-    sb, _, pbT = planes(X, want=False, wantT=True)
+    sa, paT = row_planes(dY)
+    sb, pbT = row_planes(X)
     C = torch.empty(N, K, device="cuda")
     ns = _lib.plain("eav_gemm_sp_splitk_plan", N, K, Mtok)
     ws = torch.empty(ns * N * K, device="cuda")
@@ -106,10 +116,11 @@ def bench(name, M, N, K, epi=False):
 
 
 def bench_splitk(name, M, N, K):
-    A = torch.randn(M, K, device="cuda")
-    B = torch.randn(N, K, device="cuda")
-    sa, pa, _ = planes(A)
-    sb, pb, _ = planes(B)
+    """weight-gradient shape: C[M,N] = sum over K tokens of A[t,m] B[t,n], row planes of A [K,M], B [K,N]"""
+    A = torch.randn(K, M, device="cuda")
+    B = torch.randn(K, N, device="cuda")
+    sa, pa = row_planes(A)
+    sb, pb = row_planes(B)
     C = torch.empty(M, N, device="cuda")
     ns = _lib.plain("eav_gemm_sp_splitk_plan", M, N, K)
     ws = torch.empty(max(ns, 1) * M * N, device="cuda")
@@ -148,7 +159,8 @@ if __name__ == "__main__":
     checks()
     print("-- single-accumulator mode (lo not lifted by 2^11)")
     _lib.call("eav_gemm_sp_set_tile", 4)
-    checks()
+    for a in ((512, 384, 768), (1000, 200, 100), (9712, 768, 3072), (9712, 2304, 768)):
+        check(*a)
     _lib.call("eav_gemm_sp_set_tile", 0)
     if len(sys.argv) > 1 and sys.argv[1] == "check":
         sys.exit(0)

@@ -63,6 +63,10 @@ struct SpArgs {
   const float* resid;       // [M,N] (ldr) or null, added after the activation
   float* pre;               // [M,N] (ldc) or null: value before the activation
   unsigned* amax;           // or null: atomicMax of the bits of |stored value|
+  unsigned char* planes;    // or null: the stored value (after the activation) also leaves as row planes [M][Np/8][2][8],
+  const float* slotP;       //   scaled by slotP[EAV_SLOT_SIGMA] - a scale known BEFORE the launch (eav_tf_forward_scales);
+  int64_t ldp;              //   row pitch of the planes in bytes; C may then be null (no fp32 copy of the value)
+  float lomul;
   int M, N, nkt;            // nkt = Kp / 32
   int64_t ldA, ldB;         // row strides in bytes
   int ldc, ldr;
@@ -107,6 +111,21 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   const float e = __builtin_amdgcn_exp2f(-(z * z) * 1.4426950408889634f);
   const float hq = 0.5f * p * t * e;
   return (x < 0.f ? hq : 1.0f - hq) + x * e * 0.3989422804014327f;
+}
+
+// Four consecutive values of one row -> this lane's half of the 8-value hi / lo pieces; the partner lane (the other half of
+// the group of 8 columns) gets the halves exchanged so that each lane stores one whole 16-byte piece: `first` (the lane
+// holding columns 0-3 of the group) the hi piece, the other one the lo piece.  xorm = lane distance of the partner.
+__device__ __forceinline__ uint4 plane_piece4(float t0, float t1, float t2, float t3, float lomul, bool first, int xorm) {
+  _Float16 h[4] = {(_Float16)t0, (_Float16)t1, (_Float16)t2, (_Float16)t3};
+  _Float16 l[4] = {(_Float16)((t0 - (float)h[0]) * lomul), (_Float16)((t1 - (float)h[1]) * lomul),
+                   (_Float16)((t2 - (float)h[2]) * lomul), (_Float16)((t3 - (float)h[3]) * lomul)};
+  const uint2 hh = *reinterpret_cast<const uint2*>(h), ll = *reinterpret_cast<const uint2*>(l);
+  const uint2 send = first ? ll : hh;
+  uint2 recv;
+  recv.x = __shfl_xor(send.x, xorm, 64);
+  recv.y = __shfl_xor(send.y, xorm, 64);
+  return first ? make_uint4(hh.x, hh.y, recv.x, recv.y) : make_uint4(recv.x, recv.y, ll.x, ll.y);
 }
 
 // WM x WN waves, each a (32 RM) x (32 RN) block of RM x RN MFMA tiles.
@@ -223,7 +242,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
   auto issue1 = [&](int buf, int i) {
     const int c = wave + NW * i;
     const unsigned dst = lds0 + buf * STAGE + c * 1024;
-    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gp[i]), "s"(dst) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gp[i]), "s"(dst) : "memory");   // (m0 is a reserved register: nothing hipcc emits for gfx950 in this kernel depends on it)
     if constexpr (TR) gp[i] += gstep[i];
     else gp[i] += 128;
   };
@@ -406,6 +425,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
           for (int r = 0; r < 16; ++r) acc[i][j][r] += acx[TWOACC ? i : 0][TWOACC ? j : 0][r] * (1.f / 2048.f);
     }
     const float alpha = g.alpha * g.slotA[EAV_SLOT_ISIGMA] * g.slotB[EAV_SLOT_ISIGMA];
+    const float psig = g.planes ? g.slotP[EAV_SLOT_SIGMA] : 0.f;
     const int M = g.M, N = g.N;
     float vmax = 0.f;
     float* pre = g.pre ? g.pre + (g.kt_per_split > 0 ? 0 : z * g.sC) : nullptr;
@@ -469,8 +489,18 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             if (ok(r)) {
-              C[o + 8 * (r >> 2) + (r & 3)] = a[r];
+              if (g.C) C[o + 8 * (r >> 2) + (r & 3)] = a[r];
               if (g.gelu != 3) vmax = fmaxf(vmax, fabsf(a[r]));
+            }
+          }
+          if (g.planes) {     // lanes l and l ^ 32 hold the two halves of every group of 8 columns (N % 8 == 0)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const uint4 pc = plane_piece4(a[4 * q] * psig, a[4 * q + 1] * psig, a[4 * q + 2] * psig, a[4 * q + 3] * psig,
+                                            g.lomul, kh == 0, 32);
+              const int cg = col - 4 * kh + 8 * q;          // first column of the group
+              if (rowok && cg + 7 < N)
+                *reinterpret_cast<uint4*>(g.planes + (int64_t)row * g.ldp + (int64_t)(cg >> 3) * 32 + kh * 16) = pc;
             }
           }
           __builtin_amdgcn_sched_barrier(0);   // keep the next block's loads behind this block's stores (register pressure)
@@ -549,10 +579,20 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
               v[4 * k] += c4[k].x; v[4 * k + 1] += c4[k].y; v[4 * k + 2] += c4[k].z; v[4 * k + 3] += c4[k].w;
             }
           }
+          if (g.C) {
 #pragma unroll
-          for (int k = 0; k < 4; ++k)
-            *reinterpret_cast<float4*>(C + o + (int64_t)8 * k * g.ldc) =
-                make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+            for (int k = 0; k < 4; ++k)
+              *reinterpret_cast<float4*>(C + o + (int64_t)8 * k * g.ldc) =
+                  make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+          }
+          if (g.planes) {     // neighbouring lanes hold the two halves of a group of 8 columns: 16-byte piece stores
+            unsigned char* pp = g.planes + (int64_t)(rowb + prow) * g.ldp + (int64_t)((colb + 4 * pc4) >> 3) * 32 + (pc4 & 1) * 16;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              *reinterpret_cast<uint4*>(pp + (int64_t)8 * k * g.ldp) =
+                  plane_piece4(v[4 * k] * psig, v[4 * k + 1] * psig, v[4 * k + 2] * psig, v[4 * k + 3] * psig, g.lomul,
+                               (pc4 & 1) == 0, 1);
+          }
           if (g.gelu != 3) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) vmax = fmaxf(vmax, fabsf(v[r]));
@@ -561,7 +601,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
         }
       }
     };
-    const bool aligned = (((uintptr_t)C | (uintptr_t)pre | (uintptr_t)g.resid | (uintptr_t)g.bias) & 15) == 0 &&
+    const bool aligned = (((uintptr_t)C | (uintptr_t)pre | (uintptr_t)g.resid | (uintptr_t)g.bias | (uintptr_t)g.planes) & 15) == 0 &&
                          ((g.ldc | g.ldr | (int)(g.sC & 3)) & 3) == 0;
     if (aligned && m0 + BM <= M && n0 + BN <= N) epilogue_linear();
     else epilogue_elements();
@@ -860,25 +900,43 @@ extern "C" int eav_gemm_sp_set_tile(int which) {
   return EAV_OK;
 }
 
-extern "C" int eav_gemm_sp(const void* A, const void* B, float* C, const float* slotA, const float* slotB, int M, int N,
-                           int K, int ldc, int batch, int64_t sA_bytes, int64_t sC, float alpha, const float* bias,
-                           int gelu, float* pre, const float* resid, int ldr, int accumulate, float* amax_slot,
-                           void* stream) {
-  EAV_REQUIRE(A && B && C && slotA && slotB && M > 0 && N > 0 && K > 0 && batch > 0, "eav_gemm_sp: bad arguments");
+// eav_gemm_sp that ALSO (or only: C = NULL) writes the stored value as row planes [M][Np/8][2][8] scaled by
+// planes_slot[EAV_SLOT_SIGMA]: the consumer GEMM reads them directly, no conversion pass.  The scale must be known before
+// the launch - a rigorous bound of |output| (eav_tf_forward_scales), not its measured maximum.  N % 8 == 0.
+extern "C" int eav_gemm_sp_planes(const void* A, const void* B, float* C, const float* slotA, const float* slotB, int M,
+                                  int N, int K, int ldc, int batch, int64_t sA_bytes, int64_t sC, float alpha,
+                                  const float* bias, int gelu, float* pre, const float* resid, int ldr, int accumulate,
+                                  float* amax_slot, void* planes_out, const float* planes_slot, void* stream) {
+  EAV_REQUIRE(A && B && (C || planes_out) && slotA && slotB && M > 0 && N > 0 && K > 0 && batch > 0,
+              "eav_gemm_sp: bad arguments");
   EAV_REQUIRE((((uintptr_t)A | (uintptr_t)B) & 15) == 0 && (sA_bytes & 15) == 0,
               "eav_gemm_sp: operand planes must be 16-byte aligned");
   EAV_REQUIRE(!(resid && batch > 1), "eav_gemm_sp: residual epilogue is not batched");
   EAV_REQUIRE(gelu >= 0 && gelu <= 3 && (gelu != 2 || pre), "eav_gemm_sp: gelu = 2 (backward) reads the pre-activation from `pre`");
   EAV_REQUIRE(gelu != 3 || (!pre && !resid && !accumulate), "eav_gemm_sp: gelu = 3 stores the pre-activation only");
+  EAV_REQUIRE(!planes_out || (planes_slot && batch == 1 && (N & 7) == 0 && gelu != 3 && ((uintptr_t)planes_out & 15) == 0),
+              "eav_gemm_sp: plane output needs its scale slot, batch 1, N %% 8 == 0");
+  EAV_REQUIRE(C || !accumulate, "eav_gemm_sp: accumulate needs C");
   SpArgs g;
   const int Kp = eav_sp_kpad(K);
   g.A = (const unsigned char*)A; g.B = (const unsigned char*)B; g.C = C; g.slotA = slotA; g.slotB = slotB;
   g.bias = bias; g.resid = resid; g.pre = pre; g.amax = reinterpret_cast<unsigned*>(amax_slot);
+  g.planes = (unsigned char*)planes_out; g.slotP = planes_slot; g.ldp = (int64_t)eav_sp_kpad(N) * 4;
+  g.lomul = g_loshift ? 2048.f : 1.f;
   g.M = M; g.N = N; g.nkt = Kp / 32; g.ldA = (int64_t)Kp * 4; g.ldB = (int64_t)Kp * 4; g.ldc = ldc; g.ldr = ldr;
   g.sA = sA_bytes; g.sC = sC; g.alpha = alpha; g.gelu = gelu; g.accumulate = accumulate; g.kt_per_split = 0;
   dispatch(g, batch, (hipStream_t)stream);
   EAV_CHECK_LAUNCH("eav_gemm_sp");
   return EAV_OK;
+}
+
+extern "C" int eav_gemm_sp(const void* A, const void* B, float* C, const float* slotA, const float* slotB, int M, int N,
+                           int K, int ldc, int batch, int64_t sA_bytes, int64_t sC, float alpha, const float* bias,
+                           int gelu, float* pre, const float* resid, int ldr, int accumulate, float* amax_slot,
+                           void* stream) {
+  EAV_REQUIRE(C, "eav_gemm_sp: bad arguments");
+  return eav_gemm_sp_planes(A, B, C, slotA, slotB, M, N, K, ldc, batch, sA_bytes, sC, alpha, bias, gelu, pre, resid, ldr,
+                            accumulate, amax_slot, nullptr, nullptr, stream);
 }
 
 // split-K plan for the weight-gradient shapes (small M x N output, long contraction): enough slices to put ~2
@@ -904,7 +962,8 @@ extern "C" int eav_gemm_sp_splitk(const void* A, const void* B, float* C, float*
   const int nsplit = eav_gemm_sp_splitk_plan(M, N, T);
   SpArgs g;
   g.A = (const unsigned char*)A; g.B = (const unsigned char*)B; g.slotA = slotA; g.slotB = slotB;
-  g.bias = nullptr; g.resid = nullptr; g.pre = nullptr; g.amax = nullptr;
+  g.bias = nullptr; g.resid = nullptr; g.pre = nullptr; g.amax = nullptr; g.planes = nullptr; g.slotP = nullptr;
+  g.ldp = 0; g.lomul = 2048.f;
   g.M = M; g.N = N; g.nkt = cdiv(T, 32); g.ldA = (int64_t)eav_sp_kpad(M) * 4; g.ldB = (int64_t)eav_sp_kpad(N) * 4;
   g.ldc = N; g.ldr = 0; g.sA = 0; g.sC = 0; g.alpha = 1.f; g.gelu = 0;
   hipStream_t st = (hipStream_t)stream;

@@ -15,7 +15,9 @@ constexpr int LN_MAXQ = 4;  // float4 per lane: D <= 1024
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ y,
                                                             float* __restrict__ mean_o, float* __restrict__ rstd_o,
-                                                            int M, int D, float eps, unsigned* __restrict__ amax) {
+                                                            int M, int D, float eps, unsigned* __restrict__ amax,
+                                                            unsigned char* __restrict__ planes,
+                                                            const float* __restrict__ pslot, int64_t ldp, float lomul) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -51,8 +53,29 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
       const float4 g = g4[q], b = b4[q];
       const float4 o = make_float4((v[i].x - mean) * rstd * g.x + b.x, (v[i].y - mean) * rstd * g.y + b.y,
                                    (v[i].z - mean) * rstd * g.z + b.z, (v[i].w - mean) * rstd * g.w + b.w);
-      dst[q] = o;
+      if (y) dst[q] = o;
       vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
+      if (planes) {
+        // row planes of the split-operand GEMMs straight from the registers (D % 8 == 0: lanes 2p, 2p + 1 hold the two
+        // halves of the group of 8 columns p; they swap halves so that each stores one whole 16-byte piece - hi / lo).
+        // The scale is a bound of |y| known before the launch (eav_tf_forward_scales), not a measured maximum.
+        const float sg = pslot[EAV_SLOT_SIGMA];
+        const float t[4] = {o.x * sg, o.y * sg, o.z * sg, o.w * sg};
+        _Float16 h[4], l[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          h[e] = (_Float16)t[e];
+          l[e] = (_Float16)((t[e] - (float)h[e]) * lomul);
+        }
+        const uint2 hh = *reinterpret_cast<const uint2*>(h), ll = *reinterpret_cast<const uint2*>(l);
+        const bool first = (q & 1) == 0;
+        const uint2 send = first ? ll : hh;
+        uint2 recv;
+        recv.x = __shfl_xor(send.x, 1, 64);
+        recv.y = __shfl_xor(send.y, 1, 64);
+        *reinterpret_cast<uint4*>(planes + (int64_t)row * ldp + (int64_t)(q >> 1) * 32 + (first ? 0 : 16)) =
+            first ? make_uint4(hh.x, hh.y, recv.x, recv.y) : make_uint4(recv.x, recv.y, ll.x, ll.y);
+      }
     }
   }
   if (lane == 0) {
@@ -354,6 +377,92 @@ __global__ __launch_bounds__(256) void pair_mean_kernel(float* __restrict__ seq,
 
 int grid_for(int64_t n) { return (int)(n < 1 ? 1 : (cdiv64(n, 256) > 4096 ? 4096 : cdiv64(n, 256))); }
 
+// ------------------------------------------------------------------------------------ a-priori operand scales
+// max over the rows of ||w_r||_2 (bits, atomicMax - zero `out` first): one wave per row
+__global__ __launch_bounds__(256) void rownorm_max_kernel(const float* __restrict__ w, int R, int C, int64_t ld,
+                                                          unsigned* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  float best = 0.f;
+  for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < R; r += gridDim.x * 4) {
+    const float* src = w + (int64_t)r * ld;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s = fmaf(src[c], src[c], s);
+    best = fmaxf(best, sqrtf(wave_sum(s)));
+  }
+  if (lane == 0 && best == best) atomicMax(out, __float_as_uint(best));
+}
+
+__device__ __forceinline__ float sigma_of_bound(float b) {
+  // the power of two that puts b in [2^14, 2^15) (as sigma_from_bits in gemm_sp.hip); 1 for 0 / non-finite
+  const unsigned bits = __float_as_uint(b);
+  const int e = (int)((bits >> 23) & 0xff);
+  if (b <= 0.f || e == 0xff) return 1.f;
+  int se = 14 - (e - 127);
+  se = max(-126, min(126, se));
+  return __uint_as_float((unsigned)(se + 127) << 23);
+}
+
+// Operand scales of one encoder layer's forward from RIGOROUS bounds of the tensors, so that their producers can emit
+// the fp16 hi / lo planes directly (no measured maximum, no conversion pass).  With xhat the normalised row of a
+// LayerNorm, |xhat_k| <= sqrt(D - 1) and ||xhat||_2 <= sqrt(D), hence for y = gamma xhat + beta:
+//     |y_k| <= sqrt(D) max|gamma| + max|beta|,        ||y||_2 <= sqrt(D) max|gamma| + ||beta||_2,
+// and for the MLP's hidden activation a = GELU(y2 W1^T + b1), |GELU(x)| <= |x|:
+//     |a| <= ||y2||_2 max_n ||W1_n||_2 + max|b1|.
+// The bounds overshoot the actual maxima by a factor ~sqrt(D) / 4-5 (3 bits at D = 768); the planes keep full precision
+// for elements down to 2^-29 of the SCALE, so nothing is lost.  One block per layer; layer l's parameters start at
+// p0 + l stride (the flat parameter buffer lays the layers out identically), its slots at slots + l slot_stride.
+__global__ __launch_bounds__(256) void tf_forward_scales_kernel(const float* __restrict__ p0, int64_t stride, int off_g1,
+                                                                int off_b1, int off_g2, int off_b2, int off_bfc1, int D,
+                                                                int FF, const float* __restrict__ wnorm_fc1,
+                                                                float* __restrict__ slots, int64_t slot_stride,
+                                                                int k_y1, int k_y2, int k_act, int slot_floats) {
+  __shared__ float red[4 * 7];
+  const int l = blockIdx.x;
+  const float* p = p0 + (int64_t)l * stride;
+  float v[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // max|g1| max|b1| max|g2| max|b2| sum b2^2 max|bfc1| (spare)
+  for (int i = threadIdx.x; i < D; i += 256) {
+    v[0] = fmaxf(v[0], fabsf(p[off_g1 + i]));
+    v[1] = fmaxf(v[1], fabsf(p[off_b1 + i]));
+    v[2] = fmaxf(v[2], fabsf(p[off_g2 + i]));
+    v[3] = fmaxf(v[3], fabsf(p[off_b2 + i]));
+    v[4] += p[off_b2 + i] * p[off_b2 + i];
+  }
+  for (int i = threadIdx.x; i < FF; i += 256) v[5] = fmaxf(v[5], fabsf(p[off_bfc1 + i]));
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    float a = v[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float b = __shfl_xor(a, o, 64);
+      a = (k == 4) ? a + b : fmaxf(a, b);
+    }
+    if (lane == 0) red[wave * 7 + k] = a;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k)
+      t[k] = (k == 4) ? (red[k] + red[7 + k]) + (red[14 + k] + red[21 + k])
+                      : fmaxf(fmaxf(red[k], red[7 + k]), fmaxf(red[14 + k], red[21 + k]));
+    const float sd = sqrtf((float)D);
+    const float b_y1 = sd * t[0] + t[1], b_y2 = sd * t[2] + t[3];
+    const float n_y2 = sd * t[2] + sqrtf(t[4]);
+    const float b_act = n_y2 * wnorm_fc1[l] + t[5];
+    float* s = slots + (int64_t)l * slot_stride;
+    const float bounds[3] = {b_y1, b_y2, b_act};
+    const int ks[3] = {k_y1, k_y2, k_act};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      // 1.0001: the bound is evaluated in fp32 - keep it a bound under its own rounding
+      const float sg = sigma_of_bound(bounds[k] * 1.0001f);
+      s[(int64_t)ks[k] * slot_floats + EAV_SLOT_SIGMA] = sg;
+      s[(int64_t)ks[k] * slot_floats + EAV_SLOT_ISIGMA] = 1.f / sg;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int eav_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean,
@@ -361,7 +470,8 @@ extern "C" int eav_layernorm_fwd(const float* x, const float* gamma, const float
   EAV_REQUIRE(x && gamma && beta && y && M > 0 && D > 0 && (D & 3) == 0 && D <= 1024,
               "eav_layernorm_fwd: need D %% 4 == 0 and D <= 1024");
   hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y,
-                     mean, rstd, M, D, eps, (unsigned*)nullptr);
+                     mean, rstd, M, D, eps, (unsigned*)nullptr, (unsigned char*)nullptr, (const float*)nullptr,
+                     (int64_t)0, 0.f);
   EAV_CHECK_LAUNCH("eav_layernorm_fwd");
   return EAV_OK;
 }
@@ -373,8 +483,25 @@ extern "C" int eav_layernorm_fwd_amax(const float* x, const float* gamma, const 
   EAV_REQUIRE(x && gamma && beta && y && amax_slot && M > 0 && D > 0 && (D & 3) == 0 && D <= 1024,
               "eav_layernorm_fwd_amax: need D %% 4 == 0 and D <= 1024");
   hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y,
-                     mean, rstd, M, D, eps, reinterpret_cast<unsigned*>(amax_slot));
+                     mean, rstd, M, D, eps, reinterpret_cast<unsigned*>(amax_slot), (unsigned char*)nullptr,
+                     (const float*)nullptr, (int64_t)0, 0.f);
   EAV_CHECK_LAUNCH("eav_layernorm_fwd_amax");
+  return EAV_OK;
+}
+
+// LayerNorm whose output leaves as the row planes [M][Dp/8][2][8] of the split-operand GEMM that consumes it (no fp32
+// copy, no conversion pass; y may be given as well).  scale_slot[EAV_SLOT_SIGMA] is a scale known before the launch
+// (eav_tf_forward_scales); D % 8 == 0; the pad columns / rows of the planes are not written (allocate zero-filled).
+extern "C" int eav_layernorm_fwd_planes(const float* x, const float* gamma, const float* beta, float* y, void* planes,
+                                        const float* scale_slot, float* mean, float* rstd, int M, int D, float eps,
+                                        void* stream) {
+  EAV_REQUIRE(x && gamma && beta && planes && scale_slot && M > 0 && D > 0 && (D & 7) == 0 && D <= 1024 &&
+                  ((uintptr_t)planes & 15) == 0,
+              "eav_layernorm_fwd_planes: need D %% 8 == 0 and D <= 1024");
+  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y,
+                     mean, rstd, M, D, eps, (unsigned*)nullptr, (unsigned char*)planes, scale_slot,
+                     (int64_t)((D + 31) / 32 * 32) * 4, 2048.f);
+  EAV_CHECK_LAUNCH("eav_layernorm_fwd_planes");
   return EAV_OK;
 }
 
@@ -491,5 +618,31 @@ extern "C" int eav_pair_mean(float* seq, float* pooled, int B, int D, int backwa
   hipLaunchKernelGGL(pair_mean_kernel, dim3(grid_for((int64_t)B * D)), dim3(256), 0, (hipStream_t)stream, seq, pooled,
                      B, D, backward);
   EAV_CHECK_LAUNCH("eav_pair_mean");
+  return EAV_OK;
+}
+
+// max_r ||w_r||_2 of a [R, C] matrix into *out (a float whose bits are combined with atomicMax: zero it first)
+extern "C" int eav_rownorm_max(const float* w, int R, int C, int64_t ld, float* out, void* stream) {
+  EAV_REQUIRE(w && out && R > 0 && C > 0 && ld >= C, "eav_rownorm_max: bad arguments");
+  const int blocks = cdiv(R, 4) < 1024 ? cdiv(R, 4) : 1024;
+  hipLaunchKernelGGL(rownorm_max_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, R, C, ld,
+                     reinterpret_cast<unsigned*>(out));
+  EAV_CHECK_LAUNCH("eav_rownorm_max");
+  return EAV_OK;
+}
+
+// sigma / 1 / sigma of the forward operand slots y1 (LayerNorm-before output), y2 (LayerNorm-after output) and act
+// (GELU output) of every layer from rigorous bounds (see tf_forward_scales_kernel).  params = first float of layer 0 in
+// the flat parameter buffer, layer_stride floats per layer, off_* = offsets of layernorm_before.{weight,bias},
+// layernorm_after.{weight,bias}, mlp.fc1.bias inside a layer; wnorm_fc1 [layers] = eav_rownorm_max of mlp.fc1.weight;
+// slots = slot of layer 0's first forward operand, slot_stride floats per layer, k_* = slot index within a layer.
+extern "C" int eav_tf_forward_scales(const float* params, int64_t layer_stride, int layers, int off_g1, int off_b1,
+                                     int off_g2, int off_b2, int off_bfc1, int D, int FF, const float* wnorm_fc1,
+                                     float* slots, int64_t slot_stride, int k_y1, int k_y2, int k_act, void* stream) {
+  EAV_REQUIRE(params && wnorm_fc1 && slots && layers > 0 && D > 0 && FF > 0, "eav_tf_forward_scales: bad arguments");
+  hipLaunchKernelGGL(tf_forward_scales_kernel, dim3(layers), dim3(256), 0, (hipStream_t)stream, params, layer_stride,
+                     off_g1, off_b1, off_g2, off_b2, off_bfc1, D, FF, wnorm_fc1, slots, slot_stride, k_y1, k_y2, k_act,
+                     EAV_SP_SLOT);
+  EAV_CHECK_LAUNCH("eav_tf_forward_scales");
   return EAV_OK;
 }

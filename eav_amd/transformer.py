@@ -188,7 +188,9 @@ class Encoder(nn.Module):
         # logits unchanged - and bf16 operands for the backward products only).  EAV_ENCODER_PRECISION overrides.
         self.precision = os.environ.get("EAV_ENCODER_PRECISION", DEFAULT_PRECISION)
         self.overlap_wgrad = True     # split mode: weight-gradient GEMMs on a side stream (see _wgrad_sp)
-        self._side, self._wgrad_done, self._wready = None, {}, {}
+        # split mode: LayerNorm / fc1 write their consumers' operand planes (a-priori scales); EAV_FUSED_PLANES=0 for A/B runs
+        self.fused_planes = os.environ.get("EAV_FUSED_PLANES", "1") != "0"
+        self._side, self._aux, self._wgrad_done, self._wready = None, None, {}, {}
         self._part_busy, self._ring_pos = {}, {}
         self._wplanes = None          # split mode: {weight key: (planes, planes of the transpose, slot index)}
         self._wplanes_key = None
@@ -442,7 +444,9 @@ class Encoder(nn.Module):
             or self._wplanes_key != key
         if everything and (self._wplanes is None or self._wplanes["_dev"] != dev or (need_T and not have_T)):
             wp = {"_T": need_T, "_dev": dev,
-                  "_slots": torch.zeros(len(keys), self.SLOT, dtype=torch.float32, device=dev)}
+                  "_slots": torch.zeros(len(keys), self.SLOT, dtype=torch.float32, device=dev),
+                  # max_n ||W1_n||_2 per layer: input of the a-priori scale of the MLP activation (eav_tf_forward_scales)
+                  "_wnorm_fc1": torch.zeros(self.cfg.layers, dtype=torch.float32, device=dev)}
             for n, (k, _, out, inn) in enumerate(keys):
                 wp[k] = (torch.empty(out, 2 * kp(inn), dtype=torch.float16, device=dev),
                          torch.empty(inn, 2 * kp(out), dtype=torch.float16, device=dev) if need_T else None, n)
@@ -467,6 +471,7 @@ class Encoder(nn.Module):
             st = _lib.stream_ptr()
             if len(stale) == len(keys):
                 wp["_slots"].zero_()
+                wp["_wnorm_fc1"].zero_()
             for k, src, out, inn in stale:
                 pl, plT, n = wp[k]
                 if len(stale) != len(keys):
@@ -474,6 +479,11 @@ class Encoder(nn.Module):
                 slot = wp["_slots"].data_ptr() + 4 * self.SLOT * n
                 _lib.call("eav_sp_absmax", src, out, inn, inn, slot, st)
                 _lib.call("eav_sp_convert", src, out, inn, inn, slot, _lib.ptr(pl), _lib.ptr(plT), st)
+                if k.startswith("fc1"):
+                    li = int(k[3:])
+                    if len(stale) != len(keys):
+                        wp["_wnorm_fc1"][li].zero_()
+                    _lib.call("eav_rownorm_max", src, out, inn, inn, wp["_wnorm_fc1"].data_ptr() + 4 * li, st)
                 if side is not None:
                     ev = torch.cuda.Event()
                     ev.record(side)
@@ -507,16 +517,22 @@ class Encoder(nn.Module):
         return ring[i]
 
     def _reduce_async(self, buf, off_bytes, nparts, stride, n, out):
+        """Final fixed-order reduction of a partial-sum buffer into a gradient nothing downstream reads: off the main stream.
+        It gets its OWN stream (not the weight-gradient stream): a 24-block kernel queued in order between persistent GEMMs
+        waits for a CU whose LDS is not taken by two GEMM workgroups, and held the weight gradients behind it back by
+        ~130 us per launch at ViT B=128 (9.6 ms of side-stream time per step)."""
         if not (self.overlap_wgrad and self.kernel_events is None):
             self._call("eav_reduce_partials", _lib.ptr(buf) + off_bytes, nparts, stride, n, 1.0, out, self._st)
             return
-        side = self._side_stream(buf.device)
+        if self._aux is None or self._aux.device != buf.device:
+            self._aux = torch.cuda.Stream(device=buf.device)
+        aux = self._aux
         ready = torch.cuda.Event()
         ready.record()
-        side.wait_event(ready)
-        _lib.call("eav_reduce_partials", _lib.ptr(buf) + off_bytes, nparts, stride, n, 1.0, out, side.cuda_stream)
+        aux.wait_event(ready)
+        _lib.call("eav_reduce_partials", _lib.ptr(buf) + off_bytes, nparts, stride, n, 1.0, out, aux.cuda_stream)
         done = torch.cuda.Event()
-        done.record(side)
+        done.record(aux)
         self._part_busy[buf.data_ptr()] = done
 
     def _to_planes_bias(self, src, R, C, slot, dst, bias_grad):
@@ -570,9 +586,11 @@ class Encoder(nn.Module):
             torch.cuda.current_stream().wait_event(ev)
 
     def _join_wgrads(self):
-        if self._side is not None and (self._wgrad_done or self._part_busy):
+        if self._side is not None and self._wgrad_done:
             torch.cuda.current_stream().wait_stream(self._side)
             self._wgrad_done.clear()
+        if self._aux is not None and self._part_busy:
+            torch.cuda.current_stream().wait_stream(self._aux)
             self._part_busy.clear()
 
     def _launch_forward(self, x):
@@ -678,9 +696,24 @@ class Encoder(nn.Module):
         w = lambda k: P(self._pmap[k])  # noqa: E731
         s_y1, s_qkv, s_ao, s_y2, s_act = (fslot(1 + self.FS * i + k) for k in range(5))
         y, ao, act = ws.y1[0], ws.ao[j], ws.act[0]
-        L("eav_layernorm_fwd_amax", P(hin), w(f"{Lk}.layernorm_before.weight"), w(f"{Lk}.layernorm_before.bias"), P(y),
-          stp, stp + 4 * M, M, D, c.eps, s_y1, st)
-        self._to_planes(P(y), M, D, D, s_y1, ws.y1p[j], amax_done=True)
+        # Producers write the operand planes themselves where a rigorous bound of the tensor exists BEFORE it is computed
+        # (LayerNorm outputs, the MLP's GELU output: eav_tf_forward_scales) - no fp32 copy, no measured maximum, no
+        # conversion pass for y1, y2, act.  The attention output keeps the measured scale (its kernel emits max|O|).
+        fusedp = self.fused_planes and D % 8 == 0 and FF % 8 == 0
+        if fusedp:
+            self._wp(f"fc1{i}")        # (waits for the side-stream refresh of this layer's fc1 planes / row norms)
+            offs = self._flat[2]
+            base = offs[f"{Lk}.attention.q_proj.weight"][0]
+            o = lambda k: offs[f"{Lk}.{k}"][0] - base  # noqa: E731
+            L("eav_tf_forward_scales", P(self._flat[0]) + 4 * base, 0, 1, o("layernorm_before.weight"),
+              o("layernorm_before.bias"), o("layernorm_after.weight"), o("layernorm_after.bias"), o("mlp.fc1.bias"), D, FF,
+              self._wplanes["_wnorm_fc1"].data_ptr() + 4 * i, s_y1, 0, 0, 3, 4, st)
+            L("eav_layernorm_fwd_planes", P(hin), w(f"{Lk}.layernorm_before.weight"), w(f"{Lk}.layernorm_before.bias"),
+              None, P(ws.y1p[j]), s_y1, stp, stp + 4 * M, M, D, c.eps, st)
+        else:
+            L("eav_layernorm_fwd_amax", P(hin), w(f"{Lk}.layernorm_before.weight"), w(f"{Lk}.layernorm_before.bias"),
+              P(y), stp, stp + 4 * M, M, D, c.eps, s_y1, st)
+            self._to_planes(P(y), M, D, D, s_y1, ws.y1p[j], amax_done=True)
         qkv = P(ws.qkv[0 if ws.fused else j])
         wpl, wsl = self._wp(f"qkv{i}")
         self._gemm_sp(P(ws.y1p[j]), s_y1, wpl, wsl, qkv, M, 3 * D, D, 3 * D, bias=w(f"{Lk}.attention.q_proj.bias"),
@@ -702,15 +735,27 @@ class Encoder(nn.Module):
         wpl, wsl = self._wp(f"o{i}")
         self._gemm_sp(P(ws.aop[j]), s_ao, wpl, wsl, P(ws.hmid[j]), M, D, D, D, bias=w(f"{Lk}.attention.o_proj.bias"),
                       resid=P(hin), ldr=D)
-        L("eav_layernorm_fwd_amax", P(ws.hmid[j]), w(f"{Lk}.layernorm_after.weight"),
-          w(f"{Lk}.layernorm_after.bias"), P(y), stp + 8 * M, stp + 12 * M, M, D, c.eps, s_y2, st)
-        self._to_planes(P(y), M, D, D, s_y2, ws.y2p[j], amax_done=True)
-        wpl, wsl = self._wp(f"fc1{i}")
-        # fc1 stores the PRE-activation only (kept per layer for the backward; a scratch buffer in the frozen phase) and
-        # max|GELU|; the conversion applies the GELU while it splits - the activation never exists in fp32
-        pre = P(ws.pre[j]) if ws.full else P(act)
-        self._gemm_sp(P(ws.y2p[j]), s_y2, wpl, wsl, pre, M, FF, D, FF, bias=w(f"{Lk}.mlp.fc1.bias"), gelu=3, amax=s_act)
-        self._call("eav_sp_convert_gelu", pre, M, FF, FF, s_act, P(ws.actp[j]), None, self._st)
+        wpl, wsl = None, None
+        if fusedp:
+            L("eav_layernorm_fwd_planes", P(ws.hmid[j]), w(f"{Lk}.layernorm_after.weight"),
+              w(f"{Lk}.layernorm_after.bias"), None, P(ws.y2p[j]), s_y2, stp + 8 * M, stp + 12 * M, M, D, c.eps, st)
+            wpl, wsl = self._wp(f"fc1{i}")
+            # fc1: bias + erf-GELU in the epilogue; the pre-activation is kept (fp32) for the backward only, the
+            # activation leaves as planes - it never exists in fp32
+            self._call("eav_gemm_sp_planes", P(ws.y2p[j]), wpl, None, s_y2, wsl, M, FF, D, FF, 1, 0, 0, 1.0,
+                       w(f"{Lk}.mlp.fc1.bias"), 1, P(ws.pre[j]) if ws.full else None, None, 0, 0, None, P(ws.actp[j]),
+                       s_act, st)
+        else:
+            L("eav_layernorm_fwd_amax", P(ws.hmid[j]), w(f"{Lk}.layernorm_after.weight"),
+              w(f"{Lk}.layernorm_after.bias"), P(y), stp + 8 * M, stp + 12 * M, M, D, c.eps, s_y2, st)
+            self._to_planes(P(y), M, D, D, s_y2, ws.y2p[j], amax_done=True)
+            wpl, wsl = self._wp(f"fc1{i}")
+            # fc1 stores the PRE-activation only (kept per layer for the backward; a scratch buffer in the frozen phase)
+            # and max|GELU|; the conversion applies the GELU while it splits - the activation never exists in fp32
+            pre = P(ws.pre[j]) if ws.full else P(act)
+            self._gemm_sp(P(ws.y2p[j]), s_y2, wpl, wsl, pre, M, FF, D, FF, bias=w(f"{Lk}.mlp.fc1.bias"), gelu=3,
+                          amax=s_act)
+            self._call("eav_sp_convert_gelu", pre, M, FF, FF, s_act, P(ws.actp[j]), None, self._st)
         wpl, wsl = self._wp(f"fc2{i}")
         self._gemm_sp(P(ws.actp[j]), s_act, wpl, wsl, P(hout), M, D, FF, D, bias=w(f"{Lk}.mlp.fc2.bias"),
                       resid=P(ws.hmid[j]), ldr=D)

@@ -266,11 +266,36 @@ int eav_gelu_bwd_amax(float* dact, const float* pre, int64_t n, float* amax_slot
 int eav_gemm_sp(const void* A, const void* B, float* C, const float* slotA, const float* slotB, int M, int N, int K,
                 int ldc, int batch, int64_t sA_bytes, int64_t sC, float alpha, const float* bias, int gelu, float* pre,
                 const float* resid, int ldr, int accumulate, float* amax_slot, void* stream);
-/* long-contraction form (weight gradients): eav_gemm_sp_splitk_plan(M,N,K) K-slices, ws [nsplit][M][N] partials summed
- * in fixed order (deterministic); C[M,N] dense (ldc = N). */
+/* eav_gemm_sp that also - or only (C = NULL) - writes the stored value (after the activation) as the row planes
+ * [M][Np/8][2][8] of the NEXT product, scaled by planes_slot[EAV_SLOT sigma]: no fp32 activation tensor, no conversion
+ * pass.  The scale must be known before the launch: eav_tf_forward_scales derives it from a rigorous bound of |output|.
+ * N % 8 == 0, batch 1.  (fc1 of HF's ASTMLP / ViTMLP: bias + erf-GELU, pre-activation kept in `pre` for the backward.) */
+int eav_gemm_sp_planes(const void* A, const void* B, float* C, const float* slotA, const float* slotB, int M, int N, int K,
+                       int ldc, int batch, int64_t sA_bytes, int64_t sC, float alpha, const float* bias, int gelu,
+                       float* pre, const float* resid, int ldr, int accumulate, float* amax_slot, void* planes_out,
+                       const float* planes_slot, void* stream);
+/* nn.LayerNorm whose output leaves as the row planes of the product that consumes it (y optional, may be NULL);
+ * scale_slot as above; D % 8 == 0. */
+int eav_layernorm_fwd_planes(const float* x, const float* gamma, const float* beta, float* y, void* planes,
+                             const float* scale_slot, float* mean, float* rstd, int M, int D, float eps, void* stream);
+/* max over the rows of ||w_r||_2 into *out (float bits combined with atomicMax: zero it first) */
+int eav_rownorm_max(const float* w, int R, int C, int64_t ld, float* out, void* stream);
+/* sigma, 1/sigma of the operand slots of LayerNorm-before output (k_y1), LayerNorm-after output (k_y2) and the MLP's GELU
+ * output (k_act) of `layers` encoder layers from rigorous bounds: |LN out| <= sqrt(D) max|gamma| + max|beta|,
+ * |GELU(y2 W1^T + b1)| <= (sqrt(D) max|gamma2| + ||beta2||_2) max_n ||W1_n||_2 + max|b1|.  params: first float of layer 0
+ * in the flat parameter buffer, layer_stride floats per layer, off_*: offsets of layernorm_before.{weight,bias},
+ * layernorm_after.{weight,bias}, mlp.fc1.bias within a layer; wnorm_fc1 [layers]: eav_rownorm_max of mlp.fc1.weight;
+ * slots: layer 0's first forward slot, slot_stride floats per layer. */
+int eav_tf_forward_scales(const float* params, int64_t layer_stride, int layers, int off_g1, int off_b1, int off_g2,
+                          int off_b2, int off_bfc1, int D, int FF, const float* wnorm_fc1, float* slots,
+                          int64_t slot_stride, int k_y1, int k_y2, int k_act, void* stream);
+/* long-contraction form (weight gradients): C[M,N] = sum_t A[t,m] B[t,n] over ROW planes A [Tp][Mp/8][2][8], B
+ * [Tp][Np/8][2][8] - the contraction runs over the rows (tokens), read with transposing LDS loads; Tp = T rounded up to
+ * 32 and the rows >= T must be ZERO.  eav_gemm_sp_splitk_plan(M,N,T) token slices, ws [nsplit][M][N] partials summed in
+ * fixed order (deterministic); C[M,N] dense (ldc = N). */
 int eav_gemm_sp_splitk_plan(int M, int N, int K);
 int eav_gemm_sp_splitk(const void* A, const void* B, float* C, float* ws, const float* slotA, const float* slotB, int M,
-                       int N, int K, int accumulate, void* stream);
+                       int N, int T, int accumulate, void* stream);
 int eav_gemm_sp_set_tile(int which);   /* tuning hook: 0 heuristic, 1 = 128x128 tiles, 2 = 256x128 */
 int eav_sp_set_convert_blocks(int n);  /* tuning hook: resident-block cap of eav_sp_convert (default 512; 0 = one block per tile) */
 /* The same fused attention on the fp16 matrix cores with split operands (csrc/attention_sp.hip; fp32-grade, 3 MFMAs per

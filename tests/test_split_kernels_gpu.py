@@ -336,3 +336,107 @@ def test_pre_activation_only_epilogue_and_gelu_conversion():
     assert torch.equal(pre3, pre1)
     assert float(s3[:2048:32].view(torch.int32).max()) == float(s1[:2048:32].view(torch.int32).max())
     assert torch.equal(p3.view(torch.int16), p1.view(torch.int16)) and torch.equal(p3T.view(torch.int16), p1T.view(torch.int16))
+
+
+def decode_planes(pl, R, C, sigma):
+    """planes [Rp, 2*Cp] f16 ([R][Cp/8][2][8]) -> fp64 [R, C]: (hi + lo 2^-11) / sigma"""
+    v = pl[:R].view(R, -1, 2, 8).double()
+    return ((v[:, :, 0, :] + v[:, :, 1, :] / 2048.0).reshape(R, -1)[:, :C]) / sigma
+
+
+@pytest.mark.parametrize("M,D", [(37, 64), (1214, 768), (300, 1024), (5, 8)])
+def test_layernorm_writes_the_operand_planes_itself(M, D):
+    """eav_layernorm_fwd_planes: the LayerNorm output as row planes scaled by a slot's sigma (no fp32 copy, no
+    conversion pass) == the fp32 kernel's output to split precision (2^-22 of the scale), statistics identical, pad
+    columns / rows untouched."""
+    torch.manual_seed(M + D)
+    x = torch.randn(M, D, device="cuda") * 3 + 0.5
+    x[M // 2] = 0.467                                   # a constant row (AST padding value): finite, zero output + beta
+    g = torch.rand(D, device="cuda") + 0.5
+    b = torch.randn(D, device="cuda") * 0.1
+    y = torch.empty_like(x)
+    st = torch.empty(2, M, device="cuda")
+    _lib.call("eav_layernorm_fwd", P(x), P(g), P(b), P(y), P(st), P(st) + 4 * M, M, D, 1e-12, None)
+    slot = torch.zeros(SLOT, device="cuda")
+    sigma = 2.0 ** (14 - np.floor(np.log2(float(np.sqrt(D) * g.abs().max() + b.abs().max()))))
+    slot[2048], slot[2049] = sigma, 1.0 / sigma
+    pl = torch.full(((M + 31) // 32 * 32, 2 * kpad(D)), 7.0, dtype=torch.float16, device="cuda")
+    st2 = torch.empty(2, M, device="cuda")
+    y2 = torch.empty_like(x)
+    _lib.call("eav_layernorm_fwd_planes", P(x), P(g), P(b), P(y2), P(pl), P(slot), P(st2), P(st2) + 4 * M, M, D, 1e-12, None)
+    assert torch.equal(y2, y) and torch.equal(st2, st)
+    got = decode_planes(pl, M, D, sigma)
+    assert (got - y.double()).abs().max().item() <= 2.0 ** -21 * (2.0 ** 15 / sigma)
+    assert float(y.abs().max()) * sigma < 2.0 ** 15                      # the bound holds
+    assert (pl[M:] == 7).all() and (pl[:, 2 * D:] == 7).all()             # pad rows / columns are not written
+    _lib.call("eav_layernorm_fwd_planes", P(x), P(g), P(b), None, P(pl), P(slot), P(st2), P(st2) + 4 * M, M, D, 1e-12, None)
+    assert torch.equal(decode_planes(pl, M, D, sigma), got)               # y is optional
+
+
+@pytest.mark.parametrize("shape", [(256, 384, 96), (1000, 200, 100), (9712, 3072, 768), (130, 128, 64)])
+@pytest.mark.parametrize("gelu", [0, 1])
+def test_gemm_epilogue_writes_the_next_operand_planes(shape, gelu):
+    """eav_gemm_sp_planes: bias [+ erf-GELU] in the epilogue, the result leaves as the row planes of the next product
+    (aligned tiles and ragged last tiles, N % 8 == 0) - equal to the fp32 output of the same launch to split precision;
+    the pre-activation is stored as before; C may be NULL."""
+    M, N, K = shape
+    torch.manual_seed(M + N + K + gelu)
+    A = torch.randn(M, K, device="cuda")
+    B = torch.randn(N, K, device="cuda") * 0.05
+    bias = torch.randn(N, device="cuda") * 0.3
+    sa, pa, _ = planes(A)
+    sb, pb, _ = planes(B)
+    C = torch.empty(M, N, device="cuda")
+    pre = torch.empty(M, N, device="cuda")
+    ref = A.double() @ B.double().t() + bias.double()
+    bound = float((A.norm(dim=1).max() * B.norm(dim=1).max() + bias.abs().max()))
+    sigma = 2.0 ** (14 - np.floor(np.log2(bound)))
+    slot = torch.zeros(SLOT, device="cuda")
+    slot[2048], slot[2049] = sigma, 1.0 / sigma
+    pl = torch.full(((M + 31) // 32 * 32, 2 * kpad(N)), 7.0, dtype=torch.float16, device="cuda")
+    _lib.call("eav_gemm_sp_planes", P(pa), P(pb), P(C), P(sa), P(sb), M, N, K, N, 1, 0, 0, 1.0, P(bias), gelu,
+              P(pre) if gelu else None, None, 0, 0, None, P(pl), P(slot), None)
+    want = torch.nn.functional.gelu(ref) if gelu else ref
+    assert (C.double() - want).abs().max().item() < 2e-5
+    if gelu:
+        assert (pre.double() - ref).abs().max().item() < 2e-5
+    got = decode_planes(pl, M, N, sigma)
+    assert (got - C.double()).abs().max().item() <= 2.0 ** -21 * (2.0 ** 15 / sigma)
+    assert (pl[M:] == 7).all() and (pl[:, 2 * N:] == 7).all()
+    pl2 = torch.zeros_like(pl)
+    _lib.call("eav_gemm_sp_planes", P(pa), P(pb), None, P(sa), P(sb), M, N, K, N, 1, 0, 0, 1.0, P(bias), gelu,
+              P(pre) if gelu else None, None, 0, 0, None, P(pl2), P(slot), None)
+    assert torch.equal(pl2[:M, :2 * N], pl[:M, :2 * N])                   # no fp32 copy needed
+
+
+def test_forward_scales_are_bounds_and_row_norms_are_exact():
+    torch.manual_seed(5)
+    R, C = 3072, 768
+    w = torch.randn(R, C, device="cuda") * 0.02
+    w[77] *= 9
+    out = torch.zeros(1, device="cuda")
+    _lib.call("eav_rownorm_max", P(w), R, C, C, P(out), None)
+    assert abs(float(out) - float(w.double().norm(dim=1).max())) < 1e-5 * float(out)
+    # one layer laid out as [g1 | b1 | g2 | b2 | bfc1]
+    D, FF = C, R
+    g1, b1, g2, b2 = (torch.rand(D, device="cuda") + 0.5, torch.randn(D, device="cuda") * 0.2,
+                      torch.rand(D, device="cuda") * 3, torch.randn(D, device="cuda") * 0.2)
+    bf = torch.randn(FF, device="cuda") * 0.5
+    flat = torch.cat([g1, b1, g2, b2, bf]).contiguous()
+    slots = torch.zeros(5, SLOT, device="cuda")
+    _lib.call("eav_tf_forward_scales", P(flat), 0, 1, 0, D, 2 * D, 3 * D, 4 * D, D, FF, P(out), P(slots), 0, 0, 3, 4, None)
+    sd = np.sqrt(D)
+    b_y1 = sd * float(g1.abs().max()) + float(b1.abs().max())
+    b_y2 = sd * float(g2.abs().max()) + float(b2.abs().max())
+    b_act = (sd * float(g2.abs().max()) + float(b2.double().norm())) * float(out) + float(bf.abs().max())
+    for k, bnd in ((0, b_y1), (3, b_y2), (4, b_act)):
+        sg = float(slots[k, 2048])
+        assert sg == 2.0 ** (14 - np.floor(np.log2(bnd * 1.0001))) and float(slots[k, 2049]) == 1.0 / sg, (k, sg, bnd)
+    assert float(slots[1, 2048]) == 0 and float(slots[2, 2048]) == 0      # the other slots are not touched
+    # the bounds hold on data: LayerNorm rows and the MLP activation they feed
+    x = torch.randn(500, D, device="cuda") * torch.exp(torch.randn(500, 1, device="cuda"))
+    xh = (x - x.mean(1, keepdim=True)) / x.var(1, unbiased=False, keepdim=True).sqrt()
+    y2 = xh * g2 + b2
+    assert float(y2.abs().max()) <= b_y2
+    act = torch.nn.functional.gelu(y2 @ w.t() + bf)
+    assert float(act.abs().max()) <= b_act

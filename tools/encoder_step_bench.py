@@ -44,6 +44,19 @@ with ctx:
         step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
+if os.environ.get("SPLIT_TIMES"):     # forward / backward / optimiser separately (a synchronisation between the parts)
+    tf = tb = to = 0.0
+    for _ in range(n):
+        opt.zero_grad()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        loss = crit(model(x).logits, y)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        loss.backward()
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+        opt.step()
+        torch.cuda.synchronize(); t3 = time.perf_counter()
+        tf += t1 - t0; tb += t2 - t1; to += t3 - t2
+    print(f"   forward {tf / n * 1e3:.2f} ms  backward {tb / n * 1e3:.2f} ms  optimiser {to / n * 1e3:.2f} ms")
 gf = {"ast": 783.1, "vit": 105.4}[kind] * B
 print(f"{kind} B={B} {prec}: {dt * 1e3:.1f} ms/step, {B / dt:.1f} samples/s, {gf / dt / 1e3:.1f} TFLOP/s; "
       f"peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")

@@ -89,7 +89,24 @@ def cpu_baseline_encoder(kind):
 
 
 # ---------------------------------------------------------------------------------------------- encoders (AST / ViT)
-def bench_encoder(kind, dev, world, sync_factory, steps=4, warmup=2, blocks=3):
+def encoder_gemm_bytes(kind, B, freeze):
+    """Algorithmic HBM bytes of the dense projections of one train step: every operand and every result once - A and B
+    operand planes (hi + lo fp16 = 4 B per element), fp32 / plane results (4 B per element); per layer qkv, o, fc1, fc2
+    forward, their data gradients and (unfrozen) their weight gradients, plus the patch projection."""
+    from eav_amd import transformer as T
+    c = T.make_config(kind)
+    M, D, FF, L = B * c.ntok, c.hidden, c.ff, c.layers
+    g = lambda m, n, k: 4 * (m * k + n * k + m * n)  # noqa: E731
+    fwd = g(M, 3 * D, D) + g(M, D, D) + g(M, FF, D) + g(M, D, FF)
+    total = L * fwd + g(B * c.npatch, D, c.kp)
+    if not freeze:
+        dgrad = g(M, D, 3 * D) + g(M, D, D) + g(M, D, FF) + g(M, FF, D)
+        wgrad = g(3 * D, D, M) + g(D, D, M) + g(FF, D, M) + g(D, FF, M)
+        total += L * (dgrad + wgrad) + g(D, c.kp, B * c.npatch)
+    return int(total)
+
+
+def bench_encoder(kind, dev, world, sync_factory, steps=4, warmup=2, blocks=3, batch=None, runs=None, global_batch=None):
     """Frozen (classifier only) and unfrozen AdamW train steps of the 12-layer AST / ViT-B/16 on synthetic input
     (BASELINE.json configs[2], configs[3]); batch sizes are the reference drivers' (8 / 128).  Default precision
     "split" (fp32-grade on the fp16 matrix cores), exact-fp32 MFMA beside it."""
@@ -99,7 +116,7 @@ def bench_encoder(kind, dev, world, sync_factory, steps=4, warmup=2, blocks=3):
     cfg = T.make_config(kind)
     torch.manual_seed(0)
     model = T.Encoder(cfg).to(dev).train()
-    B = ENC[kind]["B"]
+    B = batch or ENC[kind]["B"]
     x, y = (synth.mel_batch(5, B) if kind == "ast" else synth.frame_batch(5, B))
     x, y = torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
     opt = FusedAdam(model.parameters(), lr=5e-6, weight_decay=0.01, decoupled=True)
@@ -108,12 +125,17 @@ def bench_encoder(kind, dev, world, sync_factory, steps=4, warmup=2, blocks=3):
     sync = sync_factory(model._flat[1])
     if sync is not None:
         model.grad_ready_hook = sync.bucket          # all-reduce buckets overlap the backward
+        if global_batch:
+            sync.set_batch(B, global_batch)
     res = {}
-    runs = (("unfrozen", False, "split"), ("frozen", True, "split"), ("unfrozen_fp32", False, "fp32"),
-            ("frozen_fp32", True, "fp32"))
+    runs = runs or (("unfrozen", False, "split"), ("frozen", True, "split"), ("unfrozen_fp32", False, "fp32"),
+                    ("frozen_fp32", True, "fp32"), ("unfrozen_bf16", False, "bf16"))
     notes = {"split": "fp16 MFMA, operands split into hi + lo fp16 planes, 3 MFMAs per product, fp32 accumulate: "
                       "fp32-grade (not worse than the exact-fp32 kernels against float64; logits within 1e-4 of HF)",
-             "fp32": "exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)"}
+             "fp32": "exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)",
+             "bf16": "bf16 MFMA operands (rounded while staging), fp32 accumulate - the literal reading of BASELINE.json "
+                     "configs[2] / [3]; its logits leave the 1e-3 bound (logit_error below), hence the split default"}
+    ref_logits = {}
     for phase, freeze, prec in runs:
         model.precision = prec
         for k, p in model.named_parameters():
@@ -130,6 +152,14 @@ def bench_encoder(kind, dev, world, sync_factory, steps=4, warmup=2, blocks=3):
             opt.step()
         for _ in range(warmup):
             step()
+        # logits of this precision against the exact-fp32 kernels on the same weights (measured, not assumed)
+        with torch.no_grad():
+            keep = model.precision
+            lg = model(x).logits.float().clone()
+            model.precision = "fp32"
+            l32 = model(x).logits.float().clone()
+            model.precision = keep
+        logit_err = float((lg - l32).abs().max().item())
         per_block = []
         for _ in range(blocks):
             torch.cuda.synchronize()
@@ -140,7 +170,8 @@ def bench_encoder(kind, dev, world, sync_factory, steps=4, warmup=2, blocks=3):
             per_block.append((time.perf_counter() - t0) / steps)
         dt = statistics.median(per_block)
         # dominant kernel family, timed live with HIP events on the launch stream in a separate pass
-        names = {"split": ("eav_gemm_sp", "eav_gemm_sp_splitk"), "fp32": ("eav_gemm_f32", "eav_gemm_f32_splitk")}[prec]
+        names = {"split": ("eav_gemm_sp", "eav_gemm_sp_planes", "eav_gemm_sp_splitk"),
+                 "fp32": ("eav_gemm_f32", "eav_gemm_f32_splitk"), "bf16": ("eav_gemm_bf16", "eav_gemm_bf16_splitk")}[prec]
         model.kernel_events = {k: [] for k in names}
         step()
         torch.cuda.synchronize()
@@ -148,15 +179,22 @@ def bench_encoder(kind, dev, world, sync_factory, steps=4, warmup=2, blocks=3):
         model.kernel_events = None
         gflop = ENC[kind]["gflop_fwd"] * (1 if freeze else 3) * B
         gemm_gflop = gflop * ENC[kind]["gemm_share"]
-        peak = PEAK_F16_MFMA_TFLOPS if prec == "split" else PEAK_F32_MFMA_TFLOPS
+        peak = PEAK_F32_MFMA_TFLOPS if prec == "fp32" else PEAK_F16_MFMA_TFLOPS
+        abytes = encoder_gemm_bytes(kind, B, freeze)
         ach = gemm_gflop / gemm_ms if gemm_ms > 0 else 0.0          # GFLOP / ms = TFLOP/s
         res[phase] = {
             "value": round(B * world / dt, 2), "unit": "samples/s", "ms_per_step": round(dt * 1e3, 3),
             "ms_per_step_blocks": [round(t * 1e3, 3) for t in per_block], "batch_per_gpu": B, "precision": notes[prec],
             "step_tflops": round(gflop / dt / 1e3, 2),
-            "roofline": {"bound": "mfma", "kernel": "gemm_sp_kernel" if prec == "split" else "gemm_f32_kernel",
+            "max_abs_logit_difference_vs_exact_fp32_kernels": logit_err,
+            "roofline": {"bound": "mfma", "kernel": {"split": "gemm_sp_kernel", "fp32": "gemm_f32_kernel",
+                                                     "bf16": "gemm_bf16_kernel"}[prec],
                          "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                          "traffic": _pmc_traffic(kind, prec, freeze),
+                         "algorithmic_bytes": abytes,
+                         "algorithmic_bytes_note": "sum over the step's dense projections of operand planes (4 B / element) "
+                                                   "+ results (4 B / element), each once; per launch = / gemm_launches",
+                         "hbm_gbps_if_algorithmic": round(abytes / gemm_ms / 1e6, 1) if gemm_ms > 0 else None,
                          "traffic_unit": "mean HBM bytes per GEMM launch of the unfrozen split step (rocprofv3 --pmc "
                                          "FETCH_SIZE / WRITE_SIZE passes, gfx950-corrected; profiles/*_pmc.json)",
                          "note": "algorithmic 2MNK flops of every dense projection of the step / summed kernel time "
@@ -179,10 +217,192 @@ def _pmc_traffic(kind, prec, freeze):
         import glob
         f = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{kind}_pmc.json")))[-1]
         k = json.load(open(f))["kernels"]
-        e = next(v for name, v in k.items() if name.startswith("gemm_sp_kernel"))
-        return int(e["hbm_read_bytes"] + e["hbm_write_bytes"])
+        es = [v for name, v in k.items() if name.startswith("gemm_sp_kernel")]
+        n = sum(e.get("launches", 1) for e in es)
+        return int(sum((e["hbm_read_bytes"] + e["hbm_write_bytes"]) * e.get("launches", 1) for e in es) / max(n, 1))
     except Exception:
         return None
+
+
+
+# ---------------------------------------------------------------------------------------------- encoders, N > 1 legs
+def bench_encoder_multi(kind, dev, rank, world, steps=3, warmup=1):
+    """The data-parallel legs of the AST / ViT fine-tune beyond the weak-scaling phases of bench_encoder:
+    `strong` - fixed GLOBAL batch (AST 32, ViT 128: the reference drivers' batch sizes times 4 / 1) split over the ranks,
+    per-layer gradient buckets all-reduced from inside the backward (345 MB per step);
+    `subject_sharded` - the 42 independent per-subject fine-tunes (Dataload_audio.py:82-115, Transformer_Vision.py:136-152)
+    round-robin over the ranks, each a fresh head + AdamW state, two frozen and two unfrozen steps at the reference batch
+    size, no data-path collective, one all_gather of a per-subject result at the end."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from eav_amd import dist as eav_dist, synth, transformer as T
+    from eav_amd.optim import CrossEntropyLoss, FusedAdam
+    out = {}
+    gb = {"ast": 32, "vit": 128}[kind]
+    if gb % world == 0:
+        r = bench_encoder(kind, dev, world, lambda g: eav_dist.GradSync([g]), steps=steps, warmup=warmup, blocks=1,
+                          batch=gb // world, runs=(("unfrozen", False, "split"),), global_batch=gb)["unfrozen"]
+        out["strong"] = {"value": r["value"], "unit": "samples/s", "ms_per_step": r["ms_per_step"], "global_batch": gb,
+                         "per_gpu_batch": gb // world,
+                         "allreduce_bytes_per_step": 4 * sum(int(np.prod(v)) for v in
+                                                             T.param_shapes(T.make_config(kind)).values()),
+                         "note": "unfrozen step, fixed global batch; gradient buckets (one per layer) all-reduced from "
+                                 "inside the backward"}
+    # ---- Mode S
+    cfg = T.make_config(kind)
+    torch.manual_seed(0)
+    model = T.Encoder(cfg).to(dev).train()
+    B = ENC[kind]["B"]
+    x, y = (synth.mel_batch(5, B) if kind == "ast" else synth.frame_batch(5, B))
+    x, y = torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
+    crit = CrossEntropyLoss()
+    init = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    subs = eav_dist.subjects_for_rank(rank, world)
+    mine = torch.zeros(42, device=dev)
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s_ in subs:
+        model.load_state_dict(init)                                   # a fresh model per subject
+        opt = FusedAdam(model.parameters(), lr=5e-4, weight_decay=0.01, decoupled=True)
+        for freeze in (True, True, False, False):
+            for k, p in model.named_parameters():
+                p.requires_grad = (not freeze) or k.startswith("classifier.")
+            opt.zero_grad()
+            loss = crit(model(x).logits, y)
+            loss.backward()
+            opt.step()
+        mine[s_ - 1] = loss.detach()
+    torch.cuda.synchronize()
+    ds = time.perf_counter() - t0
+    gathered = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(gathered, mine)
+    t = torch.tensor([ds], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ds = float(t.item())
+    out["subject_sharded"] = {"value": round(42 * 4 * B / ds, 2), "unit": "samples/s", "seconds": round(ds, 4),
+                              "subjects": 42, "steps_per_subject": "2 frozen + 2 unfrozen", "batch": B,
+                              "subjects_on_busiest_rank": len(eav_dist.subjects_for_rank(0, world)),
+                              "scaling": "strong (total work fixed: 42 subjects; ideal speed-up 42 / ceil(42/N))",
+                              "all_subjects_reported": bool((torch.stack(gathered).sum(0) > 0).all().item())}
+    del model
+    torch.cuda.empty_cache()
+    return out
+
+
+# ---------------------------------------------------------------------------------------------- front-ends (SURVEY 8f 1-3)
+def bench_preprocess(dev, with_cpu=True):
+    """Throughput of the three pre-processing front-ends either side of the hot path, each with its algorithmic HBM bytes
+    against the 8 TB/s peak and the reference's own CPU path timed beside it on a bounded sample:
+    AST log-mel features (Transformer_Audio.py:38-42), ViT frame pre-processing (Transformer_Vision.py:52-59), EEG
+    decimation + band-pass (Dataload_eeg.py:85-121)."""
+    import numpy as np
+    import torch
+    from eav_amd import eeg_data, preprocess, synth
+
+    def gpu_time(fn, reps=5):
+        fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / reps * 1e-3
+
+    res = {}
+    # ---- AST log-mel: 5 s clips at 16 kHz -> [1024, 128]
+    n, L = 64, 80000
+    wav = torch.from_numpy(synth.normal(31, (n, L), 0.0, 0.1)).to(dev)
+    dt = gpu_time(lambda: preprocess.waveforms_to_input_values(wav, device=dev))
+    ab = n * (L * 4 + 1024 * 128 * 4)
+    res["ast_log_mel"] = {"value": round(n / dt, 1), "unit": "clips/s", "ms_per_clip": round(dt / n * 1e3, 4),
+                          "kernel": "eav_ast_fbank (float64 DFT up to the log, like the numpy reference)",
+                          "roofline": {"bound": "hbm", "algorithmic_bytes": ab, "achieved": round(ab / dt / 1e9, 1),
+                                       "peak": 8000.0, "unit": "GB/s", "frac": round(ab / dt / 8e12, 4),
+                                       "note": "arithmetic-bound in fp64 (498 frames x 512-point DFT per clip), far from the "
+                                               "HBM roof by construction"}}
+    # ---- ViT frames: uint8 [56,56,3] -> float32 [3,224,224]
+    nf = 2500
+    frames = torch.from_numpy((synth.uniform(32, (nf, 56, 56, 3), 0, 256)).astype(np.uint8)).to(dev)
+    dt = gpu_time(lambda: preprocess.frames_to_pixel_values(frames, device=dev))
+    ab = nf * (56 * 56 * 3 + 3 * 224 * 224 * 4)
+    res["vit_frames"] = {"value": round(nf / dt, 1), "unit": "frames/s", "us_per_frame": round(dt / nf * 1e6, 3),
+                         "kernel": "eav_resize_normalize_u8 (Pillow-exact 8-bit bilinear resize + rescale + normalise)",
+                         "roofline": {"bound": "hbm", "algorithmic_bytes": ab, "achieved": round(ab / dt / 1e9, 1),
+                                      "peak": 8000.0, "unit": "GB/s", "frac": round(ab / dt / 8e12, 4)}}
+    # ---- EEG: one subject's recording [30 ch, 10000 samples, 200 trials] float64: decimate by 5, Butterworth-5 band-pass
+    ch, t_, tri = 30, 10000, 200
+    rec = torch.from_numpy(synth.normal(33, (ch, t_ * tri)).astype(np.float64)).to(dev)
+    from scipy.signal import butter
+    sos = butter(5, [0.5, 45], btype="bandpass", fs=100, output="sos")   # the driver's band (Dataload_eeg.py:177)
+    dec = [None]
+
+    def eeg():
+        dec[0] = eeg_data.decimate(rec, 5)
+        return eeg_data.sosfilt(sos, dec[0])
+    dt = gpu_time(eeg, reps=3)
+    nd = dec[0].shape[1]
+    ab = ch * 8 * (t_ * tri + nd + 2 * nd)
+    res["eeg_filters"] = {"value": round(dt, 5), "unit": "s/subject", "higher_is_better": False,
+                          "kernel": "eav_decimate_fir_f64 + eav_sosfilt_f64 (exact chunk-parallel IIR), float64",
+                          "roofline": {"bound": "hbm", "algorithmic_bytes": ab, "achieved": round(ab / dt / 1e9, 1),
+                                       "peak": 8000.0, "unit": "GB/s", "frac": round(ab / dt / 8e12, 4)}}
+    if with_cpu:
+        from oracle import preprocess_oracle as po
+        from scipy.signal import resample_poly, sosfilt
+        w = wav[:4].cpu().numpy()
+        t0 = time.perf_counter()
+        po.ast_fbank(w)
+        d = (time.perf_counter() - t0) / 4
+        res["ast_log_mel"]["cpu_baseline"] = {"value": round(1 / d, 2), "unit": "clips/s", "cores": 1, "kind": "port",
+                                              "sample": "4 clips through oracle/preprocess_oracle.ast_fbank (numpy)"}
+        fr = frames[:24].cpu().numpy()
+        t0 = time.perf_counter()
+        po.vit_preprocess(fr)
+        d = (time.perf_counter() - t0) / 24
+        res["vit_frames"]["cpu_baseline"] = {"value": round(1 / d, 1), "unit": "frames/s", "cores": 1, "kind": "port",
+                                             "sample": "24 frames through oracle/preprocess_oracle.vit_preprocess (numpy)"}
+        r = rec.cpu().numpy()
+        t0 = time.perf_counter()
+        sosfilt(sos, resample_poly(r, 1, 5, axis=1), axis=-1)
+        d = time.perf_counter() - t0
+        res["eeg_filters"]["cpu_baseline"] = {"value": round(d, 3), "unit": "s/subject", "cores": 1, "kind": "reference",
+                                              "sample": "scipy.signal.resample_poly + sosfilt on the same recording - the "
+                                                        "calls Dataload_eeg.py:85-121 makes"}
+    return res
+
+
+def bench_epoch(dev, epochs=5):
+    """Trainer_uni.train() as the reference driver calls it (EEGNet_tor.py:159-162) on one synthetic subject split 50 / 50
+    by EAVDataSplit: wall time per epoch INCLUDING validate() (4 optimiser steps of <= 64 trials + the test pass)."""
+    import contextlib
+    import io
+    import torch
+    from eav_amd import synth
+    from eav_amd.datasplit import EAVDataSplit
+    from eav_amd.eegnet import EEGNet_tor, Trainer_uni
+    xs, ys = synth.eeg_subject(7, 400, CHANS, SAMPLES)
+    tr_x, tr_y, te_x, te_y = EAVDataSplit(xs, ys).get_split(h_idx=40)
+    torch.manual_seed(0)
+    model = EEGNet_tor(nb_classes=5, Chans=CHANS, Samples=SAMPLES, kernLength=KLEN, dropoutRate=0.5)
+    tr = Trainer_uni(model, [tr_x[:, None], tr_y, te_x[:, None], te_y], lr=1e-5, batch_size=B_PER_GPU, num_epochs=2,
+                     device=dev)
+    with contextlib.redirect_stdout(io.StringIO()):
+        tr.train()                                    # warm-up: graphs of both BatchNorm modes captured
+        torch.cuda.synchronize()
+        tr.num_epochs = epochs
+        t0 = time.perf_counter()
+        tr.train()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / epochs
+    n = len(tr_y)
+    return {"seconds_per_epoch": round(dt, 5), "train_trials": int(n), "test_trials": int(len(te_y)),
+            "train_samples_per_s_including_validate": round(n / dt, 1), "epochs_timed": epochs, "batch_size": B_PER_GPU,
+            "note": "Trainer_uni.train(): hipGraph-replayed full batches, eager last batch, validate() every epoch with loss / "
+                    "hits accumulated on the device (one read-back per epoch); eval-mode training after epoch 1 (Q4)"}
 
 
 # ---------------------------------------------------------------------------------------------- alternative EEG encoders
@@ -462,6 +682,7 @@ def main():
     model.train()
 
     multi = None
+    run_sync_bytes = 4 * model._flat[1].numel() if world > 1 else 0
     if world > 1:
         multi = {}
         # ---- the other data-parallel leg (strong when the headline is weak and vice versa)
@@ -474,7 +695,8 @@ def main():
             multi["weak" if strong else "strong"] = {
                 "value": round(args.steps * other * world / d2, 2), "unit": "samples/s",
                 "ms_per_step": round(d2 / args.steps * 1e3, 4), "per_gpu_batch": other, "global_batch": other * world,
-                "note": "data parallel, one RCCL all-reduce of the 0.68 MB flat gradient buffer per step"}
+                "allreduce_bytes_per_step": 4 * r2.model._flat[1].numel(),
+                "note": f"data parallel, one all-reduce ({eav_dist.backend_name()}) of the flat gradient buffer per step"}
             del r2
             torch.cuda.empty_cache()
         # ---- Mode S: the 42 per-subject trainings are independent - subjects round-robin over ranks, no collective on
@@ -512,14 +734,22 @@ def main():
             "all_subjects_reported": bool((losses > 0).all().item()),
             "note": "independent per-subject trainings, no data-path collective; one all_gather of results"}
 
-    encoders = alt = None
+    encoders = alt = pre = epoch = enc_multi = None
     if not args.no_encoders:
         del run.xs
         del run, model
         torch.cuda.empty_cache()
         mk = (lambda g: eav_dist.GradSync([g])) if world > 1 else (lambda g: None)
         encoders = {k: bench_encoder(k, dev, world, mk) for k in ("ast", "vit")}
+        # SURVEY.md:616 asks AST at the reference batch (8) AND at a throughput batch (32)
+        encoders["ast"]["unfrozen_b32"] = bench_encoder("ast", dev, world, mk, batch=32, blocks=1,
+                                                        runs=(("unfrozen", False, "split"),))["unfrozen"]
+        if world > 1:
+            enc_multi = {k: bench_encoder_multi(k, dev, rank, world) for k in ("ast", "vit")}
         alt = bench_alt_eeg(dev) if world == 1 else None
+        if world == 1:
+            epoch = bench_epoch(dev)
+            pre = bench_preprocess(dev, with_cpu=not args.no_cpu_baseline) if rank == 0 else None
 
     if rank == 0:
         dom = max(kern_ms, key=kern_ms.get)
@@ -552,7 +782,9 @@ def main():
             "config": {"workload": "EEGNet_tor(5, Chans=30, Samples=10000, kernLength=300, F1=8, D=8, F2=64) "
                                    f"train step on x[{per_gpu},1,30,10000] fp32 per GPU (BASELINE.json configs[1])",
                        "global_batch": per_gpu * world, "per_gpu_batch": per_gpu,
-                       "parallelism": f"dp{world}" + (" (RCCL grad all-reduce)" if world > 1 else ""),
+                       "parallelism": f"dp{world}" + (f" (gradient all-reduce over torch.distributed backend "
+                                                      f"'{eav_dist.backend_name()}'" + (" = RCCL)" if
+                                                      eav_dist.backend_name() == "nccl" else ")") if world > 1 else ""),
                        "optimizer": "Adam lr=1e-5", "dropout": 0.5, "final_loss": round(final_loss, 5),
                        "launch": "hipGraph replay of the whole step (Trainer_uni's own path: GraphStep)"},
             "repeat_blocks": {"ms_per_step": [round(v, 4) for v in blocks_ms],
@@ -596,7 +828,16 @@ def main():
                                                   "ViT-B/16, frames [128,3,224,224] per GPU (BASELINE.json configs[3])"))
         out["modalities"] = modalities
         if multi is not None:
+            multi["backend"] = eav_dist.backend_name()
+            multi["rccl_ranks"] = dist.get_world_size()
+            multi["eegnet_allreduce_bytes_per_step"] = int(run_sync_bytes)
+            if enc_multi is not None:
+                multi["ast"], multi["vit"] = enc_multi["ast"], enc_multi["vit"]
             out["multi_gpu"] = multi
+        if pre is not None:
+            out["preprocess"] = pre
+        if epoch is not None:
+            out["trainer_epoch"] = epoch
         if alt is not None:
             out["alt_eeg_encoders"] = {"note": "SURVEY 8f row 4: canonical EEGNet (CNN_EEG.py) and ShallowConvNet + "
                                                "12-layer transformer (Transformer_EEG.py); fp32, hipGraph-replayed "

@@ -122,11 +122,19 @@ __device__ __forceinline__ float store_rows_T(float* __restrict__ patch, const f
   }
   return vmax;
 }
-__device__ __forceinline__ void emit_amax(unsigned* slot, float vmax, int lane, int salt) {
+// row0: first of the (up to) 32 output rows [row0, row0 + 32) of the [B*N, .] tensor this wave wrote, or < 0: the
+// maximum also goes to the entries of the one or two 128-row blocks they lie in (per-row-block operand scales)
+__device__ __forceinline__ void emit_amax(unsigned* slot, float vmax, int lane, int salt, int row0 = -1) {
   if (!slot) return;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
-  if (lane == 0 && vmax == vmax) atomicMax(slot + EAV_SLOT_SHARD(salt), __float_as_uint(vmax));
+  if (lane == 0 && vmax == vmax) {
+    atomicMax(slot + EAV_SLOT_SHARD(salt), __float_as_uint(vmax));
+    if (row0 >= 0) {
+      eav_slot_blockmax(slot, row0, vmax);
+      if (((row0 + 31) >> 7) != (row0 >> 7)) eav_slot_blockmax(slot, row0 + 31, vmax);
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ forward
@@ -253,7 +261,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_sp_kernel(const u8* __res
   __syncthreads();   // every wave is done with the tiles before the patch area is reused
   const float vmax = store_rows_T(reinterpret_cast<float*>(smem) + wave * (32 * 33), o0, o1, inv,
                                   ao + (int64_t)b * N * D + h * 64, D, q0, N, lane);
-  emit_amax(amax, vmax, lane, (int)blockIdx.x * NW + wave);
+  emit_amax(amax, vmax, lane, (int)blockIdx.x * NW + wave, q0 < N ? b * N + q0 : -1);
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dQ
@@ -380,7 +388,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_q_sp_kernel(
   const float mul = scale * (1.f / DS_DOWN) * isd * isg * isg;
   const float vmax = store_rows_T(reinterpret_cast<float*>(smem) + wave * (32 * 33), g0, g1, mul,
                                   dqkv + (int64_t)b * N * 3 * D + h * 64, 3 * D, q0, N, lane);
-  emit_amax(amax_out, vmax, lane, (int)blockIdx.x * NW + wave);
+  emit_amax(amax_out, vmax, lane, (int)blockIdx.x * NW + wave, q0 < N ? b * N + q0 : -1);
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
@@ -517,7 +525,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_kv_sp_kernel(
   const float mv = isd / SP;
   float vmax = store_rows_T(patch, gk0, gk1, mk, base + D, 3 * D, k0, N, lane);
   vmax = fmaxf(vmax, store_rows_T(patch, gv0, gv1, mv, base + 2 * D, 3 * D, k0, N, lane));
-  emit_amax(amax_out, vmax, lane, (int)blockIdx.x * NW + wave);
+  emit_amax(amax_out, vmax, lane, (int)blockIdx.x * NW + wave, k0 < N ? b * N + k0 : -1);
 }
 
 // ------------------------------------------------------------------------------------------------ operand preparation

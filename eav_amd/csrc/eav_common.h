@@ -67,6 +67,26 @@ __device__ __forceinline__ void block_sum_256(float (&v)[NV], float* red) {
 #define EAV_SLOT_SHARD(i) (32 * ((i) & 63))
 #define EAV_SLOT_SIGMA 2048
 #define EAV_SLOT_ISIGMA 2049
+// Per-row-block refinement of the tensor-wide scale (rows = output rows of the products that read the planes as their A
+// operand, e.g. the tokens of a gradient tensor): word EAV_SLOT_BMAX + (b & 1023) holds the bits of max|x| over the rows
+// [128 b, 128 b + 128) (producers atomicMax it next to the tensor-wide shards; blocks beyond 1024 alias, which only makes
+// the entry an over-estimate), word EAV_SLOT_BEXP + (b & 1023) the boost exponent k_b >= 0 the conversion chose: the
+// planes of block b hold sigma 2^k_b x.  k_b = 0 unless the block's maximum is >= 2^8 below the tensor's - then the block
+// gets its own power of two, so a row keeps fp32-grade relative precision however small it is next to the largest row.
+#define EAV_SLOT_BMAX 2080
+#define EAV_SLOT_BEXP 3104
+#define EAV_SLOT_NBLK 1024
+#define EAV_BOOST_MIN 8
+__device__ __forceinline__ void eav_slot_blockmax(unsigned* slot, int row, float vmax) {
+  if (vmax == vmax) atomicMax(slot + EAV_SLOT_BMAX + ((row >> 7) & (EAV_SLOT_NBLK - 1)), __float_as_uint(vmax));
+}
+// boost exponent of row block b given the tensor-wide maximum bits (0: unknown / not small enough)
+__device__ __forceinline__ int eav_slot_boost(const float* slot, int b, unsigned gbits) {
+  const unsigned bb = __float_as_uint(slot[EAV_SLOT_BMAX + (b & (EAV_SLOT_NBLK - 1))]);
+  if (bb == 0u || gbits == 0u) return 0;
+  const int k = (int)((gbits >> 23) & 0xff) - (int)((bb >> 23) & 0xff);
+  return k >= EAV_BOOST_MIN ? (k > 60 ? 60 : k) : 0;
+}
 __device__ __forceinline__ unsigned eav_slot_bits(const float* slot) {
   unsigned bits = 0u;
 #pragma unroll 8

@@ -320,9 +320,42 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
   };
   // more: a K-tile t+1 exists (read its first fragments); more2: a K-tile t+2 exists (issue its DMA);
   // next_m0 >= 0 (last K-tile only): issue the next output tile's first two stages instead
+  // TR: boost exponents of the token block the NEXT K-tile lies in (loaded a tile ahead: scalar loads, consumed after the
+  // explicit waits of a whole iteration).  A boosted block's fragments are scaled back by 2^-k before their MFMAs: the
+  // boost serves the products whose OUTPUT rows are these rows; in a contraction over the rows a small row's share of
+  // the sum is small anyway, and un-boosting (fp16, may round into the subnormals) costs nothing next to the large rows.
+  int kAn = 0, kBn = 0;
+  auto load_boost = [&](int t) {
+    if constexpr (TR) {
+      const int b = ((kt0 + t) >> 2) & (EAV_SLOT_NBLK - 1);
+      kAn = reinterpret_cast<const int*>(g.slotA)[EAV_SLOT_BEXP + b];
+      kBn = reinterpret_cast<const int*>(g.slotB)[EAV_SLOT_BEXP + b];
+    }
+  };
+  auto pow2h = [](int k) -> _Float16 {       // 2^-k as fp16 (subnormal for 15 <= k <= 24, 0 beyond)
+    const unsigned short bits = k <= 14 ? (unsigned short)((15 - k) << 10) : (k <= 24 ? (unsigned short)(1u << (24 - k)) : 0);
+    return __builtin_bit_cast(_Float16, bits);
+  };
+  auto unboost = [&](Frags& f, int ka, int kb) {
+    if (ka) {
+      const _Float16 sa = pow2h(ka);
+#pragma unroll
+      for (int i = 0; i < RM; ++i) { f.ah[i] *= sa; f.al[i] *= sa; }
+    }
+    if (kb) {
+      const _Float16 sb = pow2h(kb);
+#pragma unroll
+      for (int j = 0; j < RN; ++j) { f.bh[j] *= sb; f.bl[j] *= sb; }
+    }
+  };
   auto iter = [&](auto more_c, auto more2_c, int t, int next_m0, int next_n0) {
     constexpr bool more = decltype(more_c)::value, more2 = decltype(more2_c)::value;
     const int buf = t & 1;
+    const int ka = kAn, kb = kBn;
+    if constexpr (TR) {
+      load_boost(t + 1);
+      if (ka | kb) unboost(f0, ka, kb);
+    }
     const unsigned char* sa = smem + buf * STAGE + offA;
     const unsigned char* sb = smem + buf * STAGE + offB;
     const unsigned char* sa2 = smem + (buf ^ 1) * STAGE + offA;
@@ -344,6 +377,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     SB();
+    if constexpr (TR) {
+      if (ka | kb) unboost(f1, ka, kb);
+    }
     if (!more && next_m0 >= 0) set_sources(next_m0, next_n0);
 #pragma unroll
     for (int m = 0; m < NMF; ++m) {          // phase B
@@ -408,6 +444,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
       if constexpr (TR) read_frag_tr(f0, smem, 0, r);
       else read_frag(f0, smem + offA, smem + offB, 0, r);
     }
+    load_boost(0);
     {
       int t = 0;
       for (; t + 2 < nk; ++t) iter(std::true_type{}, std::true_type{}, t, -1, -1);
@@ -424,7 +461,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[i][j][r] += acx[TWOACC ? i : 0][TWOACC ? j : 0][r] * (1.f / 2048.f);
     }
-    const float alpha = g.alpha * g.slotA[EAV_SLOT_ISIGMA] * g.slotB[EAV_SLOT_ISIGMA];
+    float alpha = g.alpha * g.slotA[EAV_SLOT_ISIGMA] * g.slotB[EAV_SLOT_ISIGMA];
+    // row of the A planes this wave's output rows come from (batched launches: z selects a slab of sA / ldA rows)
+    const int arow = (g.kt_per_split > 0 || g.ldA == 0 ? 0 : (int)(z * (g.sA / g.ldA))) + m0 + wm * 32 * RM;
+    if constexpr (!TR) {
+      // per-row-block boosts of the operands (EAV_SLOT_BEXP; 0 unless a block was >= 2^8 below its tensor's maximum)
+      const int kx = reinterpret_cast<const int*>(g.slotA)[EAV_SLOT_BEXP + ((arow >> 7) & (EAV_SLOT_NBLK - 1))] +
+                     reinterpret_cast<const int*>(g.slotB)[EAV_SLOT_BEXP + (((n0 + wn * 32 * RN) >> 7) & (EAV_SLOT_NBLK - 1))];
+      if (kx) alpha *= __uint_as_float((unsigned)(127 - min(kx, 126)) << 23);
+    }
     const float psig = g.planes ? g.slotP[EAV_SLOT_SIGMA] : 0.f;
     const int M = g.M, N = g.N;
     float vmax = 0.f;
@@ -608,8 +653,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
     if (g.amax) {
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
-      if (lane == 0 && vmax == vmax)
+      if (lane == 0 && vmax == vmax) {
         atomicMax(g.amax + EAV_SLOT_SHARD(tl * NW + wave + 17 * blockIdx.z), __float_as_uint(vmax));
+        if constexpr (!TR) eav_slot_blockmax(g.amax, arow, vmax);     // (rows of the OUTPUT: same numbering for z = 0)
+      }
     }
   }
   if constexpr (PF) {
@@ -675,31 +722,36 @@ __global__ void sp_splitk_reduce_kernel(const float* __restrict__ ws, int nsplit
 // max |v| of a strided matrix into slot[0] (bits; atomicMax on non-negative floats = integer max: order-independent)
 __global__ __launch_bounds__(256) void sp_absmax_kernel(const float* __restrict__ src, int R, int C4, int64_t ld,
                                                         unsigned* __restrict__ slot) {
-  // grid (column chunks of 256 float4, row slabs): no index division, 16 B per lane along the row
+  // grid (column chunks of 256 float4, 128-row blocks, 4 slabs of 32 rows): 16 B per lane along the row, four row loads
+  // in flight; the maximum goes to a tensor-wide shard AND to the row block's entry (EAV_SLOT_BMAX)
   const int c = blockIdx.x * 256 + threadIdx.x;
+  const int r0 = blockIdx.y * 128 + blockIdx.z * 32, r1 = min(R, r0 + 32);
   float m = 0.f;
   if (c < C4) {
     const float* p = src + 4 * (int64_t)c;
-    int r = blockIdx.y;
-    for (; r + 3 * (int)gridDim.y < R; r += 4 * gridDim.y) {
+    int r = r0;
+    for (; r + 3 < r1; r += 4) {
       const float4 a = *reinterpret_cast<const float4*>(p + (int64_t)r * ld);
-      const float4 b = *reinterpret_cast<const float4*>(p + (int64_t)(r + gridDim.y) * ld);
-      const float4 cc = *reinterpret_cast<const float4*>(p + (int64_t)(r + 2 * gridDim.y) * ld);
-      const float4 d = *reinterpret_cast<const float4*>(p + (int64_t)(r + 3 * gridDim.y) * ld);
+      const float4 b = *reinterpret_cast<const float4*>(p + (int64_t)(r + 1) * ld);
+      const float4 cc = *reinterpret_cast<const float4*>(p + (int64_t)(r + 2) * ld);
+      const float4 d = *reinterpret_cast<const float4*>(p + (int64_t)(r + 3) * ld);
       m = fmaxf(m, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
       m = fmaxf(m, fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w))));
       m = fmaxf(m, fmaxf(fmaxf(fabsf(cc.x), fabsf(cc.y)), fmaxf(fabsf(cc.z), fabsf(cc.w))));
       m = fmaxf(m, fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fmaxf(fabsf(d.z), fabsf(d.w))));
     }
-    for (; r < R; r += gridDim.y) {
+    for (; r < r1; ++r) {
       const float4 a = *reinterpret_cast<const float4*>(p + (int64_t)r * ld);
       m = fmaxf(m, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
     }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-  if ((threadIdx.x & 63) == 0 && m == m)
-    atomicMax(slot + EAV_SLOT_SHARD((blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)), __float_as_uint(m));
+  if ((threadIdx.x & 63) == 0 && m == m) {
+    atomicMax(slot + EAV_SLOT_SHARD(((blockIdx.y * 4 + blockIdx.z) * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)),
+              __float_as_uint(m));
+    eav_slot_blockmax(slot, r0, m);
+  }
 }
 
 // sigma = 2^(14 - floor(log2 amax)): max|sigma v| in [2^14, 2^15); 1 for an all-zero / non-finite tensor
@@ -738,10 +790,11 @@ __global__ __launch_bounds__(256) void sp_convert_kernel(const float* __restrict
   __shared__ float tile[64][65];
   __shared__ uint4 pimg[64 * 16 + 64];     // planes image: row r = 16 pieces (8 groups x hi, lo), one piece of padding per row
   __shared__ uint4 timg[64 * 16 + 64];     // the same for the transposed planes (row = tile column)
-  const float sigma = sigma_from_bits(eav_slot_bits(slot));
+  const unsigned gbits = eav_slot_bits(slot);
+  const float sigma0 = sigma_from_bits(gbits);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    slot[EAV_SLOT_SIGMA] = sigma;
-    slot[EAV_SLOT_ISIGMA] = 1.f / sigma;
+    slot[EAV_SLOT_SIGMA] = sigma0;
+    slot[EAV_SLOT_ISIGMA] = 1.f / sigma0;
   }
   const int t = threadIdx.x;
   const int cg = t & 7, rr = t >> 3;
@@ -780,6 +833,13 @@ __global__ __launch_bounds__(256) void sp_convert_kernel(const float* __restrict
     if (nid < ntiles) load_tile(nid, nxt);
     const int by = id / ntx, bx = id - by * ntx;
     const int r0 = by * 64, c0 = bx * 64;
+    // Row blocks (128 rows) whose maximum is >= 2^8 below the tensor's get their own power of two on top of sigma (boost
+    // exponent kb, published in EAV_SLOT_BEXP for the consumers): rows keep fp32-grade RELATIVE precision however small
+    // they are next to the largest row.  Not when transposed planes are written too (there the rows are contracted).
+    const int kb = dstT ? 0 : min(eav_slot_boost(slot, by >> 1, gbits), 253 - (int)(__float_as_uint(sigma0) >> 23));
+    const float sigma = __uint_as_float(__float_as_uint(sigma0) + ((unsigned)kb << 23));
+    if (bx == 0 && (by & 1) == 0 && t == 0 && !dstT)
+      reinterpret_cast<int*>(slot)[EAV_SLOT_BEXP + ((by >> 1) & (EAV_SLOT_NBLK - 1))] = kb;
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
       float tv[8];
@@ -848,10 +908,8 @@ extern "C" int eav_sp_absmax(const float* src, int R, int C, int64_t ld, float* 
   EAV_REQUIRE(src && slot && R > 0 && C > 0, "eav_sp_absmax: bad arguments");
   EAV_REQUIRE((C & 3) == 0 && (ld & 3) == 0 && ((uintptr_t)src & 15) == 0,
               "eav_sp_absmax: columns / leading dimension must be multiples of 4, src 16-byte aligned");
-  const int gx = cdiv(C / 4, 256);
-  const int gy = std::max(1, std::min(cdiv(R, 16), 1024 / gx));
-  hipLaunchKernelGGL(sp_absmax_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, src, R, C / 4, ld,
-                     reinterpret_cast<unsigned*>(slot));
+  hipLaunchKernelGGL(sp_absmax_kernel, dim3(cdiv(C / 4, 256), cdiv(R, 128), 4), dim3(256), 0, (hipStream_t)stream, src, R,
+                     C / 4, ld, reinterpret_cast<unsigned*>(slot));
   EAV_CHECK_LAUNCH("eav_sp_absmax");
   return EAV_OK;
 }

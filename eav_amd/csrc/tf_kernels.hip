@@ -156,6 +156,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     const int next = row + gridDim.x * 4;
     if (next < M) fetch(next);
     const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
+    float rmax = 0.f;
     float4* dst = reinterpret_cast<float4*>(dx + (int64_t)row * D);
 #pragma unroll
     for (int i = 0; i < LN_MAXQ; ++i) {
@@ -167,13 +168,17 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
           o.x += pv[i].x; o.y += pv[i].y; o.z += pv[i].z; o.w += pv[i].w;
         }
         dst[q] = o;
-        vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
+        rmax = fmaxf(rmax, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
       }
+    }
+    if (amax) {       // this row's maximum into its 128-row block's entry (per-row-block operand scales, eav_common.h)
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) rmax = fmaxf(rmax, __shfl_xor(rmax, o, 64));
+      if (lane == 0) eav_slot_blockmax(amax, row, rmax);
+      vmax = fmaxf(vmax, rmax);
     }
   }
   if (amax) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
     if (lane == 0 && vmax == vmax) atomicMax(amax + EAV_SLOT_SHARD(blockIdx.x * 4 + wave), __float_as_uint(vmax));
   }
   if (!part) return;

@@ -370,7 +370,7 @@ class Encoder(nn.Module):
         return ws
 
     # ------------------------------------------------------------------ split-operand (fp16 hi/lo planes) plumbing
-    SLOT = 2080   # floats per scale slot (include/eav_hip.h EAV_SP_SLOT)
+    SLOT = 4128   # floats per scale slot (include/eav_hip.h EAV_SP_SLOT)
     FS, BS = 5, 6   # slots per layer: forward y1, qkv, ao, y2, act; backward dh(fc2), dact, dh(o), dao, dS, dqkv
 
     def _alloc_split(self, ws, dev, nsave):
@@ -404,7 +404,7 @@ class Encoder(nn.Module):
             ws.np_cs2 = _lib.plain("eav_sp_convert_colsum_nparts", M)
             ws.part_cs2 = torch.empty(ws.np_cs2, max(FF, 3 * D), dtype=torch.float32, device=dev)
             ws.part_cs2_pool = [ws.part_cs2] + [torch.empty_like(ws.part_cs2) for _ in range(3)]
-            ws.bslots = torch.zeros(1 + self.BS * Lr, self.SLOT, dtype=torch.float32, device=dev)
+            ws.bslots = torch.zeros(2 + self.BS * Lr, self.SLOT, dtype=torch.float32, device=dev)
             if ws.fused:
                 ws.dorow = torch.empty(M, 2 * D, dtype=torch.float16, device=dev)
                 ws.doT = torch.empty(ws.B, H, 64, 2 * Npad, dtype=torch.float16, device=dev)
@@ -969,9 +969,12 @@ class Encoder(nn.Module):
                 gflat[offs[f"{pre}.embeddings.distillation_token"][0]:][:D].copy_(gpos[D:2 * D])
             MP = B * c.npatch
             if sp:
-                # demb is a row subset of dh, whose maximum layer 0's LayerNorm backward left in bslot(0)
-                self._to_planes(P(ws.demb), MP, D, D, bslot(0), ws.dembp, amax_done=True)
-                self._wgrad_sp(ws.dembp, bslot(0), ws.colp, fslot(0),
+                # demb (the patch rows of dh) gets its own maximum pass: the slot layer 0's LayerNorm backward filled is
+                # indexed by the rows of dh (cls / distillation rows included), and the per-row-block maxima must be the
+                # converted tensor's own
+                s_demb = bslot(1 + self.BS * c.layers)
+                self._to_planes(P(ws.demb), MP, D, D, s_demb, ws.dembp)
+                self._wgrad_sp(ws.dembp, s_demb, ws.colp, fslot(0),
                                gp(f"{pre}.embeddings.patch_embeddings.projection.weight"), D, c.kp, MP)
             else:
                 self._wgrad(P(ws.demb), P(ws.col), gp(f"{pre}.embeddings.patch_embeddings.projection.weight"), D, c.kp,

@@ -33,7 +33,7 @@ from .eegnet import DeviceLoader, GraphStep, cached_workspace
 from .optim import CrossEntropyLoss, FusedAdam, flatten_parameters
 
 NF, KC, POOL, STRIDE, HD = 40, 13, 35, 7, 64     # filters / conv taps / pool window / pool stride / attention tile
-SLOT = 2080                                      # floats per operand-scale slot (EAV_SP_SLOT, include/eav_hip.h)
+SLOT = 4128                                      # floats per operand-scale slot (EAV_SP_SLOT, include/eav_hip.h)
 
 
 class PatchEmbedding(nn.Module):

@@ -240,7 +240,8 @@ int eav_gemm_bf16_splitk(const float* A, const float* B, float* C, float* ws, in
  * max|x| (one per 128-byte line), sigma and 1/sigma: zero it, let producers atomicMax the shards
  * (eav_sp_absmax or a GEMM's amax_slot), then eav_sp_convert writes the planes of X (dst: contraction over columns)
  * and / or of X^T (dstT: contraction over rows) and fills sigma. */
-#define EAV_SP_SLOT 2080   /* shard i at word 32*i (one 128-byte line each), sigma at word 2048, 1/sigma at 2049 */
+#define EAV_SP_SLOT 4128   /* shard i at word 32*i (one 128-byte line each), sigma at word 2048, 1/sigma at 2049; words
+                            * 2080.. : max|x| bits per 128-row block, 3104.. : boost exponent per 128-row block (1024 each) */
 int eav_sp_kpad(int K);
 int eav_sp_absmax(const float* src, int R, int C, int64_t ld, float* slot, void* stream);
 int eav_sp_convert(const float* src, int R, int C, int64_t ld, float* slot, void* dst, void* dstT, void* stream);

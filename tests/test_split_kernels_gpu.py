@@ -10,7 +10,7 @@ from eav_amd import _lib
 
 pytestmark = pytest.mark.gpu
 P = _lib.ptr
-SLOT = 2080
+SLOT = 4128
 
 
 def kpad(k):
@@ -440,3 +440,80 @@ def test_forward_scales_are_bounds_and_row_norms_are_exact():
     assert float(y2.abs().max()) <= b_y2
     act = torch.nn.functional.gelu(y2 @ w.t() + bf)
     assert float(act.abs().max()) <= b_act
+
+
+@pytest.mark.parametrize("shape", [(2048, 768, 768), (9712, 768, 3072), (1000, 200, 100)])
+def test_rows_of_any_magnitude_keep_fp32_grade_relative_precision(shape):
+    """Per-row-block operand scales: with log-normal ROW scales of sigma = 4 (ten decimal orders between the rows - what a
+    gradient tensor looks like when a few tokens carry almost all of the loss) every output element is as accurate,
+    relative to sum |a||b| of ITS OWN row, as the exact-fp32 MFMA kernel's (bound: 2x).  A 128-row block whose maximum is
+    >= 2^8 below the tensor's gets its own power of two (EAV_SLOT_BMAX / EAV_SLOT_BEXP); one scale per tensor loses the lo
+    piece of rows 2^29 below the maximum (6.7e-5 on this case before)."""
+    M, N, K = shape
+    torch.manual_seed(M + N + K)
+    A = torch.randn(M, K, device="cuda")
+    B = torch.randn(N, K, device="cuda") * 0.02
+    rows = torch.exp(torch.randn(M, 1, device="cuda") * 4)
+    rows, _ = rows.sort(dim=0)                      # slowly varying along the rows (blocks differ, rows of a block agree)
+    A = A * rows
+    ref = A.double() @ B.double().t()
+    den = A.double().abs() @ B.double().abs().t()
+    e_sp = ((gemm_sp(A, B).double() - ref).abs() / den).max().item()
+    e_32 = ((gemm_f32(A, B).double() - ref).abs() / den).max().item()
+    assert e_sp <= 2 * e_32, (e_sp, e_32)
+    slot, pl, _ = planes(A)
+    bexp = slot[3104:3104 + (M + 127) // 128].view(torch.int32)
+    assert int(bexp.max()) >= 8 and int(bexp.min()) == 0           # small blocks were boosted, the largest was not
+    # unsorted rows: a block's scale is set by its largest row - rows are then precise relative to their BLOCK's maximum
+    A2 = A[torch.randperm(M, device="cuda")]
+    ref2 = A2.double() @ B.double().t()
+    blockmax = torch.stack([A2[i:i + 128].abs().max() for i in range(0, M, 128)]).repeat_interleave(128)[:M].double()
+    e2 = ((gemm_sp(A2, B).double() - ref2).abs() / (blockmax[:, None] * B.double().abs().sum(1)[None, :])).max().item()
+    assert e2 < 1e-6
+
+
+def test_weight_gradient_undoes_the_row_block_boosts():
+    """The token-contracting product reads the same planes: a boosted token block's fragments are scaled back before the
+    MFMAs.  dY with token blocks 2^12 .. 2^30 below the largest, X plain: dW equals the float64 product to 2e-7 of
+    sum |a||b| - with and without the boosts - and the bias-gradient partials of the boosted conversion are the plain
+    column sums."""
+    tokens, N, K = 4096, 256, 384
+    torch.manual_seed(11)
+    dY = torch.randn(tokens, N, device="cuda")
+    X = torch.randn(tokens, K, device="cuda")
+    scale = torch.ones(tokens, 1, device="cuda")
+    scale[128:256] = 2.0 ** -12
+    scale[1024:1536] = 2.0 ** -20
+    scale[2048:2176] = 2.0 ** -30
+    dY = dY * scale
+    sa, pa = row_planes(dY)
+    sb, pb = row_planes(X)
+    bexp = sa[3104:3104 + tokens // 128].view(torch.int32).cpu().tolist()
+    assert bexp[1] == 12 and bexp[8] == 20 and bexp[16] == 30 and bexp[0] == 0
+    C = torch.empty(N, K, device="cuda")
+    ns = _lib.plain("eav_gemm_sp_splitk_plan", N, K, tokens)
+    ws = torch.empty(max(ns, 1) * N * K, device="cuda")
+    _lib.call("eav_gemm_sp_splitk", P(pa), P(pb), P(C), P(ws), P(sa), P(sb), N, K, tokens, 0, None)
+    ref = dY.double().t() @ X.double()
+    den = dY.double().abs().t() @ X.double().abs()
+    assert ((C.double() - ref).abs() / den).max().item() < 2e-7
+    # only the small blocks contribute (X zero elsewhere): their un-boosted fragments still carry them exactly enough
+    X2 = X.clone()
+    X2[:128] = 0
+    X2[256:1024] = 0
+    X2[1536:] = 0
+    sb2, pb2 = row_planes(X2)
+    _lib.call("eav_gemm_sp_splitk", P(pa), P(pb2), P(C), P(ws), P(sa), P(sb2), N, K, tokens, 0, None)
+    ref2 = dY.double().t() @ X2.double()
+    den2 = dY.double().abs().t() @ X2.double().abs()
+    assert ((C.double() - ref2).abs() / den2).max().item() < 1e-5
+    # bias gradient of the boosted conversion
+    slot = torch.zeros(SLOT, device="cuda")
+    _lib.call("eav_sp_absmax", P(dY), tokens, N, N, P(slot), None)
+    npart = _lib.plain("eav_sp_convert_colsum_nparts", tokens)
+    part = torch.empty(npart, N, device="cuda")
+    pl = torch.zeros(tokens, 2 * kpad(N), dtype=torch.float16, device="cuda")
+    _lib.call("eav_sp_convert_colsum", P(dY), tokens, N, N, P(slot), P(pl), None, P(part), None)
+    got = part.double().sum(0)
+    want = dY.double().sum(0)
+    assert (got - want).abs().max().item() <= 1e-5 * dY.double().abs().sum(0).max().item()

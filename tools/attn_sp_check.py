@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from eav_amd import _lib  # noqa: E402
 
 P = _lib.ptr
-SLOT = 2080
+SLOT = 4128
 
 
 def prep(x, B, N, ncols, secw, tmask, amax=True):

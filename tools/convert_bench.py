@@ -8,7 +8,7 @@ _lib.load()
 raw = ctypes.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "eav_amd", "libeav_hip.so"))
 for R, C in ((9712, 768), (9712, 3072), (25216, 768), (25216, 3072), (25216, 2304)):
     x = torch.randn(R, C, device="cuda")
-    slot = torch.zeros(2080, device="cuda")
+    slot = torch.zeros(4128, device="cuda")
     _lib.call("eav_sp_absmax", P(x), R, C, C, P(slot), None)
     d = torch.empty(R, 2 * kpad(C), dtype=torch.float16, device="cuda")
     dT = torch.empty(C, 2 * kpad(R), dtype=torch.float16, device="cuda")

@@ -20,7 +20,7 @@ for tag, M in (("ast B=8", 9712), ("vit B=128", 25216)):
     sa, pa, _ = planes(A)
     sb, pb, _ = planes(B)
     pre = torch.empty(M, N, device="cuda")
-    slot = torch.zeros(2080, device="cuda")
+    slot = torch.zeros(4128, device="cuda")
     pl = torch.zeros((M + 31) // 32 * 32, 2 * kpad(N), dtype=torch.float16, device="cuda")
 
     def unfused():
@@ -29,7 +29,7 @@ for tag, M in (("ast B=8", 9712), ("vit B=128", 25216)):
                   P(slot), None)
         _lib.call("eav_sp_convert_gelu", P(pre), M, N, N, P(slot), P(pl), None, None)
 
-    slot2 = torch.zeros(2080, device="cuda")
+    slot2 = torch.zeros(4128, device="cuda")
     slot2[2048], slot2[2049] = 4096.0, 1 / 4096.0
 
     def fused():

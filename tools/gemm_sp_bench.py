@@ -19,7 +19,7 @@ def kpad(k):
 def planes(x, want=True, wantT=False):
     """x [R,C] fp32 device -> (slot, planes [R, 2*Cp] f16 | None, planesT [C, 2*Rp] f16 | None)"""
     R, C = x.shape
-    slot = torch.zeros(2080, device="cuda")
+    slot = torch.zeros(4128, device="cuda")
     _lib.call("eav_sp_absmax", P(x), R, C, x.stride(0), P(slot), None)
     d = torch.empty(R, 2 * kpad(C), dtype=torch.float16, device="cuda") if want else None
     dT = torch.empty(C, 2 * kpad(R), dtype=torch.float16, device="cuda") if wantT else None
@@ -30,7 +30,7 @@ def planes(x, want=True, wantT=False):
 def row_planes(x):
     """row planes with the rows zero-padded to a multiple of 32 (operands of the token-contracting eav_gemm_sp_splitk)"""
     R, C = x.shape
-    slot = torch.zeros(2080, device="cuda")
+    slot = torch.zeros(4128, device="cuda")
     _lib.call("eav_sp_absmax", P(x), R, C, x.stride(0), P(slot), None)
     d = torch.zeros((R + 31) // 32 * 32, 2 * kpad(C), dtype=torch.float16, device="cuda")
     _lib.call("eav_sp_convert", P(x), R, C, x.stride(0), P(slot), P(d), None, None)
@@ -130,7 +130,7 @@ def bench_splitk(name, M, N, K):
 
 def bench_convert(R, C):
     x = torch.randn(R, C, device="cuda")
-    slot = torch.zeros(2080, device="cuda")
+    slot = torch.zeros(4128, device="cuda")
     d = torch.empty(R, 2 * kpad(C), dtype=torch.float16, device="cuda")
     dT = torch.empty(C, 2 * kpad(R), dtype=torch.float16, device="cuda")
     gb = R * C * 4 / 1e9

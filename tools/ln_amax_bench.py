@@ -6,7 +6,7 @@ for M in (9712, 25216):
     D = 768
     x = torch.randn(M, D, device="cuda"); g = torch.ones(D, device="cuda"); b = torch.zeros(D, device="cuda")
     y = torch.empty_like(x); mean = torch.empty(M, device="cuda"); rstd = torch.empty(M, device="cuda")
-    slot = torch.zeros(2080, device="cuda")
+    slot = torch.zeros(4128, device="cuda")
     def t(f, n=20):
         for _ in range(3): f()
         a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -309,12 +309,12 @@ __global__ __launch_bounds__(256, 3) void fir_wgrad_kernel(
 
 }  // namespace
 
-static int fir_grid(int nwork) { return nwork < 512 ? nwork : 512; }
-static int wgrad_grid(int nwork) { return nwork < 768 ? nwork : 768; }
+static int fir_grid(int64_t nwork) { return nwork < 512 ? (int)nwork : 512; }
+static int wgrad_grid(int64_t nwork) { return nwork < 768 ? (int)nwork : 768; }
 
 extern "C" int eav_eegnet_fir_fwd_nparts(int B, int C, int S) {
   int ntiles = cdiv(S, TILE), nseg = cdiv(ntiles, TPS);
-  return fir_grid(B * C * nseg);
+  return fir_grid((int64_t)B * C * nseg);
 }
 
 extern "C" int eav_eegnet_fir_fwd_indexed(const float* x, const int64_t* xidx, const float* w1, float* y1,
@@ -353,7 +353,7 @@ static void wgrad_geometry(int S, int* nchunk, int* CH) {
 extern "C" int eav_eegnet_fir_wgrad_nparts(int B, int C, int S) {
   int nchunk, CH;
   wgrad_geometry(S, &nchunk, &CH);
-  return wgrad_grid(B * C * nchunk);
+  return wgrad_grid((int64_t)B * C * nchunk);
 }
 
 // part: [nparts][8][klen] floats; sum over parts = dL/d(firstConv.weight)

@@ -524,10 +524,10 @@ extern "C" int eav_fir_dy_scale(const float* bn_params, const float* dzmax_part,
   return EAV_OK;
 }
 
-static int wgrad_split_grid(int nwork) { return nwork < 1536 ? nwork : 1536; }
+static int wgrad_split_grid(int64_t nwork) { return nwork < 1536 ? (int)nwork : 1536; }
 
 extern "C" int eav_eegnet_fir_wgrad_split_nparts(int B, int C, int S) {
-  return wgrad_split_grid(B * C * cdiv(S + 1, WCH));
+  return wgrad_split_grid((int64_t)B * C * cdiv(S + 1, WCH));
 }
 
 extern "C" int eav_eegnet_fir_wgrad_split(const float* x, const float* y1, const float* g1, const float* bn_params,

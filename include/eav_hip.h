@@ -297,15 +297,17 @@ int eav_tf_forward_scales(const float* params, int64_t layer_stride, int layers,
 int eav_gemm_sp_splitk_plan(int M, int N, int K);
 int eav_gemm_sp_splitk(const void* A, const void* B, float* C, float* ws, const float* slotA, const float* slotB, int M,
                        int N, int T, int accumulate, void* stream);
-int eav_gemm_sp_set_tile(int which);   /* tuning hook: 0 heuristic, 1 = 128x128 tiles, 2 = 256x128 */
-int eav_sp_set_convert_blocks(int n);  /* tuning hook: resident-block cap of eav_sp_convert (default 512; 0 = one block per tile) */
+/* TEST / TUNING ONLY - process-global state, not part of the drop-in boundary: the trainers never call these; the kernel
+ * benchmarks under tools/ and tests/test_split_kernels_gpu.py use them to A/B tile shapes inside one process. */
+int eav_gemm_sp_set_tile(int which);   /* 0 heuristic, 1 = 128x128 tiles, 2 = 256x128, +4 single accumulator, +8 non-persistent */
+int eav_sp_set_convert_blocks(int n);  /* resident-block cap of eav_sp_convert (default 512; 0 = one block per tile) */
 /* The same fused attention on the fp16 matrix cores with split operands (csrc/attention_sp.hip; fp32-grade, 3 MFMAs per
  * product).  eav_attn_sp_prep converts an fp32 activation src [B*N, ncols] (qkv or dO; slot holds its max|x| shards, see
  * EAV_SP_SLOT) into row planes [B*N][ncols/8][2][8] f16 and, for the column sections (of secw columns) selected by
  * tmask, per-head transposed planes [B][ncols/64][64][Npad/8][2][8] (Npad = eav_attn_sp_npad(N), zero beyond N); here
  * lo = fp16(sigma x - hi) without the 2^11 lift of the GEMM planes.  amax_slot (optional) receives max|output| shards. */
 int eav_attn_sp_npad(int N);
-int eav_attn_sp_set_nw4_above(int n);   /* tuning hook: 128-row (4-wave) workgroups for N > n (default 128) */
+int eav_attn_sp_set_nw4_above(int n);   /* TEST / TUNING ONLY (as eav_gemm_sp_set_tile): 128-row (4-wave) workgroups for N > n (default 128) */
 int eav_attn_sp_prep(const float* src, float* slot, void* rowp, void* tp, int B, int N, int ncols, int secw,
                      unsigned tmask, void* stream);
 int eav_attn_fwd_sp(const void* rowp, const void* tp, const float* slot, float* ao, float* lse, float* amax_slot, int B,

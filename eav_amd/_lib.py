@@ -104,6 +104,7 @@ SIGNATURES = {
     "eav_bn_elu_pool_fwd_absmax": [_p, _p, _p, _p, _i, _i, _i, _i, _f, _u64, _p, _p, _p],
     "eav_bn_elu_pool_bwd_apply_absmax": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _u64, _p, _p, _p],
     "eav_eegnet_fir_wgrad_split": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "eav_eegnet_block1_infer": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "eav_tconv_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "eav_tconv_wgrad": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "eav_spatial_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],

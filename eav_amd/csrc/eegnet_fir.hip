@@ -307,6 +307,127 @@ __global__ __launch_bounds__(256, 3) void fir_wgrad_kernel(
   }
 }
 
+// -------------------------------------------------------------------------------- inference: x -> block-1 output
+// No-grad evaluation (Trainer_uni.validate, EEGNet_tor.py:118-135; BatchNorm on running statistics, no dropout):
+//     p2[b, f*8+d, t/4] = mean_{e<4} ELU(bn2(sum_c w2[f*8+d, c] ELU(bn1(FIR_f(x[b,c,:]))[4(t/4)+e])))
+// in ONE pass - the FIR output y1 [B,8,C,S] (614 MB at the benchmark shape), its ELU and the depthwise output z
+// [B,64,S] never exist in memory.  Same Toeplitz MFMA tile as fir_fwd_kernel (8 filters x 128 samples per wave), but a
+// work item is (sample b, 4 tiles = 512 samples, one per wave) and walks the C electrodes: each lane keeps the 4 filters x
+// 8 depth multipliers x 4 samples of z it owns in 128 registers (one wave per SIMD, 512-register budget; the f32 MFMA
+// reaches its issue rate from a single dependent accumulator chain), and since a lane's four samples are exactly one
+// AvgPool(1,4) window, BN2 -> ELU -> pool is lane-local.  x rows are double-buffered in LDS (one barrier per electrode)
+// with the next row's loads in flight during the MFMA phase.
+template <int NSTEP>
+__global__ __launch_bounds__(256, 1) void fir_dw_infer_kernel(const float* __restrict__ x, const float* __restrict__ w1,
+                                                              const float* __restrict__ bn1, const float* __restrict__ w2,
+                                                              const float* __restrict__ bn2, float* __restrict__ p2,
+                                                              int B, int C, int S, int klen, int padl, int nseg,
+                                                              const int64_t* __restrict__ xidx) {
+  constexpr int TPB = 4;                          // tiles per work item: one per wave
+  constexpr int HALO = 2 * NSTEP;
+  constexpr int SEG_M4 = TPB * 32 + NSTEP / 2;    // floats per polyphase plane
+  __shared__ __attribute__((aligned(16))) float xs[2][4 * SEG_M4];
+  __shared__ __attribute__((aligned(16))) float w2s[32 * 64];      // [c][f*8+d]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = lane & 31, kk = lane >> 5;
+  float a[NSTEP];
+  {
+    const int f = n >> 2, sft = n & 3;
+#pragma unroll
+    for (int p = 0; p < NSTEP; ++p) {
+      const int j = 2 * p + kk - sft;
+      a[p] = (j >= 0 && j < klen) ? w1[f * klen + j] : 0.f;
+    }
+  }
+  for (int i = threadIdx.x; i < C * 64; i += 256) {
+    const int c = i >> 6, fd = i & 63;
+    w2s[i] = w2[fd * C + c];
+  }
+  float sc1[4], sh1[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    sc1[g] = bn1[2 * F1 + 2 * g + kk];
+    sh1[g] = bn1[3 * F1 + 2 * g + kk];
+  }
+  const int T2 = S >> 2;
+  const int nwork = B * nseg;
+  constexpr int NLD = (TPB * TILE + HALO + 255) / 256;
+  float xr[NLD];
+  auto fetch = [&](int work, int c) {
+    const int b = work / nseg, seg = work - b * nseg;
+    const int useg0 = seg * TPB * TILE;
+    const float* xrow = x + ((xidx ? xidx[b] : (int64_t)b) * C + c) * S;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int idx = threadIdx.x + 256 * i;
+      const int t = useg0 + idx - padl;
+      xr[i] = (idx < TPB * TILE + HALO && t >= 0 && t < S) ? xrow[t] : 0.f;
+    }
+  };
+  int it = 0;                                     // electrode iterations so far: LDS buffer = it & 1
+  if ((int)blockIdx.x < nwork) fetch(blockIdx.x, 0);
+  for (int work = blockIdx.x; work < nwork; work += gridDim.x) {
+    const int b = work / nseg, seg = work - b * nseg;
+    const int t0 = (seg * TPB + wave) * TILE;      // first sample of this wave's tile
+    float z[4][8][4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int d = 0; d < 8; ++d)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) z[g][d][e] = 0.f;
+    for (int c = 0; c < C; ++c, ++it) {
+      float* buf = xs[it & 1];
+#pragma unroll
+      for (int i = 0; i < NLD; ++i) {
+        const int idx = threadIdx.x + 256 * i;
+        if (idx < TPB * TILE + HALO) buf[(idx & 3) * SEG_M4 + (idx >> 2)] = xr[i];
+      }
+      __syncthreads();      // (also orders the w2s fill before its first use; the other buffer was read an iteration ago)
+      if (c + 1 < C) fetch(work, c + 1);
+      else if (work + (int)gridDim.x < nwork) fetch(work + gridDim.x, 0);
+      const float* pe = buf + kk * SEG_M4 + wave * 32 + n;
+      const float* po = buf + (2 + kk) * SEG_M4 + wave * 32 + n;
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int p = 0; p < NSTEP; ++p) {
+        const float bv = (p & 1) ? po[p >> 1] : pe[p >> 1];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[p], bv, acc, 0, 0, 0);
+      }
+      // acc[4g + e] = y1[f = 2g + kk][t0 + 4n + e]: firstBN (running statistics) -> ELU -> this electrode's column of the
+      // depthwise weights
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 wa = *reinterpret_cast<const float4*>(w2s + c * 64 + (2 * g + kk) * 8);
+        const float4 wb = *reinterpret_cast<const float4*>(w2s + c * 64 + (2 * g + kk) * 8 + 4);
+        const float wv[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = elu_f(fmaf(sc1[g], acc[4 * g + e], sh1[g]));
+#pragma unroll
+          for (int d = 0; d < 8; ++d) z[g][d][e] = fmaf(wv[d], v, z[g][d][e]);
+        }
+      }
+    }
+    // depthwiseBN (running statistics) -> ELU -> AvgPool(1,4): the lane's four samples are one pooling window
+    const int tp = (t0 >> 2) + n;
+    if (tp < T2) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+          const int fd = (2 * g + kk) * 8 + d;
+          const float s2 = bn2[2 * 64 + fd], h2 = bn2[3 * 64 + fd];
+          const float v = (elu_f(fmaf(s2, z[g][d][0], h2)) + elu_f(fmaf(s2, z[g][d][1], h2))) +
+                          (elu_f(fmaf(s2, z[g][d][2], h2)) + elu_f(fmaf(s2, z[g][d][3], h2)));
+          p2[((int64_t)b * 64 + fd) * T2 + tp] = 0.25f * v;
+        }
+    }
+  }
+}
+
 }  // namespace
 
 static int fir_grid(int64_t nwork) { return nwork < 512 ? (int)nwork : 512; }
@@ -389,5 +510,28 @@ extern "C" int eav_eegnet_fir_wgrad_indexed(const float* x, const int64_t* xidx,
   else EAV_FIR_WG(10);
 #undef EAV_FIR_WG
   EAV_CHECK_LAUNCH("eav_eegnet_fir_wgrad");
+  return EAV_OK;
+}
+
+// No-grad forward of block 1 in eval mode: x [B,C,S] (or rows xidx of a resident data set) -> p2 [B,64,S/4] =
+// AvgPool4(ELU(depthwiseBN(depthwiseConv(ELU(firstBN(firstConv(x))))))) with both BatchNorms on their running statistics
+// (bn1 / bn2: mean, invstd, scale, shift as eav_bn_finalize writes them in eval mode).  S % 4 == 0, C <= 32.
+extern "C" int eav_eegnet_block1_infer(const float* x, const int64_t* xidx, const float* w1, const float* bn1,
+                                       const float* w2, const float* bn2, float* p2, int B, int C, int S, int klen,
+                                       void* stream) {
+  EAV_REQUIRE(x && w1 && bn1 && w2 && bn2 && p2 && B > 0 && C > 0 && C <= 32 && S >= 4 && (S & 3) == 0,
+              "eav_eegnet_block1_infer: bad arguments (need C <= 32, S %% 4 == 0)");
+  EAV_REQUIRE(klen >= 1 && klen <= 300, "eav_eegnet_block1_infer: kernLength %d outside [1,300]", klen);
+  const int ntiles = cdiv(S, TILE), nseg = cdiv(ntiles, 4);
+  const int64_t nwork = (int64_t)B * nseg;
+  const int grid = nwork < 256 ? (int)nwork : 256;
+#define EAV_FIR_INF(NS)                                                                                          \
+  hipLaunchKernelGGL(fir_dw_infer_kernel<NS>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, w1, bn1, w2, bn2, p2, \
+                     B, C, S, klen, (klen - 1) / 2, nseg, xidx)
+  if (klen <= 65) EAV_FIR_INF(34);
+  else if (klen <= 129) EAV_FIR_INF(66);
+  else EAV_FIR_INF(152);
+#undef EAV_FIR_INF
+  EAV_CHECK_LAUNCH("eav_eegnet_block1_infer");
   return EAV_OK;
 }

@@ -198,6 +198,7 @@ class EEGNet_tor(nn.Module):
         # opt-in because its arithmetic is not a plain fp32 fma chain
         self.fir_precision = "fp32"
         self._fwd_counter = None               # device uint64: number of training forwards (dropout stream)
+        self._infer = False                    # set per call: no-grad eval-mode forward (fused block-1 kernel)
 
     # ------------------------------------------------------------------ plumbing
     def _ensure_flat(self):
@@ -228,6 +229,8 @@ class EEGNet_tor(nn.Module):
             raise _lib.EavError("model and input are on different devices")
         x = x.contiguous().float()
         self._ensure_flat()
+        # no-grad evaluation (validate(), EEGNet_tor.py:118-135): block 1 runs as one fused kernel, see _launch_forward
+        self._infer = (not torch.is_grad_enabled()) and (not self.training)
         return _EEGNetFn.apply(x, self, *self._params())
 
     def forward_indexed(self, data, idx):
@@ -247,6 +250,7 @@ class EEGNet_tor(nn.Module):
         if self.firstConv.weight.device != data.device:
             raise _lib.EavError("model and input are on different devices")
         self._ensure_flat()
+        self._infer = (not torch.is_grad_enabled()) and (not self.training)
         return _EEGNetFn.apply(IndexedBatch(data, idx), self, *self._params())
 
     # ------------------------------------------------------------------ kernels
@@ -308,7 +312,17 @@ class EEGNet_tor(nn.Module):
         if self.fir_precision not in ("fp32", "split"):
             raise ValueError(f"fir_precision {self.fir_precision!r}: expected 'fp32' or 'split'")
         split = self.fir_precision == "split"
-        if split:
+        infer = self._infer and not training and not split and S % 4 == 0
+        if infer:
+            # validate(): x -> block-1 output in ONE kernel (FIR -> firstBN -> ELU -> depthwiseConv -> depthwiseBN -> ELU ->
+            # AvgPool4; BatchNorms on running statistics): y1 (614 MB at [64,1,30,10000]) and z are never written
+            bnfin(ws.part_fir, ws.np_fir, 8, B * C * S, g1w, g1b, bn1, ws.bn1)          # eval mode: running statistics only
+            bnfin(ws.part_dw, B * ws.nchunk, 64, B * S, g2w, g2b, bn2, ws.bn2)
+            if isinstance(x, IndexedBatch):
+                L("eav_eegnet_block1_infer", P(x.data), P(x.idx), w1, P(ws.bn1), w2, P(ws.bn2), P(ws.p2), B, C, S, K, st)
+            else:
+                L("eav_eegnet_block1_infer", P(x), None, w1, P(ws.bn1), w2, P(ws.bn2), P(ws.p2), B, C, S, K, st)
+        elif split:
             L("eav_absmax_scale", P(x), B * C * S, 1.0, P(ws.part_amax), P(ws.scale_x), st)
             L("eav_absmax_scale", w1, 8 * K, 1.0, P(ws.part_amax), P(ws.scale_w), st)
             L("eav_eegnet_fir_fwd_split", P(x), w1, P(ws.scale_x), P(ws.scale_w), P(ws.y1), P(ws.part_fir), B, C, S, K,
@@ -318,11 +332,12 @@ class EEGNet_tor(nn.Module):
                 L("eav_eegnet_fir_fwd_indexed", P(x.data), P(x.idx), w1, P(ws.y1), P(ws.part_fir), B, C, S, K, st)
             else:
                 L("eav_eegnet_fir_fwd", P(x), w1, P(ws.y1), P(ws.part_fir), B, C, S, K, st)
-        bnfin(ws.part_fir, ws.np_fir, 8, B * C * S, g1w, g1b, bn1, ws.bn1)
-        L("eav_eegnet_dw_fwd", P(ws.y1), P(ws.bn1), w2, P(ws.z), P(ws.part_dw), B, C, S, st)
-        bnfin(ws.part_dw, B * ws.nchunk, 64, B * S, g2w, g2b, bn2, ws.bn2)
-        L("eav_bn_elu_pool_fwd_absmax", P(ws.z), P(ws.bn2), P(ws.p2), P(ws.rowmax_p2) if split else None, B, 64, S, 4,
-          drop, seed1, m1, cnt, st)
+        if not infer:
+            bnfin(ws.part_fir, ws.np_fir, 8, B * C * S, g1w, g1b, bn1, ws.bn1)
+            L("eav_eegnet_dw_fwd", P(ws.y1), P(ws.bn1), w2, P(ws.z), P(ws.part_dw), B, C, S, st)
+            bnfin(ws.part_dw, B * ws.nchunk, 64, B * S, g2w, g2b, bn2, ws.bn2)
+            L("eav_bn_elu_pool_fwd_absmax", P(ws.z), P(ws.bn2), P(ws.p2), P(ws.rowmax_p2) if split else None, B, 64, S, 4,
+              drop, seed1, m1, cnt, st)
         L("eav_conv64_prep_weights", w3, P(ws.wTf), P(ws.wTb), st)
         if split:
             L("eav_absmax_finish", P(ws.rowmax_p2), B * 64, 1.0, P(ws.scale_p2), st)

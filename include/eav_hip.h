@@ -48,6 +48,13 @@ int eav_renorm_rows(float* w, int rows, int cols, float maxnorm, void* stream);
 int eav_eegnet_fir_fwd_nparts(int B, int C, int S);
 int eav_eegnet_fir_fwd(const float* x, const float* w1, float* y1, float* stat_part, int B, int C, int S, int klen,
                        void* stream);
+/* No-grad evaluation of block 1 (Trainer_uni.validate, EEGNet_tor.py:118-135; model.eval(): BatchNorm on running
+ * statistics, no dropout): x [B,C,S] (or rows xidx of a resident [*,C,S] array; xidx may be NULL) -> p2 [B,64,S/4] =
+ * AvgPool(1,4)(ELU(depthwiseBN(depthwiseConv(ELU(firstBN(firstConv(x))))))) in one pass - the FIR output, its ELU and the
+ * depthwise output never exist in memory.  bn1 / bn2: mean, invstd, scale, shift (8 / 64 floats each) as eav_bn_finalize
+ * writes them in eval mode; w2 = depthwiseConv.weight [64,C].  C <= 32, S % 4 == 0, klen <= 300. */
+int eav_eegnet_block1_infer(const float* x, const int64_t* xidx, const float* w1, const float* bn1, const float* w2,
+                            const float* bn2, float* p2, int B, int C, int S, int klen, void* stream);
 /* firstConv weight gradient fused with firstBN backward (autograd of EEGNet_tor.py:51-52):
  * bn_params = mean, invstd, scale, shift, m1, m2 (8 floats each); part [nparts][8][klen].
  * y1 == NULL: BatchNorm in eval mode (m1 = m2 = 0, the gradient through firstBN is scale * g1; y1 is not read). */

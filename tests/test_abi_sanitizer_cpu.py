@@ -1,4 +1,4 @@
-"""Host half of the C ABI under AddressSanitizer + UBSan (no GPU needed): `make -C eav_amd/csrc asan` builds
+"""Host half of the C ABI under AddressSanitizer + UBSan (no GPU needed): `make -C eav_amd/csrc -f asan.mk` builds
 libeav_hip_asan.so (host code instrumented, device code plain - GPU ASan is not available on this pool); a child process
 preloads the ASan runtime, loads the library and drives every entry point on the paths that return before anything would
 be launched - the plan / size helpers over a grid of shapes (integer arithmetic, divisions, clamps) and every status
@@ -51,7 +51,7 @@ print("asan-ok", n_plain, n_status)
 
 def test_host_half_of_the_abi_is_clean_under_asan_and_ubsan(tmp_path):
     csrc = os.path.join(ROOT, "eav_amd", "csrc")
-    r = subprocess.run(["make", "-C", csrc, "-j8", "asan"], capture_output=True, text=True, timeout=1500)
+    r = subprocess.run(["make", "-C", csrc, "-f", "asan.mk", "-j8", "asan"], capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     libpath = os.path.join(ROOT, "eav_amd", "libeav_hip_asan.so")
     rts = sorted(glob.glob("/opt/rocm*/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so"))

@@ -317,6 +317,23 @@ __global__ __launch_bounds__(256, 3) void fir_wgrad_kernel(
 // reaches its issue rate from a single dependent accumulator chain), and since a lane's four samples are exactly one
 // AvgPool(1,4) window, BN2 -> ELU -> pool is lane-local.  x rows are double-buffered in LDS (one barrier per electrode)
 // with the next row's loads in flight during the MFMA phase.
+// ELU for the inference kernel: expm1 as its Taylor polynomial on (-0.5, 0] (truncation < 6e-9) and v_exp_f32 - 1 below
+// (absolute error < 1e-7, the result is in (-1, -0.39]) - a dozen VALU instructions against libm's ~40 with branches
+__device__ __forceinline__ float elu_fast(float v) {
+  const float x = fminf(v, 0.f);
+  float p = 1.f / 40320.f;
+  p = fmaf(p, x, 1.f / 5040.f);
+  p = fmaf(p, x, 1.f / 720.f);
+  p = fmaf(p, x, 1.f / 120.f);
+  p = fmaf(p, x, 1.f / 24.f);
+  p = fmaf(p, x, 1.f / 6.f);
+  p = fmaf(p, x, 0.5f);
+  p = fmaf(p, x, 1.f);
+  p *= x;
+  const float q = __expf(x) - 1.f;
+  return v > 0.f ? v : (x > -0.5f ? p : q);
+}
+
 template <int NSTEP>
 __global__ __launch_bounds__(256, 1) void fir_dw_infer_kernel(const float* __restrict__ x, const float* __restrict__ w1,
                                                               const float* __restrict__ bn1, const float* __restrict__ w2,
@@ -376,6 +393,26 @@ __global__ __launch_bounds__(256, 1) void fir_dw_infer_kernel(const float* __res
       for (int d = 0; d < 8; ++d)
 #pragma unroll
         for (int e = 0; e < 4; ++e) z[g][d][e] = 0.f;
+    // One wave per SIMD: nothing else hides the VALU tail of an electrode (firstBN -> ELU -> 8 depth multipliers: 16 ELUs +
+    // 128 FMAs per lane), so it is software-pipelined by hand - the tail of electrode c - 1 (accumulator accp) is cut into
+    // 32 half-units of <= 12 VALU instructions, one after every 4th MFMA of electrode c: each sits in the 64-cycle shadow
+    // of the dependent MFMA chain.
+    f32x16 accp;
+    float wv[8], ev = 0.f;
+    auto tail_half = [&](int u, int cprev) {      // u in [0, 32): (g, e) = (u >> 3, (u >> 1) & 3), half = u & 1
+      const int g = u >> 3, e = (u >> 1) & 3;
+      if ((u & 7) == 0) {
+        const float4 wa = *reinterpret_cast<const float4*>(w2s + cprev * 64 + (2 * g + kk) * 8);
+        const float4 wb = *reinterpret_cast<const float4*>(w2s + cprev * 64 + (2 * g + kk) * 8 + 4);
+        wv[0] = wa.x; wv[1] = wa.y; wv[2] = wa.z; wv[3] = wa.w; wv[4] = wb.x; wv[5] = wb.y; wv[6] = wb.z; wv[7] = wb.w;
+      }
+      if ((u & 1) == 0) {
+        ev = elu_fast(fmaf(sc1[g], accp[4 * g + e], sh1[g]));
+      } else {
+#pragma unroll
+        for (int d = 0; d < 8; ++d) z[g][d][e] = fmaf(wv[d], ev, z[g][d][e]);
+      }
+    };
     for (int c = 0; c < C; ++c, ++it) {
       float* buf = xs[it & 1];
 #pragma unroll
@@ -391,26 +428,21 @@ __global__ __launch_bounds__(256, 1) void fir_dw_infer_kernel(const float* __res
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      constexpr int EVERY = NSTEP >= 128 ? 4 : (NSTEP >= 64 ? 2 : 1);
 #pragma unroll
       for (int p = 0; p < NSTEP; ++p) {
         const float bv = (p & 1) ? po[p >> 1] : pe[p >> 1];
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[p], bv, acc, 0, 0, 0);
-      }
-      // acc[4g + e] = y1[f = 2g + kk][t0 + 4n + e]: firstBN (running statistics) -> ELU -> this electrode's column of the
-      // depthwise weights
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float4 wa = *reinterpret_cast<const float4*>(w2s + c * 64 + (2 * g + kk) * 8);
-        const float4 wb = *reinterpret_cast<const float4*>(w2s + c * 64 + (2 * g + kk) * 8 + 4);
-        const float wv[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float v = elu_f(fmaf(sc1[g], acc[4 * g + e], sh1[g]));
-#pragma unroll
-          for (int d = 0; d < 8; ++d) z[g][d][e] = fmaf(wv[d], v, z[g][d][e]);
+        if (c > 0 && p % EVERY == EVERY - 1 && p / EVERY < 32) {
+          __builtin_amdgcn_sched_barrier(0);
+          tail_half(p / EVERY, c - 1);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
+      accp = acc;
     }
+#pragma unroll
+    for (int u = 0; u < 32; ++u) tail_half(u, C - 1);     // the last electrode's tail: nothing left to hide it behind
     // depthwiseBN (running statistics) -> ELU -> AvgPool(1,4): the lane's four samples are one pooling window
     const int tp = (t0 >> 2) + n;
     if (tp < T2) {

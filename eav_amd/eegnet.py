@@ -198,7 +198,11 @@ class EEGNet_tor(nn.Module):
         # opt-in because its arithmetic is not a plain fp32 fma chain
         self.fir_precision = "fp32"
         self._fwd_counter = None               # device uint64: number of training forwards (dropout stream)
-        self._infer = False                    # set per call: no-grad eval-mode forward (fused block-1 kernel)
+        self._infer = False                    # set per call: no-grad eval-mode forward
+        # validate()'s forward with block 1 as ONE kernel (eav_eegnet_block1_infer: y1 / z never written).  Opt-in: at the
+        # benchmark shape [64,1,30,10000] it measures 1.35 ms against 1.30 ms for the training kernels in eval mode - with its
+        # 128 z accumulators per lane it runs one wave per SIMD and cannot hide its VALU tail behind another wave's MFMAs
+        self.fused_eval = False
 
     # ------------------------------------------------------------------ plumbing
     def _ensure_flat(self):
@@ -312,7 +316,7 @@ class EEGNet_tor(nn.Module):
         if self.fir_precision not in ("fp32", "split"):
             raise ValueError(f"fir_precision {self.fir_precision!r}: expected 'fp32' or 'split'")
         split = self.fir_precision == "split"
-        infer = self._infer and not training and not split and S % 4 == 0
+        infer = self.fused_eval and self._infer and not training and not split and S % 4 == 0
         if infer:
             # validate(): x -> block-1 output in ONE kernel (FIR -> firstBN -> ELU -> depthwiseConv -> depthwiseBN -> ELU ->
             # AvgPool4; BatchNorms on running statistics): y1 (614 MB at [64,1,30,10000]) and z are never written

@@ -484,13 +484,14 @@ def test_indexed_batch_equals_gathered_batch(training):
 
 @pytest.mark.parametrize("S,B", [(500, 5), (10000, 3), (132, 2)])
 def test_no_grad_eval_forward_fuses_block1_and_matches_the_unfused_path(S, B):
-    """validate() (EEGNet_tor.py:118-135) runs the model in eval mode under no_grad: block 1 is then ONE kernel
+    """validate() (EEGNet_tor.py:118-135) runs the model in eval mode under no_grad: with `fused_eval` block 1 is ONE kernel
     (eav_eegnet_block1_infer: FIR -> firstBN -> ELU -> depthwiseConv -> depthwiseBN -> ELU -> AvgPool4, nothing of it
     written to memory).  Same probabilities as the eval-mode forward of the training kernels (which the reference goldens
     pin), also with the batch addressed in place."""
     from oracle import eegnet_oracle as orc
     sd = eegnet_weights(51, S)
     model = build(S, sd).eval()
+    model.fused_eval = True
     x, _ = synth.eeg_batch(510, B, 30, S)
     xd = torch.from_numpy(x).cuda()
     ref = model(xd).detach().clone()                       # grad enabled: the unfused eval-mode kernels
@@ -500,8 +501,8 @@ def test_no_grad_eval_forward_fuses_block1_and_matches_the_unfused_path(S, B):
         big = torch.cat([xd, xd.flip(0)], 0).contiguous()
         idx = torch.arange(B, 2 * B, device="cuda")
         got_idx = model.forward_indexed(big, idx).clone()
-    close(got, ref, 1e-5, 2e-6, "fused no-grad forward")
-    close(got_idx, model(xd.flip(0).contiguous()).detach(), 1e-5, 2e-6, "fused no-grad forward, indexed batch")
+    close(got, ref.cpu().numpy(), 1e-5, 2e-6, "fused no-grad forward")
+    close(got_idx, model(xd.flip(0).contiguous()).detach().cpu().numpy(), 1e-5, 2e-6, "fused no-grad forward, indexed batch")
     P = {k: torch.from_numpy(sd[k].copy()) for k in orc.PARAM_NAMES}
     Bf = {k: torch.from_numpy(sd[k].copy()) for k in orc.BUFFER_NAMES}
     want = orc.forward(P, Bf, torch.from_numpy(x), False, apply_renorm=False)

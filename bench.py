@@ -218,8 +218,8 @@ def _pmc_traffic(kind, prec, freeze):
         f = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{kind}_pmc.json")))[-1]
         k = json.load(open(f))["kernels"]
         es = [v for name, v in k.items() if name.startswith("gemm_sp_kernel")]
-        n = sum(e.get("launches", 1) for e in es)
-        return int(sum((e["hbm_read_bytes"] + e["hbm_write_bytes"]) * e.get("launches", 1) for e in es) / max(n, 1))
+        n = sum(e.get("calls", 1) for e in es)
+        return int(sum((e["hbm_read_bytes"] + e["hbm_write_bytes"]) * e.get("calls", 1) for e in es) / max(n, 1))
     except Exception:
         return None
 
@@ -757,8 +757,9 @@ def main():
         try:  # HBM bytes per launch from the separate --pmc passes (tools/pmc_summary.py), if committed
             import glob
             f = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_eegnet_hbm_traffic.json")))[-1]
-            traffic = json.load(open(f))["kernels"][dom.replace("eav_eegnet_", "") + "_kernel"]["total_bytes"]
-            traffic_src = os.path.relpath(f, ROOT)
+            tj = json.load(open(f))
+            traffic = tj["kernels"][dom.replace("eav_eegnet_", "") + "_kernel"]["total_bytes"]
+            traffic_src = os.path.relpath(f, ROOT) + (f" (profiled at commit {tj['commit']})" if tj.get("commit") else "")
         except Exception:
             pass
         achieved = FIR_FLOP_PER_LAUNCH * per_gpu / B_PER_GPU / (kern_ms[dom] * 1e-3) / 1e12

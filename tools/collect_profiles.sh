@@ -19,6 +19,8 @@ for K in "ast 8" "vit 128"; do
   timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/${N}_fetch -o $N -- $ENC > $OUT/${N}_fetch.log 2>&1
   timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/${N}_write -o $N -- $ENC > $OUT/${N}_write.log 2>&1
   timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY -d $OUT/${N}_mfma -o $N -- $ENC > $OUT/${N}_mfma.log 2>&1
+  # the same step on ONE stream (NO_OVERLAP=1): kernel durations without the stretch two concurrent streams put on them
+  NO_OVERLAP=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${N}_serial -o $N -- $ENC > $OUT/${N}_serial.log 2>&1
 done
 # keep the merge-back small: counter / stats csv only
 find $OUT -name "*.csv" -size +40M -delete

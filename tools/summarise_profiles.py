@@ -15,8 +15,14 @@ import re
 import shutil
 import sys
 
+import subprocess
+
 tag = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+try:        # the tree the counters were collected from (run right after the gpurun call, before further edits)
+    commit = subprocess.run(["git", "-C", root, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip()
+except OSError:
+    commit = None
 src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
@@ -75,7 +81,14 @@ for run in ("eeg", "ast", "vit"):
     note = ("mean per launch over the profiled run; hbm_read = 2 x FETCH_SIZE x 1024 (gfx950 correction), hbm_write = "
             "WRITE_SIZE x 1024; mfma_pipe_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs); "
             "counters come from separate --pmc passes of the same command (tools/collect_profiles.sh)")
-    json.dump({"note": note, "total_kernel_ms": round(total / 1e6, 3), "kernels": out},
+    serial = os.path.join(src, f"{run}_serial", f"{run}_kernel_stats.csv")
+    if os.path.exists(serial):      # single-stream run of the same step: durations without the two-stream stretch
+        shutil.copy(serial, os.path.join(dst, f"{tag}_{run}_serial_kernel_stats.csv"))
+        sd = durations(os.path.join(src, f"{run}_serial", f"{run}_kernel_trace.csv"))
+        for k, e in out.items():
+            if k in sd:
+                e["avg_us_single_stream"] = round(sum(sd[k]) / len(sd[k]) / 1e3, 2)
+    json.dump({"note": note, "commit": commit, "total_kernel_ms": round(total / 1e6, 3), "kernels": out},
               open(os.path.join(dst, f"{tag}_{run}_pmc.json"), "w"), indent=1)
     print(run, "total kernel ms", round(total / 1e6, 2))
     for k, e in list(out.items())[:14]:
@@ -92,4 +105,5 @@ if os.path.exists(p):
     for k in list(ker):            # bare template names too ("fir_wgrad_kernel<10, false>" -> "fir_wgrad_kernel")
         b = k.split("<")[0]
         ker.setdefault(b, ker[k])
-    json.dump({"note": d["note"], "kernels": ker}, open(os.path.join(dst, f"{tag}_eegnet_hbm_traffic.json"), "w"), indent=1)
+    json.dump({"note": d["note"], "commit": d.get("commit"), "kernels": ker},
+              open(os.path.join(dst, f"{tag}_eegnet_hbm_traffic.json"), "w"), indent=1)

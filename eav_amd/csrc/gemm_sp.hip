@@ -191,12 +191,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
   // contraction; nothing of the next tile is in L2 yet, unlike the other mode where the next K-tile of a row is the
   // neighbouring line of a panel its XCD is already streaming), and one K-tile of cover (1.3 us) is less than an HBM miss
   // (2.3 us per K-tile measured with one workgroup per CU and nothing else running).  One extra load per wave and
-  // K-tile - lane l touches 128-byte line l & 7 of the wave's chunk l >> 3 of the tile THREE ahead, destination a
-  // register nobody reads - pulls that tile into L2 two tiles before its LDS-DMA is issued; the mid-tile wait becomes
+  // K-tile - lane l touches 128-byte line l & 7 of the wave's chunk l >> 3 of the tile PFD (= 2) ahead, destination a
+  // register nobody reads - pulls that tile into L2 before its LDS-DMA is issued; the mid-tile wait becomes
   // vmcnt(1) so that only the DMAs, not the newest prefetch, are waited for.
   const unsigned char* pf = nullptr;
   int64_t pfstep = 0;
-  constexpr int PFD = 3;
+#ifndef EAV_TR_PFD
+#define EAV_TR_PFD 2
+#endif
+  constexpr int PFD = EAV_TR_PFD;   // tiles ahead (measured 2 >= 3 > 4 > 6: the L2 share of a workgroup is ~2 token tiles)
   constexpr bool PF = TR;   // (in the other mode the same prefetch costs 7-16 %: its next K-tile is mostly L2-resident already)
   auto set_sources = [&](int m0, int n0) {
     if constexpr (TR) {
@@ -320,16 +323,19 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
   };
   // more: a K-tile t+1 exists (read its first fragments); more2: a K-tile t+2 exists (issue its DMA);
   // next_m0 >= 0 (last K-tile only): issue the next output tile's first two stages instead
-  // TR: boost exponents of the token block the NEXT K-tile lies in (loaded a tile ahead: scalar loads, consumed after the
-  // explicit waits of a whole iteration).  A boosted block's fragments are scaled back by 2^-k before their MFMAs: the
-  // boost serves the products whose OUTPUT rows are these rows; in a contraction over the rows a small row's share of
-  // the sum is small anyway, and un-boosting (fp16, may round into the subnormals) costs nothing next to the large rows.
-  int kAn = 0, kBn = 0;
-  auto load_boost = [&](int t) {
+  // TR: boost exponents of the token blocks of this workgroup's K range, one block per lane (64 blocks = 256 K-tiles per
+  // window, reloaded when the walk crosses a window).  A boosted block's fragments are scaled back by 2^-k before their
+  // MFMAs: the boost serves the products whose OUTPUT rows are these rows; in a contraction over the rows a small row's
+  // share of the sum is small anyway, and un-boosting (fp16, may round into the subnormals) costs nothing next to the
+  // large rows.  `anyb` (no lane holds a boost: the common case) keeps the whole mechanism out of the K loop.
+  int kvecA = 0, kvecB = 0;
+  bool anyb = false;
+  auto load_boost_window = [&](int blk0) {
     if constexpr (TR) {
-      const int b = ((kt0 + t) >> 2) & (EAV_SLOT_NBLK - 1);
-      kAn = reinterpret_cast<const int*>(g.slotA)[EAV_SLOT_BEXP + b];
-      kBn = reinterpret_cast<const int*>(g.slotB)[EAV_SLOT_BEXP + b];
+      const int b = (blk0 + lane) & (EAV_SLOT_NBLK - 1);
+      kvecA = reinterpret_cast<const int*>(g.slotA)[EAV_SLOT_BEXP + b];
+      kvecB = reinterpret_cast<const int*>(g.slotB)[EAV_SLOT_BEXP + b];
+      anyb = __any((kvecA | kvecB) != 0);
     }
   };
   auto pow2h = [](int k) -> _Float16 {       // 2^-k as fp16 (subnormal for 15 <= k <= 24, 0 beyond)
@@ -351,10 +357,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
   auto iter = [&](auto more_c, auto more2_c, int t, int next_m0, int next_n0) {
     constexpr bool more = decltype(more_c)::value, more2 = decltype(more2_c)::value;
     const int buf = t & 1;
-    const int ka = kAn, kb = kBn;
+    int ka = 0, kb = 0;
     if constexpr (TR) {
-      load_boost(t + 1);
-      if (ka | kb) unboost(f0, ka, kb);
+      const int rel = ((kt0 + t) >> 2) - (kt0 >> 2);
+      if (t > 0 && (rel & 63) == 0 && ((kt0 + t) & 3) == 0) load_boost_window((kt0 >> 2) + rel);
+      if (anyb) {
+        ka = __builtin_amdgcn_readlane(kvecA, rel & 63);
+        kb = __builtin_amdgcn_readlane(kvecB, rel & 63);
+        if (ka | kb) unboost(f0, ka, kb);
+      }
     }
     const unsigned char* sa = smem + buf * STAGE + offA;
     const unsigned char* sb = smem + buf * STAGE + offB;
@@ -444,7 +455,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
       if constexpr (TR) read_frag_tr(f0, smem, 0, r);
       else read_frag(f0, smem + offA, smem + offB, 0, r);
     }
-    load_boost(0);
+    load_boost_window(kt0 >> 2);
     {
       int t = 0;
       for (; t + 2 < nk; ++t) iter(std::true_type{}, std::true_type{}, t, -1, -1);

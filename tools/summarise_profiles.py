@@ -78,7 +78,11 @@ for run in ("eeg", "ast", "vit"):
                 e["wave_cycles_parked"] = round(mean(mfma, "SQ_WAIT_ANY") / wc, 3)
                 e["wave_cycles_issue_stalled"] = round(mean(mfma, "SQ_WAIT_INST_ANY") / wc, 3)
         out[k] = e
-    note = ("mean per launch over the profiled run; hbm_read = 2 x FETCH_SIZE x 1024 (gfx950 correction), hbm_write = "
+    note = ("two HIP streams run concurrently in the encoder step (weight gradients beside the main chain): a kernel's "
+            "duration there includes the time its workgroups wait for CUs the other stream holds, so mfma_pipe_busy / "
+            "hbm_gb_per_s of the two-stream run are per-kernel LOWER bounds that ADD across concurrent kernels; the "
+            "*_single_stream fields divide the same counters by the kernel's duration in the NO_OVERLAP=1 run.  "
+            "mean per launch over the profiled run; hbm_read = 2 x FETCH_SIZE x 1024 (gfx950 correction), hbm_write = "
             "WRITE_SIZE x 1024; mfma_pipe_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs); "
             "counters come from separate --pmc passes of the same command (tools/collect_profiles.sh)")
     serial = os.path.join(src, f"{run}_serial", f"{run}_kernel_stats.csv")
@@ -88,6 +92,10 @@ for run in ("eeg", "ast", "vit"):
         for k, e in out.items():
             if k in sd:
                 e["avg_us_single_stream"] = round(sum(sd[k]) / len(sd[k]) / 1e3, 2)
+                if "mfma_pipe_busy" in e:      # same busy cycles over the un-stretched duration
+                    e["mfma_pipe_busy_single_stream"] = round(e["mfma_pipe_busy"] * e["avg_us"] / e["avg_us_single_stream"], 4)
+                if "hbm_gb_per_s" in e:
+                    e["hbm_gb_per_s_single_stream"] = round(e["hbm_gb_per_s"] * e["avg_us"] / e["avg_us_single_stream"], 1)
     json.dump({"note": note, "commit": commit, "total_kernel_ms": round(total / 1e6, 3), "kernels": out},
               open(os.path.join(dst, f"{tag}_{run}_pmc.json"), "w"), indent=1)
     print(run, "total kernel ms", round(total / 1e6, 2))

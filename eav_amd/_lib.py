@@ -68,12 +68,15 @@ SIGNATURES = {
     "eav_layernorm_bwd_amax": [_p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _p, _p],
     "eav_gelu_bwd_amax": [_p, _p, _i64, _p, _p],
     "eav_gemm_sp": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i64, _i64, _f, _p, _i, _p, _p, _i, _i, _p, _p],
+    "eav_gemm_sp_x1": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i64, _i64, _f, _p, _i, _p, _p, _i, _i, _p, _p],
+    "eav_gemm_sp_splitk_x1": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "eav_gemm_sp_planes": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i64, _i64, _f, _p, _i, _p, _p, _i, _i, _p, _p, _p, _p],
     "eav_layernorm_fwd_planes": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p],
     "eav_rownorm_max": [_p, _i, _i, _i64, _p, _p],
     "eav_tf_forward_scales": [_p, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _i64, _i, _i, _i, _p],
     "eav_gemm_sp_splitk": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "eav_gemm_sp_set_tile": [_i],
+    "eav_gemm_sp_set_splitk": [_i],
     "eav_sp_set_convert_blocks": [_i],
     "eav_attn_sp_set_nw4_above": [_i],
     "eav_attn_sp_prep": [_p, _p, _p, _p, _i, _i, _i, _i, C.c_uint, _p],

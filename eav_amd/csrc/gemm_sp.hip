@@ -21,9 +21,10 @@
 // deterministic; separate lines keep the L2 atomics from serialising), then sigma and 1/sigma, which eav_sp_convert
 // writes; the GEMM folds 1/(sigma_A sigma_B) into alpha.  Nothing crosses to the host.
 //
-// Kernel: 128 x 128 x 32 tiles, 4 waves, 2 workgroups per CU (a 256 x 128 / 8-wave form stays as a tuning hook), each
-// wave a 64 x 64 block of 2 x 2 MFMA tiles = 24 MFMAs per K-tile.  Operands go HBM/L2 -> LDS with global_load_lds_dwordx4
-// (no VGPR round trip, no ds_write), double-buffered, ONE barrier per K-tile.  LDS image: row r, piece p (0..7) at
+// Kernel: 256 x 128 x 32 tiles, 8 waves, three LDS stages, one workgroup per CU for products that fill the chip;
+// 128 x 128 x 32, 4 waves, two stages, 2 workgroups per CU for smaller ones and for the token-contracting (weight-gradient)
+// mode; each wave a 64 x 64 block of 2 x 2 MFMA tiles = 24 MFMAs per K-tile.  Operands go HBM/L2 -> LDS with
+// global_load_lds_dwordx4 (no VGPR round trip, no ds_write), ONE barrier per K-tile.  LDS image: row r, piece p (0..7) at
 // 16-byte slot r*8 + (p ^ ((r>>1)&7)); the XOR is applied to the per-lane SOURCE address (the LDS-DMA destination is
 // lane-linear) and again on the fragment read, which makes every ds_read_b128 conflict-free.  Workgroups are persistent:
 // tile ids are remapped so that each XCD's L2 sees a compact group of tiles (8 tile-rows x all tile-columns at a time),
@@ -34,6 +35,13 @@
 
 #include "eav_common.h"
 #include "../../include/eav_hip.h"
+
+// timing-only ablation of the main loop (tools/probes/tr_ablate.sh builds variants; results are garbage): 1 = no fragment
+// reads, 2 = no LDS-DMA, 4 = no MFMAs, 16 / 32 = every tile streams the A / B rows of tile 0 (L2-hot operand)
+#ifndef EAV_ABL
+#define EAV_ABL 0
+#endif
+
 
 namespace {
 
@@ -138,20 +146,32 @@ __device__ __forceinline__ uint4 plane_piece4(float t0, float t1, float t2, floa
 // fragment is two ds_read_b64_tr_b16 (tokens 4h .. 4h+3, h = 0, 1); the 32 lanes of a half-wave then touch the 16
 // distinct 16-byte slots {row r = t & 3} x {4 feature groups} in both 8-byte halves: conflict-free.  Rows of the planes
 // beyond the token count (up to the next multiple of 32) must be ZERO - they are contracted like real tokens.
-template <int WM, int WN, int RM, int RN, bool TWOACC, bool TR>
+//
+// TERMS = 3: the fp32-grade product above.  TERMS = 1: hi.hi only - a plain fp16 product of the scaled operands (11-bit
+// operand mantissas, fp32 accumulation), a third of the MFMA work on the same planes; the opt-in mode of the backward
+// products (Encoder.grad_terms = 1; the forward - the logits - stays on three terms).
+//
+// NS = LDS stages.  2: a stage is in flight for one K-tile period.  3 (the 256 x 128 / 8-wave form, one workgroup per CU;
+// the epilogue patches then alias stage 2): two periods, and 96 KB instead of 64 KB in flight per CU - the loop is bound by
+// the latency of the L2 -> LDS stream, not by the matrix pipes (timing ablation, tools/probes/tr_ablate.py: DMA alone
+// 290 us, MFMAs alone 199 us of the 342 us of a [25216 x 3072] x [768 x 3072]^T product).
+template <int WM, int WN, int RM, int RN, bool TWOACC, bool TR, int TERMS = 3, int NS = 2>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_kernel(SpArgs g) {
   constexpr int NW = WM * WN, BM = 32 * RM * WM, BN = 32 * RN * WN;
   constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
   constexpr int NCH = (BM + BN) / 8;      // 1-KB chunks (8 rows x 128 B; TR: 2 tokens x 512 B) per stage
   constexpr int CPW = NCH / NW;           // chunks per wave
   constexpr int NT = RM * RN;             // MFMA tiles per wave
-  constexpr int NMF = 3 * NT;             // MFMAs per K-step of 16
-  constexpr int NRD = (TR ? 4 : 2) * (RM + RN);      // fragment reads per K-step
-  static_assert(NCH % NW == 0 && CPW <= NMF && NRD <= (TR ? 2 : 1) * NMF,
+  constexpr int NMF = TERMS * NT;         // MFMAs per K-step of 16
+  constexpr int NRD = (TR ? 2 : 1) * (TERMS == 1 ? 1 : 2) * (RM + RN);      // fragment reads per K-step (hi pieces first)
+  static_assert(TERMS == 3 || (TERMS == 1 && !TWOACC), "three terms, or the hi.hi term alone in one accumulator");
+  static_assert(NCH % NW == 0 && CPW <= 2 * NMF && NRD <= (TR ? 2 : 1) * NMF,
                 "stage chunks / fragment reads must fit the MFMA slots");
   static_assert(!TR || (BM == 128 && BN == 128 && RM == 2 && RN == 2), "the token-major image is laid out for 128 x 128");
+  static_assert(NS == 2 || (NS == 3 && NW * 4096 <= STAGE), "two stages, or three with the patches inside the third");
   // + one 32 x 32 fp32 patch per wave: the epilogue turns accumulator blocks into row-linear order through it
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE + NW * 4096];
+  // (at offset 2 STAGE in both forms; NS = 3: that is stage 2, free while the epilogue runs)
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[NS == 2 ? 2 * STAGE + NW * 4096 : 3 * STAGE];
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -169,7 +189,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
     n0 = (rem / gm) * BN;
   };
 
-  const int z = blockIdx.z;
+  const int z = blockIdx.z, tl0 = blockIdx.x, tstep = gridDim.x;
   const unsigned char* Ab = g.A;
   float* C = g.C;
   int kt0 = 0, kt1 = g.nkt;
@@ -187,30 +207,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
   // ---- per-lane global source pointers of this wave's chunks (row clamped: ragged tiles re-read the last row)
   const unsigned char* gp[CPW];
   int64_t gstep[TR ? CPW : 1];                           // TR: bytes from one K-tile (32 tokens) to the next
-  // TR: L2 prefetch.  A token tile is fresh HBM data for every workgroup (the operands are streamed once along the
-  // contraction; nothing of the next tile is in L2 yet, unlike the other mode where the next K-tile of a row is the
-  // neighbouring line of a panel its XCD is already streaming), and one K-tile of cover (1.3 us) is less than an HBM miss
-  // (2.3 us per K-tile measured with one workgroup per CU and nothing else running).  One extra load per wave and
-  // K-tile - lane l touches 128-byte line l & 7 of the wave's chunk l >> 3 of the tile PFD (= 2) ahead, destination a
-  // register nobody reads - pulls that tile into L2 before its LDS-DMA is issued; the mid-tile wait becomes
-  // vmcnt(1) so that only the DMAs, not the newest prefetch, are waited for.
-  const unsigned char* pf = nullptr;
-  int64_t pfstep = 0;
-#ifndef EAV_TR_PFD
-#define EAV_TR_PFD 2
-#endif
-  constexpr int PFD = EAV_TR_PFD;   // tiles ahead (measured 2 >= 3 > 4 > 6: the L2 share of a workgroup is ~2 token tiles)
-  constexpr bool PF = TR;   // (in the other mode the same prefetch costs 7-16 %: its next K-tile is mostly L2-resident already)
   auto set_sources = [&](int m0, int n0) {
-    if constexpr (TR) {
-      const int c = wave + NW * (lane >> 3), j = lane & 7;
-      const bool isA = 8 * c < BM;
-      const int tk = 2 * (isA ? c : c - BM / 8) + (j >> 2);
-      const int64_t ld = isA ? g.ldA : g.ldB;
-      const int64_t colb = min((int64_t)(isA ? m0 : n0) * 4 + (j & 3) * 128, ld - 128);
-      pf = (isA ? Ab : g.B) + ((int64_t)(kt0 + PFD) * 32 + tk) * ld + colb;
-      pfstep = 32 * ld;
-    }
 #pragma unroll
     for (int i = 0; i < CPW; ++i) {
       const int c = wave + NW * i;                       // wave-uniform chunk id
@@ -227,10 +224,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
         const int row = 8 * c + (lane >> 3);               // row in the combined [A tile; B tile] image
         const int p = (lane & 7) ^ ((row >> 1) & 7);       // piece held by this lane's slot
         if (8 * c < BM) {
-          const int gr = min(m0 + row, g.M - 1);
+          const int gr = min(((EAV_ABL & 16) ? 0 : m0) + row, g.M - 1);
           gp[i] = Ab + (int64_t)gr * g.ldA + (int64_t)kt0 * 128 + p * 16;
         } else {
-          const int gr = min(n0 + row - BM, g.N - 1);
+          const int gr = min(((EAV_ABL & 32) ? 0 : n0) + row - BM, g.N - 1);
           gp[i] = g.B + (int64_t)gr * g.ldB + (int64_t)kt0 * 128 + p * 16;
         }
       }
@@ -285,7 +282,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
   // land under this tile's epilogue (a K = 768 problem otherwise spends a quarter of its time in cold prologues).
   struct Frags { f16x8 ah[RM], al[RM], bh[RN], bl[RN]; };
   Frags f0, f1;
-  float pfsink = 0.f;       // destination of the TR prefetch loads: live to the end of the kernel, never read
   f32x16 acc[RM][RN], acx[TWOACC ? RM : 1][TWOACC ? RN : 1];
 #define SB() __builtin_amdgcn_sched_barrier(0)
 #define MM(c, a, b) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
@@ -346,17 +342,25 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
     if (ka) {
       const _Float16 sa = pow2h(ka);
 #pragma unroll
-      for (int i = 0; i < RM; ++i) { f.ah[i] *= sa; f.al[i] *= sa; }
+      for (int i = 0; i < RM; ++i) {
+        f.ah[i] *= sa;
+        if constexpr (TERMS > 1) f.al[i] *= sa;
+      }
     }
     if (kb) {
       const _Float16 sb = pow2h(kb);
 #pragma unroll
-      for (int j = 0; j < RN; ++j) { f.bh[j] *= sb; f.bl[j] *= sb; }
+      for (int j = 0; j < RN; ++j) {
+        f.bh[j] *= sb;
+        if constexpr (TERMS > 1) f.bl[j] *= sb;
+      }
     }
   };
-  auto iter = [&](auto more_c, auto more2_c, int t, int next_m0, int next_n0) {
-    constexpr bool more = decltype(more_c)::value, more2 = decltype(more2_c)::value;
-    const int buf = t & 1;
+  // flags of K-tile t: more = a K-tile t + 1 exists (read its first fragments); more2 = a K-tile t + NS exists (issue its
+  // DMA into this K-tile's buffer); newer (NS = 3) = a K-tile t + 2 exists: its stage may stay in flight over the mid-tile
+  // wait.  buf / nbuf = buffers of K-tiles t / t + 1.
+  auto iter = [&](auto more_c, auto more2_c, auto newer_c, int t, int buf, int nbuf, int next_m0, int next_n0) {
+    constexpr bool more = decltype(more_c)::value, more2 = decltype(more2_c)::value, newer = decltype(newer_c)::value;
     int ka = 0, kb = 0;
     if constexpr (TR) {
       const int rel = ((kt0 + t) >> 2) - (kt0 >> 2);
@@ -369,22 +373,24 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
     }
     const unsigned char* sa = smem + buf * STAGE + offA;
     const unsigned char* sb = smem + buf * STAGE + offB;
-    const unsigned char* sa2 = smem + (buf ^ 1) * STAGE + offA;
-    const unsigned char* sb2 = smem + (buf ^ 1) * STAGE + offB;
+    const unsigned char* sa2 = smem + nbuf * STAGE + offA;
+    const unsigned char* sb2 = smem + nbuf * STAGE + offB;
     SB();
 #pragma unroll
     for (int m = 0; m < NMF; ++m) {          // phase A
-      mfma_slot(f0, m);
+      if (!(EAV_ABL & 4)) mfma_slot(f0, m);
       SB();
-      if constexpr (TR) {
-        read_frag_tr(f1, smem + buf * STAGE, 1, m);
-        if (m + NMF < NRD) read_frag_tr(f1, smem + buf * STAGE, 1, m + NMF);
-      } else {
-        if (m < NRD) read_frag(f1, sa, sb, 1, m);
+      if (!(EAV_ABL & 1)) {
+        if constexpr (TR) {
+          read_frag_tr(f1, smem + buf * STAGE, 1, m);
+          if (m + NMF < NRD) read_frag_tr(f1, smem + buf * STAGE, 1, m + NMF);
+        } else {
+          if (m < NRD) read_frag(f1, sa, sb, 1, m);
+        }
       }
       SB();
     }
-    if (PF && t >= 1 && t + PFD - 1 < nk) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");   // newest = the prefetch of t - 1
+    if constexpr (newer) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(CPW) : "memory");   // all but the newest stage
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     SB();
@@ -394,40 +400,40 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
     if (!more && next_m0 >= 0) set_sources(next_m0, next_n0);
 #pragma unroll
     for (int m = 0; m < NMF; ++m) {          // phase B
-      mfma_slot(f1, m);
+      if (!(EAV_ABL & 4)) mfma_slot(f1, m);
       SB();
-      if constexpr (TR) {
-        if (more) {
-          read_frag_tr(f0, smem + (buf ^ 1) * STAGE, 0, m);
-          if (m + NMF < NRD) read_frag_tr(f0, smem + (buf ^ 1) * STAGE, 0, m + NMF);
+      if (!(EAV_ABL & 1)) {
+        if constexpr (TR) {
+          if (more) {
+            read_frag_tr(f0, smem + nbuf * STAGE, 0, m);
+            if (m + NMF < NRD) read_frag_tr(f0, smem + nbuf * STAGE, 0, m + NMF);
+          }
+        } else {
+          if (more && m < NRD) read_frag(f0, sa2, sb2, 0, m);
         }
-      } else {
-        if (more && m < NRD) read_frag(f0, sa2, sb2, 0, m);
       }
-      if (more2 && m < CPW) issue1(buf, m);
+      if (more2 && m < CPW && !(EAV_ABL & 2)) issue1(buf, m);
+      if (more2 && m + NMF < CPW && !(EAV_ABL & 2)) issue1(buf, m + NMF);          // (one term: 4 slots for 8 chunks)
       if (!more && next_m0 >= 0) {
         if (m < CPW) issue1(0, m);
         else if (m < 2 * CPW && nk > 1) issue1(1, m - CPW);
       }
       SB();
     }
-    if (!more && next_m0 >= 0 && nk > 1) {       // the rest of the next tile's second stage (2 CPW may exceed the slots)
+    if (!more && next_m0 >= 0) {                 // the rest of the next tile's first two stages (2 CPW may exceed the slots)
 #pragma unroll
-      for (int m = NMF; m < 2 * CPW; ++m) issue1(1, m - CPW);
-    }
-    if constexpr (PF && more2) {
-      if (t + PFD < nk) {                          // after this iteration's DMAs: the newest VMEM operation in flight
-        asm volatile("global_load_dword %0, %1, off" : "+v"(pfsink) : "v"(pf) : "memory");
-        pf += pfstep;
+      for (int m = NMF; m < 2 * CPW; ++m) {
+        if (m < CPW) issue1(0, m);
+        else if (nk > 1) issue1(1, m - CPW);
       }
     }
   };
 
   bool primed = false;
-  for (int tl = blockIdx.x; tl < nb; tl += gridDim.x) {
+  for (int tl = tl0; tl < nb; tl += tstep) {
     int m0, n0, nm0 = -1, nn0 = -1;
     tile_origin(tl, m0, n0);
-    if (tl + (int)gridDim.x < nb) tile_origin(tl + gridDim.x, nm0, nn0);
+    if (tl + tstep < nb) tile_origin(tl + tstep, nm0, nn0);
     if (!primed) {
       set_sources(m0, n0);
 #pragma unroll
@@ -448,7 +454,18 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
           if (TWOACC) acx[i][j][r] = 0.f;
         }
     // stages 0 and 1 of this tile (issued in the prologue, or under the previous tile's last K-tile and epilogue)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (NS == 3) {
+      __builtin_amdgcn_s_barrier();          // every wave is done with its epilogue patch (inside stage 2)
+      if (nk > 2) {
+#pragma unroll
+        for (int i = 0; i < CPW; ++i) issue1(2, i);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CPW) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int r = 0; r < NRD; ++r) {
@@ -457,10 +474,18 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
     }
     load_boost_window(kt0 >> 2);
     {
-      int t = 0;
-      for (; t + 2 < nk; ++t) iter(std::true_type{}, std::true_type{}, t, -1, -1);
-      if (t + 1 < nk) { iter(std::true_type{}, std::false_type{}, t, -1, -1); ++t; }
-      if (t < nk) iter(std::false_type{}, std::false_type{}, t, nm0, nn0);
+      constexpr std::true_type Y{};
+      constexpr std::false_type F{};
+      int t = 0, b = 0;
+      auto nx = [](int x) { return x + 1 == NS ? 0 : x + 1; };
+      if constexpr (NS == 2) {
+        for (; t + 2 < nk; ++t, b = nx(b)) iter(Y, Y, F, t, b, nx(b), -1, -1);
+      } else {
+        for (; t + 3 < nk; ++t, b = nx(b)) iter(Y, Y, Y, t, b, nx(b), -1, -1);
+        if (t + 2 < nk) { iter(Y, F, Y, t, b, nx(b), -1, -1); ++t; b = nx(b); }
+      }
+      if (t + 1 < nk) { iter(Y, F, F, t, b, nx(b), -1, -1); ++t; b = nx(b); }
+      if (t < nk) iter(F, F, F, t, b, nx(b), nm0, nn0);
     }
 
     // ---- epilogue of this tile (the next tile's first stages are in flight)
@@ -665,14 +690,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
       if (lane == 0 && vmax == vmax) {
-        atomicMax(g.amax + EAV_SLOT_SHARD(tl * NW + wave + 17 * blockIdx.z), __float_as_uint(vmax));
+        atomicMax(g.amax + EAV_SLOT_SHARD(tl * NW + wave + 17 * z), __float_as_uint(vmax));
         if constexpr (!TR) eav_slot_blockmax(g.amax, arow, vmax);     // (rows of the OUTPUT: same numbering for z = 0)
       }
     }
-  }
-  if constexpr (PF) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("" ::"v"(pfsink));
   }
 #undef MM
 #undef SB
@@ -684,33 +705,40 @@ int g_force_tile = 0;   // test / tuning hook: 0 = heuristic, 1 = 128x128, 2 = 2
 // VGPRs, same speed at 2 waves per SIMD; full precision only down to 2^-15 of the maximum) - kept as a tuning hook.
 int g_loshift = 11;
 int g_persist = 1;      // tuning hook: 0 = one workgroup per output tile
+int g_splitk_force = 0; // tuning hook (eav_gemm_sp_set_splitk): slices of eav_gemm_sp_splitk, 0 = the plan
 
-template <int WM, int WN, int RM, int RN, bool TR = false>
-void launch(SpArgs& g, int nz, hipStream_t st) {
+template <int WM, int WN, int RM, int RN, bool TR = false, int NS = 2>
+void launch(SpArgs& g, int nz, hipStream_t st, int terms = 3) {
   g.tm = cdiv(g.M, 32 * RM * WM);
   g.tn = cdiv(g.N, 32 * RN * WN);
   // persistent workgroups: as many as stay resident (2 per CU for 4-wave tiles, 1 for 8-wave tiles), a multiple of 8 so
   // that every workgroup's tiles stay on one XCD; fewer tiles than that: one workgroup per tile
   const int resident = (WM * WN <= 4 ? 2 : 1) * 256 * (g_persist ? 1 : 1 << 20);
   const int nb = g.tm * g.tn, gx = nb <= resident ? nb : resident;
-  if (g_loshift) {
+  if (terms == 1) {
+    hipLaunchKernelGGL((gemm_sp_kernel<WM, WN, RM, RN, false, TR, 1, NS>), dim3(gx, 1, nz), dim3(64 * WM * WN), 0, st, g);
+  } else if (g_loshift) {
     if constexpr (RM * RN <= 4)
-      hipLaunchKernelGGL((gemm_sp_kernel<WM, WN, RM, RN, true, TR>), dim3(gx, 1, nz), dim3(64 * WM * WN), 0, st, g);
+      hipLaunchKernelGGL((gemm_sp_kernel<WM, WN, RM, RN, true, TR, 3, NS>), dim3(gx, 1, nz), dim3(64 * WM * WN), 0, st, g);
   } else {
-    if constexpr (!TR)
+    if constexpr (!TR && NS == 2)
       hipLaunchKernelGGL((gemm_sp_kernel<WM, WN, RM, RN, false, false>), dim3(gx, 1, nz), dim3(64 * WM * WN), 0, st, g);
   }
 }
 
-void dispatch(SpArgs& g, int nz, hipStream_t st) {
-  // measured (tools/gemm_sp_bench.py): the 256 x 128 / 8-wave form only wins on huge square problems (8192^3: +2 %) and
-  // loses up to 15 % on the encoder shapes, so the heuristic takes 128 x 128 (a 256 x 256 single-accumulator form gained
-  // 7-13 % only at >= 4096^3 and was dropped)
-  if (g_force_tile == 2) launch<4, 2, 2, 2>(g, nz, st);
-  else launch<2, 2, 2, 2>(g, nz, st);
+void dispatch(SpArgs& g, int nz, hipStream_t st, int terms = 3) {
+  // 256 x 128 / 8 waves / three LDS stages (one workgroup per CU, 3/4 of the L2 -> LDS bytes per flop, two stages in
+  // flight) whenever it fills the chip at least once, 128 x 128 x two workgroups per CU below that.  Alone on the GPU the
+  // two forms are within +-5 % of each other on the encoder shapes (tools/gemm_sp_bench.py; +10 % at 8192^3); inside the
+  // training step the large form is 3 % (ViT B=128: 57.2 -> 55.5 ms) / 1.5-2 % (AST B=8) faster - its 144 KB of LDS keep
+  // the side stream's weight-gradient workgroups off the CUs it runs on, the two persistent kernels take turns instead of
+  // sharing every CU's LDS bandwidth and L2 (tools/encoder_step_bench.py with SP_TILE=1 / 2, same box).
+  const bool big = g_force_tile == 2 || (g_force_tile == 0 && cdiv(g.M, 256) * cdiv(g.N, 128) >= 256);
+  if (big) launch<4, 2, 2, 2, false, 3>(g, nz, st, terms);
+  else launch<2, 2, 2, 2>(g, nz, st, terms);
 }
 
-void dispatch_tr(SpArgs& g, int nz, hipStream_t st) { launch<2, 2, 2, 2, true>(g, nz, st); }
+void dispatch_tr(SpArgs& g, int nz, hipStream_t st, int terms = 3) { launch<2, 2, 2, 2, true>(g, nz, st, terms); }
 
 __global__ void sp_splitk_reduce_kernel(const float* __restrict__ ws, int nsplit, int64_t n, float* __restrict__ out,
                                         int accumulate) {
@@ -962,6 +990,11 @@ extern "C" int eav_sp_convert_colsum(const float* src, int R, int C, int64_t ld,
 
 extern "C" int eav_sp_set_convert_blocks(int n) { g_convert_blocks = n > 0 ? n : 1 << 30; return EAV_OK; }
 
+extern "C" int eav_gemm_sp_set_splitk(int slices) {
+  g_splitk_force = slices;
+  return EAV_OK;
+}
+
 extern "C" int eav_gemm_sp_set_tile(int which) {
   g_force_tile = which & 3;
   g_loshift = (which & 4) ? 0 : 11;
@@ -972,10 +1005,10 @@ extern "C" int eav_gemm_sp_set_tile(int which) {
 // eav_gemm_sp that ALSO (or only: C = NULL) writes the stored value as row planes [M][Np/8][2][8] scaled by
 // planes_slot[EAV_SLOT_SIGMA]: the consumer GEMM reads them directly, no conversion pass.  The scale must be known before
 // the launch - a rigorous bound of |output| (eav_tf_forward_scales), not its measured maximum.  N % 8 == 0.
-extern "C" int eav_gemm_sp_planes(const void* A, const void* B, float* C, const float* slotA, const float* slotB, int M,
-                                  int N, int K, int ldc, int batch, int64_t sA_bytes, int64_t sC, float alpha,
-                                  const float* bias, int gelu, float* pre, const float* resid, int ldr, int accumulate,
-                                  float* amax_slot, void* planes_out, const float* planes_slot, void* stream) {
+static int gemm_sp_impl(const void* A, const void* B, float* C, const float* slotA, const float* slotB, int M,
+                        int N, int K, int ldc, int batch, int64_t sA_bytes, int64_t sC, float alpha,
+                        const float* bias, int gelu, float* pre, const float* resid, int ldr, int accumulate,
+                        float* amax_slot, void* planes_out, const float* planes_slot, void* stream, int terms) {
   EAV_REQUIRE(A && B && (C || planes_out) && slotA && slotB && M > 0 && N > 0 && K > 0 && batch > 0,
               "eav_gemm_sp: bad arguments");
   EAV_REQUIRE((((uintptr_t)A | (uintptr_t)B) & 15) == 0 && (sA_bytes & 15) == 0,
@@ -994,9 +1027,28 @@ extern "C" int eav_gemm_sp_planes(const void* A, const void* B, float* C, const 
   g.lomul = g_loshift ? 2048.f : 1.f;
   g.M = M; g.N = N; g.nkt = Kp / 32; g.ldA = (int64_t)Kp * 4; g.ldB = (int64_t)Kp * 4; g.ldc = ldc; g.ldr = ldr;
   g.sA = sA_bytes; g.sC = sC; g.alpha = alpha; g.gelu = gelu; g.accumulate = accumulate; g.kt_per_split = 0;
-  dispatch(g, batch, (hipStream_t)stream);
+  dispatch(g, batch, (hipStream_t)stream, terms);
   EAV_CHECK_LAUNCH("eav_gemm_sp");
   return EAV_OK;
+}
+
+extern "C" int eav_gemm_sp_planes(const void* A, const void* B, float* C, const float* slotA, const float* slotB, int M,
+                                  int N, int K, int ldc, int batch, int64_t sA_bytes, int64_t sC, float alpha,
+                                  const float* bias, int gelu, float* pre, const float* resid, int ldr, int accumulate,
+                                  float* amax_slot, void* planes_out, const float* planes_slot, void* stream) {
+  return gemm_sp_impl(A, B, C, slotA, slotB, M, N, K, ldc, batch, sA_bytes, sC, alpha, bias, gelu, pre, resid, ldr,
+                      accumulate, amax_slot, planes_out, planes_slot, stream, 3);
+}
+
+// eav_gemm_sp with the hi.hi term only: the product of the operands rounded to fp16 (11-bit mantissas under the planes'
+// scales, fp32 accumulation) at a third of the matrix work.  Same planes, same epilogues.
+extern "C" int eav_gemm_sp_x1(const void* A, const void* B, float* C, const float* slotA, const float* slotB, int M, int N,
+                              int K, int ldc, int batch, int64_t sA_bytes, int64_t sC, float alpha, const float* bias,
+                              int gelu, float* pre, const float* resid, int ldr, int accumulate, float* amax_slot,
+                              void* stream) {
+  EAV_REQUIRE(C, "eav_gemm_sp_x1: bad arguments");
+  return gemm_sp_impl(A, B, C, slotA, slotB, M, N, K, ldc, batch, sA_bytes, sC, alpha, bias, gelu, pre, resid, ldr,
+                      accumulate, amax_slot, nullptr, nullptr, stream, 1);
 }
 
 extern "C" int eav_gemm_sp(const void* A, const void* B, float* C, const float* slotA, const float* slotB, int M, int N,
@@ -1008,27 +1060,35 @@ extern "C" int eav_gemm_sp(const void* A, const void* B, float* C, const float* 
                             accumulate, amax_slot, nullptr, nullptr, stream);
 }
 
-// split-K plan for the weight-gradient shapes (small M x N output, long contraction): enough slices to put ~2
-// workgroups on every CU, at least 8 K-tiles per slice
+// split-K plan for the weight-gradient shapes (small M x N output, long contraction).  All workgroups of a launch have
+// the same length L = K-tiles per slice and a CU works through ceil(workgroups / 256) of them at ~0.6 us per K-tile
+// (two resident workgroups share its matrix pipes and its L2 -> LDS stream; ~15 K-tiles of start-up + epilogue each), then
+// the slabs are reduced (64 KB per tile and slice at ~3.5 TB/s).  The slice count minimises that estimate - fitted to
+// tools/splitk_sweep.py on the AST / ViT shapes (ViT fc1, 144 tiles: 7 slices = 1008 workgroups = 4 per CU, 0.35 ms; the
+// previous "~512 workgroups" rule took 4 slices = 3 per CU of almost twice the length, 0.41-0.48 ms).  At least 8 K-tiles
+// per slice, at most 32 slices.
 extern "C" int eav_gemm_sp_splitk_plan(int M, int N, int K) {
-  const int tiles = cdiv(M, 128) * cdiv(N, 128);
-  int ns = cdiv(512, tiles);
-  const int maxs = std::max(1, eav_sp_kpad(K) / 32 / 8);
-  if (ns > maxs) ns = maxs;
-  if (ns > 32) ns = 32;
-  return ns < 1 ? 1 : ns;
+  const int tiles = cdiv(M, 128) * cdiv(N, 128), nkt = eav_sp_kpad(K) / 32;
+  const int maxs = std::min(32, std::max(1, nkt / 8));
+  int best = 1;
+  double best_cost = 1e30;
+  for (int ns = 1; ns <= maxs; ++ns) {
+    const double cost = 0.6 * cdiv(tiles * ns, 256) * (cdiv(nkt, ns) + 15) + (ns > 1 ? 0.0187 * ns * tiles : 0.0);
+    if (cost < best_cost) { best_cost = cost; best = ns; }
+  }
+  return best;
 }
 
 // Weight-gradient product C[M,N] = sum_t A[t,m] B[t,n] over ROW planes (contraction over the rows = tokens): A planes
 // [Tp][Mp/8][2][8], B planes [Tp][Np/8][2][8] with Tp = T rounded up to 32 and the rows >= T ZERO (the conversion never
 // writes them; allocate zero-filled).  Split-K over the token tiles with a fixed-order fp64 reduction of the slabs.
-extern "C" int eav_gemm_sp_splitk(const void* A, const void* B, float* C, float* ws, const float* slotA,
-                                  const float* slotB, int M, int N, int T, int accumulate, void* stream) {
+static int gemm_sp_splitk_impl(const void* A, const void* B, float* C, float* ws, const float* slotA,
+                               const float* slotB, int M, int N, int T, int accumulate, void* stream, int terms) {
   EAV_REQUIRE(A && B && C && ws && slotA && slotB && M > 0 && N > 0 && T > 0, "eav_gemm_sp_splitk: bad arguments");
   EAV_REQUIRE((N & 3) == 0 && (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)ws) & 15) == 0,
               "eav_gemm_sp_splitk: N must be a multiple of 4, buffers 16-byte aligned");
   EAV_REQUIRE(g_loshift != 0, "eav_gemm_sp_splitk: the single-accumulator tuning mode has no token-contracting kernel");
-  const int nsplit = eav_gemm_sp_splitk_plan(M, N, T);
+  const int nsplit = g_splitk_force > 0 ? g_splitk_force : eav_gemm_sp_splitk_plan(M, N, T);
   SpArgs g;
   g.A = (const unsigned char*)A; g.B = (const unsigned char*)B; g.slotA = slotA; g.slotB = slotB;
   g.bias = nullptr; g.resid = nullptr; g.pre = nullptr; g.amax = nullptr; g.planes = nullptr; g.slotP = nullptr;
@@ -1038,18 +1098,29 @@ extern "C" int eav_gemm_sp_splitk(const void* A, const void* B, float* C, float*
   hipStream_t st = (hipStream_t)stream;
   if (nsplit <= 1) {
     g.C = C; g.accumulate = accumulate; g.kt_per_split = 0;
-    dispatch_tr(g, 1, st);
+    dispatch_tr(g, 1, st, terms);
     EAV_CHECK_LAUNCH("eav_gemm_sp_splitk");
     return EAV_OK;
   }
   g.C = ws; g.accumulate = 0;
   g.kt_per_split = cdiv(g.nkt, nsplit);
   const int nz = cdiv(g.nkt, g.kt_per_split);
-  dispatch_tr(g, nz, st);
+  dispatch_tr(g, nz, st, terms);
   EAV_CHECK_LAUNCH("eav_gemm_sp_splitk");
   const int64_t n = (int64_t)M * N;
   hipLaunchKernelGGL(sp_splitk_reduce_kernel, dim3((unsigned)cdiv64(n, 1024)), dim3(256), 0, st, ws, nz, n, C,
                      accumulate);
   EAV_CHECK_LAUNCH("eav_gemm_sp_splitk(reduce)");
   return EAV_OK;
+}
+
+extern "C" int eav_gemm_sp_splitk(const void* A, const void* B, float* C, float* ws, const float* slotA,
+                                  const float* slotB, int M, int N, int T, int accumulate, void* stream) {
+  return gemm_sp_splitk_impl(A, B, C, ws, slotA, slotB, M, N, T, accumulate, stream, 3);
+}
+
+// eav_gemm_sp_splitk with the hi.hi term only (see eav_gemm_sp_x1)
+extern "C" int eav_gemm_sp_splitk_x1(const void* A, const void* B, float* C, float* ws, const float* slotA,
+                                     const float* slotB, int M, int N, int T, int accumulate, void* stream) {
+  return gemm_sp_splitk_impl(A, B, C, ws, slotA, slotB, M, N, T, accumulate, stream, 1);
 }

@@ -188,6 +188,11 @@ class Encoder(nn.Module):
         # logits unchanged - and bf16 operands for the backward products only).  EAV_ENCODER_PRECISION overrides.
         self.precision = os.environ.get("EAV_ENCODER_PRECISION", DEFAULT_PRECISION)
         self.overlap_wgrad = True     # split mode: weight-gradient GEMMs on a side stream (see _wgrad_sp)
+        # split mode, backward GEMMs only (data and weight gradients): 3 = the fp32-grade three-term product (default),
+        # 1 = the hi.hi term alone - operands rounded to fp16 under the planes' scales (11-bit mantissas; fp32
+        # accumulation), i.e. classic fp16 mixed-precision gradients: 3e-4 relative gradient error instead of 3e-7, a
+        # third of the backward's matrix work.  The forward - the logits - always runs on three terms.
+        self.grad_terms = int(os.environ.get("EAV_GRAD_TERMS", "3"))
         # split mode: LayerNorm / fc1 write their consumers' operand planes (a-priori scales); EAV_FUSED_PLANES=0 for A/B runs
         self.fused_planes = os.environ.get("EAV_FUSED_PLANES", "1") != "0"
         self._side, self._aux, self._wgrad_done, self._wready = None, None, {}, {}
@@ -546,7 +551,9 @@ class Encoder(nn.Module):
     def _gemm_sp(self, A, slotA, B, slotB, C, M, N, K, ldc, batch=1, sA=0, sC=0, alpha=1.0, bias=None, gelu=0,
                  pre=None, resid=None, ldr=0, acc=0, amax=None):
         """C[M,N] = epilogue(alpha A[M,K] . B[N,K]^T) on planes."""
-        self._call("eav_gemm_sp", A, B, C, slotA, slotB, M, N, K, ldc, batch, sA, sC, float(alpha), bias, gelu, pre,
+        # (backward products with grad_terms = 1: the hi.hi term alone - see the class attribute)
+        name = "eav_gemm_sp_x1" if (self._phase == "bwd" and self.grad_terms == 1) else "eav_gemm_sp"
+        self._call(name, A, B, C, slotA, slotB, M, N, K, ldc, batch, sA, sC, float(alpha), bias, gelu, pre,
                    resid, ldr, acc, amax, self._st)
 
     def _wgrad_sp(self, AT, slotA, BT, slotB, C, M, N, K):
@@ -559,15 +566,16 @@ class Encoder(nn.Module):
         tails of its own GEMMs.  Ordering: the side stream waits for the event recorded after the conversion that
         produced A; the main stream waits for a weight gradient only before it overwrites that gradient's A planes
         (one layer later) and at the end of the backward."""
+        name = "eav_gemm_sp_splitk_x1" if self.grad_terms == 1 else "eav_gemm_sp_splitk"
         if not self.overlap_wgrad or (self.kernel_events is not None and "eav_gemm_sp_splitk" in self.kernel_events):
-            self._call("eav_gemm_sp_splitk", _lib.ptr(AT), _lib.ptr(BT), C, _lib.ptr(self._ws.splitk), slotA, slotB, M,
+            self._call(name, _lib.ptr(AT), _lib.ptr(BT), C, _lib.ptr(self._ws.splitk), slotA, slotB, M,
                        N, K, 0, self._st)
             return
         self._side_stream(AT.device)
         ready = torch.cuda.Event()
         ready.record()
         self._side.wait_event(ready)
-        _lib.call("eav_gemm_sp_splitk", _lib.ptr(AT), _lib.ptr(BT), C, _lib.ptr(self._ws.splitk), slotA, slotB, M, N, K,
+        _lib.call(name, _lib.ptr(AT), _lib.ptr(BT), C, _lib.ptr(self._ws.splitk), slotA, slotB, M, N, K,
                   0, self._side.cuda_stream)
         done = torch.cuda.Event()
         done.record(self._side)

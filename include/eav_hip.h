@@ -304,9 +304,19 @@ int eav_tf_forward_scales(const float* params, int64_t layer_stride, int layers,
 int eav_gemm_sp_splitk_plan(int M, int N, int K);
 int eav_gemm_sp_splitk(const void* A, const void* B, float* C, float* ws, const float* slotA, const float* slotB, int M,
                        int N, int T, int accumulate, void* stream);
+/* One-term forms: the hi.hi product alone - the operands rounded to fp16 under the planes' scales (11-bit mantissas, fp32
+ * accumulation), a third of the matrix work on the SAME planes, same epilogues.  The opt-in precision of the backward
+ * products (Encoder.grad_terms = 1): gradients then carry ~2^-11 relative rounding per operand, the forward (logits)
+ * stays on the three-term product. */
+int eav_gemm_sp_x1(const void* A, const void* B, float* C, const float* slotA, const float* slotB, int M, int N, int K,
+                   int ldc, int batch, int64_t sA_bytes, int64_t sC, float alpha, const float* bias, int gelu, float* pre,
+                   const float* resid, int ldr, int accumulate, float* amax_slot, void* stream);
+int eav_gemm_sp_splitk_x1(const void* A, const void* B, float* C, float* ws, const float* slotA, const float* slotB, int M,
+                          int N, int T, int accumulate, void* stream);
 /* TEST / TUNING ONLY - process-global state, not part of the drop-in boundary: the trainers never call these; the kernel
  * benchmarks under tools/ and tests/test_split_kernels_gpu.py use them to A/B tile shapes inside one process. */
 int eav_gemm_sp_set_tile(int which);   /* 0 heuristic, 1 = 128x128 tiles, 2 = 256x128, +4 single accumulator, +8 non-persistent */
+int eav_gemm_sp_set_splitk(int slices);  /* eav_gemm_sp_splitk: forced slice count (0 = the plan; ws must hold it) */
 int eav_sp_set_convert_blocks(int n);  /* resident-block cap of eav_sp_convert (default 512; 0 = one block per tile) */
 /* The same fused attention on the fp16 matrix cores with split operands (csrc/attention_sp.hip; fp32-grade, 3 MFMAs per
  * product).  eav_attn_sp_prep converts an fp32 activation src [B*N, ncols] (qkv or dO; slot holds its max|x| shards, see

@@ -517,3 +517,82 @@ def test_weight_gradient_undoes_the_row_block_boosts():
     got = part.double().sum(0)
     want = dY.double().sum(0)
     assert (got - want).abs().max().item() <= 1e-5 * dY.double().abs().sum(0).max().item()
+
+
+@pytest.mark.parametrize("shape", [(512, 384, 768), (1000, 200, 100), (9712, 768, 3072), (300, 130, 40), (2500, 2304, 768)])
+def test_one_term_products_are_the_fp16_product_of_the_planes(shape):
+    """eav_gemm_sp_x1 / eav_gemm_sp_splitk_x1 (Encoder.grad_terms = 1): the hi.hi term alone - EXACTLY the product of the
+    hi planes (fp16 values, fp32 accumulation) up to summation order, i.e. within a few 1e-7 of the float64 product of the
+    decoded hi pieces, and within ~2^-11 per operand (tolerance 1e-3 of sum|a||b|) of the true product; same epilogues."""
+    M, N, K = shape
+    torch.manual_seed(M + N)
+    A = torch.randn(M, K, device="cuda") * (1 + torch.arange(K, device="cuda") % 5)
+    B = torch.randn(N, K, device="cuda") * 0.02
+    bias = torch.randn(N, device="cuda")
+    sa, pa, _ = planes(A)
+    sb, pb, _ = planes(B)
+    C = torch.empty(M, N, device="cuda")
+    _lib.call("eav_gemm_sp_x1", P(pa), P(pb), P(C), P(sa), P(sb), M, N, K, N, 1, 0, 0, 1.0, P(bias), 0, None, None, 0, 0,
+              None, None)
+    Kp = kpad(K)
+
+    def hi(pl, R):      # decode the hi pieces: planes [R][Kp/8][2][8]
+        return pl.view(R, Kp // 8, 2, 8)[:, :, 0, :].reshape(R, Kp)[:, :K].double()
+    ref_hi = hi(pa, M) @ hi(pb, N).t() * (sa[2049].double() * sb[2049].double()) + bias.double()
+    den = A.double().abs() @ B.double().abs().t() + bias.double().abs()
+    assert ((C.double() - ref_hi).abs() / den).max().item() < 3e-7
+    ref = A.double() @ B.double().t() + bias.double()
+    assert ((C.double() - ref).abs() / den).max().item() < 1e-3
+    assert ((C.double() - ref).norm() / ref.norm()).item() < 6e-4
+    # token-contracting form on the transposed problem: dW[N', K'] = sum_t X[t, n] Y[t, k]
+    X, Y = A[:, :min(K, 256)].contiguous(), A[:, -min(K, 136):].contiguous() * 1e-3
+    sx, px = row_planes(X)
+    sy, py = row_planes(Y)
+    n1, n2 = X.shape[1], Y.shape[1]
+    W = torch.empty(n1, n2, device="cuda")
+    ns = _lib.plain("eav_gemm_sp_splitk_plan", n1, n2, M)
+    ws = torch.empty(max(ns, 1) * n1 * n2, device="cuda")
+    _lib.call("eav_gemm_sp_splitk_x1", P(px), P(py), P(W), P(ws), P(sx), P(sy), n1, n2, M, 0, None)
+    refw = X.double().t() @ Y.double()
+    denw = X.double().abs().t() @ Y.double().abs()
+    assert ((W.double() - refw).abs() / denw).max().item() < 1e-3
+    assert ((W.double() - refw).norm() / refw.norm()).item() < 6e-4
+    W2 = torch.empty_like(W)
+    _lib.call("eav_gemm_sp_splitk_x1", P(px), P(py), P(W2), P(ws), P(sx), P(sy), n1, n2, M, 0, None)
+    assert torch.equal(W, W2)
+
+
+@pytest.mark.parametrize("shape", [(512, 384, 768), (1000, 200, 100), (9712, 768, 3072), (25216, 768, 64), (700, 2304, 96)])
+def test_three_stage_256x128_form_gives_the_same_bits(shape):
+    """The 256 x 128 / 8-wave / three-LDS-stage form of the kernel (tuning hook eav_gemm_sp_set_tile(2); epilogue patches
+    aliased onto stage 2) against the default 128 x 128 form: the same MFMA sequence per output element, so bit-equal -
+    with every epilogue option, ragged edges, K of one to many K-tiles and several tiles per persistent workgroup."""
+    M, N, K = shape
+    torch.manual_seed(M)
+    A = torch.randn(M, K, device="cuda")
+    B = torch.randn(N, K, device="cuda") * 0.05
+    bias = torch.randn(N, device="cuda")
+    resid = torch.randn(M, N, device="cuda")
+    outs = []
+    for tile in (1, 2):
+        _lib.call("eav_gemm_sp_set_tile", tile)
+        try:
+            pre = torch.zeros(M, N, device="cuda")
+            amax = torch.zeros(SLOT, device="cuda")
+            C = gemm_sp(A, B, bias=bias, gelu=1, pre=pre, resid=resid, amax=amax)
+            C1 = gemm_sp(A, B, C=C.clone(), acc=1, alpha=0.5)
+            _lib.call("eav_gemm_sp_x1", *x1_args(A, B, C2 := torch.empty(M, N, device="cuda")))
+        finally:
+            _lib.call("eav_gemm_sp_set_tile", 0)
+        outs.append((C, pre, C1, C2, amax[:2048].max()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
+def x1_args(A, B, C):
+    M, K = A.shape
+    N = B.shape[0]
+    sa, pa, _ = planes(A)
+    sb, pb, _ = planes(B)
+    x1_args.keep = (sa, pa, sb, pb)
+    return (P(pa), P(pb), P(C), P(sa), P(sb), M, N, K, N, 1, 0, 0, 1.0, None, 0, None, None, 0, 0, None, None)

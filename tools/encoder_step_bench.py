@@ -17,6 +17,9 @@ model = T.Encoder(T.make_config(kind)).cuda().train()
 model.precision = prec
 if os.environ.get("NO_OVERLAP"):
     model.overlap_wgrad = False
+if os.environ.get("SPLITK"):          # forced slice count of the weight-gradient products (tuning hook)
+    from eav_amd import _lib
+    _lib.call("eav_gemm_sp_set_splitk", int(os.environ["SPLITK"]))
 if os.environ.get("SP_TILE"):
     from eav_amd import _lib
     _lib.call("eav_gemm_sp_set_tile", int(os.environ["SP_TILE"]))

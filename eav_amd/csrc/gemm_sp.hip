@@ -726,14 +726,16 @@ void launch(SpArgs& g, int nz, hipStream_t st, int terms = 3) {
   }
 }
 
-void dispatch(SpArgs& g, int nz, hipStream_t st, int terms = 3) {
-  // 256 x 128 / 8 waves / three LDS stages (one workgroup per CU, 3/4 of the L2 -> LDS bytes per flop, two stages in
-  // flight) whenever it fills the chip at least once, 128 x 128 x two workgroups per CU below that.  Alone on the GPU the
-  // two forms are within +-5 % of each other on the encoder shapes (tools/gemm_sp_bench.py; +10 % at 8192^3); inside the
-  // training step the large form is 3 % (ViT B=128: 57.2 -> 55.5 ms) / 1.5-2 % (AST B=8) faster - its 144 KB of LDS keep
-  // the side stream's weight-gradient workgroups off the CUs it runs on, the two persistent kernels take turns instead of
-  // sharing every CU's LDS bandwidth and L2 (tools/encoder_step_bench.py with SP_TILE=1 / 2, same box).
-  const bool big = g_force_tile == 2 || (g_force_tile == 0 && cdiv(g.M, 256) * cdiv(g.N, 128) >= 256);
+void dispatch(SpArgs& g, int nz, hipStream_t st, int terms = 3, bool shared_gpu = false) {
+  // 128 x 128 tiles x two workgroups per CU when the product has the GPU to itself (the forward): alone the two forms are
+  // within +-5 % on the encoder shapes and the small one wins where the epilogue is heavy or the tile count quantises
+  // badly (fc1 + GELU, o-proj; tools/gemm_sp_bench.py; forward-only step ViT B=128 17.35 against 18.1 ms).  256 x 128 / 8
+  // waves / three LDS stages (one workgroup per CU, 3/4 of the L2 -> LDS bytes per flop, two stages in flight) when the
+  // caller says another persistent GEMM is running beside this one (EAV_GEMM_SHARED_GPU: the backward's data-gradient
+  // products next to the side stream's weight gradients) and the product fills the chip: its 144 KB of LDS keep the other
+  // kernel's workgroups off the CUs it runs on - the two take turns instead of sharing every CU's LDS bandwidth and L2
+  // (ViT B=128 step 57.6 -> 55.9 ms, tools/encoder_step_bench.py with SP_TILE=1 / 0 on one box; +10 % alone at 8192^3).
+  const bool big = g_force_tile == 2 || (g_force_tile == 0 && shared_gpu && cdiv(g.M, 256) * cdiv(g.N, 128) >= 256);
   if (big) launch<4, 2, 2, 2, false, 3>(g, nz, st, terms);
   else launch<2, 2, 2, 2>(g, nz, st, terms);
 }
@@ -1008,7 +1010,8 @@ extern "C" int eav_gemm_sp_set_tile(int which) {
 static int gemm_sp_impl(const void* A, const void* B, float* C, const float* slotA, const float* slotB, int M,
                         int N, int K, int ldc, int batch, int64_t sA_bytes, int64_t sC, float alpha,
                         const float* bias, int gelu, float* pre, const float* resid, int ldr, int accumulate,
-                        float* amax_slot, void* planes_out, const float* planes_slot, void* stream, int terms) {
+                        float* amax_slot, void* planes_out, const float* planes_slot, void* stream, int flags) {
+  const int terms = (flags & EAV_GEMM_ONE_TERM) ? 1 : 3;
   EAV_REQUIRE(A && B && (C || planes_out) && slotA && slotB && M > 0 && N > 0 && K > 0 && batch > 0,
               "eav_gemm_sp: bad arguments");
   EAV_REQUIRE((((uintptr_t)A | (uintptr_t)B) & 15) == 0 && (sA_bytes & 15) == 0,
@@ -1027,7 +1030,7 @@ static int gemm_sp_impl(const void* A, const void* B, float* C, const float* slo
   g.lomul = g_loshift ? 2048.f : 1.f;
   g.M = M; g.N = N; g.nkt = Kp / 32; g.ldA = (int64_t)Kp * 4; g.ldB = (int64_t)Kp * 4; g.ldc = ldc; g.ldr = ldr;
   g.sA = sA_bytes; g.sC = sC; g.alpha = alpha; g.gelu = gelu; g.accumulate = accumulate; g.kt_per_split = 0;
-  dispatch(g, batch, (hipStream_t)stream, terms);
+  dispatch(g, batch, (hipStream_t)stream, terms, (flags & EAV_GEMM_SHARED_GPU) != 0);
   EAV_CHECK_LAUNCH("eav_gemm_sp");
   return EAV_OK;
 }
@@ -1037,7 +1040,17 @@ extern "C" int eav_gemm_sp_planes(const void* A, const void* B, float* C, const 
                                   const float* bias, int gelu, float* pre, const float* resid, int ldr, int accumulate,
                                   float* amax_slot, void* planes_out, const float* planes_slot, void* stream) {
   return gemm_sp_impl(A, B, C, slotA, slotB, M, N, K, ldc, batch, sA_bytes, sC, alpha, bias, gelu, pre, resid, ldr,
-                      accumulate, amax_slot, planes_out, planes_slot, stream, 3);
+                      accumulate, amax_slot, planes_out, planes_slot, stream, 0);
+}
+
+// eav_gemm_sp_planes with options: EAV_GEMM_ONE_TERM (the hi.hi term alone, see eav_gemm_sp_x1), EAV_GEMM_SHARED_GPU (a
+// second persistent GEMM runs beside this one: prefer the one-workgroup-per-CU form, see dispatch)
+extern "C" int eav_gemm_sp_ex(const void* A, const void* B, float* C, const float* slotA, const float* slotB, int M, int N,
+                              int K, int ldc, int batch, int64_t sA_bytes, int64_t sC, float alpha, const float* bias,
+                              int gelu, float* pre, const float* resid, int ldr, int accumulate, float* amax_slot,
+                              void* planes_out, const float* planes_slot, int flags, void* stream) {
+  return gemm_sp_impl(A, B, C, slotA, slotB, M, N, K, ldc, batch, sA_bytes, sC, alpha, bias, gelu, pre, resid, ldr,
+                      accumulate, amax_slot, planes_out, planes_slot, stream, flags);
 }
 
 // eav_gemm_sp with the hi.hi term only: the product of the operands rounded to fp16 (11-bit mantissas under the planes'
@@ -1048,7 +1061,7 @@ extern "C" int eav_gemm_sp_x1(const void* A, const void* B, float* C, const floa
                               void* stream) {
   EAV_REQUIRE(C, "eav_gemm_sp_x1: bad arguments");
   return gemm_sp_impl(A, B, C, slotA, slotB, M, N, K, ldc, batch, sA_bytes, sC, alpha, bias, gelu, pre, resid, ldr,
-                      accumulate, amax_slot, nullptr, nullptr, stream, 1);
+                      accumulate, amax_slot, nullptr, nullptr, stream, EAV_GEMM_ONE_TERM);
 }
 
 extern "C" int eav_gemm_sp(const void* A, const void* B, float* C, const float* slotA, const float* slotB, int M, int N,

@@ -193,6 +193,9 @@ class Encoder(nn.Module):
         # accumulation), i.e. classic fp16 mixed-precision gradients: 3e-4 relative gradient error instead of 3e-7, a
         # third of the backward's matrix work.  The forward - the logits - always runs on three terms.
         self.grad_terms = int(os.environ.get("EAV_GRAD_TERMS", "3"))
+        # the same switch for the forward products (comparison only: 16-bit matrix operands everywhere - the logits then
+        # move by a few 1e-3, outside north_star's bound; bench.py reports the leg beside the literal bf16 one)
+        self.fwd_terms = int(os.environ.get("EAV_FWD_TERMS", "3"))
         # split mode: LayerNorm / fc1 write their consumers' operand planes (a-priori scales); EAV_FUSED_PLANES=0 for A/B runs
         self.fused_planes = os.environ.get("EAV_FUSED_PLANES", "1") != "0"
         self._side, self._aux, self._wgrad_done, self._wready = None, None, {}, {}
@@ -551,10 +554,12 @@ class Encoder(nn.Module):
     def _gemm_sp(self, A, slotA, B, slotB, C, M, N, K, ldc, batch=1, sA=0, sC=0, alpha=1.0, bias=None, gelu=0,
                  pre=None, resid=None, ldr=0, acc=0, amax=None):
         """C[M,N] = epilogue(alpha A[M,K] . B[N,K]^T) on planes."""
-        # (backward products with grad_terms = 1: the hi.hi term alone - see the class attribute)
-        name = "eav_gemm_sp_x1" if (self._phase == "bwd" and self.grad_terms == 1) else "eav_gemm_sp"
-        self._call(name, A, B, C, slotA, slotB, M, N, K, ldc, batch, sA, sC, float(alpha), bias, gelu, pre,
-                   resid, ldr, acc, amax, self._st)
+        # flags: backward products with grad_terms = 1 run on the hi.hi term alone (see the class attribute); the backward's
+        # data gradients share the GPU with the side stream's weight gradients (EAV_GEMM_SHARED_GPU: see csrc/gemm_sp.hip)
+        bwd = self._phase == "bwd"
+        flags = (1 if (self.grad_terms if bwd else self.fwd_terms) == 1 else 0) | (2 if bwd and self.overlap_wgrad else 0)
+        self._call("eav_gemm_sp_ex", A, B, C, slotA, slotB, M, N, K, ldc, batch, sA, sC, float(alpha), bias, gelu, pre,
+                   resid, ldr, acc, amax, None, None, flags, self._st)
 
     def _wgrad_sp(self, AT, slotA, BT, slotB, C, M, N, K):
         """C[M,N] = sum over the K tokens of A[t,m] B[t,n]: ROW planes of A [K,M] and B [K,N] (the contraction runs over the
@@ -567,7 +572,7 @@ class Encoder(nn.Module):
         produced A; the main stream waits for a weight gradient only before it overwrites that gradient's A planes
         (one layer later) and at the end of the backward."""
         name = "eav_gemm_sp_splitk_x1" if self.grad_terms == 1 else "eav_gemm_sp_splitk"
-        if not self.overlap_wgrad or (self.kernel_events is not None and "eav_gemm_sp_splitk" in self.kernel_events):
+        if not self.overlap_wgrad or (self.kernel_events is not None and name in self.kernel_events):
             self._call(name, _lib.ptr(AT), _lib.ptr(BT), C, _lib.ptr(self._ws.splitk), slotA, slotB, M,
                        N, K, 0, self._st)
             return
@@ -750,9 +755,9 @@ class Encoder(nn.Module):
             wpl, wsl = self._wp(f"fc1{i}")
             # fc1: bias + erf-GELU in the epilogue; the pre-activation is kept (fp32) for the backward only, the
             # activation leaves as planes - it never exists in fp32
-            self._call("eav_gemm_sp_planes", P(ws.y2p[j]), wpl, None, s_y2, wsl, M, FF, D, FF, 1, 0, 0, 1.0,
+            self._call("eav_gemm_sp_ex", P(ws.y2p[j]), wpl, None, s_y2, wsl, M, FF, D, FF, 1, 0, 0, 1.0,
                        w(f"{Lk}.mlp.fc1.bias"), 1, P(ws.pre[j]) if ws.full else None, None, 0, 0, None, P(ws.actp[j]),
-                       s_act, st)
+                       s_act, 1 if self.fwd_terms == 1 else 0, st)
         else:
             L("eav_layernorm_fwd_amax", P(ws.hmid[j]), w(f"{Lk}.layernorm_after.weight"),
               w(f"{Lk}.layernorm_after.bias"), P(y), stp + 8 * M, stp + 12 * M, M, D, c.eps, s_y2, st)

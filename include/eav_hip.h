@@ -307,10 +307,19 @@ int eav_gemm_sp_splitk(const void* A, const void* B, float* C, float* ws, const 
 /* One-term forms: the hi.hi product alone - the operands rounded to fp16 under the planes' scales (11-bit mantissas, fp32
  * accumulation), a third of the matrix work on the SAME planes, same epilogues.  The opt-in precision of the backward
  * products (Encoder.grad_terms = 1): gradients then carry ~2^-11 relative rounding per operand, the forward (logits)
- * stays on the three-term product. */
+ * stays on the three-term product unless Encoder.fwd_terms = 1 asks for the plain fp16 forward as well (comparison leg of
+ * bench.py: 16-bit matrix operands everywhere, as BASELINE.json's configs name them). */
 int eav_gemm_sp_x1(const void* A, const void* B, float* C, const float* slotA, const float* slotB, int M, int N, int K,
                    int ldc, int batch, int64_t sA_bytes, int64_t sC, float alpha, const float* bias, int gelu, float* pre,
                    const float* resid, int ldr, int accumulate, float* amax_slot, void* stream);
+/* eav_gemm_sp_planes with option flags */
+#define EAV_GEMM_ONE_TERM 1    /* the hi.hi term alone */
+#define EAV_GEMM_SHARED_GPU 2  /* a second persistent GEMM runs beside this one (the backward's data gradients next to the
+                                * side stream's weight gradients): prefer the 256 x 128 one-workgroup-per-CU form */
+int eav_gemm_sp_ex(const void* A, const void* B, float* C, const float* slotA, const float* slotB, int M, int N, int K,
+                   int ldc, int batch, int64_t sA_bytes, int64_t sC, float alpha, const float* bias, int gelu, float* pre,
+                   const float* resid, int ldr, int accumulate, float* amax_slot, void* planes_out,
+                   const float* planes_slot, int flags, void* stream);
 int eav_gemm_sp_splitk_x1(const void* A, const void* B, float* C, float* ws, const float* slotA, const float* slotB, int M,
                           int N, int T, int accumulate, void* stream);
 /* TEST / TUNING ONLY - process-global state, not part of the drop-in boundary: the trainers never call these; the kernel

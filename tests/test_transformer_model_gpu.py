@@ -215,6 +215,16 @@ def test_one_term_gradients_leave_the_logits_alone(golden_dir, kind):
     print(f"{kind}: one-term gradients: worst relative error {worst:.2e}; logit difference after one AdamW step {drift:.2e}")
     assert worst > 1e-5          # (the mode really ran)
     assert drift < 1e-3
+    # fwd_terms = 1 (comparison leg of bench.py): 16-bit matrix operands in the forward too - the logits move, measurably
+    model = T.Encoder(cfg, W).cuda().train()
+    model.precision = "split"
+    model.fwd_terms = model.grad_terms = 1
+    lg = model(xd).logits
+    CrossEntropyLoss()(lg, yd).backward()
+    err = float((lg.detach() - res[3][0]).abs().max())
+    print(f"{kind}: one-term forward: max |logit - three-term logit| = {err:.2e}")
+    assert 1e-5 < err < 3e-2
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters())
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)

@@ -23,6 +23,9 @@ if os.environ.get("SPLITK"):          # forced slice count of the weight-gradien
 if os.environ.get("SP_TILE"):
     from eav_amd import _lib
     _lib.call("eav_gemm_sp_set_tile", int(os.environ["SP_TILE"]))
+if os.environ.get("FREEZE"):          # the fine-tune's first phase: classifier head only
+    for k, p in model.named_parameters():
+        p.requires_grad = k.startswith("classifier.")
 x, y = (synth.mel_batch(5, B) if kind == "ast" else synth.frame_batch(5, B))
 x, y = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
 opt, crit = FusedAdam(model.parameters(), lr=5e-6, weight_decay=0.01, decoupled=True), CrossEntropyLoss()

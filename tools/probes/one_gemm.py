@@ -14,6 +14,8 @@ from eav_amd import _lib  # noqa: E402
 from gemm_sp_bench import P, planes, row_planes  # noqa: E402
 
 _lib.load()
+if os.environ.get("SP_TILE"):
+    _lib.call("eav_gemm_sp_set_tile", int(os.environ["SP_TILE"]))
 mode, M, N, K = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 if mode == "nt":
     A = torch.randn(M, K, device="cuda")

@@ -6,7 +6,8 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 ARGS="$@"
 i=0
-for PMC in "FETCH_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_REQ_sum TCC_READ_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" "TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RD_UNCACHED_32B_sum" "TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum" "TCC_TAG_STALL_sum TCC_EA0_RDREQ_LEVEL_sum"; do
+if [ -n "$QUICK" ]; then set -- "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_HIT_sum TCC_MISS_sum"; else set -- "FETCH_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_REQ_sum TCC_READ_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" "TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum" "TCC_TAG_STALL_sum TCC_EA0_RDREQ_LEVEL_sum"; fi
+for PMC in "$@"; do
   i=$((i+1))
   timeout 300 rocprofv3 --kernel-trace --pmc $PMC -d $OUT/p$i -o p -- python3 $R/tools/probes/one_gemm.py $ARGS > $OUT/p$i.log 2>&1
   DB=$(find $OUT/p$i -name "*.db" | head -1)

@@ -761,12 +761,13 @@ __global__ void sp_splitk_reduce_kernel(const float* __restrict__ ws, int nsplit
 
 // ------------------------------------------------------------------------------------------------------------------
 // max |v| of a strided matrix into slot[0] (bits; atomicMax on non-negative floats = integer max: order-independent)
-__global__ __launch_bounds__(256) void sp_absmax_kernel(const float* __restrict__ src, int R, int C4, int64_t ld,
-                                                        unsigned* __restrict__ slot) {
+__device__ __forceinline__ void sp_absmax_body(const float* __restrict__ src, int R, int C4, int64_t ld,
+                                               unsigned* __restrict__ slot, int slab) {
   // grid (column chunks of 256 float4, 128-row blocks, 4 slabs of 32 rows): 16 B per lane along the row, four row loads
   // in flight; the maximum goes to a tensor-wide shard AND to the row block's entry (EAV_SLOT_BMAX)
   const int c = blockIdx.x * 256 + threadIdx.x;
-  const int r0 = blockIdx.y * 128 + blockIdx.z * 32, r1 = min(R, r0 + 32);
+  const int r0 = blockIdx.y * 128 + slab * 32, r1 = min(R, r0 + 32);
+  if (r0 >= R || blockIdx.x * 256 >= C4) return;
   float m = 0.f;
   if (c < C4) {
     const float* p = src + 4 * (int64_t)c;
@@ -789,10 +790,29 @@ __global__ __launch_bounds__(256) void sp_absmax_kernel(const float* __restrict_
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
   if ((threadIdx.x & 63) == 0 && m == m) {
-    atomicMax(slot + EAV_SLOT_SHARD(((blockIdx.y * 4 + blockIdx.z) * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)),
+    atomicMax(slot + EAV_SLOT_SHARD(((blockIdx.y * 4 + slab) * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)),
               __float_as_uint(m));
     eav_slot_blockmax(slot, r0, m);
   }
+}
+
+__global__ __launch_bounds__(256) void sp_absmax_kernel(const float* __restrict__ src, int R, int C4, int64_t ld,
+                                                        unsigned* __restrict__ slot) {
+  sp_absmax_body(src, R, C4, ld, slot, blockIdx.z);
+}
+
+// One launch for a table of dense matrices (the GEMM weights of an encoder: 49 matrices after every optimiser step).
+struct PlaneJob {       // = EavPlaneJob of include/eav_hip.h
+  const float* src;     // [R, C] dense
+  unsigned char* dst;   // planes [R][Cp/8][2][8] or null
+  unsigned char* dstT;  // planes of the transpose [C][Rp/8][2][8] or null
+  float* slot;          // zeroed by the caller
+  int R, C;
+};
+
+__global__ __launch_bounds__(256) void sp_absmax_multi_kernel(const PlaneJob* __restrict__ jobs) {
+  const PlaneJob j = jobs[blockIdx.z >> 2];
+  sp_absmax_body(j.src, j.R, j.C >> 2, j.C, reinterpret_cast<unsigned*>(j.slot), blockIdx.z & 3);
 }
 
 // sigma = 2^(14 - floor(log2 amax)): max|sigma v| in [2^14, 2^15); 1 for an all-zero / non-finite tensor
@@ -819,11 +839,11 @@ __device__ __forceinline__ void split8(const float (&tv)[8], uint4& hi, uint4& l
 // dstT planes [C][Rp/8][2][8] (contraction over rows).  64 x 64 tiles; persistent blocks walk the tiles (column index
 // fastest) with the next tile's loads in flight while the current one is split, transposed through LDS and stored - a
 // streaming pass keeps its rate with a few hundred resident blocks and drops with tens of thousands (tools/copy_bench.py).
-__global__ __launch_bounds__(256) void sp_convert_kernel(const float* __restrict__ src, int R, int C, int64_t ld,
-                                                         float* __restrict__ slot, unsigned char* __restrict__ dst,
-                                                         int Cp, unsigned char* __restrict__ dstT, int Rp,
-                                                         float lomul, float* __restrict__ colsum_part, int ntx,
-                                                         int ntiles, int gelu) {
+__device__ __forceinline__ void sp_convert_body(const float* __restrict__ src, int R, int C, int64_t ld,
+                                                float* __restrict__ slot, unsigned char* __restrict__ dst, int Cp,
+                                                unsigned char* __restrict__ dstT, int Rp, float lomul,
+                                                float* __restrict__ colsum_part, int ntx, int ntiles, int gelu, int bid,
+                                                int nblocks) {
   // A thread's natural output - the hi and the lo piece of 8 values - is 32 contiguous bytes but a store carries 16: stored
   // directly, every store instruction writes 16-byte chunks with 16-byte holes (measured: 4.4 TB/s; with 32-byte holes
   // 2.5-3).  The pieces go through an LDS image of the tile's planes instead and leave in linear order: each store
@@ -833,7 +853,7 @@ __global__ __launch_bounds__(256) void sp_convert_kernel(const float* __restrict
   __shared__ uint4 timg[64 * 16 + 64];     // the same for the transposed planes (row = tile column)
   const unsigned gbits = eav_slot_bits(slot);
   const float sigma0 = sigma_from_bits(gbits);
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
+  if (bid == 0 && threadIdx.x == 0) {
     slot[EAV_SLOT_SIGMA] = sigma0;
     slot[EAV_SLOT_ISIGMA] = 1.f / sigma0;
   }
@@ -866,11 +886,11 @@ __global__ __launch_bounds__(256) void sp_convert_kernel(const float* __restrict
     }
   };
   float cur[2][8];
-  int id = blockIdx.x;
+  int id = bid;
   if (id < ntiles) load_tile(id, cur);
-  for (; id < ntiles; id += gridDim.x) {
+  for (; id < ntiles; id += nblocks) {
     float nxt[2][8];
-    const int nid = id + gridDim.x;
+    const int nid = id + nblocks;
     if (nid < ntiles) load_tile(nid, nxt);
     const int by = id / ntx, bx = id - by * ntx;
     const int r0 = by * 64, c0 = bx * 64;
@@ -930,6 +950,23 @@ __global__ __launch_bounds__(256) void sp_convert_kernel(const float* __restrict
   }
 }
 
+__global__ __launch_bounds__(256) void sp_convert_kernel(const float* __restrict__ src, int R, int C, int64_t ld,
+                                                         float* __restrict__ slot, unsigned char* __restrict__ dst,
+                                                         int Cp, unsigned char* __restrict__ dstT, int Rp,
+                                                         float lomul, float* __restrict__ colsum_part, int ntx,
+                                                         int ntiles, int gelu) {
+  sp_convert_body(src, R, C, ld, slot, dst, Cp, dstT, Rp, lomul, colsum_part, ntx, ntiles, gelu, blockIdx.x, gridDim.x);
+}
+
+// grid (blocks per matrix, matrices): every matrix of the table in one launch
+__global__ __launch_bounds__(256) void sp_convert_multi_kernel(const PlaneJob* __restrict__ jobs, float lomul) {
+  const PlaneJob j = jobs[blockIdx.y];
+  const int Cp = (j.C + 31) / 32 * 32, Rp = (j.R + 31) / 32 * 32;
+  const int ntx = (Cp + 63) / 64, nty = (Rp + 63) / 64;
+  sp_convert_body(j.src, j.R, j.C, j.C, j.slot, j.dst, Cp, j.dstT, Rp, lomul, nullptr, ntx, ntx * nty, 0, blockIdx.x,
+                  gridDim.x);
+}
+
 int g_convert_blocks = 512;   // resident-block cap of the conversion pass (tuning hook: eav_sp_set_convert_blocks)
 
 void launch_convert(const float* src, int R, int C, int64_t ld, float* slot, void* dst, void* dstT, float* colsum_part,
@@ -987,6 +1024,23 @@ extern "C" int eav_sp_convert_colsum(const float* src, int R, int C, int64_t ld,
               "eav_sp_convert_colsum: leading dimension must be a multiple of 4, buffers 16-byte aligned");
   launch_convert(src, R, C, ld, slot, dst, dstT, colsum_part, (hipStream_t)stream);
   EAV_CHECK_LAUNCH("eav_sp_convert_colsum");
+  return EAV_OK;
+}
+
+// max|x| and planes (and / or planes of the transpose) of every matrix of a device-resident table in two launches: the
+// weight refresh of an encoder after an optimiser step (49 matrices; one eav_sp_absmax + eav_sp_convert pair per matrix
+// spent ~0.9 ms of launches per step on ~0.3 ms of memory traffic).  jobs: n x EavPlaneJob in device memory; every
+// slot zeroed by the caller; C % 4 == 0, sources 16-byte aligned; maxR / maxC: the largest R and C of the table.
+extern "C" int eav_sp_refresh_planes(const void* jobs, int n, int maxR, int maxC, void* stream) {
+  EAV_REQUIRE(jobs && n > 0 && n <= 16383 && maxR > 0 && maxC > 0 && (maxC & 3) == 0, "eav_sp_refresh_planes: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(sp_absmax_multi_kernel, dim3(cdiv(maxC / 4, 256), cdiv(maxR, 128), 4 * n), dim3(256), 0, st,
+                     (const PlaneJob*)jobs);
+  EAV_CHECK_LAUNCH("eav_sp_refresh_planes(absmax)");
+  const int tiles = cdiv(eav_sp_kpad(maxC), 64) * cdiv(eav_sp_kpad(maxR), 64);
+  hipLaunchKernelGGL(sp_convert_multi_kernel, dim3(std::min(tiles, std::max(8, 2048 / n)), n), dim3(256), 0, st,
+                     (const PlaneJob*)jobs, g_loshift ? 2048.f : 1.f);
+  EAV_CHECK_LAUNCH("eav_sp_refresh_planes(convert)");
   return EAV_OK;
 }
 

@@ -383,15 +383,32 @@ __global__ __launch_bounds__(256) void pair_mean_kernel(float* __restrict__ seq,
 int grid_for(int64_t n) { return (int)(n < 1 ? 1 : (cdiv64(n, 256) > 4096 ? 4096 : cdiv64(n, 256))); }
 
 // ------------------------------------------------------------------------------------ a-priori operand scales
-// max over the rows of ||w_r||_2 (bits, atomicMax - zero `out` first): one wave per row
+// max over the rows of ||w_r||_2 (bits, atomicMax - zero `out` first): one wave per row, 16-byte loads, all loads of a
+// row in flight at once for rows of up to 1024 floats (was a scalar-load loop: 39 us for mlp.fc1.weight, now ~6)
 __global__ __launch_bounds__(256) void rownorm_max_kernel(const float* __restrict__ w, int R, int C, int64_t ld,
                                                           unsigned* __restrict__ out) {
   const int lane = threadIdx.x & 63;
+  const bool vec = (C & 3) == 0 && (ld & 3) == 0 && ((uintptr_t)w & 15) == 0;
   float best = 0.f;
   for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < R; r += gridDim.x * 4) {
     const float* src = w + (int64_t)r * ld;
     float s = 0.f;
-    for (int c = lane; c < C; c += 64) s = fmaf(src[c], src[c], s);
+    if (vec) {
+      const float4* s4 = reinterpret_cast<const float4*>(src);
+      const int n4 = C >> 2;
+      for (int c0 = 0; c0 < n4; c0 += 256) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int c = c0 + lane + 64 * u;
+          v[u] = c < n4 ? s4[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s = fmaf(v[u].x, v[u].x, fmaf(v[u].y, v[u].y, fmaf(v[u].z, v[u].z, fmaf(v[u].w, v[u].w, s))));
+      }
+    } else {
+      for (int c = lane; c < C; c += 64) s = fmaf(src[c], src[c], s);
+    }
     best = fmaxf(best, sqrtf(wave_sum(s)));
   }
   if (lane == 0 && best == best) atomicMax(out, __float_as_uint(best));

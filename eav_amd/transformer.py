@@ -480,6 +480,26 @@ class Encoder(nn.Module):
             if len(stale) == len(keys):
                 wp["_slots"].zero_()
                 wp["_wnorm_fc1"].zero_()
+                # everything is stale (the state after an optimiser step): the whole table in two launches
+                jobs = wp.get("_jobs")
+                if jobs is None or wp["_jobs_key"] != key[0]:
+                    rows = []
+                    for k, src, out, inn in stale:
+                        pl, plT, n = wp[k]
+                        rows.append([src, _lib.ptr(pl), _lib.ptr(plT) or 0,
+                                     wp["_slots"].data_ptr() + 4 * self.SLOT * n, out | (inn << 32)])     # EavPlaneJob
+                    jobs = wp["_jobs"] = torch.tensor(rows, dtype=torch.int64).to(dev)
+                    wp["_jobs_key"] = key[0]
+                _lib.call("eav_sp_refresh_planes", _lib.ptr(jobs), len(stale), max(o for _, _, o, _ in stale),
+                          max(i for _, _, _, i in stale), st)
+                for k, src, out, inn in stale:
+                    if k.startswith("fc1"):
+                        _lib.call("eav_rownorm_max", src, out, inn, inn, wp["_wnorm_fc1"].data_ptr() + 4 * int(k[3:]), st)
+                if side is not None:
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    self._wready = {k: ev for k, _, _, _ in stale}
+                stale = []
             for k, src, out, inn in stale:
                 pl, plT, n = wp[k]
                 if len(stale) != len(keys):

@@ -259,6 +259,17 @@ int eav_sp_convert_gelu(const float* src, int R, int C, int64_t ld, float* slot,
 int eav_sp_convert_colsum_nparts(int R);
 int eav_sp_convert_colsum(const float* src, int R, int C, int64_t ld, float* slot, void* dst, void* dstT,
                           float* colsum_part, void* stream);
+/* eav_sp_absmax + eav_sp_convert for a whole table of dense matrices in two launches (the weight refresh of an encoder
+ * after an optimiser step: 49 matrices).  jobs: n entries in DEVICE memory; slots zeroed by the caller; every C % 4 == 0,
+ * sources 16-byte aligned; maxR / maxC = the largest R and C in the table. */
+typedef struct EavPlaneJob {
+  const float* src;   /* [R, C] dense fp32 */
+  void* dst;          /* planes [R][Cp/8][2][8] or NULL */
+  void* dstT;         /* planes of the transpose [C][Rp/8][2][8] or NULL */
+  float* slot;        /* EAV_SP_SLOT floats */
+  int R, C;
+} EavPlaneJob;
+int eav_sp_refresh_planes(const void* jobs, int n, int maxR, int maxC, void* stream);
 /* producers that also accumulate max|output| into an operand-scale slot (zeroed by the caller) */
 int eav_layernorm_fwd_amax(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                            int M, int D, float eps, float* amax_slot, void* stream);

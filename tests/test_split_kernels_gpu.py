@@ -417,6 +417,11 @@ def test_forward_scales_are_bounds_and_row_norms_are_exact():
     out = torch.zeros(1, device="cuda")
     _lib.call("eav_rownorm_max", P(w), R, C, C, P(out), None)
     assert abs(float(out) - float(w.double().norm(dim=1).max())) < 1e-5 * float(out)
+    for r, c, ld in ((5, 1300, 1300), (9, 1027, 1031), (130, 40, 64)):     # long / unaligned (scalar path) / short rows
+        wv = torch.randn(r, ld, device="cuda")
+        o2 = torch.zeros(1, device="cuda")
+        _lib.call("eav_rownorm_max", P(wv), r, c, ld, P(o2), None)
+        assert abs(float(o2) - float(wv[:, :c].double().norm(dim=1).max())) < 1e-5 * float(o2)
     # one layer laid out as [g1 | b1 | g2 | b2 | bfc1]
     D, FF = C, R
     g1, b1, g2, b2 = (torch.rand(D, device="cuda") + 0.5, torch.randn(D, device="cuda") * 0.2,
@@ -596,3 +601,35 @@ def x1_args(A, B, C):
     sb, pb, _ = planes(B)
     x1_args.keep = (sa, pa, sb, pb)
     return (P(pa), P(pb), P(C), P(sa), P(sb), M, N, K, N, 1, 0, 0, 1.0, None, 0, None, None, 0, 0, None, None)
+
+
+def test_table_refresh_equals_the_per_matrix_passes():
+    """eav_sp_refresh_planes (every GEMM weight of an encoder in two launches) against eav_sp_absmax + eav_sp_convert per
+    matrix: the same planes, transposed planes, scales and row-block entries, bit for bit - matrices of different shapes,
+    with and without transposed planes, rows far below the matrix maximum (boost exponents) included."""
+    torch.manual_seed(3)
+    shapes = [(768, 256), (2304, 768), (768, 768), (3072, 768), (768, 3072), (40, 64), (200, 136)]
+    mats = [torch.randn(r, c, device="cuda") * (0.02 * (i + 1)) for i, (r, c) in enumerate(shapes)]
+    mats[3][256:512] *= 1e-4                      # a row block far below the maximum
+    for with_T in (True, False):
+        ref, rows, keep = [], [], []
+        slots = torch.zeros(len(mats), SLOT, device="cuda")
+        for i, w in enumerate(mats):
+            r, c = w.shape
+            s, d, dT = planes(w, True, with_T)
+            ref.append((s, d, dT))
+            d2 = torch.zeros_like(d)
+            dT2 = torch.zeros_like(dT) if with_T else None
+            keep.append((d2, dT2))
+            rows.append([w.data_ptr(), d2.data_ptr(), dT2.data_ptr() if with_T else 0, slots[i].data_ptr(), r | (c << 32)])
+        jobs = torch.tensor(rows, dtype=torch.int64).cuda()
+        _lib.call("eav_sp_refresh_planes", P(jobs), len(mats), max(r for r, _ in shapes), max(c for _, c in shapes), None)
+        for i, (s, d, dT) in enumerate(ref):
+            assert torch.equal(keep[i][0], d), (with_T, i)
+            if with_T:
+                assert torch.equal(keep[i][1], dT), (with_T, i)
+            assert torch.equal(slots[i][2048:2050], s[2048:2050])                      # sigma, 1 / sigma
+            assert torch.equal(slots[i][2080:].view(torch.int32), s[2080:].view(torch.int32))   # block maxima, boosts
+            assert float(slots[i][:2048].max()) == float(s[:2048].max())
+        if not with_T:
+            assert int(slots[3][3104:].view(torch.int32).max()) >= 8     # (the small row block of matrix 3 really is boosted)

@@ -81,6 +81,7 @@ struct SpArgs {
   int64_t sA, sC;           // batch strides (blockIdx.z): A in bytes, C / pre in floats (B is shared)
   float alpha;
   int gelu, accumulate;
+  int order;                // tile order inside an XCD (see tile_origin)
   int kt_per_split;         // > 0: split-K, slice z covers K-tiles [z*kt_per_split, ...), C[z] = partial slab
   int tm, tn;
 };
@@ -183,6 +184,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
   auto tile_origin = [&](int id, int& m0, int& n0) {
     const int q = nb >> 3, r = nb & 7, xcd = id & 7, j = id >> 3;
     const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    if (g.order == 1) {            // row-major: the tn tiles of a tile-row are consecutive (see gemm_sp_impl)
+      m0 = (lin / g.tn) * BM;
+      n0 = (lin % g.tn) * BN;
+      return;
+    }
     const int gsz = 8 * g.tn, grp = lin / gsz, first_m = grp * 8;
     const int gm = min(8, g.tm - first_m), rem = lin - grp * gsz;
     m0 = (first_m + rem % gm) * BM;
@@ -699,6 +705,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
 #undef SB
 }
 
+int g_order = 0;
 int g_force_tile = 0;   // test / tuning hook: 0 = heuristic, 1 = 128x128, 2 = 256x128
 // 11 (default): lo = fp16((t - hi) 2^11), cross terms in a second accumulator folded in with 2^-11 - both pieces stay
 // normal fp16 numbers for elements down to 2^-29 of the tensor maximum.  0: lo = fp16(t - hi), one accumulator (64 fewer
@@ -736,7 +743,8 @@ void dispatch(SpArgs& g, int nz, hipStream_t st, int terms = 3, bool shared_gpu 
   // kernel's workgroups off the CUs it runs on - the two take turns instead of sharing every CU's LDS bandwidth and L2
   // (ViT B=128 step 57.6 -> 55.9 ms, tools/encoder_step_bench.py with SP_TILE=1 / 0 on one box; +10 % alone at 8192^3).
   const bool big = g_force_tile == 2 || (g_force_tile == 0 && shared_gpu && cdiv(g.M, 256) * cdiv(g.N, 128) >= 256);
-  if (big) launch<4, 2, 2, 2, false, 3>(g, nz, st, terms);
+  if (g_force_tile == 3) launch<2, 4, 2, 2, false, 3>(g, nz, st, terms);
+  else if (big) launch<4, 2, 2, 2, false, 3>(g, nz, st, terms);
   else launch<2, 2, 2, 2>(g, nz, st, terms);
 }
 
@@ -1053,6 +1061,7 @@ extern "C" int eav_gemm_sp_set_splitk(int slices) {
 
 extern "C" int eav_gemm_sp_set_tile(int which) {
   g_force_tile = which & 3;
+  g_order = (which >> 4) & 3;      // +16: groups of 8 tile-rows, +32: row-major, 0: by shape
   g_loshift = (which & 4) ? 0 : 11;
   g_persist = (which & 8) ? 0 : 1;
   return EAV_OK;
@@ -1084,6 +1093,15 @@ static int gemm_sp_impl(const void* A, const void* B, float* C, const float* slo
   g.lomul = g_loshift ? 2048.f : 1.f;
   g.M = M; g.N = N; g.nkt = Kp / 32; g.ldA = (int64_t)Kp * 4; g.ldB = (int64_t)Kp * 4; g.ldc = ldc; g.ldr = ldr;
   g.sA = sA_bytes; g.sC = sC; g.alpha = alpha; g.gelu = gelu; g.accumulate = accumulate; g.kt_per_split = 0;
+  // Tile order inside an XCD (tile_origin).  Few tile-columns (N <= 1024): row-major - the N / BN tiles that share a panel of A
+  // are consecutive, i.e. resident together; with the 8-row groups a group (48 tiles at N = 768) straddled the rounds of 64
+  // resident workgroups and every A panel came in from the fabric twice ([25216 x 3072] x [768 x 3072]^T: 8.8 M -> 6.1 M
+  // 128-byte fabric reads per launch, TCC_EA0_RDREQ; 4.6 M in the 256 x 128 form; -2.5 % time, and the kernel runs at the
+  // package power limit - tools/probes/clock_probe.py - where fabric traffic is paid for in clock).  Many tile-columns:
+  // groups of 8 tile-rows x all columns (a round = 8 x 8 tiles) unless both operands are small enough to live in the
+  // Infinity Cache, where the row-major walk measured 5-11 % faster (AST B=8: qkv, fc1).
+  g.order = g_order ? g_order - 1
+                    : (cdiv(N, 128) <= 8 || ((int64_t)M + N) * Kp * 4 <= (48ll << 20) ? 1 : 0);
   dispatch(g, batch, (hipStream_t)stream, terms, (flags & EAV_GEMM_SHARED_GPU) != 0);
   EAV_CHECK_LAUNCH("eav_gemm_sp");
   return EAV_OK;
@@ -1157,6 +1175,7 @@ static int gemm_sp_splitk_impl(const void* A, const void* B, float* C, float* ws
   EAV_REQUIRE(g_loshift != 0, "eav_gemm_sp_splitk: the single-accumulator tuning mode has no token-contracting kernel");
   const int nsplit = g_splitk_force > 0 ? g_splitk_force : eav_gemm_sp_splitk_plan(M, N, T);
   SpArgs g;
+  g.order = 0;
   g.A = (const unsigned char*)A; g.B = (const unsigned char*)B; g.slotA = slotA; g.slotB = slotB;
   g.bias = nullptr; g.resid = nullptr; g.pre = nullptr; g.amax = nullptr; g.planes = nullptr; g.slotP = nullptr;
   g.ldp = 0; g.lomul = 2048.f;

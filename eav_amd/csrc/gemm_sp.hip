@@ -1146,19 +1146,20 @@ extern "C" int eav_gemm_sp(const void* A, const void* B, float* C, const float* 
 }
 
 // split-K plan for the weight-gradient shapes (small M x N output, long contraction).  All workgroups of a launch have
-// the same length L = K-tiles per slice and a CU works through ceil(workgroups / 256) of them at ~0.6 us per K-tile
-// (two resident workgroups share its matrix pipes and its L2 -> LDS stream; ~15 K-tiles of start-up + epilogue each), then
-// the slabs are reduced (64 KB per tile and slice at ~3.5 TB/s).  The slice count minimises that estimate - fitted to
-// tools/splitk_sweep.py on the AST / ViT shapes (ViT fc1, 144 tiles: 7 slices = 1008 workgroups = 4 per CU, 0.35 ms; the
-// previous "~512 workgroups" rule took 4 slices = 3 per CU of almost twice the length, 0.41-0.48 ms).  At least 8 K-tiles
-// per slice, at most 32 slices.
+// the same length L = K-tiles per slice (+ ~15 K-tiles' worth of start-up and epilogue); a CU works through
+// k = ceil(workgroups / 256) of them, two at a time at ~1.25 us per K-tile each, an odd last one alone at ~0.7 us; then the
+// slabs are reduced (64 KB per tile and slice at ~3.5 TB/s).  The slice count minimises that estimate - fitted to
+// tools/splitk_sweep.py on the AST / ViT shapes, where it lands within 3 % of the best measured count (ViT fc1, 144 tiles:
+// 7 slices = 1008 workgroups = 4 per CU, 0.34 ms; the previous "~512 workgroups" rule took 4 slices = 3 per CU of almost
+// twice the length, 0.41-0.48 ms).  At least 8 K-tiles per slice, at most 32 slices.
 extern "C" int eav_gemm_sp_splitk_plan(int M, int N, int K) {
   const int tiles = cdiv(M, 128) * cdiv(N, 128), nkt = eav_sp_kpad(K) / 32;
   const int maxs = std::min(32, std::max(1, nkt / 8));
   int best = 1;
   double best_cost = 1e30;
   for (int ns = 1; ns <= maxs; ++ns) {
-    const double cost = 0.6 * cdiv(tiles * ns, 256) * (cdiv(nkt, ns) + 15) + (ns > 1 ? 0.0187 * ns * tiles : 0.0);
+    const int k = cdiv(tiles * ns, 256);
+    const double cost = (cdiv(nkt, ns) + 15) * (1.25 * (k / 2) + 0.7 * (k & 1)) + (ns > 1 ? 0.0187 * ns * tiles : 0.0);
     if (cost < best_cost) { best_cost = cost; best = ns; }
   }
   return best;
@@ -1175,7 +1176,8 @@ static int gemm_sp_splitk_impl(const void* A, const void* B, float* C, float* ws
   EAV_REQUIRE(g_loshift != 0, "eav_gemm_sp_splitk: the single-accumulator tuning mode has no token-contracting kernel");
   const int nsplit = g_splitk_force > 0 ? g_splitk_force : eav_gemm_sp_splitk_plan(M, N, T);
   SpArgs g;
-  g.order = 0;
+  // a slice's tiles are spread over the 8 XCDs (tiles / 8 each): walk them so that an XCD's share is the squarer block
+  g.order = g_order ? g_order - 1 : (cdiv(N, 128) <= 8 && cdiv(M, 128) > cdiv(N, 128) ? 1 : 0);
   g.A = (const unsigned char*)A; g.B = (const unsigned char*)B; g.slotA = slotA; g.slotB = slotB;
   g.bias = nullptr; g.resid = nullptr; g.pre = nullptr; g.amax = nullptr; g.planes = nullptr; g.slotP = nullptr;
   g.ldp = 0; g.lomul = 2048.f;

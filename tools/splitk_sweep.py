@@ -27,6 +27,7 @@ def sweep(name, M, N, T, fn="eav_gemm_sp_splitk"):
             if ns * 8 > (T + 31) // 32:
                 continue
             _lib.call("eav_gemm_sp_set_splitk", ns)
+            _lib.call("eav_gemm_sp_set_tile", xcd)
             ms = timeit(lambda: _lib.call(fn, P(pa), P(pb), P(C), P(ws), P(sa), P(sb), M, N, T, 0, None), reps=20)
             if ref is None:
                 ref = C.clone()
@@ -34,6 +35,7 @@ def sweep(name, M, N, T, fn="eav_gemm_sp_splitk"):
             assert err < 1e-5, (name, xcd, ns, err)
             res.append((ms, xcd, ns))
     _lib.call("eav_gemm_sp_set_splitk", 0)
+    _lib.call("eav_gemm_sp_set_tile", 0)
     best = min(res)
     print(f"{name:10s} M={M:5d} N={N:5d} T={T:6d} plan {plan}: " +
           "  ".join(f"{ns}:{ms * 1e3:4.0f}{'*' if (ms, x, ns) == best else ''}" for ms, x, ns in res))

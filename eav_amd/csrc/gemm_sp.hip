@@ -71,6 +71,7 @@ struct SpArgs {
   const float* resid;       // [M,N] (ldr) or null, added after the activation
   float* pre;               // [M,N] (ldc) or null: value before the activation
   unsigned* amax;           // or null: atomicMax of the bits of |stored value|
+  float* colsum;            // or null: [ceil(M / 64)][N] column sums of the stored value over blocks of 64 rows (bias gradient)
   unsigned char* planes;    // or null: the stored value (after the activation) also leaves as row planes [M][Np/8][2][8],
   const float* slotP;       //   scaled by slotP[EAV_SLOT_SIGMA] - a scale known BEFORE the launch (eav_tf_forward_scales);
   int64_t ldp;              //   row pitch of the planes in bytes; C may then be null (no fp32 copy of the value)
@@ -529,6 +530,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
           const int c = col + 8 * (r >> 2) + (r & 3);
           bv[r] = (g.bias && c < N) ? g.bias[c] : 0.f;
         }
+        float csum[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) csum[r] = 0.f;
 #pragma unroll
         for (int i = 0; i < RM; ++i) {
           const int row = m0 + wm * 32 * RM + 32 * i + r32;
@@ -590,7 +594,24 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
                 *reinterpret_cast<uint4*>(g.planes + (int64_t)row * g.ldp + (int64_t)(cg >> 3) * 32 + kh * 16) = pc;
             }
           }
+          if (g.colsum) {     // column sums over this block's 32 rows (one row per lane of a wave half), fixed order
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              float t = ok(r) ? a[r] : 0.f;
+#pragma unroll
+              for (int o = 1; o < 32; o <<= 1) t += __shfl_xor(t, o, 64);
+              csum[r] += t;
+            }
+          }
           __builtin_amdgcn_sched_barrier(0);   // keep the next block's loads behind this block's stores (register pressure)
+        }
+        if (g.colsum && r32 == 0 && m0 + wm * 32 * RM < M) {
+          float* cp = g.colsum + (int64_t)((m0 + wm * 32 * RM) >> 6) * N;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int c = col + 8 * (r >> 2) + (r & 3);
+            if (c < N) cp[c] = csum[r];
+          }
         }
       }
     };
@@ -607,6 +628,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
         const int colb = n0 + wn * 32 * RN + 32 * j;
         float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (g.bias) b4 = *reinterpret_cast<const float4*>(g.bias + colb + 4 * pc4);
+        float4 cs4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int i = 0; i < RM; ++i) {
           const int rowb = m0 + wm * 32 * RM + 32 * i;
@@ -684,12 +706,25 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
 #pragma unroll
             for (int r = 0; r < 16; ++r) vmax = fmaxf(vmax, fabsf(v[r]));
           }
+          if (g.colsum) {     // lane = rows prow + 8 k, columns 4 pc4 .. + 3: four rows in the lane, then the 8 lanes of a column group
+            float4 t = make_float4((v[0] + v[4]) + (v[8] + v[12]), (v[1] + v[5]) + (v[9] + v[13]),
+                                   (v[2] + v[6]) + (v[10] + v[14]), (v[3] + v[7]) + (v[11] + v[15]));
+#pragma unroll
+            for (int o = 8; o < 64; o <<= 1) {
+              t.x += __shfl_xor(t.x, o, 64); t.y += __shfl_xor(t.y, o, 64);
+              t.z += __shfl_xor(t.z, o, 64); t.w += __shfl_xor(t.w, o, 64);
+            }
+            cs4.x += t.x; cs4.y += t.y; cs4.z += t.z; cs4.w += t.w;
+          }
           __builtin_amdgcn_sched_barrier(0);
         }
+        if (g.colsum && prow == 0)
+          *reinterpret_cast<float4*>(g.colsum + (int64_t)((m0 + wm * 32 * RM) >> 6) * N + colb + 4 * pc4) = cs4;
       }
     };
-    const bool aligned = (((uintptr_t)C | (uintptr_t)pre | (uintptr_t)g.resid | (uintptr_t)g.bias | (uintptr_t)g.planes) & 15) == 0 &&
-                         ((g.ldc | g.ldr | (int)(g.sC & 3)) & 3) == 0;
+    const bool aligned = (((uintptr_t)C | (uintptr_t)pre | (uintptr_t)g.resid | (uintptr_t)g.bias | (uintptr_t)g.planes |
+                           (uintptr_t)g.colsum) & 15) == 0 &&
+                         ((g.ldc | g.ldr | (int)(g.sC & 3) | (g.colsum ? N : 0)) & 3) == 0;
     if (aligned && m0 + BM <= M && n0 + BN <= N) epilogue_linear();
     else epilogue_elements();
     if (g.amax) {
@@ -1073,7 +1108,8 @@ extern "C" int eav_gemm_sp_set_tile(int which) {
 static int gemm_sp_impl(const void* A, const void* B, float* C, const float* slotA, const float* slotB, int M,
                         int N, int K, int ldc, int batch, int64_t sA_bytes, int64_t sC, float alpha,
                         const float* bias, int gelu, float* pre, const float* resid, int ldr, int accumulate,
-                        float* amax_slot, void* planes_out, const float* planes_slot, void* stream, int flags) {
+                        float* amax_slot, void* planes_out, const float* planes_slot, void* stream, int flags,
+                        float* colsum_part = nullptr) {
   const int terms = (flags & EAV_GEMM_ONE_TERM) ? 1 : 3;
   EAV_REQUIRE(A && B && (C || planes_out) && slotA && slotB && M > 0 && N > 0 && K > 0 && batch > 0,
               "eav_gemm_sp: bad arguments");
@@ -1085,10 +1121,12 @@ static int gemm_sp_impl(const void* A, const void* B, float* C, const float* slo
   EAV_REQUIRE(!planes_out || (planes_slot && batch == 1 && (N & 7) == 0 && gelu != 3 && ((uintptr_t)planes_out & 15) == 0),
               "eav_gemm_sp: plane output needs its scale slot, batch 1, N %% 8 == 0");
   EAV_REQUIRE(C || !accumulate, "eav_gemm_sp: accumulate needs C");
+  EAV_REQUIRE(!colsum_part || (batch == 1 && gelu != 3), "eav_gemm_sp: column sums need batch 1 and a stored value");
   SpArgs g;
   const int Kp = eav_sp_kpad(K);
   g.A = (const unsigned char*)A; g.B = (const unsigned char*)B; g.C = C; g.slotA = slotA; g.slotB = slotB;
   g.bias = bias; g.resid = resid; g.pre = pre; g.amax = reinterpret_cast<unsigned*>(amax_slot);
+  g.colsum = colsum_part;
   g.planes = (unsigned char*)planes_out; g.slotP = planes_slot; g.ldp = (int64_t)eav_sp_kpad(N) * 4;
   g.lomul = g_loshift ? 2048.f : 1.f;
   g.M = M; g.N = N; g.nkt = Kp / 32; g.ldA = (int64_t)Kp * 4; g.ldB = (int64_t)Kp * 4; g.ldc = ldc; g.ldr = ldr;
@@ -1115,14 +1153,18 @@ extern "C" int eav_gemm_sp_planes(const void* A, const void* B, float* C, const 
                       accumulate, amax_slot, planes_out, planes_slot, stream, 0);
 }
 
+// colsum_part (optional): [ceil(M / 64)][N] - row p = the column sums of the stored value over rows [64 p, 64 p + 64), the
+// partials of a bias gradient (finish with eav_reduce_partials): with planes_out the producer of a gradient tensor
+// leaves the planes AND the bias gradient behind, no conversion pass (fc2's data gradient -> the planes of dact).
 // eav_gemm_sp_planes with options: EAV_GEMM_ONE_TERM (the hi.hi term alone, see eav_gemm_sp_x1), EAV_GEMM_SHARED_GPU (a
 // second persistent GEMM runs beside this one: prefer the one-workgroup-per-CU form, see dispatch)
 extern "C" int eav_gemm_sp_ex(const void* A, const void* B, float* C, const float* slotA, const float* slotB, int M, int N,
                               int K, int ldc, int batch, int64_t sA_bytes, int64_t sC, float alpha, const float* bias,
                               int gelu, float* pre, const float* resid, int ldr, int accumulate, float* amax_slot,
-                              void* planes_out, const float* planes_slot, int flags, void* stream) {
+                              void* planes_out, const float* planes_slot, float* colsum_part, int flags,
+                              void* stream) {
   return gemm_sp_impl(A, B, C, slotA, slotB, M, N, K, ldc, batch, sA_bytes, sC, alpha, bias, gelu, pre, resid, ldr,
-                      accumulate, amax_slot, planes_out, planes_slot, stream, flags);
+                      accumulate, amax_slot, planes_out, planes_slot, stream, flags, colsum_part);
 }
 
 // eav_gemm_sp with the hi.hi term only: the product of the operands rounded to fp16 (11-bit mantissas under the planes'
@@ -1180,6 +1222,7 @@ static int gemm_sp_splitk_impl(const void* A, const void* B, float* C, float* ws
   g.order = g_order ? g_order - 1 : (cdiv(N, 128) <= 8 && cdiv(M, 128) > cdiv(N, 128) ? 1 : 0);
   g.A = (const unsigned char*)A; g.B = (const unsigned char*)B; g.slotA = slotA; g.slotB = slotB;
   g.bias = nullptr; g.resid = nullptr; g.pre = nullptr; g.amax = nullptr; g.planes = nullptr; g.slotP = nullptr;
+  g.colsum = nullptr;
   g.ldp = 0; g.lomul = 2048.f;
   g.M = M; g.N = N; g.nkt = cdiv(T, 32); g.ldA = (int64_t)eav_sp_kpad(M) * 4; g.ldB = (int64_t)eav_sp_kpad(N) * 4;
   g.ldc = N; g.ldr = 0; g.sA = 0; g.sC = 0; g.alpha = 1.f; g.gelu = 0;

@@ -414,6 +414,35 @@ __global__ __launch_bounds__(256) void rownorm_max_kernel(const float* __restric
   if (lane == 0 && best == best) atomicMax(out, __float_as_uint(best));
 }
 
+// max over the COLUMNS of ||w[:, c]||_2 (bits, atomicMax - zero `out` first): a thread owns 4 columns, a block 1024
+__global__ __launch_bounds__(256) void colnorm_max_kernel(const float* __restrict__ w, int R, int C, int64_t ld,
+                                                          unsigned* __restrict__ out) {
+  const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
+  float best = 0.f;
+  if (c < C) {
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    int r = 0;
+    for (; r + 3 < R; r += 4) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(w + (int64_t)(r + u) * ld + c);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        s.x = fmaf(v[u].x, v[u].x, s.x); s.y = fmaf(v[u].y, v[u].y, s.y);
+        s.z = fmaf(v[u].z, v[u].z, s.z); s.w = fmaf(v[u].w, v[u].w, s.w);
+      }
+    }
+    for (; r < R; ++r) {
+      const float4 v = *reinterpret_cast<const float4*>(w + (int64_t)r * ld + c);
+      s.x = fmaf(v.x, v.x, s.x); s.y = fmaf(v.y, v.y, s.y); s.z = fmaf(v.z, v.z, s.z); s.w = fmaf(v.w, v.w, s.w);
+    }
+    best = sqrtf(fmaxf(fmaxf(s.x, s.y), fmaxf(s.z, s.w)));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) best = fmaxf(best, __shfl_xor(best, o, 64));
+  if ((threadIdx.x & 63) == 0 && best == best) atomicMax(out, __float_as_uint(best));
+}
+
 __device__ __forceinline__ float sigma_of_bound(float b) {
   // the power of two that puts b in [2^14, 2^15) (as sigma_from_bits in gemm_sp.hip); 1 for 0 / non-finite
   const unsigned bits = __float_as_uint(b);
@@ -650,6 +679,37 @@ extern "C" int eav_rownorm_max(const float* w, int R, int C, int64_t ld, float* 
   hipLaunchKernelGGL(rownorm_max_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, R, C, ld,
                      reinterpret_cast<unsigned*>(out));
   EAV_CHECK_LAUNCH("eav_rownorm_max");
+  return EAV_OK;
+}
+
+extern "C" int eav_colnorm_max(const float* w, int R, int C, int64_t ld, float* out, void* stream) {
+  EAV_REQUIRE(w && out && R > 0 && C > 0 && ld >= C && (C & 3) == 0 && (ld & 3) == 0 && ((uintptr_t)w & 15) == 0,
+              "eav_colnorm_max: bad arguments (C, ld multiples of 4, w 16-byte aligned)");
+  hipLaunchKernelGGL(colnorm_max_kernel, dim3(cdiv(C, 1024)), dim3(256), 0, (hipStream_t)stream, w, R, C, ld,
+                     reinterpret_cast<unsigned*>(out));
+  EAV_CHECK_LAUNCH("eav_colnorm_max");
+  return EAV_OK;
+}
+
+// sigma / 1 / sigma of slot_out from the bound factor * max|x| * *norm, max|x| = the maximum in amax_slot's shards: the
+// operand scale of a tensor that is about to be produced, from a bound of its magnitude (e.g. the MLP's hidden-state
+// gradient dact = (dh W2) o gelu'(pre): |dact| <= 1.13 sqrt(D) max|dh| max_j ||W2[:, j]||_2) - its producer then writes
+// the planes directly (eav_gemm_sp_ex with planes_out).  One wave.
+__global__ __launch_bounds__(64) void bound_scale_kernel(float* __restrict__ slot_out, const float* __restrict__ amax_slot,
+                                                         const float* __restrict__ norm, float factor) {
+  const unsigned bits = eav_slot_bits(amax_slot);
+  if (threadIdx.x == 0) {
+    const float bound = factor * __uint_as_float(bits) * norm[0] * 1.0001f;
+    const float sg = sigma_of_bound(bound);
+    slot_out[EAV_SLOT_SIGMA] = sg;
+    slot_out[EAV_SLOT_ISIGMA] = 1.f / sg;
+  }
+}
+
+extern "C" int eav_sp_bound_scale(float* slot_out, const float* amax_slot, const float* norm, float factor, void* stream) {
+  EAV_REQUIRE(slot_out && amax_slot && norm && factor > 0.f, "eav_sp_bound_scale: bad arguments");
+  hipLaunchKernelGGL(bound_scale_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, slot_out, amax_slot, norm, factor);
+  EAV_CHECK_LAUNCH("eav_sp_bound_scale");
   return EAV_OK;
 }
 

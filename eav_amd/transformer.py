@@ -198,6 +198,9 @@ class Encoder(nn.Module):
         self.fwd_terms = int(os.environ.get("EAV_FWD_TERMS", "3"))
         # split mode: LayerNorm / fc1 write their consumers' operand planes (a-priori scales); EAV_FUSED_PLANES=0 for A/B runs
         self.fused_planes = os.environ.get("EAV_FUSED_PLANES", "1") != "0"
+        # split mode, backward: fc2's data-gradient GEMM writes the planes of dact (and the partials of fc1's bias gradient)
+        # itself, scaled by a bound of |dact| known before the launch - no fp32 dact, no conversion pass; EAV_FUSED_DACT=0
+        self.fused_dact = os.environ.get("EAV_FUSED_DACT", "1") != "0"
         self._side, self._aux, self._wgrad_done, self._wready = None, None, {}, {}
         self._part_busy, self._ring_pos = {}, {}
         self._wplanes = None          # split mode: {weight key: (planes, planes of the transpose, slot index)}
@@ -454,7 +457,9 @@ class Encoder(nn.Module):
             wp = {"_T": need_T, "_dev": dev,
                   "_slots": torch.zeros(len(keys), self.SLOT, dtype=torch.float32, device=dev),
                   # max_n ||W1_n||_2 per layer: input of the a-priori scale of the MLP activation (eav_tf_forward_scales)
-                  "_wnorm_fc1": torch.zeros(self.cfg.layers, dtype=torch.float32, device=dev)}
+                  "_wnorm_fc1": torch.zeros(self.cfg.layers, dtype=torch.float32, device=dev),
+                  # max_j ||W2[:, j]||_2 per layer: bound of the MLP hidden-state gradient (eav_sp_bound_scale)
+                  "_wcolnorm_fc2": torch.zeros(self.cfg.layers, dtype=torch.float32, device=dev)}
             for n, (k, _, out, inn) in enumerate(keys):
                 wp[k] = (torch.empty(out, 2 * kp(inn), dtype=torch.float16, device=dev),
                          torch.empty(inn, 2 * kp(out), dtype=torch.float16, device=dev) if need_T else None, n)
@@ -480,6 +485,7 @@ class Encoder(nn.Module):
             if len(stale) == len(keys):
                 wp["_slots"].zero_()
                 wp["_wnorm_fc1"].zero_()
+                wp["_wcolnorm_fc2"].zero_()
                 # everything is stale (the state after an optimiser step): the whole table in two launches
                 jobs = wp.get("_jobs")
                 if jobs is None or wp["_jobs_key"] != key[0]:
@@ -495,6 +501,8 @@ class Encoder(nn.Module):
                 for k, src, out, inn in stale:
                     if k.startswith("fc1"):
                         _lib.call("eav_rownorm_max", src, out, inn, inn, wp["_wnorm_fc1"].data_ptr() + 4 * int(k[3:]), st)
+                    elif k.startswith("fc2") and need_T:
+                        _lib.call("eav_colnorm_max", src, out, inn, inn, wp["_wcolnorm_fc2"].data_ptr() + 4 * int(k[3:]), st)
                 if side is not None:
                     ev = torch.cuda.Event()
                     ev.record(side)
@@ -512,6 +520,11 @@ class Encoder(nn.Module):
                     if len(stale) != len(keys):
                         wp["_wnorm_fc1"][li].zero_()
                     _lib.call("eav_rownorm_max", src, out, inn, inn, wp["_wnorm_fc1"].data_ptr() + 4 * li, st)
+                elif k.startswith("fc2") and need_T:
+                    li = int(k[3:])
+                    if len(stale) != len(keys):
+                        wp["_wcolnorm_fc2"][li].zero_()
+                    _lib.call("eav_colnorm_max", src, out, inn, inn, wp["_wcolnorm_fc2"].data_ptr() + 4 * li, st)
                 if side is not None:
                     ev = torch.cuda.Event()
                     ev.record(side)
@@ -579,7 +592,7 @@ class Encoder(nn.Module):
         bwd = self._phase == "bwd"
         flags = (1 if (self.grad_terms if bwd else self.fwd_terms) == 1 else 0) | (2 if bwd and self.overlap_wgrad else 0)
         self._call("eav_gemm_sp_ex", A, B, C, slotA, slotB, M, N, K, ldc, batch, sA, sC, float(alpha), bias, gelu, pre,
-                   resid, ldr, acc, amax, None, None, flags, self._st)
+                   resid, ldr, acc, amax, None, None, None, flags, self._st)
 
     def _wgrad_sp(self, AT, slotA, BT, slotB, C, M, N, K):
         """C[M,N] = sum over the K tokens of A[t,m] B[t,n]: ROW planes of A [K,M] and B [K,N] (the contraction runs over the
@@ -777,7 +790,7 @@ class Encoder(nn.Module):
             # activation leaves as planes - it never exists in fp32
             self._call("eav_gemm_sp_ex", P(ws.y2p[j]), wpl, None, s_y2, wsl, M, FF, D, FF, 1, 0, 0, 1.0,
                        w(f"{Lk}.mlp.fc1.bias"), 1, P(ws.pre[j]) if ws.full else None, None, 0, 0, None, P(ws.actp[j]),
-                       s_act, 1 if self.fwd_terms == 1 else 0, st)
+                       s_act, None, 1 if self.fwd_terms == 1 else 0, st)
         else:
             L("eav_layernorm_fwd_amax", P(ws.hmid[j]), w(f"{Lk}.layernorm_after.weight"),
               w(f"{Lk}.layernorm_after.bias"), P(y), stp + 8 * M, stp + 12 * M, M, D, c.eps, s_y2, st)
@@ -815,10 +828,23 @@ class Encoder(nn.Module):
         self._to_planes_bias(dh, M, D, b_dh2, ws.dhp, gp(f"{Lk}.mlp.fc2.bias"))
         self._wgrad_sp(ws.dhp, b_dh2, ws.actp[i], s_act, gp(f"{Lk}.mlp.fc2.weight"), D, FF, M)
         wpl, wsl = self._wp(f"fc2{i}", transposed=True)
-        # data gradient through fc2 and the GELU in one pass: the epilogue multiplies by gelu'(pre) and emits max|dact|
-        self._gemm_sp(P(ws.dhp), b_dh2, wpl, wsl, dact, M, FF, D, FF, gelu=2, pre=P(ws.pre[i]), amax=b_dact)
+        if self.fused_dact and FF % 8 == 0:
+            # data gradient through fc2 and the GELU in one pass, result straight into the planes of dact: its scale comes
+            # from |dact| = |(dh W2) gelu'(pre)| <= 1.13 sqrt(D) max|dh| max_j ||W2[:, j]||_2 (max|dh| is in b_dh2, the column
+            # norms are refreshed with the weight planes); the epilogue also leaves fc1's bias-gradient partials
+            L("eav_sp_bound_scale", b_dact, b_dh2, self._wplanes["_wcolnorm_fc2"].data_ptr() + 4 * i,
+              1.13 * float(np.sqrt(D)), st)
+            self._before_overwrite(ws.dactp)
+            part = self._part_buf("part_cs2_pool")
+            flags = (1 if self.grad_terms == 1 else 0) | (2 if self.overlap_wgrad else 0)
+            L("eav_gemm_sp_ex", P(ws.dhp), wpl, None, b_dh2, wsl, M, FF, D, FF, 1, 0, 0, 1.0, None, 2, P(ws.pre[i]), None, 0,
+              0, None, P(ws.dactp), b_dact, P(part), flags, st)
+            self._reduce_async(part, 0, ws.np_cs2, FF, FF, gp(f"{Lk}.mlp.fc1.bias"))
+        else:
+            # ... the epilogue multiplies by gelu'(pre) and emits max|dact|; one conversion pass (planes + bias gradient)
+            self._gemm_sp(P(ws.dhp), b_dh2, wpl, wsl, dact, M, FF, D, FF, gelu=2, pre=P(ws.pre[i]), amax=b_dact)
+            self._to_planes_bias(dact, M, FF, b_dact, ws.dactp, gp(f"{Lk}.mlp.fc1.bias"))
         # fc1
-        self._to_planes_bias(dact, M, FF, b_dact, ws.dactp, gp(f"{Lk}.mlp.fc1.bias"))
         self._wgrad_sp(ws.dactp, b_dact, ws.y2p[i], s_y2, gp(f"{Lk}.mlp.fc1.weight"), FF, D, M)
         wpl, wsl = self._wp(f"fc1{i}", transposed=True)
         self._gemm_sp(P(ws.dactp), b_dact, wpl, wsl, dy, M, D, FF, D)

@@ -299,6 +299,12 @@ int eav_layernorm_fwd_planes(const float* x, const float* gamma, const float* be
                              const float* scale_slot, float* mean, float* rstd, int M, int D, float eps, void* stream);
 /* max over the rows of ||w_r||_2 into *out (float bits combined with atomicMax: zero it first) */
 int eav_rownorm_max(const float* w, int R, int C, int64_t ld, float* out, void* stream);
+/* the same over the COLUMNS of w [R, C] (C, ld multiples of 4) */
+int eav_colnorm_max(const float* w, int R, int C, int64_t ld, float* out, void* stream);
+/* sigma, 1/sigma of slot_out from the bound  factor * max|x| * *norm  (max|x| = the maximum held by amax_slot's shards, norm a
+ * device scalar): the operand scale of a tensor BEFORE it is produced, so that its producer can write planes directly.
+ * Used for the MLP hidden-state gradient dact = (dh W2) o gelu'(pre): |dact| <= 1.13 sqrt(D) max|dh| max_j ||W2[:,j]||_2. */
+int eav_sp_bound_scale(float* slot_out, const float* amax_slot, const float* norm, float factor, void* stream);
 /* sigma, 1/sigma of the operand slots of LayerNorm-before output (k_y1), LayerNorm-after output (k_y2) and the MLP's GELU
  * output (k_act) of `layers` encoder layers from rigorous bounds: |LN out| <= sqrt(D) max|gamma| + max|beta|,
  * |GELU(y2 W1^T + b1)| <= (sqrt(D) max|gamma2| + ||beta2||_2) max_n ||W1_n||_2 + max|b1|.  params: first float of layer 0
@@ -327,10 +333,12 @@ int eav_gemm_sp_x1(const void* A, const void* B, float* C, const float* slotA, c
 #define EAV_GEMM_ONE_TERM 1    /* the hi.hi term alone */
 #define EAV_GEMM_SHARED_GPU 2  /* a second persistent GEMM runs beside this one (the backward's data gradients next to the
                                 * side stream's weight gradients): prefer the 256 x 128 one-workgroup-per-CU form */
+/* colsum_part (optional): [ceil(M / 64)][N], row p = column sums of the stored value over rows [64 p, 64 p + 64) - bias-gradient
+ * partials for eav_reduce_partials; batch 1. */
 int eav_gemm_sp_ex(const void* A, const void* B, float* C, const float* slotA, const float* slotB, int M, int N, int K,
                    int ldc, int batch, int64_t sA_bytes, int64_t sC, float alpha, const float* bias, int gelu, float* pre,
                    const float* resid, int ldr, int accumulate, float* amax_slot, void* planes_out,
-                   const float* planes_slot, int flags, void* stream);
+                   const float* planes_slot, float* colsum_part, int flags, void* stream);
 int eav_gemm_sp_splitk_x1(const void* A, const void* B, float* C, float* ws, const float* slotA, const float* slotB, int M,
                           int N, int T, int accumulate, void* stream);
 /* TEST / TUNING ONLY - process-global state, not part of the drop-in boundary: the trainers never call these; the kernel

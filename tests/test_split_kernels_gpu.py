@@ -633,3 +633,51 @@ def test_table_refresh_equals_the_per_matrix_passes():
             assert float(slots[i][:2048].max()) == float(s[:2048].max())
         if not with_T:
             assert int(slots[3][3104:].view(torch.int32).max()) >= 8     # (the small row block of matrix 3 really is boosted)
+
+
+@pytest.mark.parametrize("shape", [(512, 384, 96), (9712, 3072, 768), (1000, 200, 100), (25216, 264, 64), (70, 72, 40)])
+@pytest.mark.parametrize("tile", [0, 2])
+def test_gelu_backward_epilogue_leaves_planes_and_bias_gradient_partials(shape, tile):
+    """fc2's data gradient as the encoder backward launches it (eav_gemm_sp_ex: gelu = 2, C = NULL, planes_out, colsum_part):
+    the product times gelu'(pre) leaves as the row planes of the NEXT products - scaled by the bound eav_sp_bound_scale
+    derives from max|dh| and the column norms of W2 (eav_colnorm_max), which must really bound it - together with the
+    64-row column-sum partials of fc1's bias gradient.  Full and ragged tiles, both tile forms; bit-reproducible."""
+    M, N, K = shape          # tokens, FF, D
+    torch.manual_seed(M + N)
+    dh = torch.randn(M, K, device="cuda") * 1e-3 * (1 + torch.arange(M, device="cuda") % 3)[:, None]
+    W2 = torch.randn(K, N, device="cuda") * 0.03            # fc2.weight [D, FF]
+    pre = torch.randn(M, N, device="cuda") * 1.5
+    sa, pa, _ = planes(dh)
+    sb, pbT = planes(W2, want=False, wantT=True)[0::2]      # planes of W2^T [FF, D]: B operand, contraction over D
+    cn = torch.zeros(1, device="cuda")
+    _lib.call("eav_colnorm_max", P(W2), K, N, N, P(cn), None)
+    assert abs(float(cn) - float(W2.double().norm(dim=0).max())) < 1e-5 * float(cn)
+    slot = torch.zeros(SLOT, device="cuda")
+    _lib.call("eav_sp_bound_scale", P(slot), P(sa), P(cn), 1.13 * float(np.sqrt(K)), None)
+    sigma = float(slot[2048])
+    x = pre.double()
+    gp = 0.5 * (1 + torch.erf(x / np.sqrt(2))) + x * torch.exp(-x * x / 2) / np.sqrt(2 * np.pi)
+    ref = (dh.double() @ W2.double()) * gp
+    assert sigma == 2.0 ** np.round(np.log2(sigma)) and float(ref.abs().max()) * sigma < 2.0 ** 15      # a bound, a power of two
+    nparts = (M + 63) // 64
+    outs = []
+    _lib.call("eav_gemm_sp_set_tile", tile)
+    try:
+        for _ in range(2):
+            pl = torch.zeros((M + 31) // 32 * 32, 2 * kpad(N), dtype=torch.float16, device="cuda")
+            part = torch.full((nparts, N), 7.0, device="cuda")
+            _lib.call("eav_gemm_sp_ex", P(pa), P(pbT), None, P(sa), P(sb), M, N, K, N, 1, 0, 0, 1.0, None, 2, P(pre), None,
+                      0, 0, None, P(pl), P(slot), P(part), 2, None)
+            outs.append((pl, part))
+    finally:
+        _lib.call("eav_gemm_sp_set_tile", 0)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    pl, part = outs[0]
+    got = decode_planes(pl, M, N, sigma)
+    tol = 3e-7 * float((dh.double().abs() @ W2.double().abs()).max()) * 1.2 + 2.0 ** -21 * (2.0 ** 15 / sigma)
+    assert (got - ref).abs().max().item() < tol
+    assert (pl[M:] == 0).all()
+    # partial p = column sums over rows [64 p, 64 p + 64) of the value the planes hold
+    refp = torch.stack([ref[64 * p:64 * p + 64].sum(0) for p in range(nparts)])
+    assert (part.double() - refp).abs().max().item() < 64 * tol
+    assert ((part.double().sum(0) - ref.sum(0)).abs() / ref.abs().sum(0).clamp_min(1e-30)).max().item() < 1e-5

@@ -841,7 +841,8 @@ def main():
         out["modalities"] = modalities
         if multi is not None:
             multi["backend"] = eav_dist.backend_name()
-            multi["rccl_ranks"] = dist.get_world_size()
+            multi["ranks"] = dist.get_world_size()
+            multi["rccl_ranks"] = dist.get_world_size() if eav_dist.backend_name() == "nccl" else 0   # (gloo logic runs: 0)
             multi["eegnet_allreduce_bytes_per_step"] = int(run_sync_bytes)
             if enc_multi is not None:
                 multi["ast"], multi["vit"] = enc_multi["ast"], enc_multi["vit"]

@@ -94,9 +94,26 @@ __device__ __forceinline__ void load_row_frags(const u8* rowptr, int h2, f16x8 (
   }
 }
 
-// out[(row0 + r) * ld + 32*half + ..] = acc^T: lane = row, registers = 32 columns per accumulator; through an LDS patch
+// Four consecutive values of a row -> this lane's 16-byte hi or lo piece of the GEMM operand planes (gemm_sp.hip:
+// lo = fp16((t - hi) 2^11)); the neighbouring lane holds the other half of the group of 8 columns.
+__device__ __forceinline__ uint4 gemm_plane_piece4(float t0, float t1, float t2, float t3, bool first) {
+  _Float16 h[4] = {(_Float16)t0, (_Float16)t1, (_Float16)t2, (_Float16)t3};
+  _Float16 l[4] = {(_Float16)((t0 - (float)h[0]) * 2048.f), (_Float16)((t1 - (float)h[1]) * 2048.f),
+                   (_Float16)((t2 - (float)h[2]) * 2048.f), (_Float16)((t3 - (float)h[3]) * 2048.f)};
+  const uint2 hh = *reinterpret_cast<const uint2*>(h), ll = *reinterpret_cast<const uint2*>(l);
+  const uint2 send = first ? ll : hh;
+  uint2 recv;
+  recv.x = __shfl_xor(send.x, 1, 64);
+  recv.y = __shfl_xor(send.y, 1, 64);
+  return first ? make_uint4(hh.x, hh.y, recv.x, recv.y) : make_uint4(recv.x, recv.y, ll.x, ll.y);
+}
+
+// out[(row0 + r) * ld + 32*half + ..] = acc^T: lane = row, registers = 32 columns per accumulator; through an LDS patch.
+// out may be null; planes (optional): the same rows also leave as GEMM operand planes scaled by psig - planes points at the
+// first row's piece of column 0 of this head (row pitch ldp bytes).
 __device__ __forceinline__ float store_rows_T(float* __restrict__ patch, const f32x16& a0, const f32x16& a1, float mul,
-                                              float* __restrict__ out, int ld, int row0, int nrows, int lane) {
+                                              float* __restrict__ out, int ld, int row0, int nrows, int lane,
+                                              u8* __restrict__ planes = nullptr, int64_t ldp = 0, float psig = 0.f) {
   const int j = lane & 31, h2 = lane >> 5;
   float vmax = 0.f;
 #pragma unroll
@@ -113,10 +130,14 @@ __device__ __forceinline__ float store_rows_T(float* __restrict__ patch, const f
     for (int i = 0; i < 4; ++i) {
       const int idx = lane + 64 * i;
       const int row = idx >> 3, c4 = idx & 7;
-      if (row0 + row < nrows) {
-        const float* src = patch + row * 33 + 4 * c4;
-        *reinterpret_cast<float4*>(out + (int64_t)(row0 + row) * ld + 32 * half + 4 * c4) =
-            make_float4(src[0], src[1], src[2], src[3]);
+      const float* src = patch + row * 33 + 4 * c4;
+      const float4 v4 = make_float4(src[0], src[1], src[2], src[3]);
+      if (out && row0 + row < nrows) *reinterpret_cast<float4*>(out + (int64_t)(row0 + row) * ld + 32 * half + 4 * c4) = v4;
+      if (planes) {      // (uniform branch: the exchange inside runs on every lane)
+        const uint4 pc = gemm_plane_piece4(v4.x * psig, v4.y * psig, v4.z * psig, v4.w * psig, (c4 & 1) == 0);
+        if (row0 + row < nrows)
+          *reinterpret_cast<uint4*>(planes + (int64_t)(row0 + row) * ldp + (int64_t)((32 * half + 4 * c4) >> 3) * 32 +
+                                    (c4 & 1) * 16) = pc;
       }
     }
   }
@@ -161,7 +182,8 @@ template <int NW>
 __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_sp_kernel(const u8* __restrict__ rowp, const u8* __restrict__ tp,
                                                                  const float* __restrict__ slot, float* __restrict__ ao,
                                                                  float* __restrict__ lse, unsigned* __restrict__ amax,
-                                                                 int N, int Npad, int H, float scale, int ntile, int nbh) {
+                                                                 int N, int Npad, int H, float scale, int ntile, int nbh,
+                                                                 u8* __restrict__ aop, float* __restrict__ slot_ao) {
   constexpr int STAGE = 16384;   // K row tile | V^T tile
   __shared__ __attribute__((aligned(1024))) u8 smem[2 * STAGE > NW * 32 * 33 * 4 ? 2 * STAGE : NW * 32 * 33 * 4];
   const int D = H * 64;
@@ -259,8 +281,16 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_sp_kernel(const u8* __res
   const float inv = l > 0.f ? isg / (l * SP) : 0.f;
   if (h2 == 0 && q0 + j < N) lse[(int64_t)bh * N + q0 + j] = (m + log2f(l)) * LN2;
   __syncthreads();   // every wave is done with the tiles before the patch area is reused
+  // aop: the output also (or only: ao = null) leaves as the planes of the o-proj products.  O is a convex combination of V
+  // rows, |O| <= max|V| <= max|qkv|: the planes take qkv's own scale, published in slot_ao for their consumers.
+  const float psig = aop ? slot[EAV_SLOT_SIGMA] : 0.f;
+  if (aop && blockIdx.x == 0 && threadIdx.x == 0) {
+    slot_ao[EAV_SLOT_SIGMA] = psig;
+    slot_ao[EAV_SLOT_ISIGMA] = isg;
+  }
   const float vmax = store_rows_T(reinterpret_cast<float*>(smem) + wave * (32 * 33), o0, o1, inv,
-                                  ao + (int64_t)b * N * D + h * 64, D, q0, N, lane);
+                                  ao ? ao + (int64_t)b * N * D + h * 64 : nullptr, D, q0, N, lane,
+                                  aop ? aop + (int64_t)b * N * (D * 4) + h * 256 : nullptr, (int64_t)D * 4, psig);
   emit_amax(amax, vmax, lane, (int)blockIdx.x * NW + wave, q0 < N ? b * N + q0 : -1);
 }
 
@@ -632,21 +662,33 @@ extern "C" int eav_attn_sp_prep(const float* src, float* slot, void* rowp, void*
 int g_nw4_above = 128;
 extern "C" int eav_attn_sp_set_nw4_above(int n) { g_nw4_above = n; return 0; }
 
-extern "C" int eav_attn_fwd_sp(const void* rowp, const void* tp, const float* slot, float* ao, float* lse,
-                               float* amax_slot, int B, int H, int N, int head_dim, float scale, void* stream) {
-  EAV_REQUIRE(rowp && tp && slot && ao && lse && B > 0 && H > 0 && N > 0, "eav_attn_fwd_sp: bad arguments");
+// ao_planes (optional): the output as the GEMM operand planes [B*N][D/8][2][8] of the o-proj products, scaled with qkv's own
+// sigma (|O| <= max|V|), which the kernel copies into ao_slot; ao may then be null (no fp32 copy: forward-only passes).
+extern "C" int eav_attn_fwd_sp_planes(const void* rowp, const void* tp, const float* slot, float* ao, float* lse,
+                                      float* amax_slot, void* ao_planes, float* ao_slot, int B, int H, int N, int head_dim,
+                                      float scale, void* stream) {
+  EAV_REQUIRE(rowp && tp && slot && (ao || ao_planes) && lse && B > 0 && H > 0 && N > 0 && (!ao_planes || ao_slot),
+              "eav_attn_fwd_sp: bad arguments");
   EAV_REQUIRE(head_dim == 64, "eav_attn_fwd_sp: head_dim %d unsupported (needs 64)", head_dim);
   const int Npad = eav_attn_sp_npad(N);
   hipStream_t st = (hipStream_t)stream;
   if (N > g_nw4_above) {
     hipLaunchKernelGGL(attn_fwd_sp_kernel<4>, dim3(cdiv(N, 128) * B * H), dim3(256), 0, st, (const u8*)rowp,
-                       (const u8*)tp, slot, ao, lse, (unsigned*)amax_slot, N, Npad, H, scale, cdiv(N, 128), B * H);
+                       (const u8*)tp, slot, ao, lse, (unsigned*)amax_slot, N, Npad, H, scale, cdiv(N, 128), B * H,
+                       (u8*)ao_planes, ao_slot);
   } else {
     hipLaunchKernelGGL(attn_fwd_sp_kernel<2>, dim3(cdiv(N, 64) * B * H), dim3(128), 0, st, (const u8*)rowp,
-                       (const u8*)tp, slot, ao, lse, (unsigned*)amax_slot, N, Npad, H, scale, cdiv(N, 64), B * H);
+                       (const u8*)tp, slot, ao, lse, (unsigned*)amax_slot, N, Npad, H, scale, cdiv(N, 64), B * H,
+                       (u8*)ao_planes, ao_slot);
   }
   EAV_CHECK_LAUNCH("eav_attn_fwd_sp");
   return EAV_OK;
+}
+
+extern "C" int eav_attn_fwd_sp(const void* rowp, const void* tp, const float* slot, float* ao, float* lse,
+                               float* amax_slot, int B, int H, int N, int head_dim, float scale, void* stream) {
+  EAV_REQUIRE(ao, "eav_attn_fwd_sp: bad arguments");
+  return eav_attn_fwd_sp_planes(rowp, tp, slot, ao, lse, amax_slot, nullptr, nullptr, B, H, N, head_dim, scale, stream);
 }
 
 // delta: scratch [B*H, N].  slot_ds: scratch slot (zeroed by the caller).  dqkv [B*N, 3*H*64] fp32.

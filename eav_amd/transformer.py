@@ -201,6 +201,8 @@ class Encoder(nn.Module):
         # split mode, backward: fc2's data-gradient GEMM writes the planes of dact (and the partials of fc1's bias gradient)
         # itself, scaled by a bound of |dact| known before the launch - no fp32 dact, no conversion pass; EAV_FUSED_DACT=0
         self.fused_dact = os.environ.get("EAV_FUSED_DACT", "1") != "0"
+        # split mode, forward: the fused attention writes its output as the o-proj planes itself (EAV_FUSED_AO=0 for A/B runs)
+        self.fused_ao = os.environ.get("EAV_FUSED_AO", "1") != "0"
         self._side, self._aux, self._wgrad_done, self._wready = None, None, {}, {}
         self._part_busy, self._ring_pos = {}, {}
         self._wplanes = None          # split mode: {weight key: (planes, planes of the transpose, slot index)}
@@ -767,8 +769,14 @@ class Encoder(nn.Module):
         if ws.fused:
             # row planes of Q | K | V and the per-head transposes (V^T for the forward; Q^T, K^T for the backward)
             L("eav_attn_sp_prep", qkv, s_qkv, P(ws.qkvrow[j]), P(ws.qkvT[j]), ws.B, N, 3 * D, D, 7 if ws.full else 4, st)
-            L("eav_attn_fwd_sp", P(ws.qkvrow[j]), P(ws.qkvT[j]), s_qkv, P(ao), P(ws.lse[j]), s_ao, ws.B, H, N, hd,
-              scale, st)
+            if fusedp and self.fused_ao:
+                # the attention output leaves as the planes of the o-proj products (scale: qkv's own, |O| <= max|V|); its
+                # fp32 copy is written only when a backward will read it
+                L("eav_attn_fwd_sp_planes", P(ws.qkvrow[j]), P(ws.qkvT[j]), s_qkv, P(ao) if ws.full else None,
+                  P(ws.lse[j]), None, P(ws.aop[j]), s_ao, ws.B, H, N, hd, scale, st)
+            else:
+                L("eav_attn_fwd_sp", P(ws.qkvrow[j]), P(ws.qkvT[j]), s_qkv, P(ao), P(ws.lse[j]), s_ao, ws.B, H, N, hd,
+                  scale, st)
         else:
             ldn = ws.ldn
             Pm = P(ws.P[j])
@@ -777,7 +785,8 @@ class Encoder(nn.Module):
             L("eav_softmax_fwd", Pm, ws.B * H * N, N, ldn, st)
             self._gemm_f32(Pm, qkv + 8 * D, P(ao), N, hd, N, ldn, 3 * D, D, tB=1, batch=ws.B * H, heads=H,
                            sA=(H * N * ldn, N * ldn), sB=(N * 3 * D, hd), sC=(N * D, hd))
-        self._to_planes(P(ao), M, D, D, s_ao, ws.aop[j], amax_done=ws.fused)
+        if not (ws.fused and fusedp and self.fused_ao):
+            self._to_planes(P(ao), M, D, D, s_ao, ws.aop[j], amax_done=ws.fused)
         wpl, wsl = self._wp(f"o{i}")
         self._gemm_sp(P(ws.aop[j]), s_ao, wpl, wsl, P(ws.hmid[j]), M, D, D, D, bias=w(f"{Lk}.attention.o_proj.bias"),
                       resid=P(hin), ldr=D)

@@ -357,6 +357,11 @@ int eav_attn_sp_prep(const float* src, float* slot, void* rowp, void* tp, int B,
                      unsigned tmask, void* stream);
 int eav_attn_fwd_sp(const void* rowp, const void* tp, const float* slot, float* ao, float* lse, float* amax_slot, int B,
                     int H, int N, int head_dim, float scale, void* stream);
+/* the same, the output also - or only (ao = NULL: forward-only passes) - as the GEMM operand planes [B*N][D/8][2][8] of the
+ * o-proj products (lo lifted by 2^11 like eav_sp_convert's), scaled with qkv's own sigma (O is a convex combination of V
+ * rows: |O| <= max|V| <= max|qkv|), which the kernel copies into ao_slot: no conversion pass for the attention output. */
+int eav_attn_fwd_sp_planes(const void* rowp, const void* tp, const float* slot, float* ao, float* lse, float* amax_slot,
+                           void* ao_planes, float* ao_slot, int B, int H, int N, int head_dim, float scale, void* stream);
 /* dorow / dotp: planes of dO [B*N, H*64]; slot_ds: zeroed scratch slot (max|dS| travels from the dQ to the dK,dV kernel);
  * ao, dout: fp32 O and dO for delta = rowsum(dO o O); delta: scratch [B*H, N]; dqkv [B*N, 3*H*64] fp32. */
 int eav_attn_bwd_sp(const void* rowp, const void* tp, const void* dorow, const void* dotp, const float* slot,

@@ -258,6 +258,25 @@ def test_attention_sp_is_fp32_grade(cfg):
     dq32 = torch.empty_like(dqkv)
     _lib.call("eav_attn_bwd", P(qkv), P(ao32), P(dO), P(lse32), P(delta), P(dq32), B, H, N, 64, 0.125, None)
 
+    # the output as the o-proj operand planes (eav_attn_fwd_sp_planes): scale = qkv's sigma, copied into the output's slot;
+    # planes == the fp32 output of the same launch to split precision; the fp32 copy is optional; pad rows stay untouched
+    s_ao = torch.zeros(SLOT, device="cuda")
+    aop = torch.full(((B * N + 31) // 32 * 32, 2 * kpad(D)), 7.0, dtype=torch.float16, device="cuda")
+    ao2, lse2 = torch.empty_like(ao), torch.empty_like(lse)
+    _lib.call("eav_attn_fwd_sp_planes", P(rowp), P(tp), P(s_qkv), P(ao2), P(lse2), None, P(aop), P(s_ao), B, H, N, 64,
+              0.125, None)
+    assert torch.equal(ao2, ao) and torch.equal(lse2, lse)
+    sig = float(s_qkv[2048])
+    assert float(s_ao[2048]) == sig and float(s_ao[2049]) == float(s_qkv[2049])
+    assert float(ao.abs().max()) * sig < 2.0 ** 15
+    got = decode_planes(aop, B * N, D, sig)
+    assert (got - ao.double()).abs().max().item() <= 2.0 ** -21 * (2.0 ** 15 / sig)
+    assert (aop[B * N:] == 7).all()
+    aop3 = torch.zeros_like(aop)
+    _lib.call("eav_attn_fwd_sp_planes", P(rowp), P(tp), P(s_qkv), None, P(lse2), None, P(aop3), P(s_ao), B, H, N, 64,
+              0.125, None)
+    assert torch.equal(aop3[:B * N], aop[:B * N])
+
     def rel(a, r):
         return ((a.double() - r).abs().max() / r.abs().max()).item()
     assert rel(ao, ro) <= 1.5 * rel(ao32, ro) + 2e-7

@@ -640,9 +640,77 @@ __global__ __launch_bounds__(256) void attn_sp_prep_kernel(const float* __restri
   }
 }
 
+// T planes from ROW planes: the hi / lo halves of an element do not depend on the layout, so this is a pure fp16
+// transposition.  One 64-token x 64-column tile per block; grid (ncols/64, ceil(Npad/64), B); blocks of column sections
+// that are not selected return at once.
+__global__ __launch_bounds__(256) void attn_sp_transpose_kernel(const u8* __restrict__ rowp, u8* __restrict__ tp, int N,
+                                                                int Npad, int ncols, int secw, unsigned tmask) {
+  __shared__ unsigned short th[64][66], tl[64][66];
+  __shared__ uint4 pimg[64 * 17];
+  const int chunk = blockIdx.x, t0 = blockIdx.y * 64, b = blockIdx.z;
+  const int c0 = chunk * 64;
+  if (!((tmask >> (c0 / secw)) & 1u)) return;
+  const int t = threadIdx.x;
+  {
+    const int cg = t & 7, rr = t >> 3;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int tok = t0 + rr + 32 * pass;
+      uint4 hi = make_uint4(0u, 0u, 0u, 0u), lo = hi;
+      if (tok < N) {
+        const uint4* p = reinterpret_cast<const uint4*>(rowp + ((int64_t)b * N + tok) * ncols * 4 + (c0 >> 3) * 32 + cg * 32);
+        hi = p[0];
+        lo = p[1];
+      }
+      const unsigned short* hs = reinterpret_cast<const unsigned short*>(&hi);
+      const unsigned short* ls = reinterpret_cast<const unsigned short*>(&lo);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        th[rr + 32 * pass][8 * cg + e] = hs[e];
+        tl[rr + 32 * pass][8 * cg + e] = ls[e];
+      }
+    }
+  }
+  __syncthreads();
+  {
+    const int rg = t & 7, cc = t >> 3;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int d = cc + 32 * pass;
+      unsigned short hs[8], ls[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        hs[e] = th[8 * rg + e][d];
+        ls[e] = tl[8 * rg + e][d];
+      }
+      pimg[d * 17 + 2 * rg] = *reinterpret_cast<const uint4*>(hs);
+      pimg[d * 17 + 2 * rg + 1] = *reinterpret_cast<const uint4*>(ls);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int p = t + 256 * k, d = p >> 4, pc = p & 15;
+    if (t0 + 8 * (pc >> 1) < Npad)
+      *reinterpret_cast<uint4*>(tp + (((int64_t)b * (ncols / 64) + chunk) * 64 + d) * Npad * 4 + (t0 >> 3) * 32 + pc * 16) =
+          pimg[d * 17 + pc];
+  }
+}
+
 }  // namespace
 
 extern "C" int eav_attn_sp_npad(int N) { return (N + 31) / 32 * 32; }
+
+extern "C" int eav_attn_sp_transpose(const void* rowp, void* tp, int B, int N, int ncols, int secw, unsigned tmask,
+                                     void* stream) {
+  EAV_REQUIRE(rowp && tp && B > 0 && N > 0 && ncols > 0 && ncols % 64 == 0 && secw > 0 && secw % 64 == 0 &&
+                  ncols % secw == 0, "eav_attn_sp_transpose: columns and sections must be multiples of the head dimension 64");
+  const int Npad = eav_attn_sp_npad(N);
+  hipLaunchKernelGGL(attn_sp_transpose_kernel, dim3(ncols / 64, cdiv(Npad, 64), B), dim3(256), 0, (hipStream_t)stream,
+                     (const u8*)rowp, (u8*)tp, N, Npad, ncols, secw, tmask);
+  EAV_CHECK_LAUNCH("eav_attn_sp_transpose");
+  return EAV_OK;
+}
 
 extern "C" int eav_attn_sp_prep(const float* src, float* slot, void* rowp, void* tp, int B, int N, int ncols, int secw,
                                 unsigned tmask, void* stream) {

@@ -1140,6 +1140,7 @@ static int gemm_sp_impl(const void* A, const void* B, float* C, const float* slo
   // Infinity Cache, where the row-major walk measured 5-11 % faster (AST B=8: qkv, fc1).
   g.order = g_order ? g_order - 1
                     : (cdiv(N, 128) <= 8 || ((int64_t)M + N) * Kp * 4 <= (48ll << 20) ? 1 : 0);
+  if (flags & EAV_GEMM_PLANES_NOLIFT) g.lomul = 1.f;      // lo = fp16(t - hi): the attention kernels' row planes
   dispatch(g, batch, (hipStream_t)stream, terms, (flags & EAV_GEMM_SHARED_GPU) != 0);
   EAV_CHECK_LAUNCH("eav_gemm_sp");
   return EAV_OK;

@@ -458,7 +458,8 @@ __device__ __forceinline__ float sigma_of_bound(float b) {
 // LayerNorm, |xhat_k| <= sqrt(D - 1) and ||xhat||_2 <= sqrt(D), hence for y = gamma xhat + beta:
 //     |y_k| <= sqrt(D) max|gamma| + max|beta|,        ||y||_2 <= sqrt(D) max|gamma| + ||beta||_2,
 // and for the MLP's hidden activation a = GELU(y2 W1^T + b1), |GELU(x)| <= |x|:
-//     |a| <= ||y2||_2 max_n ||W1_n||_2 + max|b1|.
+//     |a| <= ||y2||_2 max_n ||W1_n||_2 + max|b1|,
+// and for the fused q/k/v projection of y1 (k_qkv >= 0): |qkv| <= ||y1||_2 max_n ||Wqkv_n||_2 + max|b_qkv|.
 // The bounds overshoot the actual maxima by a factor ~sqrt(D) / 4-5 (3 bits at D = 768); the planes keep full precision
 // for elements down to 2^-29 of the SCALE, so nothing is lost.  One block per layer; layer l's parameters start at
 // p0 + l stride (the flat parameter buffer lays the layers out identically), its slots at slots + l slot_stride.
@@ -466,46 +467,54 @@ __global__ __launch_bounds__(256) void tf_forward_scales_kernel(const float* __r
                                                                 int off_b1, int off_g2, int off_b2, int off_bfc1, int D,
                                                                 int FF, const float* __restrict__ wnorm_fc1,
                                                                 float* __restrict__ slots, int64_t slot_stride,
-                                                                int k_y1, int k_y2, int k_act, int slot_floats) {
-  __shared__ float red[4 * 7];
+                                                                int k_y1, int k_y2, int k_act, int slot_floats,
+                                                                int off_bqkv, const float* __restrict__ wnorm_qkv,
+                                                                int k_qkv) {
+  __shared__ float red[4 * 8];
   const int l = blockIdx.x;
   const float* p = p0 + (int64_t)l * stride;
-  float v[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // max|g1| max|b1| max|g2| max|b2| sum b2^2 max|bfc1| (spare)
+  // max|g1| max|b1| max|g2| max|b2| sum b2^2 max|bfc1| sum b1^2 max|bqkv|
+  float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int i = threadIdx.x; i < D; i += 256) {
     v[0] = fmaxf(v[0], fabsf(p[off_g1 + i]));
     v[1] = fmaxf(v[1], fabsf(p[off_b1 + i]));
     v[2] = fmaxf(v[2], fabsf(p[off_g2 + i]));
     v[3] = fmaxf(v[3], fabsf(p[off_b2 + i]));
     v[4] += p[off_b2 + i] * p[off_b2 + i];
+    v[6] += p[off_b1 + i] * p[off_b1 + i];
   }
   for (int i = threadIdx.x; i < FF; i += 256) v[5] = fmaxf(v[5], fabsf(p[off_bfc1 + i]));
+  if (k_qkv >= 0)
+    for (int i = threadIdx.x; i < 3 * D; i += 256) v[7] = fmaxf(v[7], fabsf(p[off_bqkv + i]));
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-  for (int k = 0; k < 7; ++k) {
+  for (int k = 0; k < 8; ++k) {
     float a = v[k];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       const float b = __shfl_xor(a, o, 64);
-      a = (k == 4) ? a + b : fmaxf(a, b);
+      a = (k == 4 || k == 6) ? a + b : fmaxf(a, b);
     }
-    if (lane == 0) red[wave * 7 + k] = a;
+    if (lane == 0) red[wave * 8 + k] = a;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    float t[7];
+    float t[8];
 #pragma unroll
-    for (int k = 0; k < 7; ++k)
-      t[k] = (k == 4) ? (red[k] + red[7 + k]) + (red[14 + k] + red[21 + k])
-                      : fmaxf(fmaxf(red[k], red[7 + k]), fmaxf(red[14 + k], red[21 + k]));
+    for (int k = 0; k < 8; ++k)
+      t[k] = (k == 4 || k == 6) ? (red[k] + red[8 + k]) + (red[16 + k] + red[24 + k])
+                                : fmaxf(fmaxf(red[k], red[8 + k]), fmaxf(red[16 + k], red[24 + k]));
     const float sd = sqrtf((float)D);
     const float b_y1 = sd * t[0] + t[1], b_y2 = sd * t[2] + t[3];
-    const float n_y2 = sd * t[2] + sqrtf(t[4]);
+    const float n_y2 = sd * t[2] + sqrtf(t[4]), n_y1 = sd * t[0] + sqrtf(t[6]);
     const float b_act = n_y2 * wnorm_fc1[l] + t[5];
+    const float b_qkv = k_qkv >= 0 ? n_y1 * wnorm_qkv[l] + t[7] : 0.f;
     float* s = slots + (int64_t)l * slot_stride;
-    const float bounds[3] = {b_y1, b_y2, b_act};
-    const int ks[3] = {k_y1, k_y2, k_act};
+    const float bounds[4] = {b_y1, b_y2, b_act, b_qkv};
+    const int ks[4] = {k_y1, k_y2, k_act, k_qkv};
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < 4; ++k) {
+      if (ks[k] < 0) continue;
       // 1.0001: the bound is evaluated in fp32 - keep it a bound under its own rounding
       const float sg = sigma_of_bound(bounds[k] * 1.0001f);
       s[(int64_t)ks[k] * slot_floats + EAV_SLOT_SIGMA] = sg;
@@ -718,13 +727,32 @@ extern "C" int eav_sp_bound_scale(float* slot_out, const float* amax_slot, const
 // the flat parameter buffer, layer_stride floats per layer, off_* = offsets of layernorm_before.{weight,bias},
 // layernorm_after.{weight,bias}, mlp.fc1.bias inside a layer; wnorm_fc1 [layers] = eav_rownorm_max of mlp.fc1.weight;
 // slots = slot of layer 0's first forward operand, slot_stride floats per layer, k_* = slot index within a layer.
+static int tf_forward_scales_impl(const float* params, int64_t layer_stride, int layers, int off_g1, int off_b1,
+                                  int off_g2, int off_b2, int off_bfc1, int D, int FF, const float* wnorm_fc1,
+                                  float* slots, int64_t slot_stride, int k_y1, int k_y2, int k_act, int off_bqkv,
+                                  const float* wnorm_qkv, int k_qkv, void* stream) {
+  EAV_REQUIRE(params && wnorm_fc1 && slots && layers > 0 && D > 0 && FF > 0 && (k_qkv < 0 || wnorm_qkv),
+              "eav_tf_forward_scales: bad arguments");
+  hipLaunchKernelGGL(tf_forward_scales_kernel, dim3(layers), dim3(256), 0, (hipStream_t)stream, params, layer_stride,
+                     off_g1, off_b1, off_g2, off_b2, off_bfc1, D, FF, wnorm_fc1, slots, slot_stride, k_y1, k_y2, k_act,
+                     EAV_SP_SLOT, off_bqkv, wnorm_qkv, k_qkv);
+  EAV_CHECK_LAUNCH("eav_tf_forward_scales");
+  return EAV_OK;
+}
+
 extern "C" int eav_tf_forward_scales(const float* params, int64_t layer_stride, int layers, int off_g1, int off_b1,
                                      int off_g2, int off_b2, int off_bfc1, int D, int FF, const float* wnorm_fc1,
                                      float* slots, int64_t slot_stride, int k_y1, int k_y2, int k_act, void* stream) {
-  EAV_REQUIRE(params && wnorm_fc1 && slots && layers > 0 && D > 0 && FF > 0, "eav_tf_forward_scales: bad arguments");
-  hipLaunchKernelGGL(tf_forward_scales_kernel, dim3(layers), dim3(256), 0, (hipStream_t)stream, params, layer_stride,
-                     off_g1, off_b1, off_g2, off_b2, off_bfc1, D, FF, wnorm_fc1, slots, slot_stride, k_y1, k_y2, k_act,
-                     EAV_SP_SLOT);
-  EAV_CHECK_LAUNCH("eav_tf_forward_scales");
-  return EAV_OK;
+  return tf_forward_scales_impl(params, layer_stride, layers, off_g1, off_b1, off_g2, off_b2, off_bfc1, D, FF, wnorm_fc1,
+                                slots, slot_stride, k_y1, k_y2, k_act, 0, nullptr, -1, stream);
+}
+
+// the same plus the slot of the fused q/k/v projection's output (k_qkv) from ||y1||_2 max_n ||Wqkv_n||_2 + max|b_qkv|:
+// off_bqkv = offset of the fused [3D] bias in a layer, wnorm_qkv [layers] = eav_rownorm_max of the fused [3D, D] weight
+extern "C" int eav_tf_forward_scales_qkv(const float* params, int64_t layer_stride, int layers, int off_g1, int off_b1,
+                                         int off_g2, int off_b2, int off_bfc1, int off_bqkv, int D, int FF,
+                                         const float* wnorm_fc1, const float* wnorm_qkv, float* slots, int64_t slot_stride,
+                                         int k_y1, int k_y2, int k_act, int k_qkv, void* stream) {
+  return tf_forward_scales_impl(params, layer_stride, layers, off_g1, off_b1, off_g2, off_b2, off_bfc1, D, FF, wnorm_fc1,
+                                slots, slot_stride, k_y1, k_y2, k_act, off_bqkv, wnorm_qkv, k_qkv, stream);
 }

@@ -203,6 +203,9 @@ class Encoder(nn.Module):
         self.fused_dact = os.environ.get("EAV_FUSED_DACT", "1") != "0"
         # split mode, forward: the fused attention writes its output as the o-proj planes itself (EAV_FUSED_AO=0 for A/B runs)
         self.fused_ao = os.environ.get("EAV_FUSED_AO", "1") != "0"
+        # split mode, forward: the fused q/k/v projection writes the attention kernels' row planes itself (scale from a bound of
+        # |qkv|), the per-head transposes are made from those planes - no fp32 qkv tensor (EAV_FUSED_QKV=0 for A/B runs)
+        self.fused_qkv = os.environ.get("EAV_FUSED_QKV", "1") != "0"
         self._side, self._aux, self._wgrad_done, self._wready = None, None, {}, {}
         self._part_busy, self._ring_pos = {}, {}
         self._wplanes = None          # split mode: {weight key: (planes, planes of the transpose, slot index)}
@@ -460,6 +463,8 @@ class Encoder(nn.Module):
                   "_slots": torch.zeros(len(keys), self.SLOT, dtype=torch.float32, device=dev),
                   # max_n ||W1_n||_2 per layer: input of the a-priori scale of the MLP activation (eav_tf_forward_scales)
                   "_wnorm_fc1": torch.zeros(self.cfg.layers, dtype=torch.float32, device=dev),
+                  # max_n ||Wqkv_n||_2 per layer: bound of the fused q/k/v projection's output
+                  "_wnorm_qkv": torch.zeros(self.cfg.layers, dtype=torch.float32, device=dev),
                   # max_j ||W2[:, j]||_2 per layer: bound of the MLP hidden-state gradient (eav_sp_bound_scale)
                   "_wcolnorm_fc2": torch.zeros(self.cfg.layers, dtype=torch.float32, device=dev)}
             for n, (k, _, out, inn) in enumerate(keys):
@@ -488,6 +493,7 @@ class Encoder(nn.Module):
                 wp["_slots"].zero_()
                 wp["_wnorm_fc1"].zero_()
                 wp["_wcolnorm_fc2"].zero_()
+                wp["_wnorm_qkv"].zero_()
                 # everything is stale (the state after an optimiser step): the whole table in two launches
                 jobs = wp.get("_jobs")
                 if jobs is None or wp["_jobs_key"] != key[0]:
@@ -505,6 +511,8 @@ class Encoder(nn.Module):
                         _lib.call("eav_rownorm_max", src, out, inn, inn, wp["_wnorm_fc1"].data_ptr() + 4 * int(k[3:]), st)
                     elif k.startswith("fc2") and need_T:
                         _lib.call("eav_colnorm_max", src, out, inn, inn, wp["_wcolnorm_fc2"].data_ptr() + 4 * int(k[3:]), st)
+                    elif k.startswith("qkv"):
+                        _lib.call("eav_rownorm_max", src, out, inn, inn, wp["_wnorm_qkv"].data_ptr() + 4 * int(k[3:]), st)
                 if side is not None:
                     ev = torch.cuda.Event()
                     ev.record(side)
@@ -527,6 +535,11 @@ class Encoder(nn.Module):
                     if len(stale) != len(keys):
                         wp["_wcolnorm_fc2"][li].zero_()
                     _lib.call("eav_colnorm_max", src, out, inn, inn, wp["_wcolnorm_fc2"].data_ptr() + 4 * li, st)
+                elif k.startswith("qkv"):
+                    li = int(k[3:])
+                    if len(stale) != len(keys):
+                        wp["_wnorm_qkv"][li].zero_()
+                    _lib.call("eav_rownorm_max", src, out, inn, inn, wp["_wnorm_qkv"].data_ptr() + 4 * li, st)
                 if side is not None:
                     ev = torch.cuda.Event()
                     ev.record(side)
@@ -753,9 +766,11 @@ class Encoder(nn.Module):
             offs = self._flat[2]
             base = offs[f"{Lk}.attention.q_proj.weight"][0]
             o = lambda k: offs[f"{Lk}.{k}"][0] - base  # noqa: E731
-            L("eav_tf_forward_scales", P(self._flat[0]) + 4 * base, 0, 1, o("layernorm_before.weight"),
-              o("layernorm_before.bias"), o("layernorm_after.weight"), o("layernorm_after.bias"), o("mlp.fc1.bias"), D, FF,
-              self._wplanes["_wnorm_fc1"].data_ptr() + 4 * i, s_y1, 0, 0, 3, 4, st)
+            qkvp = self.fused_qkv and ws.fused
+            L("eav_tf_forward_scales_qkv", P(self._flat[0]) + 4 * base, 0, 1, o("layernorm_before.weight"),
+              o("layernorm_before.bias"), o("layernorm_after.weight"), o("layernorm_after.bias"), o("mlp.fc1.bias"),
+              o("attention.q_proj.bias"), D, FF, self._wplanes["_wnorm_fc1"].data_ptr() + 4 * i,
+              self._wplanes["_wnorm_qkv"].data_ptr() + 4 * i, s_y1, 0, 0, 3, 4, 1 if qkvp else -1, st)
             L("eav_layernorm_fwd_planes", P(hin), w(f"{Lk}.layernorm_before.weight"), w(f"{Lk}.layernorm_before.bias"),
               None, P(ws.y1p[j]), s_y1, stp, stp + 4 * M, M, D, c.eps, st)
         else:
@@ -764,11 +779,23 @@ class Encoder(nn.Module):
             self._to_planes(P(y), M, D, D, s_y1, ws.y1p[j], amax_done=True)
         qkv = P(ws.qkv[0 if ws.fused else j])
         wpl, wsl = self._wp(f"qkv{i}")
-        self._gemm_sp(P(ws.y1p[j]), s_y1, wpl, wsl, qkv, M, 3 * D, D, 3 * D, bias=w(f"{Lk}.attention.q_proj.bias"),
-                      amax=s_qkv if ws.fused else None)
+        qkvp = fusedp and self.fused_qkv and ws.fused
+        if qkvp:
+            # the projection writes the row planes of Q | K | V itself (lo without the 2^11 lift: the attention kernels' format,
+            # scale = the bound eav_tf_forward_scales_qkv put into s_qkv); the per-head transposes (V^T for the forward; Q^T,
+            # K^T for the backward) are a pure fp16 transposition of those planes
+            L("eav_gemm_sp_ex", P(ws.y1p[j]), wpl, None, s_y1, wsl, M, 3 * D, D, 3 * D, 1, 0, 0, 1.0,
+              w(f"{Lk}.attention.q_proj.bias"), 0, None, None, 0, 0, None, P(ws.qkvrow[j]), s_qkv, None,
+              4 | (1 if self.fwd_terms == 1 else 0), st)
+            L("eav_attn_sp_transpose", P(ws.qkvrow[j]), P(ws.qkvT[j]), ws.B, N, 3 * D, D, 7 if ws.full else 4, st)
+        else:
+            self._gemm_sp(P(ws.y1p[j]), s_y1, wpl, wsl, qkv, M, 3 * D, D, 3 * D, bias=w(f"{Lk}.attention.q_proj.bias"),
+                          amax=s_qkv if ws.fused else None)
         if ws.fused:
-            # row planes of Q | K | V and the per-head transposes (V^T for the forward; Q^T, K^T for the backward)
-            L("eav_attn_sp_prep", qkv, s_qkv, P(ws.qkvrow[j]), P(ws.qkvT[j]), ws.B, N, 3 * D, D, 7 if ws.full else 4, st)
+            if not qkvp:
+                # row planes of Q | K | V and the per-head transposes (V^T for the forward; Q^T, K^T for the backward)
+                L("eav_attn_sp_prep", qkv, s_qkv, P(ws.qkvrow[j]), P(ws.qkvT[j]), ws.B, N, 3 * D, D, 7 if ws.full else 4,
+                  st)
             if fusedp and self.fused_ao:
                 # the attention output leaves as the planes of the o-proj products (scale: qkv's own, |O| <= max|V|); its
                 # fp32 copy is written only when a backward will read it

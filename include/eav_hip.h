@@ -314,6 +314,10 @@ int eav_sp_bound_scale(float* slot_out, const float* amax_slot, const float* nor
 int eav_tf_forward_scales(const float* params, int64_t layer_stride, int layers, int off_g1, int off_b1, int off_g2,
                           int off_b2, int off_bfc1, int D, int FF, const float* wnorm_fc1, float* slots,
                           int64_t slot_stride, int k_y1, int k_y2, int k_act, void* stream);
+int eav_tf_forward_scales_qkv(const float* params, int64_t layer_stride, int layers, int off_g1, int off_b1, int off_g2,
+                              int off_b2, int off_bfc1, int off_bqkv, int D, int FF, const float* wnorm_fc1,
+                              const float* wnorm_qkv, float* slots, int64_t slot_stride, int k_y1, int k_y2, int k_act,
+                              int k_qkv, void* stream);
 /* long-contraction form (weight gradients): C[M,N] = sum_t A[t,m] B[t,n] over ROW planes A [Tp][Mp/8][2][8], B
  * [Tp][Np/8][2][8] - the contraction runs over the rows (tokens), read with transposing LDS loads; Tp = T rounded up to
  * 32 and the rows >= T must be ZERO.  eav_gemm_sp_splitk_plan(M,N,T) token slices, ws [nsplit][M][N] partials summed in
@@ -331,6 +335,8 @@ int eav_gemm_sp_x1(const void* A, const void* B, float* C, const float* slotA, c
                    const float* resid, int ldr, int accumulate, float* amax_slot, void* stream);
 /* eav_gemm_sp_planes with option flags */
 #define EAV_GEMM_ONE_TERM 1    /* the hi.hi term alone */
+#define EAV_GEMM_PLANES_NOLIFT 4 /* planes_out with lo = fp16(sigma x - hi), no 2^11 lift: the row planes the fused attention
+                                  * reads (the fused q/k/v projection writes them directly, scale from eav_tf_forward_scales_qkv) */
 #define EAV_GEMM_SHARED_GPU 2  /* a second persistent GEMM runs beside this one (the backward's data gradients next to the
                                 * side stream's weight gradients): prefer the 256 x 128 one-workgroup-per-CU form */
 /* colsum_part (optional): [ceil(M / 64)][N], row p = column sums of the stored value over rows [64 p, 64 p + 64) - bias-gradient
@@ -355,6 +361,9 @@ int eav_attn_sp_npad(int N);
 int eav_attn_sp_set_nw4_above(int n);   /* TEST / TUNING ONLY (as eav_gemm_sp_set_tile): 128-row (4-wave) workgroups for N > n (default 128) */
 int eav_attn_sp_prep(const float* src, float* slot, void* rowp, void* tp, int B, int N, int ncols, int secw,
                      unsigned tmask, void* stream);
+/* per-head transposed planes (tp, sections selected by tmask as in eav_attn_sp_prep) from existing ROW planes rowp
+ * [B*N][ncols/8][2][8]: a pure fp16 transposition (hi and lo of an element do not depend on the layout) */
+int eav_attn_sp_transpose(const void* rowp, void* tp, int B, int N, int ncols, int secw, unsigned tmask, void* stream);
 int eav_attn_fwd_sp(const void* rowp, const void* tp, const float* slot, float* ao, float* lse, float* amax_slot, int B,
                     int H, int N, int head_dim, float scale, void* stream);
 /* the same, the output also - or only (ao = NULL: forward-only passes) - as the GEMM operand planes [B*N][D/8][2][8] of the

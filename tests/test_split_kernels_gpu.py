@@ -700,3 +700,61 @@ def test_gelu_backward_epilogue_leaves_planes_and_bias_gradient_partials(shape, 
     refp = torch.stack([ref[64 * p:64 * p + 64].sum(0) for p in range(nparts)])
     assert (part.double() - refp).abs().max().item() < 64 * tol
     assert ((part.double().sum(0) - ref.sum(0)).abs() / ref.abs().sum(0).clamp_min(1e-30)).max().item() < 1e-5
+
+
+@pytest.mark.parametrize("cfg", [(2, 3, 197), (1, 2, 1214), (3, 1, 33), (2, 2, 64)])
+def test_qkv_projection_writes_the_attention_row_planes_and_the_transposes_follow(cfg):
+    """The fused q/k/v projection as the encoder forward launches it: eav_gemm_sp_ex with EAV_GEMM_PLANES_NOLIFT writes the
+    attention kernels' row planes (lo = fp16(sigma x - hi), no lift) scaled by the bound of eav_tf_forward_scales_qkv - which
+    must bound the real output - and eav_attn_sp_transpose makes the per-head transposed planes from them: bit-equal to what
+    eav_attn_sp_prep writes from the same row planes' values, zero beyond N, unselected sections untouched."""
+    B, H, N = cfg
+    D, M = 64 * H, B * N
+    torch.manual_seed(B + H + N)
+    g1, b1 = torch.rand(D, device="cuda") + 0.5, torch.randn(D, device="cuda") * 0.2
+    x = torch.randn(M, D, device="cuda") * 2
+    y1 = torch.nn.functional.layer_norm(x, (D,), g1, b1, 1e-12)
+    Wqkv = torch.randn(3 * D, D, device="cuda") * 0.05
+    bqkv = torch.randn(3 * D, device="cuda") * 0.1
+    # one layer laid out as [g1 | b1 | g2 | b2 | bfc1 (FF = D) | bqkv]
+    flat = torch.cat([g1, b1, g1, b1, torch.zeros(D, device="cuda"), bqkv]).contiguous()
+    wn1, wnq = torch.ones(1, device="cuda"), torch.zeros(1, device="cuda")
+    _lib.call("eav_rownorm_max", P(Wqkv), 3 * D, D, D, P(wnq), None)
+    slots = torch.zeros(5, SLOT, device="cuda")
+    _lib.call("eav_tf_forward_scales_qkv", P(flat), 0, 1, 0, D, 2 * D, 3 * D, 4 * D, 5 * D, D, D, P(wn1), P(wnq), P(slots), 0,
+              0, 3, 4, 1, None)
+    ref = y1.double() @ Wqkv.double().t() + bqkv.double()
+    sig = float(slots[1, 2048])
+    assert sig == 2.0 ** np.round(np.log2(sig)) and float(ref.abs().max()) * sig < 2.0 ** 15
+    assert float(ref.abs().max()) * sig > 2.0 ** 6          # (and not absurdly loose)
+    sy, py, _ = planes(y1)
+    sw, pw, _ = planes(Wqkv)
+    rowp = torch.full((M, 6 * D), 7.0, dtype=torch.float16, device="cuda")
+    _lib.call("eav_gemm_sp_ex", P(py), P(pw), None, P(sy), P(sw), M, 3 * D, D, 3 * D, 1, 0, 0, 1.0, P(bqkv), 0, None, None, 0,
+              0, None, P(rowp), P(slots[1]), None, 4, None)
+    v = rowp.view(M, -1, 2, 8).double()
+    got = (v[:, :, 0, :] + v[:, :, 1, :]).reshape(M, -1) / sig            # lo NOT lifted
+    assert (got - ref).abs().max().item() < 4e-7 * float((y1.double().abs() @ Wqkv.double().abs().t()).max()) + 2.0 ** -24 / sig * 4
+    # transposes: a pure permutation of the fp16 halves - T[b, chunk, d, token] == row[b N + token, 64 chunk + d], hi and lo
+    Npad = _lib.plain("eav_attn_sp_npad", N)
+    tp = torch.full((B, 3 * H, 64, 2 * Npad), 7.0, dtype=torch.float16, device="cuda")
+    _lib.call("eav_attn_sp_transpose", P(rowp), P(tp), B, N, 3 * D, D, 5, None)          # Q and V sections
+    r = rowp.view(B, N, 3 * H, 8, 2, 8)                     # [b, token, chunk, group-in-chunk, hi/lo, e]
+    t = tp.view(B, 3 * H, 64, Npad // 8, 2, 8)              # [b, chunk, d, token group, hi/lo, e]
+    for hl in (0, 1):
+        want = r[:, :, :, :, hl, :].reshape(B, N, 3 * H, 64).permute(0, 2, 3, 1)          # [b, chunk, d, token]
+        have = t[:, :, :, :, hl, :].reshape(B, 3 * H, 64, Npad)
+        for sec in (0, 2):
+            sl = slice(sec * H, (sec + 1) * H)
+            assert torch.equal(have[:, sl, :, :N], want[:, sl])
+            assert (have[:, sl, :, N:] == 0).all()                                        # zero beyond N
+    assert (tp[:, H:2 * H] == 7).all()                                                    # K section not selected
+    # and eav_attn_sp_prep on the values the planes hold gives the same operands (up to fp16 rounding ties in hi)
+    held = ((v[:, :, 0, :] + v[:, :, 1, :]).reshape(M, -1) / sig).float().contiguous()
+    s2 = torch.zeros(SLOT, device="cuda")
+    s2[0] = 2.0 ** 14.5 / sig
+    rowp2, tp2 = torch.empty_like(rowp), torch.empty_like(tp)
+    _lib.call("eav_attn_sp_prep", P(held), P(s2), P(rowp2), P(tp2), B, N, 3 * D, D, 5, None)
+    assert float(s2[2048]) == sig
+    v2 = rowp2.view(M, -1, 2, 8).double()
+    assert torch.equal(v2[:, :, 0, :] + v2[:, :, 1, :], v[:, :, 0, :] + v[:, :, 1, :])

@@ -383,14 +383,16 @@ __global__ __launch_bounds__(256) void pair_mean_kernel(float* __restrict__ seq,
 int grid_for(int64_t n) { return (int)(n < 1 ? 1 : (cdiv64(n, 256) > 4096 ? 4096 : cdiv64(n, 256))); }
 
 // ------------------------------------------------------------------------------------ a-priori operand scales
-// max over the rows of ||w_r||_2 (bits, atomicMax - zero `out` first): one wave per row, 16-byte loads, all loads of a
-// row in flight at once for rows of up to 1024 floats (was a scalar-load loop: 39 us for mlp.fc1.weight, now ~6)
+// max over the rows of ||w_r||_2 (bits, atomicMax - zero `out` first): one wave per row at a time, 16-byte loads, all
+// loads of a row in flight at once for rows of up to 1024 floats; a few persistent blocks and ONE atomic per block (one
+// atomic per row to the same address serialised in the L2: 34 us for 3072 rows)
 __global__ __launch_bounds__(256) void rownorm_max_kernel(const float* __restrict__ w, int R, int C, int64_t ld,
                                                           unsigned* __restrict__ out) {
-  const int lane = threadIdx.x & 63;
+  __shared__ float red[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bool vec = (C & 3) == 0 && (ld & 3) == 0 && ((uintptr_t)w & 15) == 0;
   float best = 0.f;
-  for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < R; r += gridDim.x * 4) {
+  for (int r = blockIdx.x * 4 + wave; r < R; r += gridDim.x * 4) {
     const float* src = w + (int64_t)r * ld;
     float s = 0.f;
     if (vec) {
@@ -411,36 +413,54 @@ __global__ __launch_bounds__(256) void rownorm_max_kernel(const float* __restric
     }
     best = fmaxf(best, sqrtf(wave_sum(s)));
   }
-  if (lane == 0 && best == best) atomicMax(out, __float_as_uint(best));
+  if (lane == 0) red[wave] = best;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    best = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (best == best) atomicMax(out, __float_as_uint(best));
+  }
 }
 
-// max over the COLUMNS of ||w[:, c]||_2 (bits, atomicMax - zero `out` first): a thread owns 4 columns, a block 1024
+// max over the COLUMNS of ||w[:, c]||_2 (bits, atomicMax - zero `out` first).  A block owns 64 columns: thread (rs, cq)
+// sums the squares of columns 4 cq .. + 3 over the rows rs, rs + 16, ... (a row segment = 256 contiguous bytes per 16
+// threads), the 16 row slices are added through LDS, one atomic per block.
 __global__ __launch_bounds__(256) void colnorm_max_kernel(const float* __restrict__ w, int R, int C, int64_t ld,
                                                           unsigned* __restrict__ out) {
-  const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
-  float best = 0.f;
+  __shared__ float4 part[16][17];
+  const int cq = threadIdx.x & 15, rs = threadIdx.x >> 4;
+  const int c = blockIdx.x * 64 + 4 * cq;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (c < C) {
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    int r = 0;
-    for (; r + 3 < R; r += 4) {
+    int r = rs;
+    for (; r + 48 < R; r += 64) {
       float4 v[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(w + (int64_t)(r + u) * ld + c);
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(w + (int64_t)(r + 16 * u) * ld + c);
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         s.x = fmaf(v[u].x, v[u].x, s.x); s.y = fmaf(v[u].y, v[u].y, s.y);
         s.z = fmaf(v[u].z, v[u].z, s.z); s.w = fmaf(v[u].w, v[u].w, s.w);
       }
     }
-    for (; r < R; ++r) {
+    for (; r < R; r += 16) {
       const float4 v = *reinterpret_cast<const float4*>(w + (int64_t)r * ld + c);
       s.x = fmaf(v.x, v.x, s.x); s.y = fmaf(v.y, v.y, s.y); s.z = fmaf(v.z, v.z, s.z); s.w = fmaf(v.w, v.w, s.w);
     }
-    best = sqrtf(fmaxf(fmaxf(s.x, s.y), fmaxf(s.z, s.w)));
   }
+  part[rs][cq] = s;
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    float4 t = part[0][threadIdx.x];
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) best = fmaxf(best, __shfl_xor(best, o, 64));
-  if ((threadIdx.x & 63) == 0 && best == best) atomicMax(out, __float_as_uint(best));
+    for (int k = 1; k < 16; ++k) {
+      const float4 q = part[k][threadIdx.x];
+      t.x += q.x; t.y += q.y; t.z += q.z; t.w += q.w;
+    }
+    float best = sqrtf(fmaxf(fmaxf(t.x, t.y), fmaxf(t.z, t.w)));
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) best = fmaxf(best, __shfl_xor(best, o, 64));
+    if (threadIdx.x == 0 && best == best) atomicMax(out, __float_as_uint(best));
+  }
 }
 
 __device__ __forceinline__ float sigma_of_bound(float b) {
@@ -684,7 +704,7 @@ extern "C" int eav_pair_mean(float* seq, float* pooled, int B, int D, int backwa
 // max_r ||w_r||_2 of a [R, C] matrix into *out (a float whose bits are combined with atomicMax: zero it first)
 extern "C" int eav_rownorm_max(const float* w, int R, int C, int64_t ld, float* out, void* stream) {
   EAV_REQUIRE(w && out && R > 0 && C > 0 && ld >= C, "eav_rownorm_max: bad arguments");
-  const int blocks = cdiv(R, 4) < 1024 ? cdiv(R, 4) : 1024;
+  const int blocks = cdiv(R, 4) < 128 ? cdiv(R, 4) : 128;
   hipLaunchKernelGGL(rownorm_max_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, R, C, ld,
                      reinterpret_cast<unsigned*>(out));
   EAV_CHECK_LAUNCH("eav_rownorm_max");
@@ -694,7 +714,7 @@ extern "C" int eav_rownorm_max(const float* w, int R, int C, int64_t ld, float* 
 extern "C" int eav_colnorm_max(const float* w, int R, int C, int64_t ld, float* out, void* stream) {
   EAV_REQUIRE(w && out && R > 0 && C > 0 && ld >= C && (C & 3) == 0 && (ld & 3) == 0 && ((uintptr_t)w & 15) == 0,
               "eav_colnorm_max: bad arguments (C, ld multiples of 4, w 16-byte aligned)");
-  hipLaunchKernelGGL(colnorm_max_kernel, dim3(cdiv(C, 1024)), dim3(256), 0, (hipStream_t)stream, w, R, C, ld,
+  hipLaunchKernelGGL(colnorm_max_kernel, dim3(cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, w, R, C, ld,
                      reinterpret_cast<unsigned*>(out));
   EAV_CHECK_LAUNCH("eav_colnorm_max");
   return EAV_OK;

@@ -211,6 +211,7 @@ class Encoder(nn.Module):
         self._wplanes = None          # split mode: {weight key: (planes, planes of the transpose, slot index)}
         self._wplanes_key = None
         self._phase = "fwd"
+        self._scales_all = False
         # multi-GPU: called as hook(lo, hi) from inside the backward whenever flat_grad[lo:hi] is final
         self.grad_ready_hook = None
         if cfg.hidden % cfg.heads or (cfg.hidden // cfg.heads) % 4 or cfg.hidden % 4 or cfg.hidden > 1024:
@@ -702,6 +703,8 @@ class Encoder(nn.Module):
             Lk = f"{pre}.layers.{i}"
             stp = P(ws.st[j])
             if sp:
+                if i == 0:
+                    self._forward_scales(fslot)
                 self._layer_forward_split(i, j, hin, hout, Lk, stp, fslot, scale)
                 continue
             L("eav_layernorm_fwd", P(hin), w(f"{Lk}.layernorm_before.weight"), w(f"{Lk}.layernorm_before.bias"),
@@ -746,6 +749,33 @@ class Encoder(nn.Module):
         self._saved = (self._token, x, full, None)
         return self._token
 
+    def _forward_scales(self, fslot):
+        """A-priori operand scales (rigorous bounds: eav_tf_forward_scales_qkv) of y1, qkv, y2, act of EVERY layer in one
+        launch - the flat parameter buffer lays the layers out identically.  Falls back to one launch per layer (inside
+        _layer_forward_split) if it does not."""
+        c, ws = self.cfg, self._ws
+        self._scales_all = False
+        if not (self.fused_planes and c.hidden % 8 == 0 and c.ff % 8 == 0):
+            return
+        offs, pre = self._flat[2], c.prefix
+        first = lambda i: offs[f"{pre}.layers.{i}.attention.q_proj.weight"][0]  # noqa: E731
+        names = ("layernorm_before.weight", "layernorm_before.bias", "layernorm_after.weight", "layernorm_after.bias",
+                 "mlp.fc1.bias", "attention.q_proj.bias")
+        rel = [tuple(offs[f"{pre}.layers.{i}.{n}"][0] - first(i) for n in names) for i in range(c.layers)]
+        stride = first(1) - first(0) if c.layers > 1 else 0
+        if any(r != rel[0] for r in rel) or any(first(i) - first(0) != i * stride for i in range(c.layers)):
+            return
+        for i in range(c.layers):                      # the row norms come from the side-stream weight refresh
+            self._wp(f"fc1{i}")
+            self._wp(f"qkv{i}")
+        o = rel[0]
+        qkvp = self.fused_qkv and ws.fused
+        self._call("eav_tf_forward_scales_qkv", _lib.ptr(self._flat[0]) + 4 * first(0), stride, c.layers, o[0], o[1], o[2],
+                   o[3], o[4], o[5], c.hidden, c.ff, self._wplanes["_wnorm_fc1"].data_ptr(),
+                   self._wplanes["_wnorm_qkv"].data_ptr(), fslot(1), self.FS * self.SLOT, 0, 3, 4, 1 if qkvp else -1,
+                   self._st)
+        self._scales_all = True
+
     def _layer_forward_split(self, i, j, hin, hout, Lk, stp, fslot, scale):
         """One encoder layer with every projection on the split-operand GEMM; the attention core stays on the fp32
         kernels.  LayerNorm / attention / GELU outputs are converted to planes once (plus the transposed planes when
@@ -767,10 +797,11 @@ class Encoder(nn.Module):
             base = offs[f"{Lk}.attention.q_proj.weight"][0]
             o = lambda k: offs[f"{Lk}.{k}"][0] - base  # noqa: E731
             qkvp = self.fused_qkv and ws.fused
-            L("eav_tf_forward_scales_qkv", P(self._flat[0]) + 4 * base, 0, 1, o("layernorm_before.weight"),
-              o("layernorm_before.bias"), o("layernorm_after.weight"), o("layernorm_after.bias"), o("mlp.fc1.bias"),
-              o("attention.q_proj.bias"), D, FF, self._wplanes["_wnorm_fc1"].data_ptr() + 4 * i,
-              self._wplanes["_wnorm_qkv"].data_ptr() + 4 * i, s_y1, 0, 0, 3, 4, 1 if qkvp else -1, st)
+            if not self._scales_all:
+                L("eav_tf_forward_scales_qkv", P(self._flat[0]) + 4 * base, 0, 1, o("layernorm_before.weight"),
+                  o("layernorm_before.bias"), o("layernorm_after.weight"), o("layernorm_after.bias"), o("mlp.fc1.bias"),
+                  o("attention.q_proj.bias"), D, FF, self._wplanes["_wnorm_fc1"].data_ptr() + 4 * i,
+                  self._wplanes["_wnorm_qkv"].data_ptr() + 4 * i, s_y1, 0, 0, 3, 4, 1 if qkvp else -1, st)
             L("eav_layernorm_fwd_planes", P(hin), w(f"{Lk}.layernorm_before.weight"), w(f"{Lk}.layernorm_before.bias"),
               None, P(ws.y1p[j]), s_y1, stp, stp + 4 * M, M, D, c.eps, st)
         else:

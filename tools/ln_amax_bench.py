@@ -23,3 +23,7 @@ for M in (9712, 25216):
     _lib.call("eav_layernorm_fwd", P(x), P(g), P(b), P(y), P(mean), P(rstd), M, D, 1e-12, None)
     t2 = t(lambda: _lib.call("eav_layernorm_bwd_amax", P(dy), P(x), P(g), P(mean), P(rstd), P(dx), 1, P(part), M, D, P(slot), None))
     print(f"M={M}: layernorm_bwd (accumulate, amax) {t2:.1f} us = {4 * M * D * 4 / t2 / 1e6:.2f} TB/s")
+    t3 = t(lambda: _lib.call("eav_layernorm_bwd", P(dy), P(x), P(g), P(mean), P(rstd), P(dx), 1, P(part), M, D, None))
+    t4 = t(lambda: _lib.call("eav_layernorm_bwd", P(dy), P(x), P(g), P(mean), P(rstd), P(dx), 0, P(part), M, D, None))
+    print(f"M={M}: layernorm_bwd without the maxima {t3:.1f} us = {4 * M * D * 4 / t3 / 1e6:.2f} TB/s; not accumulating "
+          f"{t4:.1f} us = {3 * M * D * 4 / t4 / 1e6:.2f} TB/s")

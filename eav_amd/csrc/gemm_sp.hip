@@ -71,6 +71,7 @@ struct SpArgs {
   const float* resid;       // [M,N] (ldr) or null, added after the activation
   float* pre;               // [M,N] (ldc) or null: value before the activation
   unsigned* amax;           // or null: atomicMax of the bits of |stored value|
+  int noblk;                // amax: tensor-wide shards only, no 128-row block entries (EAV_GEMM_NO_BLOCKMAX)
   float* colsum;            // or null: [ceil(M / 64)][N] column sums of the stored value over blocks of 64 rows (bias gradient)
   unsigned char* planes;    // or null: the stored value (after the activation) also leaves as row planes [M][Np/8][2][8],
   const float* slotP;       //   scaled by slotP[EAV_SLOT_SIGMA] - a scale known BEFORE the launch (eav_tf_forward_scales);
@@ -732,7 +733,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
       for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
       if (lane == 0 && vmax == vmax) {
         atomicMax(g.amax + EAV_SLOT_SHARD(tl * NW + wave + 17 * z), __float_as_uint(vmax));
-        if constexpr (!TR) eav_slot_blockmax(g.amax, arow, vmax);     // (rows of the OUTPUT: same numbering for z = 0)
+        // (rows of the OUTPUT: same numbering for z = 0; skipped on request - at N = 768 the 24 waves of a tile-row, resident
+        // together, queue on one address: 93 -> 123 us for a [25216 x 768] x [768 x 768]^T product)
+        if constexpr (!TR) { if (!g.noblk) eav_slot_blockmax(g.amax, arow, vmax); }
       }
     }
   }
@@ -1140,6 +1143,7 @@ static int gemm_sp_impl(const void* A, const void* B, float* C, const float* slo
   // Infinity Cache, where the row-major walk measured 5-11 % faster (AST B=8: qkv, fc1).
   g.order = g_order ? g_order - 1
                     : (cdiv(N, 128) <= 8 || ((int64_t)M + N) * Kp * 4 <= (48ll << 20) ? 1 : 0);
+  g.noblk = (flags & EAV_GEMM_NO_BLOCKMAX) ? 1 : 0;
   if (flags & EAV_GEMM_PLANES_NOLIFT) g.lomul = 1.f;      // lo = fp16(t - hi): the attention kernels' row planes
   dispatch(g, batch, (hipStream_t)stream, terms, (flags & EAV_GEMM_SHARED_GPU) != 0);
   EAV_CHECK_LAUNCH("eav_gemm_sp");
@@ -1223,7 +1227,7 @@ static int gemm_sp_splitk_impl(const void* A, const void* B, float* C, float* ws
   g.order = g_order ? g_order - 1 : (cdiv(N, 128) <= 8 && cdiv(M, 128) > cdiv(N, 128) ? 1 : 0);
   g.A = (const unsigned char*)A; g.B = (const unsigned char*)B; g.slotA = slotA; g.slotB = slotB;
   g.bias = nullptr; g.resid = nullptr; g.pre = nullptr; g.amax = nullptr; g.planes = nullptr; g.slotP = nullptr;
-  g.colsum = nullptr;
+  g.colsum = nullptr; g.noblk = 0;
   g.ldp = 0; g.lomul = 2048.f;
   g.M = M; g.N = N; g.nkt = cdiv(T, 32); g.ldA = (int64_t)eav_sp_kpad(M) * 4; g.ldB = (int64_t)eav_sp_kpad(N) * 4;
   g.ldc = N; g.ldr = 0; g.sA = 0; g.sC = 0; g.alpha = 1.f; g.gelu = 0;

@@ -601,12 +601,13 @@ class Encoder(nn.Module):
         self._reduce_async(part, 0, ws.np_cs2, C, C, bias_grad)
 
     def _gemm_sp(self, A, slotA, B, slotB, C, M, N, K, ldc, batch=1, sA=0, sC=0, alpha=1.0, bias=None, gelu=0,
-                 pre=None, resid=None, ldr=0, acc=0, amax=None):
+                 pre=None, resid=None, ldr=0, acc=0, amax=None, blockmax=True):
         """C[M,N] = epilogue(alpha A[M,K] . B[N,K]^T) on planes."""
         # flags: backward products with grad_terms = 1 run on the hi.hi term alone (see the class attribute); the backward's
         # data gradients share the GPU with the side stream's weight gradients (EAV_GEMM_SHARED_GPU: see csrc/gemm_sp.hip)
         bwd = self._phase == "bwd"
-        flags = (1 if (self.grad_terms if bwd else self.fwd_terms) == 1 else 0) | (2 if bwd and self.overlap_wgrad else 0)
+        flags = (1 if (self.grad_terms if bwd else self.fwd_terms) == 1 else 0) | (2 if bwd and self.overlap_wgrad else 0) \
+            | (0 if blockmax else 8)
         self._call("eav_gemm_sp_ex", A, B, C, slotA, slotB, M, N, K, ldc, batch, sA, sC, float(alpha), bias, gelu, pre,
                    resid, ldr, acc, amax, None, None, None, flags, self._st)
 
@@ -923,7 +924,8 @@ class Encoder(nn.Module):
         self._to_planes_bias(dh, M, D, b_dh1, ws.dhp2, gp(f"{Lk}.attention.o_proj.bias"))
         self._wgrad_sp(ws.dhp2, b_dh1, ws.aop[i], s_ao, gp(f"{Lk}.attention.o_proj.weight"), D, D, M)
         wpl, wsl = self._wp(f"o{i}", transposed=True)
-        self._gemm_sp(P(ws.dhp2), b_dh1, wpl, wsl, dao, M, D, D, D, amax=b_dao if ws.fused else None)
+        # (dao goes to the attention operand preparation: one scale per tensor, no row-block maxima needed)
+        self._gemm_sp(P(ws.dhp2), b_dh1, wpl, wsl, dao, M, D, D, D, amax=b_dao if ws.fused else None, blockmax=False)
         # attention core
         if ws.fused:
             L("eav_attn_sp_prep", dao, b_dao, P(ws.dorow), P(ws.doT), ws.B, N, D, D, 1, st)

@@ -337,6 +337,8 @@ int eav_gemm_sp_x1(const void* A, const void* B, float* C, const float* slotA, c
 #define EAV_GEMM_ONE_TERM 1    /* the hi.hi term alone */
 #define EAV_GEMM_PLANES_NOLIFT 4 /* planes_out with lo = fp16(sigma x - hi), no 2^11 lift: the row planes the fused attention
                                   * reads (the fused q/k/v projection writes them directly, scale from eav_tf_forward_scales_qkv) */
+#define EAV_GEMM_NO_BLOCKMAX 8  /* amax_slot receives the tensor-wide maximum only, no 128-row block entries: for outputs whose
+                                 * consumer takes one scale per tensor (the attention operand preparation of dO) */
 #define EAV_GEMM_SHARED_GPU 2  /* a second persistent GEMM runs beside this one (the backward's data gradients next to the
                                 * side stream's weight gradients): prefer the 256 x 128 one-workgroup-per-CU form */
 /* colsum_part (optional): [ceil(M / 64)][N], row p = column sums of the stored value over rows [64 p, 64 p + 64) - bias-gradient

@@ -134,7 +134,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   // A wave takes the rows in groups of 16 consecutive ones (group g = gw, gw + GW, ...): a group lies inside ONE 128-row
   // block, so the block maximum (EAV_SLOT_BMAX) costs one wave reduction and one atomic per 16 rows - one atomic per ROW
   // to ~200 addresses doubled the kernel's time (ViT B=128: 95 us against 46 us without the maxima)
-  constexpr int RG = 16;
+#ifndef EAV_LN_RG
+#define EAV_LN_RG 16
+#endif
+  constexpr int RG = EAV_LN_RG;
   const int GW = gridDim.x * 4, gw = blockIdx.x * 4 + wave;
   auto next_row = [&](int r) { return ((r + 1) & (RG - 1)) ? r + 1 : r + 1 + (GW - 1) * RG; };
   int row = gw * RG;
@@ -596,7 +599,10 @@ extern "C" int eav_layernorm_fwd_planes(const float* x, const float* gamma, cons
   return EAV_OK;
 }
 
-extern "C" int eav_layernorm_bwd_nparts(int M) { return cdiv(M, 4) < 256 ? cdiv(M, 4) : 256; }
+#ifndef EAV_LN_BLOCKS
+#define EAV_LN_BLOCKS 512
+#endif
+extern "C" int eav_layernorm_bwd_nparts(int M) { return cdiv(M, 4) < EAV_LN_BLOCKS ? cdiv(M, 4) : EAV_LN_BLOCKS; }
 
 extern "C" int eav_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
                                  const float* rstd, float* dx, int accumulate, float* part, int M, int D,

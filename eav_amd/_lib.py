@@ -85,7 +85,6 @@ SIGNATURES = {
     "eav_attn_sp_set_nw4_above": [_i],
     "eav_attn_sp_prep": [_p, _p, _p, _p, _i, _i, _i, _i, C.c_uint, _p],
     "eav_attn_fwd_sp": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
-    "eav_attn_sp_transpose": [_p, _p, _i, _i, _i, _i, C.c_uint, _p],
     "eav_tf_forward_scales_qkv": [_p, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _i64, _i, _i, _i, _i, _p],
     "eav_attn_fwd_sp_planes": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
     "eav_attn_bwd_sp": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],

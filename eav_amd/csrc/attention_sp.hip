@@ -83,6 +83,27 @@ __device__ __forceinline__ f16x8 frag_row(const u8* tile, int prow, int s, int h
 __device__ __forceinline__ f16x8 frag_t(const u8* tile, int d, int s, int h2, int hl) {
   return *reinterpret_cast<const f16x8*>(tile + d * 128 + (((4 * s + 2 * h2 + hl) ^ ((d >> 1) & 7)) << 4));
 }
+// A-operand fragment "head_dim row d, tokens 16s + 8h2 .. +7" (what frag_t reads from a T tile) taken from a ROW tile with
+// two transposing reads (ds_read_b64_tr_b16: within a group of 16 lanes, lane 4r + q supplies 8 bytes of row r - here
+// token r of a block of four, features 4q .. 4q+3 - and lane j receives column j of the four rows; gemm_sp.hip).  Lane L
+// = 16 G + 4 r + q: group G covers features dbase + 16 (G & 1) .. + 15 and the token half G >> 1, so the destination lane
+// (d = L & 31, h2 = L >> 5) is exactly the MFMA's.  No transposed planes, no second copy of the tile in LDS.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+__device__ __forceinline__ f16x8 frag_tr(const u8* tile, int dbase, int s, int hl, int lane) {
+  const int G = lane >> 4, r = (lane >> 2) & 3, q = lane & 3;
+  const int piece = 2 * ((dbase >> 3) + 2 * (G & 1) + (q >> 1)) + hl;
+  const int tok = 16 * s + 8 * (G >> 1) + r;
+  f16x8 out;
+  const f16x4 a = __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (lds_s16x4_ptr)(tile + tok * 256 + ((piece ^ (tok & 15)) << 4) + ((q & 1) << 3))));
+  const f16x4 b = __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (lds_s16x4_ptr)(tile + (tok + 4) * 256 + ((piece ^ ((tok + 4) & 15)) << 4) + ((q & 1) << 3))));
+  out.lo = a;
+  out.hi = b;
+  return out;
+}
 // B-operand fragments of a stationary row straight from the row planes in global memory (4 head_dim steps, hi / lo)
 __device__ __forceinline__ void load_row_frags(const u8* rowptr, int h2, f16x8 (&hi)[4], f16x8 (&lo)[4]) {
 #pragma unroll
@@ -187,7 +208,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_sp_kernel(const u8* __res
   constexpr int STAGE = 16384;   // K row tile | V^T tile
   __shared__ __attribute__((aligned(1024))) u8 smem[2 * STAGE > NW * 32 * 33 * 4 ? 2 * STAGE : NW * 32 * 33 * 4];
   const int D = H * 64;
-  const int64_t ldrow = (int64_t)3 * D * 4, ldt = (int64_t)Npad * 4;
+  const int64_t ldrow = (int64_t)3 * D * 4;
   int tile_, bh;
   attn_block_map(ntile, nbh, tile_, bh);
   const int b = bh / H, h = bh - b * H;
@@ -199,14 +220,14 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_sp_kernel(const u8* __res
   f16x8 qh[4], ql[4];
   load_row_frags(rows_b + (int64_t)min(q0 + j, N - 1) * ldrow + h * 256, h2, qh, ql);
   const u8* kbase = rows_b + (int64_t)(D + h * 64) * 4;
-  const u8* vbase = tp + ((int64_t)(b * 3 * H + 2 * H + h) * 64) * ldt;
+  const u8* vbase = rows_b + (int64_t)(2 * D + h * 64) * 4;
   auto issue = [&](int kt, int buf) {
     u8* st = smem + buf * STAGE;
 #pragma unroll
     for (int i = 0; i < 8 / NW; ++i) {
       const int c = wave + NW * i;
       glds_row_chunk(st, c, kbase, ldrow, 32 * kt, N - 1, lane);
-      glds_t_chunk(st + 8192, c, vbase + (int64_t)kt * 128, ldt, lane);
+      glds_row_chunk(st + 8192, c, vbase, ldrow, 32 * kt, N - 1, lane);      // V ROWS: read transposed (frag_tr)
     }
   };
   const float isg = slot[EAV_SLOT_ISIGMA];
@@ -268,8 +289,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_sp_kernel(const u8* __res
     split_frag(pt + 8, 1.f, ph[1], pl[1]);
 #pragma unroll
     for (int st = 0; st < 2; ++st) {       // O^T[d][q] += V^T[d][key] . P^T[key][q]
-      const f16x8 v0h = frag_t(vt_, j, st, h2, 0), v0l = frag_t(vt_, j, st, h2, 1);
-      const f16x8 v1h = frag_t(vt_, j + 32, st, h2, 0), v1l = frag_t(vt_, j + 32, st, h2, 1);
+      const f16x8 v0h = frag_tr(vt_, 0, st, 0, lane), v0l = frag_tr(vt_, 0, st, 1, lane);
+      const f16x8 v1h = frag_tr(vt_, 32, st, 0, lane), v1l = frag_tr(vt_, 32, st, 1, lane);
       o0 = MFMA16(v0h, ph[st], o0);
       o1 = MFMA16(v1h, ph[st], o1);
       o0 = MFMA16(v0l, ph[st], o0);
@@ -305,10 +326,10 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_q_sp_kernel(
     const float* __restrict__ slot_do, const float* __restrict__ lse, const float* __restrict__ ao,
     const float* __restrict__ dout, float* __restrict__ delta, float* __restrict__ dqkv,
     unsigned* __restrict__ amax_ds, unsigned* __restrict__ amax_out, int N, int Npad, int H, float scale, int ntile, int nbh) {
-  constexpr int STAGE = 24576;   // K rows | V rows | K^T
-  __shared__ __attribute__((aligned(1024))) u8 smem[2 * STAGE];
+  constexpr int STAGE = 16384;   // K rows | V rows (K^T for the last product is read transposed from the K rows: frag_tr)
+  __shared__ __attribute__((aligned(1024))) u8 smem[2 * STAGE > NW * 32 * 33 * 4 ? 2 * STAGE : NW * 32 * 33 * 4];
   const int D = H * 64;
-  const int64_t ldrow = (int64_t)3 * D * 4, lddo = (int64_t)D * 4, ldt = (int64_t)Npad * 4;
+  const int64_t ldrow = (int64_t)3 * D * 4, lddo = (int64_t)D * 4;
   int tile_, bh;
   attn_block_map(ntile, nbh, tile_, bh);
   const int b = bh / H, h = bh - b * H;
@@ -323,7 +344,6 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_q_sp_kernel(
   load_row_frags(dorow + ((int64_t)b * N + q) * lddo + h * 256, h2, gh, gl);
   const u8* kbase = rows_b + (int64_t)(D + h * 64) * 4;
   const u8* vrbase = rows_b + (int64_t)(2 * D + h * 64) * 4;
-  const u8* ktbase = tp + ((int64_t)(b * 3 * H + H + h) * 64) * ldt;
   auto issue = [&](int kt, int buf) {
     u8* st = smem + buf * STAGE;
 #pragma unroll
@@ -331,7 +351,6 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_q_sp_kernel(
       const int c = wave + NW * i;
       glds_row_chunk(st, c, kbase, ldrow, 32 * kt, N - 1, lane);
       glds_row_chunk(st + 8192, c, vrbase, ldrow, 32 * kt, N - 1, lane);
-      glds_t_chunk(st + 16384, c, ktbase + (int64_t)kt * 128, ldt, lane);
     }
   };
   const float isg = slot[EAV_SLOT_ISIGMA], isd = slot_do[EAV_SLOT_ISIGMA];
@@ -372,7 +391,6 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_q_sp_kernel(
     if (q0 >= N) continue;
     const u8* kt_ = smem + buf * STAGE;
     const u8* vr_ = kt_ + 8192;
-    const u8* kT_ = kt_ + 16384;
     f32x16 s, dp;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
@@ -401,8 +419,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_q_sp_kernel(
     split_frag(t + 8, 2048.f, th[1], tl[1]);
 #pragma unroll
     for (int st = 0; st < 2; ++st) {       // dQ^T[d][q] += K^T[d][key] . dS^T[key][q]
-      const f16x8 k0h = frag_t(kT_, j, st, h2, 0), k0l = frag_t(kT_, j, st, h2, 1);
-      const f16x8 k1h = frag_t(kT_, j + 32, st, h2, 0), k1l = frag_t(kT_, j + 32, st, h2, 1);
+      const f16x8 k0h = frag_tr(kt_, 0, st, 0, lane), k0l = frag_tr(kt_, 0, st, 1, lane);
+      const f16x8 k1h = frag_tr(kt_, 32, st, 0, lane), k1l = frag_tr(kt_, 32, st, 1, lane);
       g0 = MFMA16(k0h, th[st], g0);
       g1 = MFMA16(k1h, th[st], g1);
       g0 = MFMA16(k0l, th[st], g0);
@@ -430,10 +448,10 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_kv_sp_kernel(
     const float* __restrict__ slot, const float* __restrict__ slot_do, const float* __restrict__ slot_ds,
     const float* __restrict__ lse, const float* __restrict__ delta, float* __restrict__ dqkv,
     unsigned* __restrict__ amax_out, int N, int Npad, int H, float scale, int ntile, int nbh) {
-  constexpr int STAGE = 32768 + 256;   // Q rows | dO rows | Q^T | dO^T | lse[32], delta[32] of the query tile
+  constexpr int STAGE = 16384 + 256;   // Q rows | dO rows | lse[32], delta[32] of the query tile (Q^T, dO^T: frag_tr)
   __shared__ __attribute__((aligned(1024))) u8 smem[2 * STAGE];
   const int D = H * 64;
-  const int64_t ldrow = (int64_t)3 * D * 4, lddo = (int64_t)D * 4, ldt = (int64_t)Npad * 4;
+  const int64_t ldrow = (int64_t)3 * D * 4, lddo = (int64_t)D * 4;
   int tile_, bh;
   attn_block_map(ntile, nbh, tile_, bh);
   const int b = bh / H, h = bh - b * H;
@@ -448,8 +466,6 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_kv_sp_kernel(
   load_row_frags(rows_b + (int64_t)key * ldrow + (2 * D + h * 64) * 4, h2, vh, vl);
   const u8* qbase = rows_b + (int64_t)(h * 64) * 4;
   const u8* gbase = dorow + (int64_t)b * N * lddo + (int64_t)(h * 64) * 4;
-  const u8* qtbase = tp + ((int64_t)(b * 3 * H + h) * 64) * ldt;
-  const u8* gtbase = dotp + ((int64_t)(b * H + h) * 64) * ldt;
   const float* lse_b = lse + (int64_t)bh * N;
   const float* del_b = delta + (int64_t)bh * N;
   auto issue = [&](int qt, int buf) {
@@ -459,12 +475,10 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_kv_sp_kernel(
       const int c = wave + NW * i;
       glds_row_chunk(st, c, qbase, ldrow, 32 * qt, N - 1, lane);
       glds_row_chunk(st + 8192, c, gbase, lddo, 32 * qt, N - 1, lane);
-      glds_t_chunk(st + 16384, c, qtbase + (int64_t)qt * 128, ldt, lane);
-      glds_t_chunk(st + 24576, c, gtbase + (int64_t)qt * 128, ldt, lane);
     }
     if (wave == 0) {   // through LDS as well: an ordinary load here would make hipcc drain the LDS-DMA queue at its use
       const float* src = (lane < 32 ? lse_b : del_b) + min(32 * qt + (lane & 31), N - 1);
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(st + 32768), 4, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(st + 16384), 4, 0, 0);
     }
   };
   const float isg = slot[EAV_SLOT_ISIGMA], isd = slot_do[EAV_SLOT_ISIGMA];
@@ -485,8 +499,6 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_kv_sp_kernel(
     if (k0 >= N) continue;
     const u8* qr_ = smem + buf * STAGE;
     const u8* gr_ = qr_ + 8192;
-    const u8* qT_ = qr_ + 16384;
-    const u8* gT_ = qr_ + 24576;
     f32x16 s, dp;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
@@ -502,7 +514,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_kv_sp_kernel(
       dp = MFMA16(bh_, vl[st], dp);
     }
     float pt[16], t[16];
-    const float* ls = reinterpret_cast<const float*>(qr_ + 32768);
+    const float* ls = reinterpret_cast<const float*>(qr_ + 16384);
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
       const int ql = 16 * g + 8 * h2;                    // 8 consecutive queries <-> registers 8g .. 8g+7
@@ -527,8 +539,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_kv_sp_kernel(
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
       {                                    // dV^T[d][key] += dO^T[d][q] . P[q][key]
-        const f16x8 a0h = frag_t(gT_, j, st, h2, 0), a0l = frag_t(gT_, j, st, h2, 1);
-        const f16x8 a1h = frag_t(gT_, j + 32, st, h2, 0), a1l = frag_t(gT_, j + 32, st, h2, 1);
+        const f16x8 a0h = frag_tr(gr_, 0, st, 0, lane), a0l = frag_tr(gr_, 0, st, 1, lane);
+        const f16x8 a1h = frag_tr(gr_, 32, st, 0, lane), a1l = frag_tr(gr_, 32, st, 1, lane);
         gv0 = MFMA16(a0h, ph[st], gv0);
         gv1 = MFMA16(a1h, ph[st], gv1);
         gv0 = MFMA16(a0l, ph[st], gv0);
@@ -537,8 +549,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_kv_sp_kernel(
         gv1 = MFMA16(a1h, pl[st], gv1);
       }
       {                                    // dK^T[d][key] += Q^T[d][q] . dS[q][key]
-        const f16x8 a0h = frag_t(qT_, j, st, h2, 0), a0l = frag_t(qT_, j, st, h2, 1);
-        const f16x8 a1h = frag_t(qT_, j + 32, st, h2, 0), a1l = frag_t(qT_, j + 32, st, h2, 1);
+        const f16x8 a0h = frag_tr(qr_, 0, st, 0, lane), a0l = frag_tr(qr_, 0, st, 1, lane);
+        const f16x8 a1h = frag_tr(qr_, 32, st, 0, lane), a1l = frag_tr(qr_, 32, st, 1, lane);
         gk0 = MFMA16(a0h, th[st], gk0);
         gk1 = MFMA16(a1h, th[st], gk1);
         gk0 = MFMA16(a0l, th[st], gk0);
@@ -640,77 +652,9 @@ __global__ __launch_bounds__(256) void attn_sp_prep_kernel(const float* __restri
   }
 }
 
-// T planes from ROW planes: the hi / lo halves of an element do not depend on the layout, so this is a pure fp16
-// transposition.  One 64-token x 64-column tile per block; grid (ncols/64, ceil(Npad/64), B); blocks of column sections
-// that are not selected return at once.
-__global__ __launch_bounds__(256) void attn_sp_transpose_kernel(const u8* __restrict__ rowp, u8* __restrict__ tp, int N,
-                                                                int Npad, int ncols, int secw, unsigned tmask) {
-  __shared__ unsigned short th[64][66], tl[64][66];
-  __shared__ uint4 pimg[64 * 17];
-  const int chunk = blockIdx.x, t0 = blockIdx.y * 64, b = blockIdx.z;
-  const int c0 = chunk * 64;
-  if (!((tmask >> (c0 / secw)) & 1u)) return;
-  const int t = threadIdx.x;
-  {
-    const int cg = t & 7, rr = t >> 3;
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-      const int tok = t0 + rr + 32 * pass;
-      uint4 hi = make_uint4(0u, 0u, 0u, 0u), lo = hi;
-      if (tok < N) {
-        const uint4* p = reinterpret_cast<const uint4*>(rowp + ((int64_t)b * N + tok) * ncols * 4 + (c0 >> 3) * 32 + cg * 32);
-        hi = p[0];
-        lo = p[1];
-      }
-      const unsigned short* hs = reinterpret_cast<const unsigned short*>(&hi);
-      const unsigned short* ls = reinterpret_cast<const unsigned short*>(&lo);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        th[rr + 32 * pass][8 * cg + e] = hs[e];
-        tl[rr + 32 * pass][8 * cg + e] = ls[e];
-      }
-    }
-  }
-  __syncthreads();
-  {
-    const int rg = t & 7, cc = t >> 3;
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-      const int d = cc + 32 * pass;
-      unsigned short hs[8], ls[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        hs[e] = th[8 * rg + e][d];
-        ls[e] = tl[8 * rg + e][d];
-      }
-      pimg[d * 17 + 2 * rg] = *reinterpret_cast<const uint4*>(hs);
-      pimg[d * 17 + 2 * rg + 1] = *reinterpret_cast<const uint4*>(ls);
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int p = t + 256 * k, d = p >> 4, pc = p & 15;
-    if (t0 + 8 * (pc >> 1) < Npad)
-      *reinterpret_cast<uint4*>(tp + (((int64_t)b * (ncols / 64) + chunk) * 64 + d) * Npad * 4 + (t0 >> 3) * 32 + pc * 16) =
-          pimg[d * 17 + pc];
-  }
-}
-
 }  // namespace
 
 extern "C" int eav_attn_sp_npad(int N) { return (N + 31) / 32 * 32; }
-
-extern "C" int eav_attn_sp_transpose(const void* rowp, void* tp, int B, int N, int ncols, int secw, unsigned tmask,
-                                     void* stream) {
-  EAV_REQUIRE(rowp && tp && B > 0 && N > 0 && ncols > 0 && ncols % 64 == 0 && secw > 0 && secw % 64 == 0 &&
-                  ncols % secw == 0, "eav_attn_sp_transpose: columns and sections must be multiples of the head dimension 64");
-  const int Npad = eav_attn_sp_npad(N);
-  hipLaunchKernelGGL(attn_sp_transpose_kernel, dim3(ncols / 64, cdiv(Npad, 64), B), dim3(256), 0, (hipStream_t)stream,
-                     (const u8*)rowp, (u8*)tp, N, Npad, ncols, secw, tmask);
-  EAV_CHECK_LAUNCH("eav_attn_sp_transpose");
-  return EAV_OK;
-}
 
 extern "C" int eav_attn_sp_prep(const float* src, float* slot, void* rowp, void* tp, int B, int N, int ncols, int secw,
                                 unsigned tmask, void* stream) {
@@ -735,7 +679,7 @@ extern "C" int eav_attn_sp_set_nw4_above(int n) { g_nw4_above = n; return 0; }
 extern "C" int eav_attn_fwd_sp_planes(const void* rowp, const void* tp, const float* slot, float* ao, float* lse,
                                       float* amax_slot, void* ao_planes, float* ao_slot, int B, int H, int N, int head_dim,
                                       float scale, void* stream) {
-  EAV_REQUIRE(rowp && tp && slot && (ao || ao_planes) && lse && B > 0 && H > 0 && N > 0 && (!ao_planes || ao_slot),
+  EAV_REQUIRE(rowp && slot && (ao || ao_planes) && lse && B > 0 && H > 0 && N > 0 && (!ao_planes || ao_slot),
               "eav_attn_fwd_sp: bad arguments");
   EAV_REQUIRE(head_dim == 64, "eav_attn_fwd_sp: head_dim %d unsupported (needs 64)", head_dim);
   const int Npad = eav_attn_sp_npad(N);
@@ -764,7 +708,7 @@ extern "C" int eav_attn_bwd_sp(const void* rowp, const void* tp, const void* dor
                                const float* slot_do, float* slot_ds, const float* ao, const float* dout,
                                const float* lse, float* delta, float* dqkv, float* amax_slot, int B, int H, int N,
                                int head_dim, float scale, void* stream) {
-  EAV_REQUIRE(rowp && tp && dorow && dotp && slot && slot_do && slot_ds && ao && dout && lse && delta && dqkv && B > 0 &&
+  EAV_REQUIRE(rowp && dorow && slot && slot_do && slot_ds && ao && dout && lse && delta && dqkv && B > 0 &&
                   H > 0 && N > 0, "eav_attn_bwd_sp: bad arguments");
   EAV_REQUIRE(head_dim == 64, "eav_attn_bwd_sp: head_dim %d unsupported (needs 64)", head_dim);
   const int Npad = eav_attn_sp_npad(N);

@@ -411,7 +411,6 @@ class Encoder(nn.Module):
         Npad = _lib.plain("eav_attn_sp_npad", N)
         if ws.fused:   # attention operands: row planes of qkv and per-head transposed planes (csrc/attention_sp.hip)
             ws.qkvrow = [torch.empty(M, 6 * D, dtype=torch.float16, device=dev) for _ in range(nsave)]
-            ws.qkvT = [torch.empty(ws.B, 3 * H, 64, 2 * Npad, dtype=torch.float16, device=dev) for _ in range(nsave)]
         if full:
             # backward operands: one set, reused by every layer.  dh is converted twice per layer (fc2 and o_proj stage)
             # and its weight gradients run on the side stream, so the two uses must not share one buffer
@@ -424,7 +423,6 @@ class Encoder(nn.Module):
             ws.bslots = torch.zeros(2 + self.BS * Lr, self.SLOT, dtype=torch.float32, device=dev)
             if ws.fused:
                 ws.dorow = torch.empty(M, 2 * D, dtype=torch.float16, device=dev)
-                ws.doT = torch.empty(ws.B, H, 64, 2 * Npad, dtype=torch.float16, device=dev)
 
     def _weight_keys(self):
         """[(cache key, parameter name of the [out, in] matrix, out, in)] of every GEMM weight."""
@@ -819,22 +817,20 @@ class Encoder(nn.Module):
             L("eav_gemm_sp_ex", P(ws.y1p[j]), wpl, None, s_y1, wsl, M, 3 * D, D, 3 * D, 1, 0, 0, 1.0,
               w(f"{Lk}.attention.q_proj.bias"), 0, None, None, 0, 0, None, P(ws.qkvrow[j]), s_qkv, None,
               4 | (1 if self.fwd_terms == 1 else 0), st)
-            L("eav_attn_sp_transpose", P(ws.qkvrow[j]), P(ws.qkvT[j]), ws.B, N, 3 * D, D, 7 if ws.full else 4, st)
         else:
             self._gemm_sp(P(ws.y1p[j]), s_y1, wpl, wsl, qkv, M, 3 * D, D, 3 * D, bias=w(f"{Lk}.attention.q_proj.bias"),
                           amax=s_qkv if ws.fused else None)
         if ws.fused:
             if not qkvp:
                 # row planes of Q | K | V and the per-head transposes (V^T for the forward; Q^T, K^T for the backward)
-                L("eav_attn_sp_prep", qkv, s_qkv, P(ws.qkvrow[j]), P(ws.qkvT[j]), ws.B, N, 3 * D, D, 7 if ws.full else 4,
-                  st)
+                L("eav_attn_sp_prep", qkv, s_qkv, P(ws.qkvrow[j]), None, ws.B, N, 3 * D, D, 0, st)
             if fusedp and self.fused_ao:
                 # the attention output leaves as the planes of the o-proj products (scale: qkv's own, |O| <= max|V|); its
                 # fp32 copy is written only when a backward will read it
-                L("eav_attn_fwd_sp_planes", P(ws.qkvrow[j]), P(ws.qkvT[j]), s_qkv, P(ao) if ws.full else None,
+                L("eav_attn_fwd_sp_planes", P(ws.qkvrow[j]), None, s_qkv, P(ao) if ws.full else None,
                   P(ws.lse[j]), None, P(ws.aop[j]), s_ao, ws.B, H, N, hd, scale, st)
             else:
-                L("eav_attn_fwd_sp", P(ws.qkvrow[j]), P(ws.qkvT[j]), s_qkv, P(ao), P(ws.lse[j]), s_ao, ws.B, H, N, hd,
+                L("eav_attn_fwd_sp", P(ws.qkvrow[j]), None, s_qkv, P(ao), P(ws.lse[j]), s_ao, ws.B, H, N, hd,
                   scale, st)
         else:
             ldn = ws.ldn
@@ -928,8 +924,8 @@ class Encoder(nn.Module):
         self._gemm_sp(P(ws.dhp2), b_dh1, wpl, wsl, dao, M, D, D, D, amax=b_dao if ws.fused else None, blockmax=False)
         # attention core
         if ws.fused:
-            L("eav_attn_sp_prep", dao, b_dao, P(ws.dorow), P(ws.doT), ws.B, N, D, D, 1, st)
-            L("eav_attn_bwd_sp", P(ws.qkvrow[i]), P(ws.qkvT[i]), P(ws.dorow), P(ws.doT), s_qkv, b_dao, b_ds,
+            L("eav_attn_sp_prep", dao, b_dao, P(ws.dorow), None, ws.B, N, D, D, 0, st)
+            L("eav_attn_bwd_sp", P(ws.qkvrow[i]), None, P(ws.dorow), None, s_qkv, b_dao, b_ds,
               P(ws.ao[i]), dao, P(ws.lse[i]), P(ws.delta), dqkv, b_dqkv, ws.B, H, N, hd, scale, st)
         else:
             qkv = P(ws.qkv[i])

@@ -169,8 +169,7 @@ class ShallowConvNet(nn.Module):
         h16 = lambda *s: torch.zeros(*s, dtype=torch.float16, device=dev)  # noqa: E731
         npad = _lib.plain("eav_attn_sp_npad", T)
         ws.qkvrow = [h16(M, 2 * 3 * HD) for _ in range(L)]
-        ws.qkvT = [h16(B, 3, 64, 2 * npad) for _ in range(L)]
-        ws.dorow, ws.doT = h16(M, 2 * HD), h16(B, 1, 64, 2 * npad)
+        ws.dorow = h16(M, 2 * HD)
         ws.fslots, ws.bslots = z(L, SLOT), z(2 * L, SLOT)
         ws.part_bn = f(B, 2 * NF)
         ws.np_ln = _lib.plain("eav_layernorm_bwd_nparts", M)
@@ -237,8 +236,8 @@ class ShallowConvNet(nn.Module):
             if split:                                                                              # :66-69
                 s_qkv = P(ws.fslots) + 4 * SLOT * l
                 L("eav_sp_absmax", qkv, M, 3 * HD, 3 * HD, s_qkv, st)
-                L("eav_attn_sp_prep", qkv, s_qkv, P(ws.qkvrow[l]), P(ws.qkvT[l]), B, T, 3 * HD, HD, 7, st)
-                L("eav_attn_fwd_sp", P(ws.qkvrow[l]), P(ws.qkvT[l]), s_qkv, P(ws.ao[l]), P(ws.lse[l]), None, B, 1, T, HD,
+                L("eav_attn_sp_prep", qkv, s_qkv, P(ws.qkvrow[l]), None, B, T, 3 * HD, HD, 0, st)
+                L("eav_attn_fwd_sp", P(ws.qkvrow[l]), None, s_qkv, P(ws.ao[l]), P(ws.lse[l]), None, B, 1, T, HD,
                   scale, st)
             else:
                 L("eav_attn_fwd", qkv, P(ws.ao[l]), P(ws.lse[l]), B, 1, T, HD, scale, st)
@@ -335,8 +334,8 @@ class ShallowConvNet(nn.Module):
                 s_qkv, s_do, s_ds = P(ws.fslots) + 4 * SLOT * l, P(ws.bslots) + 8 * SLOT * l, P(ws.bslots) + 8 * SLOT * l \
                     + 4 * SLOT
                 L("eav_sp_absmax", P(ws.dao), M, HD, HD, s_do, st)
-                L("eav_attn_sp_prep", P(ws.dao), s_do, P(ws.dorow), P(ws.doT), B, T, HD, HD, 1, st)
-                L("eav_attn_bwd_sp", P(ws.qkvrow[l]), P(ws.qkvT[l]), P(ws.dorow), P(ws.doT), s_qkv, s_do, s_ds,
+                L("eav_attn_sp_prep", P(ws.dao), s_do, P(ws.dorow), None, B, T, HD, HD, 0, st)
+                L("eav_attn_bwd_sp", P(ws.qkvrow[l]), None, P(ws.dorow), None, s_qkv, s_do, s_ds,
                   P(ws.ao[l]), P(ws.dao), P(ws.lse[l]), P(ws.delta), dqkv, None, B, 1, T, HD, scale, st)
             else:
                 L("eav_attn_bwd", qkv, P(ws.ao[l]), P(ws.dao), P(ws.lse[l]), P(ws.delta), dqkv, B, 1, T, HD, scale, st)

@@ -363,9 +363,10 @@ int eav_attn_sp_npad(int N);
 int eav_attn_sp_set_nw4_above(int n);   /* TEST / TUNING ONLY (as eav_gemm_sp_set_tile): 128-row (4-wave) workgroups for N > n (default 128) */
 int eav_attn_sp_prep(const float* src, float* slot, void* rowp, void* tp, int B, int N, int ncols, int secw,
                      unsigned tmask, void* stream);
-/* per-head transposed planes (tp, sections selected by tmask as in eav_attn_sp_prep) from existing ROW planes rowp
- * [B*N][ncols/8][2][8]: a pure fp16 transposition (hi and lo of an element do not depend on the layout) */
-int eav_attn_sp_transpose(const void* rowp, void* tp, int B, int N, int ncols, int secw, unsigned tmask, void* stream);
+/* Since round 3 the three attention kernels take their token-contracting operands (V in the forward, K in the dQ kernel,
+ * Q and dO in the dK,dV kernel) from the ROW tiles with transposing LDS reads (ds_read_b64_tr_b16): the transposed planes
+ * `tp` / `dotp` are not read any more and may be NULL (the parameters stay for binary compatibility; eav_attn_sp_prep
+ * still writes them on request). */
 int eav_attn_fwd_sp(const void* rowp, const void* tp, const float* slot, float* ao, float* lse, float* amax_slot, int B,
                     int H, int N, int head_dim, float scale, void* stream);
 /* the same, the output also - or only (ao = NULL: forward-only passes) - as the GEMM operand planes [B*N][D/8][2][8] of the

@@ -703,11 +703,10 @@ def test_gelu_backward_epilogue_leaves_planes_and_bias_gradient_partials(shape, 
 
 
 @pytest.mark.parametrize("cfg", [(2, 3, 197), (1, 2, 1214), (3, 1, 33), (2, 2, 64)])
-def test_qkv_projection_writes_the_attention_row_planes_and_the_transposes_follow(cfg):
+def test_qkv_projection_writes_the_attention_row_planes(cfg):
     """The fused q/k/v projection as the encoder forward launches it: eav_gemm_sp_ex with EAV_GEMM_PLANES_NOLIFT writes the
     attention kernels' row planes (lo = fp16(sigma x - hi), no lift) scaled by the bound of eav_tf_forward_scales_qkv - which
-    must bound the real output - and eav_attn_sp_transpose makes the per-head transposed planes from them: bit-equal to what
-    eav_attn_sp_prep writes from the same row planes' values, zero beyond N, unselected sections untouched."""
+    must bound the real output; eav_attn_sp_prep on the values the planes hold gives the same operands."""
     B, H, N = cfg
     D, M = 64 * H, B * N
     torch.manual_seed(B + H + N)
@@ -735,26 +734,12 @@ def test_qkv_projection_writes_the_attention_row_planes_and_the_transposes_follo
     v = rowp.view(M, -1, 2, 8).double()
     got = (v[:, :, 0, :] + v[:, :, 1, :]).reshape(M, -1) / sig            # lo NOT lifted
     assert (got - ref).abs().max().item() < 4e-7 * float((y1.double().abs() @ Wqkv.double().abs().t()).max()) + 2.0 ** -24 / sig * 4
-    # transposes: a pure permutation of the fp16 halves - T[b, chunk, d, token] == row[b N + token, 64 chunk + d], hi and lo
-    Npad = _lib.plain("eav_attn_sp_npad", N)
-    tp = torch.full((B, 3 * H, 64, 2 * Npad), 7.0, dtype=torch.float16, device="cuda")
-    _lib.call("eav_attn_sp_transpose", P(rowp), P(tp), B, N, 3 * D, D, 5, None)          # Q and V sections
-    r = rowp.view(B, N, 3 * H, 8, 2, 8)                     # [b, token, chunk, group-in-chunk, hi/lo, e]
-    t = tp.view(B, 3 * H, 64, Npad // 8, 2, 8)              # [b, chunk, d, token group, hi/lo, e]
-    for hl in (0, 1):
-        want = r[:, :, :, :, hl, :].reshape(B, N, 3 * H, 64).permute(0, 2, 3, 1)          # [b, chunk, d, token]
-        have = t[:, :, :, :, hl, :].reshape(B, 3 * H, 64, Npad)
-        for sec in (0, 2):
-            sl = slice(sec * H, (sec + 1) * H)
-            assert torch.equal(have[:, sl, :, :N], want[:, sl])
-            assert (have[:, sl, :, N:] == 0).all()                                        # zero beyond N
-    assert (tp[:, H:2 * H] == 7).all()                                                    # K section not selected
     # and eav_attn_sp_prep on the values the planes hold gives the same operands (up to fp16 rounding ties in hi)
     held = ((v[:, :, 0, :] + v[:, :, 1, :]).reshape(M, -1) / sig).float().contiguous()
     s2 = torch.zeros(SLOT, device="cuda")
     s2[0] = 2.0 ** 14.5 / sig
-    rowp2, tp2 = torch.empty_like(rowp), torch.empty_like(tp)
-    _lib.call("eav_attn_sp_prep", P(held), P(s2), P(rowp2), P(tp2), B, N, 3 * D, D, 5, None)
+    rowp2 = torch.empty_like(rowp)
+    _lib.call("eav_attn_sp_prep", P(held), P(s2), P(rowp2), None, B, N, 3 * D, D, 0, None)
     assert float(s2[2048]) == sig
     v2 = rowp2.view(M, -1, 2, 8).double()
     assert torch.equal(v2[:, :, 0, :] + v2[:, :, 1, :], v[:, :, 0, :] + v[:, :, 1, :])

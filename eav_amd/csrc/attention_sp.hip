@@ -165,7 +165,7 @@ __device__ __forceinline__ float store_rows_T(float* __restrict__ patch, const f
   return vmax;
 }
 // row0: first of the (up to) 32 output rows [row0, row0 + 32) of the [B*N, .] tensor this wave wrote, or < 0: the
-// maximum also goes to the entries of the one or two 128-row blocks they lie in (per-row-block operand scales)
+// maximum also goes to the entries of the one or two 32-row blocks they lie in (per-row-block operand scales)
 __device__ __forceinline__ void emit_amax(unsigned* slot, float vmax, int lane, int salt, int row0 = -1) {
   if (!slot) return;
 #pragma unroll
@@ -174,7 +174,7 @@ __device__ __forceinline__ void emit_amax(unsigned* slot, float vmax, int lane, 
     atomicMax(slot + EAV_SLOT_SHARD(salt), __float_as_uint(vmax));
     if (row0 >= 0) {
       eav_slot_blockmax(slot, row0, vmax);
-      if (((row0 + 31) >> 7) != (row0 >> 7)) eav_slot_blockmax(slot, row0 + 31, vmax);
+      if (((row0 + 31) >> EAV_BLK_SHIFT) != (row0 >> EAV_BLK_SHIFT)) eav_slot_blockmax(slot, row0 + 31, vmax);
     }
   }
 }

@@ -69,16 +69,19 @@ __device__ __forceinline__ void block_sum_256(float (&v)[NV], float* red) {
 #define EAV_SLOT_ISIGMA 2049
 // Per-row-block refinement of the tensor-wide scale (rows = output rows of the products that read the planes as their A
 // operand, e.g. the tokens of a gradient tensor): word EAV_SLOT_BMAX + (b & 1023) holds the bits of max|x| over the rows
-// [128 b, 128 b + 128) (producers atomicMax it next to the tensor-wide shards; blocks beyond 1024 alias, which only makes
-// the entry an over-estimate), word EAV_SLOT_BEXP + (b & 1023) the boost exponent k_b >= 0 the conversion chose: the
+// [32 b, 32 b + 32) (EAV_BLK_ROWS = one MFMA tile of rows / one token tile of the weight-gradient products; producers
+// atomicMax it next to the tensor-wide shards; blocks beyond 1024 - tensors of more than 32768 rows - alias, which only makes
+// the entry an over-estimate shared by the aliasing blocks), word EAV_SLOT_BEXP + (b & 1023) the boost exponent k_b >= 0 the conversion chose: the
 // planes of block b hold sigma 2^k_b x.  k_b = 0 unless the block's maximum is >= 2^8 below the tensor's - then the block
 // gets its own power of two, so a row keeps fp32-grade relative precision however small it is next to the largest row.
 #define EAV_SLOT_BMAX 2080
 #define EAV_SLOT_BEXP 3104
 #define EAV_SLOT_NBLK 1024
+#define EAV_BLK_SHIFT 5
+#define EAV_BLK_ROWS (1 << EAV_BLK_SHIFT)
 #define EAV_BOOST_MIN 8
 __device__ __forceinline__ void eav_slot_blockmax(unsigned* slot, int row, float vmax) {
-  if (vmax == vmax) atomicMax(slot + EAV_SLOT_BMAX + ((row >> 7) & (EAV_SLOT_NBLK - 1)), __float_as_uint(vmax));
+  if (vmax == vmax) atomicMax(slot + EAV_SLOT_BMAX + ((row >> EAV_BLK_SHIFT) & (EAV_SLOT_NBLK - 1)), __float_as_uint(vmax));
 }
 // boost exponent of row block b given the tensor-wide maximum bits (0: unknown / not small enough)
 __device__ __forceinline__ int eav_slot_boost(const float* slot, int b, unsigned gbits) {

@@ -327,8 +327,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
   };
   // more: a K-tile t+1 exists (read its first fragments); more2: a K-tile t+2 exists (issue its DMA);
   // next_m0 >= 0 (last K-tile only): issue the next output tile's first two stages instead
-  // TR: boost exponents of the token blocks of this workgroup's K range, one block per lane (64 blocks = 256 K-tiles per
-  // window, reloaded when the walk crosses a window).  A boosted block's fragments are scaled back by 2^-k before their
+  // TR: boost exponents of the token blocks (= K-tiles: 32 tokens) of this workgroup's K range, one block per lane (a window
+  // of 64 K-tiles, reloaded when the walk crosses it).  A boosted block's fragments are scaled back by 2^-k before their
   // MFMAs: the boost serves the products whose OUTPUT rows are these rows; in a contraction over the rows a small row's
   // share of the sum is small anyway, and un-boosting (fp16, may round into the subnormals) costs nothing next to the
   // large rows.  `anyb` (no lane holds a boost: the common case) keeps the whole mechanism out of the K loop.
@@ -371,11 +371,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
     constexpr bool more = decltype(more_c)::value, more2 = decltype(more2_c)::value, newer = decltype(newer_c)::value;
     int ka = 0, kb = 0;
     if constexpr (TR) {
-      const int rel = ((kt0 + t) >> 2) - (kt0 >> 2);
-      if (t > 0 && (rel & 63) == 0 && ((kt0 + t) & 3) == 0) load_boost_window((kt0 >> 2) + rel);
+      if (t > 0 && (t & 63) == 0) load_boost_window(kt0 + t);
       if (anyb) {
-        ka = __builtin_amdgcn_readlane(kvecA, rel & 63);
-        kb = __builtin_amdgcn_readlane(kvecB, rel & 63);
+        ka = __builtin_amdgcn_readlane(kvecA, t & 63);
+        kb = __builtin_amdgcn_readlane(kvecB, t & 63);
         if (ka | kb) unboost(f0, ka, kb);
       }
     }
@@ -480,7 +479,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
       if constexpr (TR) read_frag_tr(f0, smem, 0, r);
       else read_frag(f0, smem + offA, smem + offB, 0, r);
     }
-    load_boost_window(kt0 >> 2);
+    load_boost_window(kt0);
     {
       constexpr std::true_type Y{};
       constexpr std::false_type F{};
@@ -508,11 +507,28 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
     float alpha = g.alpha * g.slotA[EAV_SLOT_ISIGMA] * g.slotB[EAV_SLOT_ISIGMA];
     // row of the A planes this wave's output rows come from (batched launches: z selects a slab of sA / ldA rows)
     const int arow = (g.kt_per_split > 0 || g.ldA == 0 ? 0 : (int)(z * (g.sA / g.ldA))) + m0 + wm * 32 * RM;
+    // per-row-block boosts of the operands (EAV_SLOT_BEXP, one entry per 32 rows = per MFMA tile; 0 unless a block was >= 2^8
+    // below its tensor's maximum): the alpha of accumulator block (i, j) undoes 2^(kA[i] + kB[j])
+    float alf[RM][RN];
+#pragma unroll
+    for (int i = 0; i < RM; ++i)
+#pragma unroll
+      for (int j = 0; j < RN; ++j) alf[i][j] = alpha;
     if constexpr (!TR) {
-      // per-row-block boosts of the operands (EAV_SLOT_BEXP; 0 unless a block was >= 2^8 below its tensor's maximum)
-      const int kx = reinterpret_cast<const int*>(g.slotA)[EAV_SLOT_BEXP + ((arow >> 7) & (EAV_SLOT_NBLK - 1))] +
-                     reinterpret_cast<const int*>(g.slotB)[EAV_SLOT_BEXP + (((n0 + wn * 32 * RN) >> 7) & (EAV_SLOT_NBLK - 1))];
-      if (kx) alpha *= __uint_as_float((unsigned)(127 - min(kx, 126)) << 23);
+      int kA[RM], kB[RN];
+#pragma unroll
+      for (int i = 0; i < RM; ++i)
+        kA[i] = reinterpret_cast<const int*>(g.slotA)[EAV_SLOT_BEXP + (((arow + 32 * i) >> EAV_BLK_SHIFT) & (EAV_SLOT_NBLK - 1))];
+#pragma unroll
+      for (int j = 0; j < RN; ++j)
+        kB[j] = reinterpret_cast<const int*>(g.slotB)[EAV_SLOT_BEXP + (((n0 + wn * 32 * RN + 32 * j) >> EAV_BLK_SHIFT) & (EAV_SLOT_NBLK - 1))];
+#pragma unroll
+      for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j) {
+          const int kx = kA[i] + kB[j];
+          if (kx) alf[i][j] = alpha * __uint_as_float((unsigned)(127 - min(kx, 126)) << 23);
+        }
     }
     const float psig = g.planes ? g.slotP[EAV_SLOT_SIGMA] : 0.f;
     const int M = g.M, N = g.N;
@@ -542,7 +558,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
           const int64_t o = (int64_t)row * g.ldc + col;
           f32x16& a = acc[i][j];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) a[r] = alpha * a[r] + bv[r];
+          for (int r = 0; r < 16; ++r) a[r] = alf[i][j] * a[r] + bv[r];
           if (g.gelu == 2) {        // backward through GELU: scale by gelu'(pre), pre = the forward's stored pre-activation
 #pragma unroll
             for (int r = 0; r < 16; ++r) a[r] *= gelu_erf_grad(ok(r) ? pre[o + 8 * (r >> 2) + (r & 3)] : 0.f);
@@ -644,8 +660,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
           for (int k = 0; k < 4; ++k) {
             const int r = prow + 8 * k;
             const float4 x = *reinterpret_cast<const float4*>(patch + r * 32 + ((pc4 ^ (r & 7)) << 2));
-            v[4 * k] = alpha * x.x + b4.x; v[4 * k + 1] = alpha * x.y + b4.y;
-            v[4 * k + 2] = alpha * x.z + b4.z; v[4 * k + 3] = alpha * x.w + b4.w;
+            v[4 * k] = alf[i][j] * x.x + b4.x; v[4 * k + 1] = alf[i][j] * x.y + b4.y;
+            v[4 * k + 2] = alf[i][j] * x.z + b4.z; v[4 * k + 3] = alf[i][j] * x.w + b4.w;
           }
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the patch is free for the next block
           const int64_t o = (int64_t)(rowb + prow) * g.ldc + colb + 4 * pc4;     // + 8 k ldc per k
@@ -735,7 +751,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
         atomicMax(g.amax + EAV_SLOT_SHARD(tl * NW + wave + 17 * z), __float_as_uint(vmax));
         // (rows of the OUTPUT: same numbering for z = 0; skipped on request - at N = 768 the 24 waves of a tile-row, resident
         // together, queue on one address: 93 -> 123 us for a [25216 x 768] x [768 x 768]^T product)
-        if constexpr (!TR) { if (!g.noblk) eav_slot_blockmax(g.amax, arow, vmax); }
+        if constexpr (!TR) {
+          if (!g.noblk) {      // (the wave's maximum for each of its RM 32-row blocks: an over-estimate per block, which is safe)
+#pragma unroll
+            for (int i = 0; i < RM; ++i) eav_slot_blockmax(g.amax, arow + 32 * i, vmax);
+          }
+        }
       }
     }
   }
@@ -809,8 +830,8 @@ __global__ void sp_splitk_reduce_kernel(const float* __restrict__ ws, int nsplit
 // max |v| of a strided matrix into slot[0] (bits; atomicMax on non-negative floats = integer max: order-independent)
 __device__ __forceinline__ void sp_absmax_body(const float* __restrict__ src, int R, int C4, int64_t ld,
                                                unsigned* __restrict__ slot, int slab) {
-  // grid (column chunks of 256 float4, 128-row blocks, 4 slabs of 32 rows): 16 B per lane along the row, four row loads
-  // in flight; the maximum goes to a tensor-wide shard AND to the row block's entry (EAV_SLOT_BMAX)
+  // grid (column chunks of 256 float4, groups of 128 rows, 4 slabs of 32 rows): 16 B per lane along the row, four row loads
+  // in flight; the maximum goes to a tensor-wide shard AND to the slab's 32-row block entry (EAV_SLOT_BMAX)
   const int c = blockIdx.x * 256 + threadIdx.x;
   const int r0 = blockIdx.y * 128 + slab * 32, r1 = min(R, r0 + 32);
   if (r0 >= R || blockIdx.x * 256 >= C4) return;
@@ -940,15 +961,20 @@ __device__ __forceinline__ void sp_convert_body(const float* __restrict__ src, i
     if (nid < ntiles) load_tile(nid, nxt);
     const int by = id / ntx, bx = id - by * ntx;
     const int r0 = by * 64, c0 = bx * 64;
-    // Row blocks (128 rows) whose maximum is >= 2^8 below the tensor's get their own power of two on top of sigma (boost
-    // exponent kb, published in EAV_SLOT_BEXP for the consumers): rows keep fp32-grade RELATIVE precision however small
-    // they are next to the largest row.  Not when transposed planes are written too (there the rows are contracted).
-    const int kb = dstT ? 0 : min(eav_slot_boost(slot, by >> 1, gbits), 253 - (int)(__float_as_uint(sigma0) >> 23));
-    const float sigma = __uint_as_float(__float_as_uint(sigma0) + ((unsigned)kb << 23));
-    if (bx == 0 && (by & 1) == 0 && t == 0 && !dstT)
-      reinterpret_cast<int*>(slot)[EAV_SLOT_BEXP + ((by >> 1) & (EAV_SLOT_NBLK - 1))] = kb;
+    // Row blocks (32 rows: the two halves of this tile) whose maximum is >= 2^8 below the tensor's get their own power of two on
+    // top of sigma (boost exponent kb, published in EAV_SLOT_BEXP for the consumers): rows keep fp32-grade RELATIVE precision
+    // however small they are next to the largest row.  Not when transposed planes are written too (there the rows are contracted).
+    float sig[2];
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
+      const int kb = dstT ? 0 : min(eav_slot_boost(slot, 2 * by + pass, gbits), 253 - (int)(__float_as_uint(sigma0) >> 23));
+      sig[pass] = __uint_as_float(__float_as_uint(sigma0) + ((unsigned)kb << 23));
+      if (bx == 0 && t == 0 && !dstT)
+        reinterpret_cast<int*>(slot)[EAV_SLOT_BEXP + ((2 * by + pass) & (EAV_SLOT_NBLK - 1))] = kb;
+    }
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const float sigma = sig[pass];
       float tv[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) tv[e] = (gelu ? gelu_erf(cur[pass][e]) : cur[pass][e]) * sigma;
@@ -966,12 +992,17 @@ __device__ __forceinline__ void sp_convert_body(const float* __restrict__ src, i
     __syncthreads();
     if (dst) copy_out(pimg, dst, (int64_t)Cp * 4, r0, R, c0 >> 3, Cp >> 3);
     if (colsum_part && t < 64 && c0 + t < C) {   // bias gradient partial: column sums of this 64-row tile (sigma is 2^e: exact)
-      float a = 0.f, b = 0.f, c = 0.f, d = 0.f;
+      float hs[2];
 #pragma unroll
-      for (int r = 0; r < 64; r += 4) {
-        a += tile[r][t]; b += tile[r + 1][t]; c += tile[r + 2][t]; d += tile[r + 3][t];
+      for (int pass = 0; pass < 2; ++pass) {       // each half of the tile carries its own scale
+        float a = 0.f, b = 0.f, c = 0.f, d = 0.f;
+#pragma unroll
+        for (int r = 32 * pass; r < 32 * pass + 32; r += 4) {
+          a += tile[r][t]; b += tile[r + 1][t]; c += tile[r + 2][t]; d += tile[r + 3][t];
+        }
+        hs[pass] = ((a + b) + (c + d)) * (1.f / sig[pass]);
       }
-      colsum_part[(int64_t)by * C + c0 + t] = ((a + b) + (c + d)) * (1.f / sigma);
+      colsum_part[(int64_t)by * C + c0 + t] = hs[0] + hs[1];
     }
     if (dstT) {
       const int rg = t & 7, cc = t >> 3;

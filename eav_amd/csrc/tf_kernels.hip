@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     mean_n = mean_i[row];
     rstd_n = rstd_i[row];
   };
-  // A wave takes the rows in groups of 16 consecutive ones (group g = gw, gw + GW, ...): a group lies inside ONE 128-row
+  // A wave takes the rows in groups of 16 consecutive ones (group g = gw, gw + GW, ...): a group lies inside ONE 32-row
   // block, so the block maximum (EAV_SLOT_BMAX) costs one wave reduction and one atomic per 16 rows - one atomic per ROW
   // to ~200 addresses doubled the kernel's time (ViT B=128: 95 us against 46 us without the maxima)
 #ifndef EAV_LN_RG
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         rmax = fmaxf(rmax, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
       }
     }
-    if (amax) {       // the group's maximum into its 128-row block's entry (per-row-block operand scales, eav_common.h)
+    if (amax) {       // the group's maximum into its 32-row block's entry (per-row-block operand scales, eav_common.h)
       gmax = fmaxf(gmax, rmax);
       if (((row + 1) & (RG - 1)) == 0 || row + 1 >= M) {
 #pragma unroll

@@ -248,7 +248,7 @@ int eav_gemm_bf16_splitk(const float* A, const float* B, float* C, float* ws, in
  * (eav_sp_absmax or a GEMM's amax_slot), then eav_sp_convert writes the planes of X (dst: contraction over columns)
  * and / or of X^T (dstT: contraction over rows) and fills sigma. */
 #define EAV_SP_SLOT 4128   /* shard i at word 32*i (one 128-byte line each), sigma at word 2048, 1/sigma at 2049; words
-                            * 2080.. : max|x| bits per 128-row block, 3104.. : boost exponent per 128-row block (1024 each) */
+                            * 2080.. : max|x| bits per 32-row block, 3104.. : boost exponent per 32-row block (1024 each; blocks alias beyond 32768 rows) */
 int eav_sp_kpad(int K);
 int eav_sp_absmax(const float* src, int R, int C, int64_t ld, float* slot, void* stream);
 int eav_sp_convert(const float* src, int R, int C, int64_t ld, float* slot, void* dst, void* dstT, void* stream);
@@ -337,7 +337,7 @@ int eav_gemm_sp_x1(const void* A, const void* B, float* C, const float* slotA, c
 #define EAV_GEMM_ONE_TERM 1    /* the hi.hi term alone */
 #define EAV_GEMM_PLANES_NOLIFT 4 /* planes_out with lo = fp16(sigma x - hi), no 2^11 lift: the row planes the fused attention
                                   * reads (the fused q/k/v projection writes them directly, scale from eav_tf_forward_scales_qkv) */
-#define EAV_GEMM_NO_BLOCKMAX 8  /* amax_slot receives the tensor-wide maximum only, no 128-row block entries: for outputs whose
+#define EAV_GEMM_NO_BLOCKMAX 8  /* amax_slot receives the tensor-wide maximum only, no 32-row block entries: for outputs whose
                                  * consumer takes one scale per tensor (the attention operand preparation of dO) */
 #define EAV_GEMM_SHARED_GPU 2  /* a second persistent GEMM runs beside this one (the backward's data gradients next to the
                                 * side stream's weight gradients): prefer the 256 x 128 one-workgroup-per-CU form */

@@ -470,9 +470,13 @@ def test_forward_scales_are_bounds_and_row_norms_are_exact():
 def test_rows_of_any_magnitude_keep_fp32_grade_relative_precision(shape):
     """Per-row-block operand scales: with log-normal ROW scales of sigma = 4 (ten decimal orders between the rows - what a
     gradient tensor looks like when a few tokens carry almost all of the loss) every output element is as accurate,
-    relative to sum |a||b| of ITS OWN row, as the exact-fp32 MFMA kernel's (bound: 2x).  A 128-row block whose maximum is
-    >= 2^8 below the tensor's gets its own power of two (EAV_SLOT_BMAX / EAV_SLOT_BEXP); one scale per tensor loses the lo
-    piece of rows 2^29 below the maximum (6.7e-5 on this case before)."""
+    relative to sum |a||b| of ITS OWN row, as the exact-fp32 MFMA kernel's (bound: 2x).  A 32-row block (one MFMA tile of rows)
+    whose maximum is >= 2^8 below the tensor's gets its own power of two (EAV_SLOT_BMAX / EAV_SLOT_BEXP); one scale per tensor
+    loses the lo piece of rows 2^29 below the maximum (6.7e-5 on this case before).  With the rows in RANDOM order (the
+    `wide=True` case of tools/gemm_sp_bench.py) a block's scale is set by its largest row: every row is then precise relative
+    to its BLOCK's maximum, i.e. element-wise fp32-grade for the rows within 2^29 of it - all but the few ordinary rows that
+    share a block of 32 with one of the giant rows (asserted: >= 97 % of the rows meet the 2x bound; per-ROW scales would be
+    needed for the rest, section 7.1 of DESIGN.md)."""
     M, N, K = shape
     torch.manual_seed(M + N + K)
     A = torch.randn(M, K, device="cuda")
@@ -486,14 +490,23 @@ def test_rows_of_any_magnitude_keep_fp32_grade_relative_precision(shape):
     e_32 = ((gemm_f32(A, B).double() - ref).abs() / den).max().item()
     assert e_sp <= 2 * e_32, (e_sp, e_32)
     slot, pl, _ = planes(A)
-    bexp = slot[3104:3104 + (M + 127) // 128].view(torch.int32)
+    bexp = slot[3104:3104 + (M + 31) // 32].view(torch.int32)
     assert int(bexp.max()) >= 8 and int(bexp.min()) == 0           # small blocks were boosted, the largest was not
-    # unsorted rows: a block's scale is set by its largest row - rows are then precise relative to their BLOCK's maximum
-    A2 = A[torch.randperm(M, device="cuda")]
-    ref2 = A2.double() @ B.double().t()
-    blockmax = torch.stack([A2[i:i + 128].abs().max() for i in range(0, M, 128)]).repeat_interleave(128)[:M].double()
-    e2 = ((gemm_sp(A2, B).double() - ref2).abs() / (blockmax[:, None] * B.double().abs().sum(1)[None, :])).max().item()
-    assert e2 < 1e-6
+    # rows in random order: the same element-wise bound (a block's scale is set by its largest row; the other 31 rows of a
+    # block are at most ~2^24 below it), and in any case precise relative to their BLOCK's maximum
+    for seed in range(3):
+        g = torch.Generator(device="cuda").manual_seed(seed)
+        A2 = A[torch.randperm(M, device="cuda", generator=g)]
+        ref2 = A2.double() @ B.double().t()
+        den2 = A2.double().abs() @ B.double().abs().t()
+        C2 = gemm_sp(A2, B).double()
+        row_sp = ((C2 - ref2).abs() / den2).max(dim=1).values
+        e_322 = ((gemm_f32(A2, B).double() - ref2).abs() / den2).max().item()
+        frac = float((row_sp <= 2 * e_322).double().mean())
+        assert frac >= 0.97, (seed, frac)
+        blockmax = torch.stack([A2[i:i + 32].abs().max() for i in range(0, M, 32)]).repeat_interleave(32)[:M].double()
+        e2 = ((C2 - ref2).abs() / (blockmax[:, None] * B.double().abs().sum(1)[None, :])).max().item()
+        assert e2 < 1e-6
 
 
 def test_weight_gradient_undoes_the_row_block_boosts():
@@ -512,8 +525,10 @@ def test_weight_gradient_undoes_the_row_block_boosts():
     dY = dY * scale
     sa, pa = row_planes(dY)
     sb, pb = row_planes(X)
-    bexp = sa[3104:3104 + tokens // 128].view(torch.int32).cpu().tolist()
-    assert bexp[1] == 12 and bexp[8] == 20 and bexp[16] == 30 and bexp[0] == 0
+    bexp = sa[3104:3104 + tokens // 32].view(torch.int32).cpu().tolist()           # one entry per 32 tokens
+    # (a block's boost = exponent of the tensor maximum - exponent of ITS maximum: 12 or 13 for a block scaled by 2^-12)
+    assert all(bexp[i] in (12, 13) for i in range(4, 8)) and all(bexp[i] in (20, 21) for i in range(32, 48))
+    assert all(bexp[i] in (30, 31) for i in range(64, 68)) and bexp[0] == 0 and bexp[8] == 0 and bexp[68] == 0
     C = torch.empty(N, K, device="cuda")
     ns = _lib.plain("eav_gemm_sp_splitk_plan", N, K, tokens)
     ws = torch.empty(max(ns, 1) * N * K, device="cuda")

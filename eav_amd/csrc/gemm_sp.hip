@@ -773,8 +773,11 @@ int g_loshift = 11;
 int g_persist = 1;      // tuning hook: 0 = one workgroup per output tile
 int g_splitk_force = 0; // tuning hook (eav_gemm_sp_set_splitk): slices of eav_gemm_sp_splitk, 0 = the plan
 
+// Returns false when no kernel is instantiated for the requested combination (the single-accumulator tuning mode
+// g_loshift = 0 exists for the 128 x 128 two-stage column-contracting form only): the caller reports an error instead of
+// returning EAV_OK over stale output.
 template <int WM, int WN, int RM, int RN, bool TR = false, int NS = 2>
-void launch(SpArgs& g, int nz, hipStream_t st, int terms = 3) {
+bool launch(SpArgs& g, int nz, hipStream_t st, int terms = 3) {
   g.tm = cdiv(g.M, 32 * RM * WM);
   g.tn = cdiv(g.N, 32 * RN * WN);
   // persistent workgroups: as many as stay resident (2 per CU for 4-wave tiles, 1 for 8-wave tiles), a multiple of 8 so
@@ -783,16 +786,22 @@ void launch(SpArgs& g, int nz, hipStream_t st, int terms = 3) {
   const int nb = g.tm * g.tn, gx = nb <= resident ? nb : resident;
   if (terms == 1) {
     hipLaunchKernelGGL((gemm_sp_kernel<WM, WN, RM, RN, false, TR, 1, NS>), dim3(gx, 1, nz), dim3(64 * WM * WN), 0, st, g);
+    return true;
   } else if (g_loshift) {
-    if constexpr (RM * RN <= 4)
+    if constexpr (RM * RN <= 4) {
       hipLaunchKernelGGL((gemm_sp_kernel<WM, WN, RM, RN, true, TR, 3, NS>), dim3(gx, 1, nz), dim3(64 * WM * WN), 0, st, g);
+      return true;
+    }
   } else {
-    if constexpr (!TR && NS == 2)
+    if constexpr (!TR && NS == 2) {
       hipLaunchKernelGGL((gemm_sp_kernel<WM, WN, RM, RN, false, false>), dim3(gx, 1, nz), dim3(64 * WM * WN), 0, st, g);
+      return true;
+    }
   }
+  return false;
 }
 
-void dispatch(SpArgs& g, int nz, hipStream_t st, int terms = 3, bool shared_gpu = false) {
+bool dispatch(SpArgs& g, int nz, hipStream_t st, int terms = 3, bool shared_gpu = false) {
   // 128 x 128 tiles x two workgroups per CU when the product has the GPU to itself (the forward): alone the two forms are
   // within +-5 % on the encoder shapes and the small one wins where the epilogue is heavy or the tile count quantises
   // badly (fc1 + GELU, o-proj; tools/gemm_sp_bench.py; forward-only step ViT B=128 17.35 against 18.1 ms).  256 x 128 / 8
@@ -802,12 +811,12 @@ void dispatch(SpArgs& g, int nz, hipStream_t st, int terms = 3, bool shared_gpu 
   // kernel's workgroups off the CUs it runs on - the two take turns instead of sharing every CU's LDS bandwidth and L2
   // (ViT B=128 step 57.6 -> 55.9 ms, tools/encoder_step_bench.py with SP_TILE=1 / 0 on one box; +10 % alone at 8192^3).
   const bool big = g_force_tile == 2 || (g_force_tile == 0 && shared_gpu && cdiv(g.M, 256) * cdiv(g.N, 128) >= 256);
-  if (g_force_tile == 3) launch<2, 4, 2, 2, false, 3>(g, nz, st, terms);
-  else if (big) launch<4, 2, 2, 2, false, 3>(g, nz, st, terms);
-  else launch<2, 2, 2, 2>(g, nz, st, terms);
+  if (g_force_tile == 3) return launch<2, 4, 2, 2, false, 3>(g, nz, st, terms);
+  if (big) return launch<4, 2, 2, 2, false, 3>(g, nz, st, terms);
+  return launch<2, 2, 2, 2>(g, nz, st, terms);
 }
 
-void dispatch_tr(SpArgs& g, int nz, hipStream_t st, int terms = 3) { launch<2, 2, 2, 2, true>(g, nz, st, terms); }
+bool dispatch_tr(SpArgs& g, int nz, hipStream_t st, int terms = 3) { return launch<2, 2, 2, 2, true>(g, nz, st, terms); }
 
 __global__ void sp_splitk_reduce_kernel(const float* __restrict__ ws, int nsplit, int64_t n, float* __restrict__ out,
                                         int accumulate) {
@@ -1176,7 +1185,8 @@ static int gemm_sp_impl(const void* A, const void* B, float* C, const float* slo
                     : (cdiv(N, 128) <= 8 || ((int64_t)M + N) * Kp * 4 <= (48ll << 20) ? 1 : 0);
   g.noblk = (flags & EAV_GEMM_NO_BLOCKMAX) ? 1 : 0;
   if (flags & EAV_GEMM_PLANES_NOLIFT) g.lomul = 1.f;      // lo = fp16(t - hi): the attention kernels' row planes
-  dispatch(g, batch, (hipStream_t)stream, terms, (flags & EAV_GEMM_SHARED_GPU) != 0);
+  EAV_REQUIRE(dispatch(g, batch, (hipStream_t)stream, terms, (flags & EAV_GEMM_SHARED_GPU) != 0),
+              "eav_gemm_sp: no kernel for this tile form in the single-accumulator tuning mode (eav_gemm_sp_set_tile(4))");
   EAV_CHECK_LAUNCH("eav_gemm_sp");
   return EAV_OK;
 }
@@ -1265,14 +1275,14 @@ static int gemm_sp_splitk_impl(const void* A, const void* B, float* C, float* ws
   hipStream_t st = (hipStream_t)stream;
   if (nsplit <= 1) {
     g.C = C; g.accumulate = accumulate; g.kt_per_split = 0;
-    dispatch_tr(g, 1, st, terms);
+    EAV_REQUIRE(dispatch_tr(g, 1, st, terms), "eav_gemm_sp_splitk: no kernel for this mode");
     EAV_CHECK_LAUNCH("eav_gemm_sp_splitk");
     return EAV_OK;
   }
   g.C = ws; g.accumulate = 0;
   g.kt_per_split = cdiv(g.nkt, nsplit);
   const int nz = cdiv(g.nkt, g.kt_per_split);
-  dispatch_tr(g, nz, st, terms);
+  EAV_REQUIRE(dispatch_tr(g, nz, st, terms), "eav_gemm_sp_splitk: no kernel for this mode");
   EAV_CHECK_LAUNCH("eav_gemm_sp_splitk");
   const int64_t n = (int64_t)M * N;
   hipLaunchKernelGGL(sp_splitk_reduce_kernel, dim3((unsigned)cdiv64(n, 1024)), dim3(256), 0, st, ws, nz, n, C,

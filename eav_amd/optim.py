@@ -223,6 +223,17 @@ class CrossEntropyLoss:
         both once per epoch instead of synchronising twice per batch (EEGNet_tor.py:126-130 calls .item() per batch)."""
         if not scores.is_cuda or scores.dim() != 2 or scores.dtype != torch.float32 or not scores.is_contiguous():
             raise _lib.EavError("CrossEntropyLoss.accumulate: scores must be a contiguous fp32 [batch, classes] device tensor")
+        # every operand goes to the kernel as a raw pointer: a host tensor would be dereferenced on the GPU
+        if not isinstance(targets, torch.Tensor) or targets.device != scores.device or targets.dim() != 1 \
+                or targets.numel() != scores.shape[0]:
+            raise _lib.EavError(f"CrossEntropyLoss.accumulate: targets must be {scores.shape[0]} labels on {scores.device} "
+                                "(no CPU fallback: move the loader's tensors to the device)")
+        if not isinstance(loss_out, torch.Tensor) or loss_out.device != scores.device or loss_out.dtype != torch.float32 \
+                or loss_out.numel() < 1:
+            raise _lib.EavError(f"CrossEntropyLoss.accumulate: loss_out must be an fp32 tensor on {scores.device}")
+        if not isinstance(ncorrect, torch.Tensor) or ncorrect.device != scores.device or ncorrect.dtype != torch.int32 \
+                or ncorrect.numel() < 1:
+            raise _lib.EavError(f"CrossEntropyLoss.accumulate: ncorrect must be an int32 tensor on {scores.device}")
         if targets.dtype != torch.int64:
             targets = targets.long()
         if self._flag is None or self._flag.device != scores.device:

@@ -158,6 +158,38 @@ class _EncFn(torch.autograd.Function):
         return (None, None, *ctx.model._launch_backward(dlogits.contiguous(), ctx.token))
 
 
+class _HeadFn(torch.autograd.Function):
+    """The classification head alone on cached backbone features (Encoder.head): the same kernels, in the same order and
+    with the same arguments, as the tail of _launch_forward / the start of _launch_backward."""
+
+    @staticmethod
+    def forward(ctx, feat, model, *params):
+        ctx.model, ctx.B = model, feat.shape[0]
+        hw = model._head_ws(feat.shape[0], feat.device)
+        hw.feat.copy_(feat)
+        model._st = _lib.stream_ptr()
+        model._head_forward(hw.feat, hw, feat.shape[0])
+        hw.token = model._token = model._token + 1
+        ctx.token = hw.token
+        return hw.logits.clone()
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        model = ctx.model
+        hw = model._head_ws(ctx.B, dlogits.device)
+        if hw.token != ctx.token:
+            raise _lib.EavError("Encoder.head backward: activations were overwritten by a later head forward")
+        model._st = _lib.stream_ptr()
+        model._head_backward(dlogits.contiguous(), hw.feat, hw, ctx.B, False)
+        offs, gflat = model._flat[2], model._flat[1]
+        out = []
+        for k in model._names:
+            p = model._pmap[k]
+            trained = p.requires_grad and k.startswith("classifier.")
+            out.append(gflat[offs[k][0]:offs[k][0] + offs[k][1]].view(p.shape) if trained else None)
+        return (None, None, *out)
+
+
 class Encoder(nn.Module):
     """ASTForAudioClassification / ViTForImageClassification (5-class head) on the HIP kernels."""
 
@@ -177,6 +209,8 @@ class Encoder(nn.Module):
             _set_param(self, k, v)
         self._names = list(shapes)
         self._ws = None
+        self._ws_cache = {}           # batch size -> workspace (a ragged last batch must not evict the full-batch one)
+        self._hws = {}                # batch size -> head-only workspace (Encoder.head)
         self._flat = None
         self._token = 0
         self._saved = None
@@ -206,7 +240,7 @@ class Encoder(nn.Module):
         # split mode, forward: the fused q/k/v projection writes the attention kernels' row planes itself (scale from a bound of
         # |qkv|), the per-head transposes are made from those planes - no fp32 qkv tensor (EAV_FUSED_QKV=0 for A/B runs)
         self.fused_qkv = os.environ.get("EAV_FUSED_QKV", "1") != "0"
-        self._side, self._aux, self._wgrad_done, self._wready = None, None, {}, {}
+        self._side, self._aux, self._wgrad_done, self._wready, self._wnorm_ready = None, None, {}, {}, None
         self._part_busy, self._ring_pos = {}, {}
         self._wplanes = None          # split mode: {weight key: (planes, planes of the transpose, slot index)}
         self._wplanes_key = None
@@ -249,6 +283,7 @@ class Encoder(nn.Module):
         self.cfg.num_labels = head.weight.shape[0]
         self._flat = None
         self._ws = None
+        self._ws_cache, self._hws = {}, {}
 
     def head_parameters(self):
         return list(self.classifier.parameters())
@@ -267,6 +302,8 @@ class Encoder(nn.Module):
     def _apply(self, fn, *args, **kwargs):
         self._wplanes_key = None
         self._wplanes = None
+        self._ws = None
+        self._ws_cache, self._hws = {}, {}
         return super()._apply(fn, *args, **kwargs)
 
     def head_grad_ranges(self):
@@ -482,6 +519,7 @@ class Encoder(nn.Module):
         # conversion is ever on the critical path.
         side = self._side_stream(dev) if (stale and self.overlap_wgrad and self.kernel_events is None) else None
         self._wready = {}
+        self._wnorm_ready = None
         if side is not None:
             start = torch.cuda.Event()
             start.record()                      # the weights are final (the optimiser ran on this stream)
@@ -508,7 +546,10 @@ class Encoder(nn.Module):
                 for k, src, out, inn in stale:
                     if k.startswith("fc1"):
                         _lib.call("eav_rownorm_max", src, out, inn, inn, wp["_wnorm_fc1"].data_ptr() + 4 * int(k[3:]), st)
-                    elif k.startswith("fc2") and need_T:
+                    elif k.startswith("fc2") and wp["_T"]:
+                        # (keyed on the planes HAVING transposes, not on this call's need_T: a no_grad forward right after an
+                        # optimiser step refreshes everything with need_T = False, and the next training step finds nothing
+                        # stale - its backward must still see the norms of the CURRENT weights)
                         _lib.call("eav_colnorm_max", src, out, inn, inn, wp["_wcolnorm_fc2"].data_ptr() + 4 * int(k[3:]), st)
                     elif k.startswith("qkv"):
                         _lib.call("eav_rownorm_max", src, out, inn, inn, wp["_wnorm_qkv"].data_ptr() + 4 * int(k[3:]), st)
@@ -516,29 +557,32 @@ class Encoder(nn.Module):
                     ev = torch.cuda.Event()
                     ev.record(side)
                     self._wready = {k: ev for k, _, _, _ in stale}
+                    self._wnorm_ready = ev
                 stale = []
+            # some matrices are stale (a partial update): the row / column norms first - the a-priori scales of EVERY layer
+            # are computed by one launch before layer 0 and wait for ONE event (`_wnorm_ready`), not for the conversions -
+            # then max|w| + conversion per matrix with one event each (the main stream waits for a matrix's planes right
+            # before the first GEMM that reads them: _wp)
+            for k, src, out, inn in stale:
+                li = int(k[3:]) if k[:3] in ("fc1", "fc2", "qkv") else -1
+                if k.startswith("fc1"):
+                    wp["_wnorm_fc1"][li].zero_()
+                    _lib.call("eav_rownorm_max", src, out, inn, inn, wp["_wnorm_fc1"].data_ptr() + 4 * li, st)
+                elif k.startswith("fc2") and wp["_T"]:
+                    wp["_wcolnorm_fc2"][li].zero_()
+                    _lib.call("eav_colnorm_max", src, out, inn, inn, wp["_wcolnorm_fc2"].data_ptr() + 4 * li, st)
+                elif k.startswith("qkv"):
+                    wp["_wnorm_qkv"][li].zero_()
+                    _lib.call("eav_rownorm_max", src, out, inn, inn, wp["_wnorm_qkv"].data_ptr() + 4 * li, st)
+            if stale and side is not None:
+                self._wnorm_ready = torch.cuda.Event()
+                self._wnorm_ready.record(side)
             for k, src, out, inn in stale:
                 pl, plT, n = wp[k]
-                if len(stale) != len(keys):
-                    wp["_slots"][n].zero_()
+                wp["_slots"][n].zero_()
                 slot = wp["_slots"].data_ptr() + 4 * self.SLOT * n
                 _lib.call("eav_sp_absmax", src, out, inn, inn, slot, st)
                 _lib.call("eav_sp_convert", src, out, inn, inn, slot, _lib.ptr(pl), _lib.ptr(plT), st)
-                if k.startswith("fc1"):
-                    li = int(k[3:])
-                    if len(stale) != len(keys):
-                        wp["_wnorm_fc1"][li].zero_()
-                    _lib.call("eav_rownorm_max", src, out, inn, inn, wp["_wnorm_fc1"].data_ptr() + 4 * li, st)
-                elif k.startswith("fc2") and need_T:
-                    li = int(k[3:])
-                    if len(stale) != len(keys):
-                        wp["_wcolnorm_fc2"][li].zero_()
-                    _lib.call("eav_colnorm_max", src, out, inn, inn, wp["_wcolnorm_fc2"].data_ptr() + 4 * li, st)
-                elif k.startswith("qkv"):
-                    li = int(k[3:])
-                    if len(stale) != len(keys):
-                        wp["_wnorm_qkv"][li].zero_()
-                    _lib.call("eav_rownorm_max", src, out, inn, inn, wp["_wnorm_qkv"].data_ptr() + 4 * li, st)
                 if side is not None:
                     ev = torch.cuda.Event()
                     ev.record(side)
@@ -654,6 +698,70 @@ class Encoder(nn.Module):
             torch.cuda.current_stream().wait_stream(self._aux)
             self._part_busy.clear()
 
+    # ------------------------------------------------------------------ classification head (shared by the full path
+    # and by Encoder.head on cached features: same kernels, same arguments, hence bit-equal logits and gradients)
+    def _head_forward(self, feat, hw, B):
+        """feat [B, D] = the classifier's input (AST: mean of the cls / distillation rows after the final LayerNorm,
+        HF modeling_audio_spectrogram_transformer.py ASTMLPHead; ViT: the cls row after the final LayerNorm)."""
+        c, P, L, st = self.cfg, _lib.ptr, self._call, self._st
+        D = c.hidden
+        w = lambda k: P(self._pmap[k])  # noqa: E731
+        if c.kind == "ast":
+            sh = P(hw.sth)
+            L("eav_layernorm_fwd", P(feat), w("classifier.layernorm.weight"), w("classifier.layernorm.bias"),
+              P(hw.hl), sh, sh + 4 * B, B, D, c.eps, st)
+            L("eav_dense_softmax_fwd", P(hw.hl), w("classifier.dense.weight"), w("classifier.dense.bias"),
+              P(hw.logits), None, B, D, c.num_labels, st)
+        else:
+            L("eav_dense_softmax_fwd", P(feat), w("classifier.weight"), w("classifier.bias"), P(hw.logits), None,
+              B, D, c.num_labels, st)
+
+    def _head_backward(self, dlogits, feat, hw, B, need_dfeat):
+        """Head gradients into the flat gradient buffer; d loss / d feat into hw.dpooled (AST) / hw.dseqr (ViT)."""
+        c, P, L, st = self.cfg, _lib.ptr, self._call, self._st
+        D = c.hidden
+        gflat, offs = self._flat[1], self._flat[2]
+        gp = lambda k: gflat.data_ptr() + 4 * offs[k][0]  # noqa: E731
+        w = lambda k: P(self._pmap[k])  # noqa: E731
+        if c.kind == "ast":
+            L("eav_dense_softmax_bwd", P(dlogits), None, P(hw.hl), w("classifier.dense.weight"),
+              gp("classifier.dense.weight"), gp("classifier.dense.bias"), P(hw.dhl), B, D, c.num_labels, st)
+            sh = P(hw.sth)
+            L("eav_layernorm_bwd", P(hw.dhl), P(feat), w("classifier.layernorm.weight"), sh, sh + 4 * B,
+              P(hw.dpooled), 0, P(hw.part_lnr), B, D, st)
+            npb = _lib.plain("eav_layernorm_bwd_nparts", B)
+            self._reduce(hw.part_lnr, npb, 2 * D, D, gp("classifier.layernorm.weight"))
+            L("eav_reduce_partials", P(hw.part_lnr) + 4 * D, npb, 2 * D, D, 1.0, gp("classifier.layernorm.bias"), st)
+        else:
+            L("eav_dense_softmax_bwd", P(dlogits), None, P(feat), w("classifier.weight"), gp("classifier.weight"),
+              gp("classifier.bias"), P(hw.dseqr), B, D, c.num_labels, st)
+
+    def _head_ws(self, B, dev):
+        hw = self._hws.get(B)
+        if hw is None or hw.feat.device != dev or hw.logits.shape[1] != self.cfg.num_labels:
+            c, D = self.cfg, self.cfg.hidden
+            f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
+            hw = self._hws[B] = SimpleNamespace(
+                feat=f(B, D), hl=f(B, D), sth=f(2, B), logits=f(B, c.num_labels), dhl=f(B, D), dpooled=f(B, D),
+                dseqr=f(B, D), part_lnr=f(_lib.plain("eav_layernorm_bwd_nparts", B * c.nextra), 2 * D), token=-1)
+        return hw
+
+    def last_features(self):
+        """The classifier's input of the most recent forward ([B, hidden], a copy): constant per sample while the backbone
+        is frozen (every dropout of the reference checkpoints is 0.0), which is what the trainers' frozen-phase feature
+        cache stores (finetune.FineTuneBase)."""
+        ws = self._ws
+        if ws is None:
+            raise _lib.EavError("Encoder.last_features: no forward has run")
+        return (ws.pooled if self.cfg.kind == "ast" else ws.seqr[:ws.B]).clone()
+
+    def head(self, feat):
+        """Classifier on backbone features [B, hidden] (from last_features): logits with the head's autograd graph."""
+        if not isinstance(feat, torch.Tensor) or not feat.is_cuda or feat.dim() != 2 or feat.shape[1] != self.cfg.hidden:
+            raise _lib.EavError("Encoder.head: features must be a [batch, hidden] tensor on the ROCm device")
+        self._ensure_flat()
+        return _Out(_HeadFn.apply(feat.contiguous().float(), self, *[self._pmap[k] for k in self._names]))
+
     def _launch_forward(self, x):
         c = self.cfg
         P, L = _lib.ptr, self._call
@@ -666,9 +774,18 @@ class Encoder(nn.Module):
         full = self._want_full
         ws = self._ws
         sp = self.precision == "split"
-        if ws is None or ws.B != B or ws.hs[0].device != x.device or (full and not ws.full) \
-                or ws.fused != self._fused_attention() or ws.sp != sp:
-            ws = self._ws = self._alloc(B, x.device, full)
+        ok = lambda v: (v is not None and v.B == B and v.hs[0].device == x.device and (v.full or not full)  # noqa: E731
+                        and v.fused == self._fused_attention() and v.sp == sp)
+        if not ok(ws):
+            # one workspace per batch size (at most three: the full batch, a ragged last batch, an evaluation batch) - the
+            # 5000 % 128 = 8 frames at the end of every vision epoch must not free and re-zero the 19 GB of the B = 128 one
+            ws = self._ws_cache.get(B)
+            if not ok(ws):
+                if len(self._ws_cache) >= 3:
+                    self._ws_cache.pop(next(k for k in self._ws_cache if k != B))
+                    torch.cuda.empty_cache()
+                ws = self._ws_cache[B] = self._alloc(B, x.device, full)
+            self._ws = ws
         if sp:
             self._refresh_weight_planes(x.device, full)
             ws.fslots.zero_()
@@ -736,14 +853,7 @@ class Encoder(nn.Module):
           sf + 4 * R, R, D, c.eps, st)
         if c.kind == "ast":
             L("eav_pair_mean", P(ws.seqr), P(ws.pooled), B, D, 0, st)
-            sh = P(ws.sth)
-            L("eav_layernorm_fwd", P(ws.pooled), w("classifier.layernorm.weight"), w("classifier.layernorm.bias"),
-              P(ws.hl), sh, sh + 4 * B, B, D, c.eps, st)
-            L("eav_dense_softmax_fwd", P(ws.hl), w("classifier.dense.weight"), w("classifier.dense.bias"),
-              P(ws.logits), None, B, D, c.num_labels, st)
-        else:
-            L("eav_dense_softmax_fwd", P(ws.seqr), w("classifier.weight"), w("classifier.bias"), P(ws.logits), None,
-              B, D, c.num_labels, st)
+        self._head_forward(ws.pooled if c.kind == "ast" else ws.seqr, ws, B)
         self._token += 1
         self._saved = (self._token, x, full, None)
         return self._token
@@ -764,9 +874,8 @@ class Encoder(nn.Module):
         stride = first(1) - first(0) if c.layers > 1 else 0
         if any(r != rel[0] for r in rel) or any(first(i) - first(0) != i * stride for i in range(c.layers)):
             return
-        for i in range(c.layers):                      # the row norms come from the side-stream weight refresh
-            self._wp(f"fc1{i}")
-            self._wp(f"qkv{i}")
+        if self._wnorm_ready is not None:              # the row norms come from the side-stream weight refresh
+            torch.cuda.current_stream().wait_event(self._wnorm_ready)
         o = rel[0]
         qkvp = self.fused_qkv and ws.fused
         self._call("eav_tf_forward_scales_qkv", _lib.ptr(self._flat[0]) + 4 * first(0), stride, c.layers, o[0], o[1], o[2],
@@ -994,20 +1103,9 @@ class Encoder(nn.Module):
         pre = c.prefix
         R = B * c.nextra
         # ---- head
-        if c.kind == "ast":
-            L("eav_dense_softmax_bwd", P(dlogits), None, P(ws.hl), w("classifier.dense.weight"),
-              gp("classifier.dense.weight"), gp("classifier.dense.bias"), P(ws.dhl), B, D, c.num_labels, st)
-            sh = P(ws.sth)
-            L("eav_layernorm_bwd", P(ws.dhl), P(ws.pooled), w("classifier.layernorm.weight"), sh, sh + 4 * B,
-              P(ws.dpooled), 0, P(ws.part_lnr), B, D, st)
-            npb = _lib.plain("eav_layernorm_bwd_nparts", B)
-            self._reduce(ws.part_lnr, npb, 2 * D, D, gp("classifier.layernorm.weight"))
-            L("eav_reduce_partials", P(ws.part_lnr) + 4 * D, npb, 2 * D, D, 1.0, gp("classifier.layernorm.bias"), st)
-            if full:
-                L("eav_pair_mean", P(ws.dseqr), P(ws.dpooled), B, D, 1, st)
-        else:
-            L("eav_dense_softmax_bwd", P(dlogits), None, P(ws.seqr), w("classifier.weight"), gp("classifier.weight"),
-              gp("classifier.bias"), P(ws.dseqr), B, D, c.num_labels, st)
+        self._head_backward(dlogits, ws.pooled if c.kind == "ast" else ws.seqr, ws, B, full)
+        if c.kind == "ast" and full:
+            L("eav_pair_mean", P(ws.dseqr), P(ws.dpooled), B, D, 1, st)
         if full:
             sf = P(ws.stf)
             L("eav_layernorm_bwd", P(ws.dseqr), P(ws.rows), w(f"{pre}.layernorm.weight"), sf, sf + 4 * R,

@@ -244,3 +244,27 @@ def test_unsupported_configurations_raise_not_silently_differ():
     m = EEGNet_tor(5, dropoutType="SpatialDropout2D", dropoutRate=0.5)
     assert m.spatial_dropout and isinstance(m.dropout, torch.nn.Dropout2d)
     assert not EEGNet_tor(5).spatial_dropout
+
+
+def test_bench_headline_is_compact_and_complete():
+    """bench.py's LAST stdout line must stay small enough for the driver's parser (round 3's 27 KB line was not parsed):
+    the compact headline built from a full round-3 detail record is < 4 KB and carries roofline + cpu_baseline + one short
+    record per modality."""
+    import importlib.util
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    detail = json.load(open(os.path.join(root, "profiles", "r03_bench_line.json")))
+    line = json.dumps(bench.compact_headline(detail), separators=(",", ":"))
+    assert len(line) < 4096, len(line)
+    head = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "modalities"):
+        assert k in head, k
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(head["roofline"])
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(head["cpu_baseline"])
+    assert set(head["modalities"]) == {"eegnet", "ast", "vit"} and "workload" in head["config"]
+    for m in head["modalities"].values():
+        assert {"value", "ms_per_step", "batch", "roofline", "cpu_baseline"} <= set(m)

@@ -119,3 +119,69 @@ def test_outlier_channels_and_a_sink_token_keep_parity(kind):
     for precision in ("split", "fp32"):
         worst = _compare(_gpu_step(cfg, W, x, y, precision), ref, 2e-3, 2e-4, f"{kind} outliers {precision}")
         print(f"{kind} outliers {precision}: worst gradient tensor {worst[0]} at {worst[1]:.2e} of its maximum")
+
+
+def _oracle_step_microbatched(ocfg, W, x, y, mb, stats=None):
+    """The oracle's step on a batch too large to hold its autograd graph in host memory at once: the mean-CE gradient of
+    the whole batch accumulated over sub-batches of `mb` (exact for these models: LayerNorm only, every dropout 0.0 - no op
+    couples the samples of a batch)."""
+    from oracle import vit_oracle as vo
+    import torch.nn.functional as F
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    P = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in W.items()}
+    B = x.shape[0]
+    logits, loss = [], 0.0
+    for a in range(0, B, mb):
+        lg = vo.forward(P, torch.from_numpy(x[a:a + mb]), ocfg, stats=stats)
+        ls = F.cross_entropy(lg, torch.from_numpy(y[a:a + mb]), reduction="sum") / B
+        ls.backward()
+        logits.append(lg.detach().numpy())
+        loss += float(ls.detach())
+    return np.concatenate(logits), loss, {k: p.grad.numpy() for k, p in P.items()}
+
+
+def test_ast_unfrozen_step_at_the_throughput_batch_32_matches_the_oracle():
+    """SURVEY.md:616 names B = 8 (reference) AND B = 32 (throughput) for the AST configuration; bench.py times both.
+    M = 38 848 token rows: 304 tile-rows of the persistent GEMM grid, 1 214 K-tiles in the weight-gradient products."""
+    cfg, ocfg = _cfgs("ast")
+    from oracle import vit_oracle as vo
+    W = tf_weights(17, vo.param_shapes(ocfg), std=0.02)
+    x, y = synth.mel_batch(73, 32, cfg.W, cfg.H)
+    ref = _oracle_step_microbatched(ocfg, W, x, y, 8)
+    for precision in ("split", "fp32"):
+        worst = _compare(_gpu_step(cfg, W, x, y, precision), ref, 2e-3, 1e-4, f"ast B=32 {precision}")
+        print(f"ast B=32 {precision}: worst gradient tensor {worst[0]} at {worst[1]:.2e} of its maximum")
+
+
+def _trained_like_weights(ocfg, qk_gain, head_gain):
+    """N(0, 0.02) weights give near-uniform attention and |logits| << 1, where "within 1e-3" is a loose relative bound.
+    Trained checkpoints do not look like that: scale the q / k projections (weights and biases) so that the softmax rows
+    are peaked, and the classifier so that |logits| reaches 5-10 - the regime where 1e-3 absolute is 1e-4 relative."""
+    from oracle import vit_oracle as vo
+    W = tf_weights(29, vo.param_shapes(ocfg), std=0.02)
+    for k in list(W):
+        if ".attention.q_proj." in k or ".attention.k_proj." in k:
+            W[k] = W[k] * np.float32(qk_gain)
+        if k in ("classifier.weight", "classifier.dense.weight"):
+            W[k] = W[k] * np.float32(head_gain)
+    return W
+
+
+@pytest.mark.parametrize("kind", ["ast", "vit"])
+def test_trained_like_statistics_keep_parity(kind):
+    """Peaked attention (a share of the softmax rows above 0.9 in every layer) and |logits| of 5-10 at full size, both
+    precisions: logits within north_star's 1e-3, every gradient tensor to the bounds of the plain full-size tests
+    (Transformer_Audio.py:72, Transformer_Vision.py:92 - HF attention with trained weights)."""
+    cfg, ocfg = _cfgs(kind)
+    W = _trained_like_weights(ocfg, 4.5, 9.0)
+    B = 2
+    x, y = (synth.mel_batch(74, B, cfg.W, cfg.H) if kind == "ast" else synth.frame_batch(74, B, cfg.H))
+    stats = {}
+    ref = _oracle_step_microbatched(ocfg, W, x, y, B, stats=stats)
+    print(f"{kind}: share of softmax rows with a probability above 0.9 per layer: "
+          f"{[round(v, 3) for v in stats['peaked_rows']]}; max |logit| {np.abs(ref[0]).max():.2f}")
+    assert min(stats["peaked_rows"]) > 0.01 and np.abs(ref[0]).max() > 4.0, "the weights are not trained-like"
+    assert np.isfinite(ref[0]).all() and all(np.isfinite(g).all() for g in ref[2].values())
+    for precision in ("split", "fp32"):
+        worst = _compare(_gpu_step(cfg, W, x, y, precision), ref, 2e-3, 1e-3, f"{kind} trained-like {precision}")
+        print(f"{kind} trained-like {precision}: worst gradient tensor {worst[0]} at {worst[1]:.2e} of its maximum")

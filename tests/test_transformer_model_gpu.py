@@ -341,3 +341,43 @@ def test_split_weight_planes_follow_every_kind_of_weight_update(kind):
     for _ in range(40):
         fopt.step()
     assert len(getattr(flat, "_eav_dirty", [])) <= 65
+
+
+@pytest.mark.parametrize("kind", ["vit", "ast"])
+def test_training_step_after_an_evaluation_forward_keeps_the_weight_norms(kind):
+    """FusedAdam step -> no_grad forward (the trainers' per-epoch evaluation) -> training step.  The no_grad forward
+    refreshes every weight plane WITHOUT needing the transposes, and the next training forward finds nothing stale: the
+    column norms of fc2 behind the a-priori scale of the fused dact planes (eav_sp_bound_scale) must still be those of
+    the CURRENT weights (they were left at zero once: planes written unscaled, fc1's gradients losing 2-3 digits on the
+    first step after every evaluation).  Gradients of that step must agree with the EAV_FUSED_DACT = 0 path, which measures
+    the scale instead of bounding it, to rounding."""
+    from eav_amd import transformer as T
+    from eav_amd.optim import CrossEntropyLoss, FusedAdam
+    cfg = T.make_config(kind, hidden=128, layers=2, heads=2, ff=256)
+    W = _weights(kind, 13, 0.08, hidden=128, layers=2, heads=2, ff=256)
+    x, y = _batch(kind, cfg, 6, 4)
+    xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+
+    def run(fused):
+        model = T.Encoder(cfg, W).cuda().train()
+        model.precision, model.fused_dact = "split", fused
+        opt = FusedAdam(model.parameters(), lr=1e-3, weight_decay=0.01, decoupled=True)
+        opt.zero_grad()
+        CrossEntropyLoss()(model(xd).logits, yd).backward()
+        opt.step()
+        model.eval()
+        with torch.no_grad():
+            model(xd)                                   # evaluation right after the optimiser step
+        model.train()
+        opt.zero_grad()
+        CrossEntropyLoss()(model(xd).logits, yd).backward()
+        torch.cuda.synchronize()
+        norms = model._wplanes["_wcolnorm_fc2"].clone()
+        return {k: p.grad.clone() for k, p in model.named_parameters()}, norms
+
+    g1, norms = run(True)
+    g0, _ = run(False)
+    assert (norms > 0).all(), "fc2 column norms were not recomputed for the current weights"
+    for k in g1:
+        scale = float(g0[k].abs().max())
+        assert float((g1[k] - g0[k]).abs().max()) <= 2e-5 * scale + 1e-12, (k, float((g1[k] - g0[k]).abs().max()), scale)

@@ -97,3 +97,51 @@ def test_vision_trainer_matches_reference(golden_dir, tmp_path, monkeypatch, pre
     pred, acc, f1 = trial_vote(tr.outputs_test, g["te_y"], frames_per_trial=2)
     ref_pred = np.argmax(g["outputs_test"].reshape(-1, 2, 5).mean(1), 1)
     assert np.array_equal(pred, ref_pred) and 0.0 <= acc <= 1.0 and 0.0 <= f1 <= 1.0
+
+
+@pytest.mark.parametrize("precision", ["fp32", "split"])
+@pytest.mark.parametrize("kind", ["ast", "vit"])
+def test_frozen_phase_feature_cache_changes_nothing(golden_dir, tmp_path, monkeypatch, kind, precision):
+    """train(freeze=True) keeps the classifier's input of every sample after the first epoch and runs the later frozen
+    epochs on the head alone (finetune.FineTuneBase; Transformer_Audio.py:44-56,113 / Transformer_Vision.py:61-77,151 re-run
+    the backbone every epoch).  Three frozen epochs + one unfrozen epoch with and without the cache, ragged last batches
+    included: in the exact-fp32 arithmetic outputs_test, the head's weights and its AdamW state are BIT-equal; in the split
+    arithmetic (whose patch-plane scale depends on which samples share a batch) they agree to rounding."""
+    from eav_amd.audio import AudioModelTrainer
+    from eav_amd.vision import ImageClassifierTrainer
+    monkeypatch.setenv("EAV_ENCODER_PRECISION", precision)
+    path = _save_model_dir(tmp_path, kind, 5)
+    monkeypatch.chdir(tmp_path)
+    if kind == "ast":
+        x = synth.normal(95, (11, 80000), 0.0, 0.1)
+        y = synth.labels(96, 11)
+        data = [x[:7], y[:7], x[7:], y[7:]]
+    else:
+        x = (synth.uniform(97, (11, 2, 56, 56, 3)) * 255).astype(np.uint8)
+        y = synth.labels(98, 11)
+        data = [x[:7], y[:7], x[7:], y[7:]]
+
+    def run(cache):
+        import torch
+        torch.manual_seed(3)                                    # same head init, same shuffles
+        with redirect_stdout(io.StringIO()):
+            tr = (AudioModelTrainer(data, path, sub="s", num_classes=5, batch_size=4) if kind == "ast" else
+                  ImageClassifierTrainer(data, path, sub="s", num_labels=5, batch_size=4))
+            tr.cache_frozen_features = cache
+            tr.train(epochs=3, lr=5e-4, freeze=True)
+            tr.train(epochs=1, lr=5e-6, freeze=False)
+        head = {k: v.detach().clone() for k, v in tr.model.classifier.state_dict().items()}
+        state = [(tr.optimizer.state[p]["step"], tr.optimizer.state[p]["exp_avg"].clone(),
+                  tr.optimizer.state[p]["exp_avg_sq"].clone()) for p in tr.model.classifier.parameters()]
+        return tr.outputs_test, head, state
+
+    out1, head1, st1 = run(True)
+    out0, head0, st0 = run(False)
+    if precision == "fp32":
+        assert np.array_equal(out1, out0)
+        assert all(bool((head1[k] == head0[k]).all()) for k in head0)
+        assert all(a[0] == b[0] and bool((a[1] == b[1]).all()) and bool((a[2] == b[2]).all()) for a, b in zip(st1, st0))
+    else:
+        assert np.abs(out1 - out0).max() < 2e-5
+        assert all(float((head1[k] - head0[k]).abs().max()) < 2e-5 for k in head0)
+        assert all(a[0] == b[0] for a, b in zip(st1, st0))

@@ -379,5 +379,7 @@ def test_training_step_after_an_evaluation_forward_keeps_the_weight_norms(kind):
     g0, _ = run(False)
     assert (norms > 0).all(), "fc2 column norms were not recomputed for the current weights"
     for k in g1:
+        if k.endswith("k_proj.bias"):       # analytically zero (softmax is shift invariant): rounding noise on both sides
+            continue
         scale = float(g0[k].abs().max())
         assert float((g1[k] - g0[k]).abs().max()) <= 2e-5 * scale + 1e-12, (k, float((g1[k] - g0[k]).abs().max()), scale)

@@ -186,8 +186,7 @@ def bench_encoder(kind, dev, world, sync_factory, steps=4, warmup=2, blocks=3, b
             per_block.append((time.perf_counter() - t0) / steps)
         dt = statistics.median(per_block)
         # dominant kernel family, timed live with HIP events on the launch stream in a separate pass
-        sp_names = ("eav_gemm_sp", "eav_gemm_sp_ex", "eav_gemm_sp_ws", "eav_gemm_sp_planes", "eav_gemm_sp_splitk",
-                    "eav_gemm_sp_splitk_x1")
+        sp_names = ("eav_gemm_sp", "eav_gemm_sp_ex", "eav_gemm_sp_planes", "eav_gemm_sp_splitk", "eav_gemm_sp_splitk_x1")
         names = {"split": sp_names, "split_g1": sp_names, "split_11": sp_names,
                  "fp32": ("eav_gemm_f32", "eav_gemm_f32_splitk"), "bf16": ("eav_gemm_bf16", "eav_gemm_bf16_splitk")}[prec]
         gemm_ms, gemm_launches = 0.0, 0

@@ -71,7 +71,6 @@ SIGNATURES = {
     "eav_gemm_sp_x1": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i64, _i64, _f, _p, _i, _p, _p, _i, _i, _p, _p],
     "eav_gemm_sp_splitk_x1": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "eav_gemm_sp_ex": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i64, _i64, _f, _p, _i, _p, _p, _i, _i, _p, _p, _p, _p, _i, _p],
-    "eav_gemm_sp_ws": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i64, _i64, _f, _p, _i, _p, _p, _i, _i, _p, _p, _p, _p, _i, _p, _p],
     "eav_colnorm_max": [_p, _i, _i, _i64, _p, _p],
     "eav_sp_bound_scale": [_p, _p, _p, _f, _p],
     "eav_gemm_sp_planes": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i64, _i64, _f, _p, _i, _p, _p, _i, _i, _p, _p, _p, _p],
@@ -144,7 +143,6 @@ SIGNATURES = {
 # helpers that return a plain value (no status)
 PLAIN = {
     "eav_abi_version": ([], _i),
-    "eav_gemm_sp_tail_ws_bytes": ([], _i64),
     "eav_last_error": ([], C.c_char_p),
     "eav_eegnet_fir_fwd_nparts": ([_i, _i, _i], _i),
     "eav_eegnet_fir_wgrad_nparts": ([_i, _i, _i], _i),

@@ -86,17 +86,6 @@ struct SpArgs {
   int order;                // tile order inside an XCD (see tile_origin)
   int kt_per_split;         // > 0: split-K, slice z covers K-tiles [z*kt_per_split, ...), C[z] = partial slab
   int tm, tn;
-  // Tail split (column-contracting products, see launch()): the first `nfull` tiles are whole work items; each of the
-  // remaining `ntail` tiles - the last, partly filled round of the persistent grid, or a product with fewer tiles than
-  // resident workgroups - is cut into `nchunk` K-chunks of `chunk_kt` K-tiles that run on otherwise idle workgroups.
-  // Item id >= nfull: e = id - nfull, chunk = e / ntail8, tile = nfull + e % ntail8 (ntail8 = ntail rounded up to 8, so
-  // that an item keeps the XCD of its tile; e % ntail8 >= ntail: no work).  Partial accumulators go to
-  // tail_ws[(tile - nfull) nchunk + chunk] (one BM x BN fp32 slab each, accumulator layout); the LAST chunk to arrive at
-  // tail_cnt[tile - nfull] (agent-scope counter) sums the slabs in chunk order - bit-reproducible whoever is last - and
-  // runs the epilogue.  nchunk <= 1: off.
-  float* tail_ws;
-  unsigned* tail_cnt;
-  int nfull, ntail, ntail8, nchunk, chunk_kt;
 };
 
 // erf-GELU without the libm erff (two divergent branches, ~60 instructions): with z = |x| / sqrt 2,
@@ -211,7 +200,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
   const int z = blockIdx.z, tl0 = blockIdx.x, tstep = gridDim.x;
   const unsigned char* Ab = g.A;
   float* C = g.C;
-  int kt0 = 0, kt1 = g.nkt;       // K-tile range of the CURRENT work item (the launch's range unless the item is a tail chunk)
+  int kt0 = 0, kt1 = g.nkt;
   if (g.kt_per_split > 0) {
     kt0 = z * g.kt_per_split;
     kt1 = min(g.nkt, kt0 + g.kt_per_split);
@@ -220,31 +209,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
     Ab += z * g.sA;
     C += z * g.sC;
   }
-  int nk = kt1 - kt0;
+  const int nk = kt1 - kt0;
   if (nk <= 0) return;
-  const int lkt0 = kt0, lnk = nk;
-  const bool tails = !TR && g.nchunk > 1;
-  const int nitems = tails ? g.nfull + g.ntail8 * g.nchunk : nb;
-  // work item -> tile id, K-tile range, (tail index, chunk) or (-1, 0); false: an empty padding item
-  auto item = [&](int id, int& tile, int& k0, int& nkk, int& ti, int& ch) -> bool {
-    tile = id; k0 = lkt0; nkk = lnk; ti = -1; ch = 0;
-    if (tails && id >= g.nfull) {
-      const int e = id - g.nfull;
-      ch = e / g.ntail8;
-      ti = e - ch * g.ntail8;
-      if (ti >= g.ntail) return false;
-      tile = g.nfull + ti;
-      k0 = ch * g.chunk_kt;
-      nkk = min(g.nkt, k0 + g.chunk_kt) - k0;
-      return nkk > 0;
-    }
-    return true;
-  };
 
   // ---- per-lane global source pointers of this wave's chunks (row clamped: ragged tiles re-read the last row)
   const unsigned char* gp[CPW];
   int64_t gstep[TR ? CPW : 1];                           // TR: bytes from one K-tile (32 tokens) to the next
-  auto set_sources = [&](int m0, int n0, int kt0) {
+  auto set_sources = [&](int m0, int n0) {
 #pragma unroll
     for (int i = 0; i < CPW; ++i) {
       const int c = wave + NW * i;                       // wave-uniform chunk id
@@ -396,8 +367,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
   // flags of K-tile t: more = a K-tile t + 1 exists (read its first fragments); more2 = a K-tile t + NS exists (issue its
   // DMA into this K-tile's buffer); newer (NS = 3) = a K-tile t + 2 exists: its stage may stay in flight over the mid-tile
   // wait.  buf / nbuf = buffers of K-tiles t / t + 1.
-  auto iter = [&](auto more_c, auto more2_c, auto newer_c, int t, int buf, int nbuf, int next_m0, int next_n0,
-                  int next_k0, int next_nk) {
+  auto iter = [&](auto more_c, auto more2_c, auto newer_c, int t, int buf, int nbuf, int next_m0, int next_n0) {
     constexpr bool more = decltype(more_c)::value, more2 = decltype(more2_c)::value, newer = decltype(newer_c)::value;
     int ka = 0, kb = 0;
     if constexpr (TR) {
@@ -434,7 +404,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
     if constexpr (TR) {
       if (ka | kb) unboost(f1, ka, kb);
     }
-    if (!more && next_m0 >= 0) set_sources(next_m0, next_n0, next_k0);
+    if (!more && next_m0 >= 0) set_sources(next_m0, next_n0);
 #pragma unroll
     for (int m = 0; m < NMF; ++m) {          // phase B
       if (!(EAV_ABL & 4)) mfma_slot(f1, m);
@@ -453,7 +423,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
       if (more2 && m + NMF < CPW && !(EAV_ABL & 2)) issue1(buf, m + NMF);          // (one term: 4 slots for 8 chunks)
       if (!more && next_m0 >= 0) {
         if (m < CPW) issue1(0, m);
-        else if (m < 2 * CPW && next_nk > 1) issue1(1, m - CPW);
+        else if (m < 2 * CPW && nk > 1) issue1(1, m - CPW);
       }
       SB();
     }
@@ -461,25 +431,18 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
 #pragma unroll
       for (int m = NMF; m < 2 * CPW; ++m) {
         if (m < CPW) issue1(0, m);
-        else if (next_nk > 1) issue1(1, m - CPW);
+        else if (nk > 1) issue1(1, m - CPW);
       }
     }
   };
 
   bool primed = false;
-  for (int id = tl0; id < nitems; id += tstep) {
-    int tl, ti, ch, m0, n0, nm0 = -1, nn0 = -1, nkt0 = 0, nnk = 0;
-    if (!item(id, tl, kt0, nk, ti, ch)) continue;      // (padding items sit at the end of the walk: nothing was primed for them)
+  for (int tl = tl0; tl < nb; tl += tstep) {
+    int m0, n0, nm0 = -1, nn0 = -1;
     tile_origin(tl, m0, n0);
-    for (int nid = id + tstep; nid < nitems; nid += tstep) {      // the next item with work
-      int ntl, nti, nch;
-      if (item(nid, ntl, nkt0, nnk, nti, nch)) {
-        tile_origin(ntl, nm0, nn0);
-        break;
-      }
-    }
+    if (tl + tstep < nb) tile_origin(tl + tstep, nm0, nn0);
     if (!primed) {
-      set_sources(m0, n0, kt0);
+      set_sources(m0, n0);
 #pragma unroll
       for (int i = 0; i < CPW; ++i) issue1(0, i);
       if (nk > 1) {
@@ -523,13 +486,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
       int t = 0, b = 0;
       auto nx = [](int x) { return x + 1 == NS ? 0 : x + 1; };
       if constexpr (NS == 2) {
-        for (; t + 2 < nk; ++t, b = nx(b)) iter(Y, Y, F, t, b, nx(b), -1, -1, 0, 0);
+        for (; t + 2 < nk; ++t, b = nx(b)) iter(Y, Y, F, t, b, nx(b), -1, -1);
       } else {
-        for (; t + 3 < nk; ++t, b = nx(b)) iter(Y, Y, Y, t, b, nx(b), -1, -1, 0, 0);
-        if (t + 2 < nk) { iter(Y, F, Y, t, b, nx(b), -1, -1, 0, 0); ++t; b = nx(b); }
+        for (; t + 3 < nk; ++t, b = nx(b)) iter(Y, Y, Y, t, b, nx(b), -1, -1);
+        if (t + 2 < nk) { iter(Y, F, Y, t, b, nx(b), -1, -1); ++t; b = nx(b); }
       }
-      if (t + 1 < nk) { iter(Y, F, F, t, b, nx(b), -1, -1, 0, 0); ++t; b = nx(b); }
-      if (t < nk) iter(F, F, F, t, b, nx(b), nm0, nn0, nkt0, nnk);
+      if (t + 1 < nk) { iter(Y, F, F, t, b, nx(b), -1, -1); ++t; b = nx(b); }
+      if (t < nk) iter(F, F, F, t, b, nx(b), nm0, nn0);
     }
 
     // ---- epilogue of this tile (the next tile's first stages are in flight)
@@ -540,64 +503,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
         for (int j = 0; j < RN; ++j)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[i][j][r] += acx[TWOACC ? i : 0][TWOACC ? j : 0][r] * (1.f / 2048.f);
-    }
-    // ---- tail chunk: publish the partial accumulators; the last chunk of the tile to arrive sums them and carries on
-    // (release -> ticket -> acquire at agent scope: correct wherever the chunks of a tile ran - per-XCD L2s are not coherent)
-    if constexpr (!TR) {
-      if (ti >= 0) {
-        float* slab = g.tail_ws + ((int64_t)ti * g.nchunk + ch) * (BM * BN);
-#pragma unroll
-        for (int i = 0; i < RM; ++i)
-#pragma unroll
-          for (int j = 0; j < RN; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q)       // one store instruction = 1 KB contiguous (the reader uses the same map)
-              *reinterpret_cast<float4*>(slab + (((((i * RN + j) * 4 + q) * NW + wave) * 64 + lane) << 2)) =
-                  make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (also lands the next item's first stages)
-        __builtin_amdgcn_s_barrier();
-        volatile int* flag = reinterpret_cast<volatile int*>(smem + 2 * STAGE);      // (the epilogue patch area: free here)
-        if (t == 0) {
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (restates the wait behind buffer_wbl2 where hipcc cannot drop it)
-          const unsigned ticket = __hip_atomic_fetch_add(g.tail_cnt + ti, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const bool last = ticket == (unsigned)(g.nchunk - 1);
-          if (last) {
-            __hip_atomic_store(g.tail_cnt + ti, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // ready for the next launch
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-          }
-          *flag = last ? 1 : 0;
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();
-        const bool last = *flag != 0;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                        // the flag word is patch memory again
-        if (!last) continue;
-#pragma unroll
-        for (int i = 0; i < RM; ++i)
-#pragma unroll
-          for (int j = 0; j < RN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        const float* sl = g.tail_ws + (int64_t)ti * g.nchunk * (BM * BN);
-        for (int c = 0; c < g.nchunk; ++c, sl += BM * BN) {       // fixed order: the sum does not depend on who arrived last
-#pragma unroll
-          for (int i = 0; i < RM; ++i)
-#pragma unroll
-            for (int j = 0; j < RN; ++j) {
-              float4 v[4];
-#pragma unroll
-              for (int q = 0; q < 4; ++q)
-                v[q] = *reinterpret_cast<const float4*>(sl + (((((i * RN + j) * 4 + q) * NW + wave) * 64 + lane) << 2));
-#pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                acc[i][j][4 * q] += v[q].x; acc[i][j][4 * q + 1] += v[q].y;
-                acc[i][j][4 * q + 2] += v[q].z; acc[i][j][4 * q + 3] += v[q].w;
-              }
-            }
-        }
-      }
     }
     float alpha = g.alpha * g.slotA[EAV_SLOT_ISIGMA] * g.slotB[EAV_SLOT_ISIGMA];
     // row of the A planes this wave's output rows come from (batched launches: z selects a slab of sA / ldA rows)
@@ -867,7 +772,6 @@ int g_force_tile = 0;   // test / tuning hook: 0 = heuristic, 1 = 128x128, 2 = 2
 int g_loshift = 11;
 int g_persist = 1;      // tuning hook: 0 = one workgroup per output tile
 int g_splitk_force = 0; // tuning hook (eav_gemm_sp_set_splitk): slices of eav_gemm_sp_splitk, 0 = the plan
-int g_tail = 1;         // tuning hook (eav_gemm_sp_set_tile(64)): 0 = never split the tail round (A/B runs)
 
 // Returns false when no kernel is instantiated for the requested combination (the single-accumulator tuning mode
 // g_loshift = 0 exists for the 128 x 128 two-stage column-contracting form only): the caller reports an error instead of
@@ -879,25 +783,7 @@ bool launch(SpArgs& g, int nz, hipStream_t st, int terms = 3) {
   // persistent workgroups: as many as stay resident (2 per CU for 4-wave tiles, 1 for 8-wave tiles), a multiple of 8 so
   // that every workgroup's tiles stay on one XCD; fewer tiles than that: one workgroup per tile
   const int resident = (WM * WN <= 4 ? 2 : 1) * 256 * (g_persist ? 1 : 1 << 20);
-  const int nb = g.tm * g.tn;
-  int gx = nb <= resident ? nb : resident;
-  // Tail split: the last round of the persistent walk (or the only one) fills r = nb mod resident of the resident
-  // workgroups.  When at least half of them would idle, each of those r tiles is cut into s = resident / r K-chunks
-  // (>= 4 K-tiles each, <= 8 chunks) that run side by side; the chunk that arrives last sums the partial tiles in chunk
-  // order and runs the epilogue (gemm_sp_kernel).  ViT B=128, N = 768: 1182 tiles = 2.31 rounds of 512 -> 2 rounds + 158
-  // tiles x 3 chunks; ViT B=16 (a rank's share at 8 GPUs): 150 tiles -> 450 work items.
-  g.nchunk = 1; g.nfull = nb; g.ntail = g.ntail8 = 0; g.chunk_kt = g.nkt;
-  if (!TR && g.tail_ws && g_tail && nz == 1 && g.kt_per_split == 0 && g_persist) {
-    const int nfull = nb / resident * resident, r = nb - nfull, r8 = (r + 7) & ~7;
-    const int s = r > 0 ? std::min(std::min(resident / r8, g.nkt / 4), 8) : 1;
-    if (s >= 2) {
-      g.chunk_kt = cdiv(g.nkt, s);
-      g.nchunk = cdiv(g.nkt, g.chunk_kt);
-      g.nfull = nfull; g.ntail = r; g.ntail8 = r8;
-      if (g.nchunk < 2) { g.nchunk = 1; g.nfull = nb; }
-      else gx = nfull > 0 ? resident : r8 * g.nchunk;
-    }
-  }
+  const int nb = g.tm * g.tn, gx = nb <= resident ? nb : resident;
   if (terms == 1) {
     hipLaunchKernelGGL((gemm_sp_kernel<WM, WN, RM, RN, false, TR, 1, NS>), dim3(gx, 1, nz), dim3(64 * WM * WN), 0, st, g);
     return true;
@@ -1256,7 +1142,6 @@ extern "C" int eav_gemm_sp_set_tile(int which) {
   g_order = (which >> 4) & 3;      // +16: groups of 8 tile-rows, +32: row-major, 0: by shape
   g_loshift = (which & 4) ? 0 : 11;
   g_persist = (which & 8) ? 0 : 1;
-  g_tail = (which & 64) ? 0 : 1;
   return EAV_OK;
 }
 
@@ -1267,7 +1152,7 @@ static int gemm_sp_impl(const void* A, const void* B, float* C, const float* slo
                         int N, int K, int ldc, int batch, int64_t sA_bytes, int64_t sC, float alpha,
                         const float* bias, int gelu, float* pre, const float* resid, int ldr, int accumulate,
                         float* amax_slot, void* planes_out, const float* planes_slot, void* stream, int flags,
-                        float* colsum_part = nullptr, void* tail_ws = nullptr) {
+                        float* colsum_part = nullptr) {
   const int terms = (flags & EAV_GEMM_ONE_TERM) ? 1 : 3;
   EAV_REQUIRE(A && B && (C || planes_out) && slotA && slotB && M > 0 && N > 0 && K > 0 && batch > 0,
               "eav_gemm_sp: bad arguments");
@@ -1299,10 +1184,6 @@ static int gemm_sp_impl(const void* A, const void* B, float* C, const float* slo
   g.order = g_order ? g_order - 1
                     : (cdiv(N, 128) <= 8 || ((int64_t)M + N) * Kp * 4 <= (48ll << 20) ? 1 : 0);
   g.noblk = (flags & EAV_GEMM_NO_BLOCKMAX) ? 1 : 0;
-  // tail workspace (eav_gemm_sp_tail_ws_bytes; zero-filled once by the caller): counters, then the partial-tile slabs
-  EAV_REQUIRE(((uintptr_t)tail_ws & 15) == 0, "eav_gemm_sp: the tail workspace must be 16-byte aligned");
-  g.tail_cnt = reinterpret_cast<unsigned*>(tail_ws);
-  g.tail_ws = tail_ws ? reinterpret_cast<float*>((unsigned char*)tail_ws + 4096) : nullptr;
   if (flags & EAV_GEMM_PLANES_NOLIFT) g.lomul = 1.f;      // lo = fp16(t - hi): the attention kernels' row planes
   EAV_REQUIRE(dispatch(g, batch, (hipStream_t)stream, terms, (flags & EAV_GEMM_SHARED_GPU) != 0),
               "eav_gemm_sp: no kernel for this tile form in the single-accumulator tuning mode (eav_gemm_sp_set_tile(4))");
@@ -1330,22 +1211,6 @@ extern "C" int eav_gemm_sp_ex(const void* A, const void* B, float* C, const floa
                               void* stream) {
   return gemm_sp_impl(A, B, C, slotA, slotB, M, N, K, ldc, batch, sA_bytes, sC, alpha, bias, gelu, pre, resid, ldr,
                       accumulate, amax_slot, planes_out, planes_slot, stream, flags, colsum_part);
-}
-
-// eav_gemm_sp_ex with a tail workspace: products whose last (or only) round of the persistent tile walk would leave at
-// least half of the resident workgroups idle cut the tiles of that round into K-chunks (launch() above), publish partial
-// tiles in `tail_ws` and let the last chunk to arrive finish the tile - bit-reproducible.  tail_ws: eav_gemm_sp_tail_ws_bytes()
-// bytes, ZERO-FILLED ONCE by the caller (its head holds arrival counters that every launch leaves at zero), used by one
-// launch at a time (launches of one stream are ordered; give every concurrent stream its own).  NULL: never split.
-extern "C" int64_t eav_gemm_sp_tail_ws_bytes(void) { return 4096 + (int64_t)512 * 128 * 128 * 4; }
-
-extern "C" int eav_gemm_sp_ws(const void* A, const void* B, float* C, const float* slotA, const float* slotB, int M, int N,
-                              int K, int ldc, int batch, int64_t sA_bytes, int64_t sC, float alpha, const float* bias,
-                              int gelu, float* pre, const float* resid, int ldr, int accumulate, float* amax_slot,
-                              void* planes_out, const float* planes_slot, float* colsum_part, int flags, void* tail_ws,
-                              void* stream) {
-  return gemm_sp_impl(A, B, C, slotA, slotB, M, N, K, ldc, batch, sA_bytes, sC, alpha, bias, gelu, pre, resid, ldr,
-                      accumulate, amax_slot, planes_out, planes_slot, stream, flags, colsum_part, tail_ws);
 }
 
 // eav_gemm_sp with the hi.hi term only: the product of the operands rounded to fp16 (11-bit mantissas under the planes'
@@ -1403,7 +1268,7 @@ static int gemm_sp_splitk_impl(const void* A, const void* B, float* C, float* ws
   g.order = g_order ? g_order - 1 : (cdiv(N, 128) <= 8 && cdiv(M, 128) > cdiv(N, 128) ? 1 : 0);
   g.A = (const unsigned char*)A; g.B = (const unsigned char*)B; g.slotA = slotA; g.slotB = slotB;
   g.bias = nullptr; g.resid = nullptr; g.pre = nullptr; g.amax = nullptr; g.planes = nullptr; g.slotP = nullptr;
-  g.colsum = nullptr; g.noblk = 0; g.tail_ws = nullptr; g.tail_cnt = nullptr;
+  g.colsum = nullptr; g.noblk = 0;
   g.ldp = 0; g.lomul = 2048.f;
   g.M = M; g.N = N; g.nkt = cdiv(T, 32); g.ldA = (int64_t)eav_sp_kpad(M) * 4; g.ldB = (int64_t)eav_sp_kpad(N) * 4;
   g.ldc = N; g.ldr = 0; g.sA = 0; g.sC = 0; g.alpha = 1.f; g.gelu = 0;

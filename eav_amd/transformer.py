@@ -240,8 +240,6 @@ class Encoder(nn.Module):
         # split mode, forward: the fused q/k/v projection writes the attention kernels' row planes itself (scale from a bound of
         # |qkv|), the per-head transposes are made from those planes - no fp32 qkv tensor (EAV_FUSED_QKV=0 for A/B runs)
         self.fused_qkv = os.environ.get("EAV_FUSED_QKV", "1") != "0"
-        self.tail_split = os.environ.get("EAV_GEMM_TAIL", "1") != "0"
-        self._tailbuf = None
         self._side, self._aux, self._wgrad_done, self._wready, self._wnorm_ready = None, None, {}, {}, None
         self._part_busy, self._ring_pos = {}, {}
         self._wplanes = None          # split mode: {weight key: (planes, planes of the transpose, slot index)}
@@ -652,19 +650,8 @@ class Encoder(nn.Module):
         bwd = self._phase == "bwd"
         flags = (1 if (self.grad_terms if bwd else self.fwd_terms) == 1 else 0) | (2 if bwd and self.overlap_wgrad else 0) \
             | (0 if blockmax else 8)
-        self._call("eav_gemm_sp_ws", A, B, C, slotA, slotB, M, N, K, ldc, batch, sA, sC, float(alpha), bias, gelu, pre,
-                   resid, ldr, acc, amax, None, None, None, flags, self._tail_ws(), self._st)
-
-    def _tail_ws(self):
-        """Workspace of the GEMM's tail split (csrc/gemm_sp.hip launch(): partly filled rounds of the persistent tile walk run
-        as K-chunks): zero-filled once, one per model - every column-contracting product runs on the main stream, in order.
-        EAV_GEMM_TAIL=0 turns the split off (A/B runs)."""
-        if not self.tail_split:
-            return None
-        dev = self._flat[0].device
-        if self._tailbuf is None or self._tailbuf.device != dev:
-            self._tailbuf = torch.zeros(_lib.plain("eav_gemm_sp_tail_ws_bytes") // 4, dtype=torch.float32, device=dev)
-        return self._tailbuf.data_ptr()
+        self._call("eav_gemm_sp_ex", A, B, C, slotA, slotB, M, N, K, ldc, batch, sA, sC, float(alpha), bias, gelu, pre,
+                   resid, ldr, acc, amax, None, None, None, flags, self._st)
 
     def _wgrad_sp(self, AT, slotA, BT, slotB, C, M, N, K):
         """C[M,N] = sum over the K tokens of A[t,m] B[t,n]: ROW planes of A [K,M] and B [K,N] (the contraction runs over the
@@ -936,9 +923,9 @@ class Encoder(nn.Module):
             # the projection writes the row planes of Q | K | V itself (lo without the 2^11 lift: the attention kernels' format,
             # scale = the bound eav_tf_forward_scales_qkv put into s_qkv); the per-head transposes (V^T for the forward; Q^T,
             # K^T for the backward) are a pure fp16 transposition of those planes
-            L("eav_gemm_sp_ws", P(ws.y1p[j]), wpl, None, s_y1, wsl, M, 3 * D, D, 3 * D, 1, 0, 0, 1.0,
+            L("eav_gemm_sp_ex", P(ws.y1p[j]), wpl, None, s_y1, wsl, M, 3 * D, D, 3 * D, 1, 0, 0, 1.0,
               w(f"{Lk}.attention.q_proj.bias"), 0, None, None, 0, 0, None, P(ws.qkvrow[j]), s_qkv, None,
-              4 | (1 if self.fwd_terms == 1 else 0), self._tail_ws(), st)
+              4 | (1 if self.fwd_terms == 1 else 0), st)
         else:
             self._gemm_sp(P(ws.y1p[j]), s_y1, wpl, wsl, qkv, M, 3 * D, D, 3 * D, bias=w(f"{Lk}.attention.q_proj.bias"),
                           amax=s_qkv if ws.fused else None)
@@ -974,9 +961,9 @@ class Encoder(nn.Module):
             wpl, wsl = self._wp(f"fc1{i}")
             # fc1: bias + erf-GELU in the epilogue; the pre-activation is kept (fp32) for the backward only, the
             # activation leaves as planes - it never exists in fp32
-            self._call("eav_gemm_sp_ws", P(ws.y2p[j]), wpl, None, s_y2, wsl, M, FF, D, FF, 1, 0, 0, 1.0,
+            self._call("eav_gemm_sp_ex", P(ws.y2p[j]), wpl, None, s_y2, wsl, M, FF, D, FF, 1, 0, 0, 1.0,
                        w(f"{Lk}.mlp.fc1.bias"), 1, P(ws.pre[j]) if ws.full else None, None, 0, 0, None, P(ws.actp[j]),
-                       s_act, None, 1 if self.fwd_terms == 1 else 0, self._tail_ws(), st)
+                       s_act, None, 1 if self.fwd_terms == 1 else 0, st)
         else:
             L("eav_layernorm_fwd_amax", P(ws.hmid[j]), w(f"{Lk}.layernorm_after.weight"),
               w(f"{Lk}.layernorm_after.bias"), P(y), stp + 8 * M, stp + 12 * M, M, D, c.eps, s_y2, st)
@@ -1023,8 +1010,8 @@ class Encoder(nn.Module):
             self._before_overwrite(ws.dactp)
             part = self._part_buf("part_cs2_pool")
             flags = (1 if self.grad_terms == 1 else 0) | (2 if self.overlap_wgrad else 0)
-            L("eav_gemm_sp_ws", P(ws.dhp), wpl, None, b_dh2, wsl, M, FF, D, FF, 1, 0, 0, 1.0, None, 2, P(ws.pre[i]), None, 0,
-              0, None, P(ws.dactp), b_dact, P(part), flags, self._tail_ws(), st)
+            L("eav_gemm_sp_ex", P(ws.dhp), wpl, None, b_dh2, wsl, M, FF, D, FF, 1, 0, 0, 1.0, None, 2, P(ws.pre[i]), None, 0,
+              0, None, P(ws.dactp), b_dact, P(part), flags, st)
             self._reduce_async(part, 0, ws.np_cs2, FF, FF, gp(f"{Lk}.mlp.fc1.bias"))
         else:
             # ... the epilogue multiplies by gelu'(pre) and emits max|dact|; one conversion pass (planes + bias gradient)

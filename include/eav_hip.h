@@ -347,23 +347,11 @@ int eav_gemm_sp_ex(const void* A, const void* B, float* C, const float* slotA, c
                    int ldc, int batch, int64_t sA_bytes, int64_t sC, float alpha, const float* bias, int gelu, float* pre,
                    const float* resid, int ldr, int accumulate, float* amax_slot, void* planes_out,
                    const float* planes_slot, float* colsum_part, int flags, void* stream);
-/* eav_gemm_sp_ex + a tail workspace: a product whose last (or only) round of the persistent tile walk would leave at least
- * half of the resident workgroups idle (ViT B=128 at N = 768: 1182 tiles = 2.31 rounds of 512; every product of a rank's
- * small share in a data-parallel run) cuts the tiles of that round into K-chunks; partial tiles meet in tail_ws and the
- * chunk that arrives last sums them in chunk order and runs the epilogue - bit-reproducible.  tail_ws:
- * eav_gemm_sp_tail_ws_bytes() bytes, ZERO-FILLED ONCE by the caller (arrival counters that every launch leaves at zero, then
- * slabs), used by one launch at a time (one per stream); NULL = eav_gemm_sp_ex.  Replaces the library GEMMs under
- * nn.Linear in Transformer_Audio.py:72 / Transformer_Vision.py:92 like the other eav_gemm_sp_* entry points. */
-int64_t eav_gemm_sp_tail_ws_bytes(void);
-int eav_gemm_sp_ws(const void* A, const void* B, float* C, const float* slotA, const float* slotB, int M, int N, int K,
-                   int ldc, int batch, int64_t sA_bytes, int64_t sC, float alpha, const float* bias, int gelu, float* pre,
-                   const float* resid, int ldr, int accumulate, float* amax_slot, void* planes_out,
-                   const float* planes_slot, float* colsum_part, int flags, void* tail_ws, void* stream);
 int eav_gemm_sp_splitk_x1(const void* A, const void* B, float* C, float* ws, const float* slotA, const float* slotB, int M,
                           int N, int T, int accumulate, void* stream);
 /* TEST / TUNING ONLY - process-global state, not part of the drop-in boundary: the trainers never call these; the kernel
  * benchmarks under tools/ and tests/test_split_kernels_gpu.py use them to A/B tile shapes inside one process. */
-int eav_gemm_sp_set_tile(int which);   /* 0 heuristic, 1 = 128x128 tiles, 2 = 256x128, +4 single accumulator, +8 non-persistent, +64 no tail split */
+int eav_gemm_sp_set_tile(int which);   /* 0 heuristic, 1 = 128x128 tiles, 2 = 256x128, +4 single accumulator, +8 non-persistent */
 int eav_gemm_sp_set_splitk(int slices);  /* eav_gemm_sp_splitk: forced slice count (0 = the plan; ws must hold it) */
 int eav_sp_set_convert_blocks(int n);  /* resident-block cap of eav_sp_convert (default 512; 0 = one block per tile) */
 /* The same fused attention on the fp16 matrix cores with split operands (csrc/attention_sp.hip; fp32-grade, 3 MFMAs per

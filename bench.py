@@ -727,6 +727,8 @@ def compact_headline(out):
     line["roofline"]["flop_per_launch"] = out["roofline"].get("flop_per_launch")
     line["roofline"]["avg_kernel_ms"] = out["roofline"].get("avg_kernel_ms", {}).get(
         out["roofline"]["kernel"].replace("_kernel", ""))
+    if out["roofline"].get("fir_kernels"):
+        line["roofline"]["fir_kernels"] = out["roofline"]["fir_kernels"]
     if out.get("cpu_baseline"):
         line["cpu_baseline"] = _short_cpu(out["cpu_baseline"])
     mods = {}
@@ -930,12 +932,15 @@ def main():
     dt, loss = run.timed(args.steps, args.warmup)           # THE timed region: exactly K steps
     final_loss = float(loss.item())
     # dominant kernels, timed live with HIP events on the launch stream: the same launches issued eagerly
-    timed = ("eav_eegnet_fir_fwd", "eav_eegnet_fir_wgrad")
+    # (the FIR runs as overlap-save FFT blocks at this shape - eav_eegnet_fir_*_fft - or as Toeplitz GEMMs on the fp32 matrix
+    # cores with EAV_FIR_ALGO=mfma; whichever ran has events)
+    timed = ("eav_eegnet_fir_fwd", "eav_eegnet_fir_wgrad", "eav_eegnet_fir_fwd_fft", "eav_eegnet_fir_wgrad_fft",
+             "eav_eegnet_dw_bwd_fused", "eav_eegnet_dw_fwd")
     model.kernel_events = {k: [] for k in timed}
     for i in range(min(args.steps, 20)):
         run.eager_step(args.warmup + i)
     torch.cuda.synchronize()
-    kern_ms = {k: sum(a.elapsed_time(b) for a, b in v) / max(len(v), 1) for k, v in model.kernel_events.items()}
+    kern_ms = {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in model.kernel_events.items() if v}
     model.kernel_events = None
     blocks_ms = [dt / args.steps * 1e3]
     for _ in range(args.repeats):                            # spread of the same K-step block
@@ -1056,26 +1061,48 @@ def main():
 
     if rank == 0:
         dom = max(kern_ms, key=kern_ms.get)
+        kname = {"eav_eegnet_fir_fwd": "fir_fwd_kernel", "eav_eegnet_fir_wgrad": "fir_wgrad_kernel",
+                 "eav_eegnet_fir_fwd_fft": "fir_fft_fwd_kernel", "eav_eegnet_fir_wgrad_fft": "fir_fft_wgrad_kernel",
+                 "eav_eegnet_dw_bwd_fused": "dw_bwd_kernel", "eav_eegnet_dw_fwd": "dw_fwd_kernel"}
+        el = per_gpu * CHANS * SAMPLES * 4                      # bytes of one [B,30,S] fp32 tensor; y1 / g1 = 8 of them
+        # algorithmic HBM bytes per launch (every operand and result once)
+        abytes = {"eav_eegnet_fir_fwd": 9 * el, "eav_eegnet_fir_fwd_fft": 9 * el,            # x in, y1 out
+                  "eav_eegnet_fir_wgrad": 17 * el, "eav_eegnet_fir_wgrad_fft": 17 * el,      # y1, g1, x in
+                  "eav_eegnet_dw_bwd_fused": int((8 + 8 + 64 / 30 + 16 / 30) * el),          # y1, z, dp2 in, g1 out
+                  "eav_eegnet_dw_fwd": int((8 + 64 / 30) * el)}                              # y1 in, z out
         traffic, traffic_src = None, None
         try:  # HBM bytes per launch from the separate --pmc passes (tools/pmc_summary.py), if committed
             import glob
             f = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_eegnet_hbm_traffic.json")))[-1]
             tj = json.load(open(f))
-            traffic = tj["kernels"][dom.replace("eav_eegnet_", "") + "_kernel"]["total_bytes"]
+            traffic = tj["kernels"][kname[dom]]["total_bytes"]
             traffic_src = os.path.relpath(f, ROOT) + (f" (profiled at commit {tj['commit']})" if tj.get("commit") else "")
         except Exception:
             pass
-        achieved = FIR_FLOP_PER_LAUNCH * per_gpu / B_PER_GPU / (kern_ms[dom] * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": dom.replace("eav_eegnet_", "") + "_kernel",
-                    "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-                    "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc, gfx950-corrected)",
-                    "traffic_source": traffic_src, "flop_per_launch": FIR_FLOP_PER_LAUNCH * per_gpu / B_PER_GPU,
-                    # fir_wgrad reads y1 and g1 ([B,8,30,S] fp32 each) and x ([B,30,S]) once: SURVEY 8(d) / DESIGN section 3
-                    "algorithmic_bytes": per_gpu * (2 * 8 + 1) * CHANS * SAMPLES * 4,
-                    "measured_peaks": peaks,
-                    "frac_of_measured_mfma_peak": round(achieved / peaks["f32_mfma_tflops"], 4),
-                    "avg_kernel_ms": {k.replace("eav_eegnet_", ""): round(v, 4) for k, v in kern_ms.items()}}
+        fir_flop = FIR_FLOP_PER_LAUNCH * per_gpu / B_PER_GPU
+        kms = {kname[k].replace("_kernel", ""): round(v, 4) for k, v in kern_ms.items()}
+        if dom in ("eav_eegnet_fir_fwd", "eav_eegnet_fir_wgrad"):       # Toeplitz GEMM on the fp32 matrix cores
+            achieved = fir_flop / (kern_ms[dom] * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "kernel": kname[dom], "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                        "frac_of_measured_mfma_peak": round(achieved / peaks["f32_mfma_tflops"], 4)}
+        else:                                                           # HBM-bound kernels (FFT FIR, depthwise passes)
+            gbps = abytes[dom] / (kern_ms[dom] * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": kname[dom], "achieved": round(gbps, 1), "peak": 8000.0, "unit": "GB/s",
+                        "frac": round(gbps / 8000.0, 4),
+                        "frac_of_measured_copy_rate": round(gbps / 1e3 / peaks["hbm_copy_tb_per_s"], 4)}
+        roofline.update({"traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc, gfx950-corrected)",
+                         "traffic_source": traffic_src, "algorithmic_bytes": abytes[dom], "flop_per_launch": fir_flop,
+                         "measured_peaks": peaks, "avg_kernel_ms": kms})
+        # the K = 300 FIR in direct form is 92.16 GFLOP per pass: what the FFT kernels deliver in those terms
+        fir = {}
+        for k in ("eav_eegnet_fir_fwd_fft", "eav_eegnet_fir_wgrad_fft", "eav_eegnet_fir_fwd", "eav_eegnet_fir_wgrad"):
+            if k in kern_ms:
+                tf = fir_flop / (kern_ms[k] * 1e-3) / 1e12
+                fir[kname[k]] = {"ms": round(kern_ms[k], 4), "direct_form_tflops": round(tf, 1),
+                                 "direct_form_frac_of_fp32_peak": round(tf / PEAK_F32_MFMA_TFLOPS, 3),
+                                 "hbm_gbps_algorithmic": round(abytes[k] / (kern_ms[k] * 1e-3) / 1e9, 1)}
+        roofline["fir_kernels"] = fir
         cpu_eeg = cpu_baseline_eegnet() if (world == 1 and not args.no_cpu_baseline) else None
         value = round(args.steps * per_gpu * world / dt, 2)
         out = {

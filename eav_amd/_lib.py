@@ -35,6 +35,8 @@ SIGNATURES = {
     "eav_eegnet_fir_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
     "eav_eegnet_fir_wgrad": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "eav_eegnet_fir_fwd_indexed": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "eav_eegnet_fir_fwd_fft": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "eav_eegnet_fir_wgrad_fft": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "eav_eegnet_fir_wgrad_indexed": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "eav_eegnet_dw_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _p],
     "eav_eegnet_dw_bwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
@@ -145,6 +147,9 @@ PLAIN = {
     "eav_abi_version": ([], _i),
     "eav_last_error": ([], C.c_char_p),
     "eav_eegnet_fir_fwd_nparts": ([_i, _i, _i], _i),
+    "eav_eegnet_fir_fwd_fft_nparts": ([_i, _i, _i], _i),
+    "eav_eegnet_fir_wgrad_fft_ws_floats": ([_i, _i, _i], _i64),
+    "eav_eegnet_fir_fft_max_taps": ([], _i),
     "eav_eegnet_fir_wgrad_nparts": ([_i, _i, _i], _i),
     "eav_conv64_ntiles": ([_i], _i),
     "eav_tconv_fwd_nparts": ([_i, _i, _i, _i, _i], _i),

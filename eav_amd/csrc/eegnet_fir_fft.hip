@@ -1,0 +1,445 @@
+// EEGNet temporal FIR (firstConv, up to 321 taps, 1 -> 8 filters) and its weight gradient by FFT, exact fp32 arithmetic.
+//
+// Reference op: nn.Conv2d(1, F1=8, (1, kernLength=300), padding='same', bias=False) (CNN_torch/EEGNet_tor.py:24,51) and
+// the weight gradient autograd derives for it (:109).  The direct form costs 2 x 300 flops per output and filter - 92 GFLOP
+// per pass at [64,1,30,10000], 0.59 ms at the fp32 matrix peak (eegnet_fir.hip reaches 0.73 / 0.83 ms).  A convolution
+// with a 300-tap filter is the same linear map evaluated by overlap-save blocks of 1024-point FFTs in ~350 flops per
+// output sample for all 8 filters together: 13 x fewer flops, so the two kernels here are bound by the HBM traffic of
+// y1 / g1 (614 MB each) instead of by arithmetic.
+//
+// Forward (per block of LB = 704 outputs of a pair of electrodes c, c+1):
+//   s[n] = x[c][t0 - padl + n] + i x[c+1][t0 - padl + n], n = 0 .. 1023 (zero outside the recording)
+//   y_f[j] = sum_k w_f[k] s[j + k]  (j < 704, k < klen: j + k <= 1023, no wrap)  = IFFT(FFT(s) . conj(FFT(w_f)))[j]
+//   Re y_f = the output of electrode c, Im y_f = that of electrode c+1 (a real filter maps real to real, imaginary to
+//   imaginary): one complex transform serves two electrodes with no unpacking.
+// Weight gradient (dy formed from g1, y1 and the BatchNorm-backward coefficients while loading, as in eegnet_fir.hip):
+//   dW_f[k] = sum_{b,c,t} dy[b,f,c,t] x[b,c,t + k - padl] = Re IFFT( sum_{b, pairs, blocks} conj(FFT(D_f)) . FFT(s) )[k]
+//   with D_f = dy_c + i dy_{c+1} of a block (704 samples, zero-padded): Re(conj(D) s') = d_c s'_c + d_{c+1} s'_{c+1}.
+//   The spectra are accumulated per workgroup in registers (wave f owns filter f), written once, summed over the
+//   workgroups in a fixed order and transformed back by a finishing kernel - bit-reproducible run to run.
+//
+// The 1024-point complex FFT runs inside ONE wave, 16 points per lane (element j of lane l = index l + 64 j on input and
+// output), as radix 16 x 16 x 4 with two exchanges through a wave-private LDS buffer:
+//   n = 64 n1 + 4 n2 + n3,  k = k1 + 16 k2 + 256 k3
+//   (1) radix-16 DFT over n1 in registers (lane = 4 n2 + n3), twiddle W^(lane k1)
+//   (2) exchange: slot 68 k1 + lane  ->  lane' = 4 k1 + n3 reads slots 68 k1 + 4 n2 + n3
+//   (3) radix-16 DFT over n2, twiddle W64^(n3 k2)
+//   (4) exchange: slot k1 + 16 k2 + 264 n3  ->  lane'' reads slots lane'' + 64 m + 264 n3 (m < 4)
+//   (5) radix-4 DFT over n3: X[lane'' + 64 (m + 4 k3)]
+// Every ds_write_b64 / ds_read_b64 of both exchanges is bank-conflict free (pitches 68 and 264 slots; checked offline
+// against the lane groups of MI355X_MICROARCH.md section LDS).  No workgroup barrier inside the transform.
+#include <algorithm>
+
+#include "eav_common.h"
+#include "../../include/eav_hip.h"
+
+namespace {
+
+constexpr int F1 = 8;
+constexpr int NF = 1024;        // transform length
+constexpr int LB = 704;         // outputs per block: 11 rows of 64 (2816 B = 22 cache lines, so every block is line aligned)
+constexpr int NROW = LB / 64;   // 11
+constexpr int WBUF = 1088;      // float2 slots of a wave's exchange buffer: max(68 x 16, 264 x 4)
+constexpr int MAXK = NF - LB + 1;   // 321 taps
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ v2f cmul(v2f a, v2f b) {       // a b
+  return a.xx * b + a.yy * (v2f){-b.y, b.x};
+}
+__device__ __forceinline__ v2f cmulc(v2f a, v2f b) {      // a conj(b)
+  return a.xx * (v2f){b.x, -b.y} + a.yy * (v2f){b.y, b.x};
+}
+template <bool INV>
+__device__ __forceinline__ v2f twmul(v2f a, v2f w) {      // forward: a w; inverse: a conj(w)
+  return INV ? cmulc(a, w) : cmul(a, w);
+}
+// multiply by -i (forward) / +i (inverse)
+template <bool INV>
+__device__ __forceinline__ v2f rot(v2f a) {
+  return INV ? (v2f){-a.y, a.x} : (v2f){a.y, -a.x};
+}
+
+template <bool INV>
+__device__ __forceinline__ void dft4(v2f& a0, v2f& a1, v2f& a2, v2f& a3) {
+  const v2f t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, t3 = rot<INV>(a1 - a3);
+  a0 = t0 + t2;
+  a1 = t1 + t3;
+  a2 = t0 - t2;
+  a3 = t1 - t3;
+}
+
+// 16-point DFT in registers: n = 4 a + b, k = c + 4 d; X[c + 4 d] = sum_b W16^(b c) W4^(b d) sum_a v[4 a + b] W4^(a c)
+template <bool INV>
+__device__ __forceinline__ void dft16(v2f (&v)[16]) {
+  constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R2 = 0.70710678118654752f;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) dft4<INV>(v[b], v[4 + b], v[8 + b], v[12 + b]);      // v[4 c + b] = y[b][c]
+  // y[b][c] *= W16^(b c), W16^m = (cos, -sin)(2 pi m / 16)
+  v[4 * 1 + 1] = twmul<INV>(v[4 * 1 + 1], (v2f){C1, -S1});      // b c = 1
+  v[4 * 2 + 1] = twmul<INV>(v[4 * 2 + 1], (v2f){R2, -R2});      // 2
+  v[4 * 3 + 1] = twmul<INV>(v[4 * 3 + 1], (v2f){S1, -C1});      // 3
+  v[4 * 1 + 2] = twmul<INV>(v[4 * 1 + 2], (v2f){R2, -R2});      // 2
+  v[4 * 2 + 2] = rot<INV>(v[4 * 2 + 2]);                        // 4: -i
+  v[4 * 3 + 2] = twmul<INV>(v[4 * 3 + 2], (v2f){-R2, -R2});     // 6
+  v[4 * 1 + 3] = twmul<INV>(v[4 * 1 + 3], (v2f){S1, -C1});      // 3
+  v[4 * 2 + 3] = twmul<INV>(v[4 * 2 + 3], (v2f){-R2, -R2});     // 6
+  v[4 * 3 + 3] = twmul<INV>(v[4 * 3 + 3], (v2f){-C1, S1});      // 9
+  // for each c: DFT over b of y[b][c] = v[4 c + b] -> X[c + 4 d]
+  v2f o[16];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    v2f y0 = v[4 * c], y1 = v[4 * c + 1], y2 = v[4 * c + 2], y3 = v[4 * c + 3];
+    dft4<INV>(y0, y1, y2, y3);
+    o[c] = y0; o[c + 4] = y1; o[c + 8] = y2; o[c + 12] = y3;
+  }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) v[k] = o[k];
+}
+
+// after dft4 over the a index the results sit at v[4 c + b]: the first loop above writes y[b][c] into (v[b], v[4 + b],
+// v[8 + b], v[12 + b]) = positions 4 c + b.  (kept as a comment: the index bookkeeping is the easy thing to get wrong)
+
+// Twiddle tables of a workgroup in LDS (16 KB): t1[k][lane] = W1024^(lane k), t2[k][lane] = W64^((lane & 3) k) - one
+// conflict-free ds_read_b64 per use instead of 64 resident VGPRs (with them the forward kernel spilled 68 registers).
+constexpr int TWSZ = 2 * 16 * 64;
+
+__device__ __forceinline__ void make_twiddles(v2f* __restrict__ twl) {      // 512 threads: one entry each, twice
+  for (int i = threadIdx.x; i < TWSZ; i += blockDim.x) {
+    const int which = i >> 10, k = (i >> 6) & 15, lane = i & 63;
+    float s, c;
+    if (which == 0) sincospif((float)(lane * k) * (1.0f / 512.0f), &s, &c);      // 2 pi m / 1024 = pi (m / 512), m exact
+    else sincospif((float)((lane & 3) * k) * (1.0f / 32.0f), &s, &c);            // 2 pi m / 64
+    twl[i] = (v2f){c, -s};
+  }
+  __syncthreads();
+}
+
+// In-wave 1024-point FFT: v[j] = x[lane + 64 j] -> v[j] = X[lane + 64 j].  INV: conjugate twiddles, no 1/N.
+template <bool INV>
+__device__ __forceinline__ void fft1024(v2f (&v)[16], v2f* __restrict__ xb, int lane, const v2f* __restrict__ twl) {
+  const v2f* t1 = twl + lane;
+  const v2f* t2 = twl + 1024 + lane;
+  dft16<INV>(v);
+#pragma unroll
+  for (int k = 1; k < 16; ++k) v[k] = twmul<INV>(v[k], t1[64 * k]);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) xb[68 * k + lane] = v[k];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  {
+    const v2f* rp = xb + 68 * (lane >> 2) + (lane & 3);
+#pragma unroll
+    for (int n2 = 0; n2 < 16; ++n2) v[n2] = rp[4 * n2];
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  dft16<INV>(v);
+#pragma unroll
+  for (int k = 1; k < 16; ++k) v[k] = twmul<INV>(v[k], t2[64 * k]);
+  {
+    v2f* wp = xb + (lane >> 2) + 264 * (lane & 3);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) wp[16 * k] = v[k];
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    v2f u0 = xb[lane + 64 * m], u1 = xb[lane + 64 * m + 264], u2 = xb[lane + 64 * m + 528], u3 = xb[lane + 64 * m + 792];
+    dft4<INV>(u0, u1, u2, u3);
+    v[m] = u0; v[m + 4] = u1; v[m + 8] = u2; v[m + 12] = u3;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+__device__ __forceinline__ float wave_sum(float a) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+  return a;
+}
+
+// segment of one electrode pair: v[j] = x[c0][t0 - padl + lane + 64 j] + i x[c0 + 1][...]
+__device__ __forceinline__ void load_segment(v2f (&v)[16], const float* __restrict__ xrow, bool has1, int S, int tbase,
+                                             int lane) {
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int t = tbase + lane + 64 * j;
+    const bool ok = t >= 0 && t < S;
+    v[j].x = ok ? xrow[t] : 0.f;
+    v[j].y = (ok && has1) ? xrow[S + t] : 0.f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------ fwd
+// Work unit = (sample b, electrode pair, block of 704 outputs), one wave each; 8 waves per workgroup share the 8 filter
+// spectra H_f = conj(FFT(w_f)) / 1024 (computed by the workgroup itself: wave f transforms filter f).
+__global__ __launch_bounds__(512, 1) void fir_fft_fwd_kernel(const float* __restrict__ x, const int64_t* __restrict__ xidx,
+                                                             const float* __restrict__ w1, float* __restrict__ y1,
+                                                             float* __restrict__ part, int C, int S, int klen, int padl,
+                                                             int npair, int nblk, int nunits) {
+  __shared__ v2f smem[F1 * NF + 8 * WBUF + TWSZ];
+  v2f* Hs = smem;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  v2f* xb = smem + F1 * NF + wave * WBUF;
+  const v2f* tw = smem + F1 * NF + 8 * WBUF;
+  make_twiddles(smem + F1 * NF + 8 * WBUF);
+  v2f v[16];
+  {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int n = lane + 64 * j;
+      v[j] = (v2f){n < klen ? w1[wave * klen + n] : 0.f, 0.f};
+    }
+    fft1024<false>(v, xb, lane, tw);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) Hs[wave * NF + j * 64 + lane] = (v2f){v[j].x, -v[j].y} * (1.0f / NF);
+  }
+  __syncthreads();
+  float sacc = 0.f;      // lane f: sum of filter f's outputs, lane 8 + f: sum of their squares (this wave's share)
+  const int wgid = blockIdx.x * 8 + wave, nwaves = gridDim.x * 8;
+  // the NEXT unit's input segment is fetched into registers before the eight inverse transforms of the current one
+  v2f nx[16];
+  auto fetch = [&](int u, v2f (&dst)[16]) {
+    const int blk = u % nblk, pr = (u / nblk) % npair, b = u / (nblk * npair);
+    const int c0 = 2 * pr;
+    const float* xrow = x + ((xidx ? xidx[b] : (int64_t)b) * C + c0) * S;
+    load_segment(dst, xrow, c0 + 1 < C, S, blk * LB - padl, lane);
+  };
+  if (wgid < nunits) fetch(wgid, nx);
+  for (int u = wgid; u < nunits; u += nwaves) {
+    const int blk = u % nblk, pr = (u / nblk) % npair, b = u / (nblk * npair);
+    const int c0 = 2 * pr, t0 = blk * LB;
+    const bool has1 = c0 + 1 < C;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = nx[j];
+    if (u + nwaves < nunits) fetch(u + nwaves, nx);
+    fft1024<false>(v, xb, lane, tw);
+    v2f z[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) z[j] = v[j];
+#pragma unroll 1
+    for (int f = 0; f < F1; ++f) {
+      const v2f* hp = Hs + f * NF + lane;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] = cmul(z[j], hp[64 * j]);
+      fft1024<true>(v, xb, lane, tw);
+      float* dst = y1 + (((int64_t)b * F1 + f) * C + c0) * S + t0 + lane;
+      float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < NROW; ++j) {
+        if (t0 + lane + 64 * j < S) {
+          dst[64 * j] = v[j].x;
+          a1 += v[j].x;
+          a2 += v[j].x * v[j].x;
+          if (has1) {
+            dst[S + 64 * j] = v[j].y;
+            a1 += v[j].y;
+            a2 += v[j].y * v[j].y;
+          }
+        }
+      }
+      a1 = wave_sum(a1);
+      a2 = wave_sum(a2);
+      if (lane == f) sacc += a1;
+      if (lane == 8 + f) sacc += a2;
+    }
+  }
+  if (lane < 16) part[wgid * 16 + lane] = sacc;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- wgrad
+// Workgroup = 8 waves, wave f owns filter f's spectrum accumulator.  Per group of 8 units: wave w transforms the input
+// segment of unit w into LDS (register layout), then every wave walks the 8 units, forms its filter's dy block, transforms
+// it and accumulates Z conj(D).  PLAIN: BatchNorm in eval mode (dy = scale g, y1 is not read).
+template <bool PLAIN>
+__global__ __launch_bounds__(512, 1) void fir_fft_wgrad_kernel(const float* __restrict__ x, const int64_t* __restrict__ xidx,
+                                                               const float* __restrict__ y1, const float* __restrict__ g1,
+                                                               const float* __restrict__ bnp, float* __restrict__ spec,
+                                                               int C, int S, int padl, int npair, int nblk, int nunits) {
+  __shared__ v2f smem[8 * NF + 8 * WBUF + TWSZ];
+  v2f* zb = smem;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, f = wave;
+  v2f* xb = smem + 8 * NF + wave * WBUF;
+  const v2f* tw = smem + 8 * NF + 8 * WBUF;
+  make_twiddles(smem + 8 * NF + 8 * WBUF);
+  const float mean = bnp[f], invstd = bnp[8 + f], sc = bnp[16 + f], m1 = bnp[32 + f], m2 = bnp[40 + f];
+  v2f acc[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc[j] = (v2f){0.f, 0.f};
+  v2f v[16];
+  const int ngroups = (nunits + 7) >> 3;
+  // raw g1 (and y1) rows of a unit for this wave's filter: .x = electrode c0, .y = electrode c0 + 1 (0 outside)
+  v2f cg[NROW], cy[NROW];
+  auto fetch_raw = [&](int u, v2f (&gr)[NROW], v2f (&yr)[NROW]) {
+    const int blk = u % nblk, pr = (u / nblk) % npair, b = u / (nblk * npair);
+    const int c0 = 2 * pr, t0 = blk * LB;
+    const bool has1 = c0 + 1 < C;
+    const int64_t off = (((int64_t)b * F1 + f) * C + c0) * S + t0 + lane;
+#pragma unroll
+    for (int j = 0; j < NROW; ++j) {
+      const bool ok = t0 + lane + 64 * j < S;
+      gr[j].x = ok ? g1[off + 64 * j] : 0.f;
+      gr[j].y = (ok && has1) ? g1[off + S + 64 * j] : 0.f;
+      if (!PLAIN) {
+        yr[j].x = ok ? y1[off + 64 * j] : 0.f;
+        yr[j].y = (ok && has1) ? y1[off + S + 64 * j] : 0.f;
+      }
+    }
+  };
+  for (int g = blockIdx.x; g < ngroups; g += gridDim.x) {
+    if (g * 8 < nunits) fetch_raw(g * 8, cg, cy);        // the group's first dy block travels under the Z transforms
+    {
+      const int u = g * 8 + wave;
+      if (u < nunits) {
+        const int blk = u % nblk, pr = (u / nblk) % npair, b = u / (nblk * npair);
+        const int c0 = 2 * pr;
+        const float* xrow = x + ((xidx ? xidx[b] : (int64_t)b) * C + c0) * S;
+        load_segment(v, xrow, c0 + 1 < C, S, blk * LB - padl, lane);
+        fft1024<false>(v, xb, lane, tw);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) zb[wave * NF + j * 64 + lane] = v[j];
+      }
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int uu = 0; uu < 8; ++uu) {
+      const int u = g * 8 + uu;
+      if (u >= nunits) break;
+      const int blk = u % nblk, pr = (u / nblk) % npair;
+      const int t0 = blk * LB;
+      const bool has1 = 2 * pr + 1 < C;
+      v2f ng[NROW], ny[NROW];
+      if (uu + 1 < 8 && u + 1 < nunits) fetch_raw(u + 1, ng, ny);      // in flight under this unit's transform
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        v2f d = (v2f){0.f, 0.f};
+        if (j < NROW && t0 + lane + 64 * j < S) {
+          if (PLAIN) {
+            d = sc * cg[j < NROW ? j : 0];
+          } else {
+            const v2f gg = cg[j < NROW ? j : 0], yy = cy[j < NROW ? j : 0];
+            d = sc * (gg - m1 - (yy - mean) * invstd * m2);
+          }
+          if (!has1) d.y = 0.f;
+        }
+        v[j] = d;
+      }
+#pragma unroll
+      for (int j = 0; j < NROW; ++j) {
+        cg[j] = ng[j];
+        if (!PLAIN) cy[j] = ny[j];
+      }
+      fft1024<false>(v, xb, lane, tw);
+      const v2f* zp = zb + uu * NF + lane;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[j] += cmulc(zp[64 * j], v[j]);
+    }
+    __syncthreads();
+  }
+  float* out = spec + ((int64_t)blockIdx.x * F1 + f) * (2 * NF);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) *reinterpret_cast<v2f*>(out + 2 * (j * 64 + lane)) = acc[j];
+}
+
+// One workgroup per filter: sum the per-workgroup spectra in a fixed order (8 waves x nparts / 8 each, then the 8 wave
+// sums in wave order), inverse transform, keep the real parts of lags 0 .. klen - 1.
+__global__ __launch_bounds__(512, 1) void fir_fft_wgrad_finish_kernel(const float* __restrict__ spec, int nparts,
+                                                                      float* __restrict__ dW, int klen) {
+  __shared__ v2f smem[8 * NF + WBUF + TWSZ];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, f = blockIdx.x;
+  make_twiddles(smem + 8 * NF + WBUF);
+  v2f v[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) v[j] = (v2f){0.f, 0.f};
+  for (int p = wave; p < nparts; p += 8) {
+    const float* src = spec + ((int64_t)p * F1 + f) * (2 * NF);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] += *reinterpret_cast<const v2f*>(src + 2 * (j * 64 + lane));
+  }
+#pragma unroll
+  for (int j = 0; j < 16; ++j) smem[wave * NF + j * 64 + lane] = v[j];
+  __syncthreads();
+  if (wave != 0) return;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    v2f a = smem[j * 64 + lane];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) a += smem[w * NF + j * 64 + lane];
+    v[j] = a;
+  }
+  fft1024<true>(v, smem + 8 * NF, lane, smem + 8 * NF + WBUF);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int n = lane + 64 * j;
+    if (n < klen) dW[f * klen + n] = v[j].x * (1.0f / NF);
+  }
+}
+
+int fft_units(int B, int C, int S, int* npair, int* nblk) {
+  *npair = (C + 1) / 2;
+  *nblk = cdiv(S, LB);
+  return B * *npair * *nblk;
+}
+
+// workgroups of 8 waves, at most one per CU; `items` work items of `per_wg` per round: the smallest grid that needs no
+// more rounds than 256 workgroups would (14400 units = 1800 rounds-of-8: 225 workgroups x 8 rounds, no partial round)
+int fft_grid(int nunits, int per_wg) {
+  const int items = cdiv(nunits, per_wg);
+  if (items <= 256) return std::max(1, items);
+  const int rounds = cdiv(items, 256);
+  return cdiv(items, rounds);
+}
+
+}  // namespace
+
+extern "C" int eav_eegnet_fir_fft_max_taps(void) { return MAXK; }
+
+// stat_part rows (16 floats each: 8 sums, 8 sums of squares) the forward writes - one per wave
+extern "C" int eav_eegnet_fir_fwd_fft_nparts(int B, int C, int S) {
+  int npair, nblk;
+  const int nunits = fft_units(B, C, S, &npair, &nblk);
+  return fft_grid(nunits, 8) * 8;
+}
+
+// y1 [B,8,C,S] = firstConv(x) for the batch x[xidx[0..B)] (xidx NULL: x itself), 'same' padding, klen <= 321 taps;
+// stat_part [eav_eegnet_fir_fwd_fft_nparts][16]: per-wave sums / sums of squares per filter (input of eav_bn_finalize).
+extern "C" int eav_eegnet_fir_fwd_fft(const float* x, const int64_t* xidx, const float* w1, float* y1, float* stat_part,
+                                      int B, int C, int S, int klen, void* stream) {
+  EAV_REQUIRE(x && w1 && y1 && stat_part && B > 0 && C > 0 && S > 0, "eav_eegnet_fir_fwd_fft: bad arguments");
+  EAV_REQUIRE(klen >= 1 && klen <= MAXK, "eav_eegnet_fir_fwd_fft: kernLength %d outside [1,%d]", klen, MAXK);
+  int npair, nblk;
+  const int nunits = fft_units(B, C, S, &npair, &nblk);
+  hipLaunchKernelGGL(fir_fft_fwd_kernel, dim3(fft_grid(nunits, 8)), dim3(512), 0, (hipStream_t)stream, x, xidx, w1, y1,
+                     stat_part, C, S, klen, (klen - 1) / 2, npair, nblk, nunits);
+  EAV_CHECK_LAUNCH("eav_eegnet_fir_fwd_fft");
+  return EAV_OK;
+}
+
+// floats of the spectrum workspace of eav_eegnet_fir_wgrad_fft
+extern "C" int64_t eav_eegnet_fir_wgrad_fft_ws_floats(int B, int C, int S) {
+  int npair, nblk;
+  const int nunits = fft_units(B, C, S, &npair, &nblk);
+  return (int64_t)fft_grid(cdiv(nunits, 8), 1) * F1 * 2 * NF;
+}
+
+// dW [8, klen] = d loss / d firstConv.weight (written, not accumulated).  g1 = d loss / d(firstBN output) [B,8,C,S];
+// y1 = the saved FIR output, or NULL for BatchNorm in eval mode (dy = scale g); bn_params as eav_bn_finalize /
+// eav_bn_bwd_finalize leave them (mean, invstd, scale at 0 / 8 / 16, the backward means m1 / m2 at 32 / 40).
+extern "C" int eav_eegnet_fir_wgrad_fft(const float* x, const int64_t* xidx, const float* y1, const float* g1,
+                                        const float* bn_params, float* ws, float* dW, int B, int C, int S, int klen,
+                                        void* stream) {
+  EAV_REQUIRE(x && g1 && bn_params && ws && dW && B > 0 && C > 0 && S > 0, "eav_eegnet_fir_wgrad_fft: bad arguments");
+  EAV_REQUIRE(klen >= 1 && klen <= MAXK, "eav_eegnet_fir_wgrad_fft: kernLength %d outside [1,%d]", klen, MAXK);
+  int npair, nblk;
+  const int nunits = fft_units(B, C, S, &npair, &nblk);
+  const int grid = fft_grid(cdiv(nunits, 8), 1);
+  hipStream_t st = (hipStream_t)stream;
+  if (y1)
+    hipLaunchKernelGGL(fir_fft_wgrad_kernel<false>, dim3(grid), dim3(512), 0, st, x, xidx, y1, g1, bn_params, ws, C, S,
+                       (klen - 1) / 2, npair, nblk, nunits);
+  else
+    hipLaunchKernelGGL(fir_fft_wgrad_kernel<true>, dim3(grid), dim3(512), 0, st, x, xidx, y1, g1, bn_params, ws, C, S,
+                       (klen - 1) / 2, npair, nblk, nunits);
+  EAV_CHECK_LAUNCH("eav_eegnet_fir_wgrad_fft");
+  hipLaunchKernelGGL(fir_fft_wgrad_finish_kernel, dim3(F1), dim3(512), 0, st, ws, grid, dW, klen);
+  EAV_CHECK_LAUNCH("eav_eegnet_fir_wgrad_fft(finish)");
+  return EAV_OK;
+}

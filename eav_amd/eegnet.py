@@ -19,6 +19,8 @@ There is no CPU path: calling the model with a non-device tensor raises.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -51,7 +53,9 @@ class _Workspace:
         self.bn1, self.bn2, self.bn3 = f(6 * 8), f(6 * 64), f(6 * 64)
         self.wTf, self.wTb = f(1024, 64), f(1024, 64)
         self.np_fir = _lib.plain("eav_eegnet_fir_fwd_nparts", B, C, S)
-        self.part_fir = f(self.np_fir, 16)
+        self.np_fir_fft = _lib.plain("eav_eegnet_fir_fwd_fft_nparts", B, C, S)
+        self.part_fir = f(max(self.np_fir, self.np_fir_fft), 16)
+        self.fft_ws = None         # spectrum partials of the FFT weight gradient, allocated on first use
         self.part_dw = f(B * nchunk, 128)
         self.np_c3 = _lib.plain("eav_conv64_fwd_nparts", B, T2)
         self.part_c3 = f(self.np_c3, 128)
@@ -197,6 +201,12 @@ class EEGNet_tor(nn.Module):
         # eegnet_conv64_split.hip) - measured error against float64 below the fp32 kernels', 2-3x faster kernels;
         # opt-in because its arithmetic is not a plain fp32 fma chain
         self.fir_precision = "fp32"
+        # How the exact-fp32 firstConv and its weight gradient are evaluated.  "fft": overlap-save blocks of 1024-point
+        # FFTs (csrc/eegnet_fir_fft.hip: ~350 flops per output sample for the 8 filters together instead of 4800 - the two
+        # kernels become HBM-bound); "mfma": the Toeplitz GEMMs on the fp32 matrix cores (csrc/eegnet_fir.hip); "auto"
+        # (default): FFT for recordings of at least two 704-sample blocks and kernels of <= 321 taps, MFMA for short epochs
+        # (the reference's own [B,1,30,500], where one FFT block would be mostly padding).  EAV_FIR_ALGO overrides.
+        self.fir_algo = os.environ.get("EAV_FIR_ALGO", "auto")
         self._fwd_counter = None               # device uint64: number of training forwards (dropout stream)
         self._infer = False                    # set per call: no-grad eval-mode forward
         # validate()'s forward with block 1 as ONE kernel (eav_eegnet_block1_infer: y1 / z never written).  Opt-in: at the
@@ -205,6 +215,13 @@ class EEGNet_tor(nn.Module):
         self.fused_eval = False
 
     # ------------------------------------------------------------------ plumbing
+    def _use_fft(self):
+        if self.fir_algo not in ("auto", "fft", "mfma"):
+            raise ValueError(f"fir_algo {self.fir_algo!r}: expected 'auto', 'fft' or 'mfma'")
+        if self.fir_algo == "mfma" or self.kernLength > _lib.plain("eav_eegnet_fir_fft_max_taps"):
+            return False
+        return self.fir_algo == "fft" or self.Samples >= 1408
+
     def _ensure_flat(self):
         p0 = self.firstConv.weight
         if self._flat is None or self._flat[0].device != p0.device or getattr(p0, "_eav_flat", None) is None \
@@ -316,6 +333,7 @@ class EEGNet_tor(nn.Module):
         if self.fir_precision not in ("fp32", "split"):
             raise ValueError(f"fir_precision {self.fir_precision!r}: expected 'fp32' or 'split'")
         split = self.fir_precision == "split"
+        np_fir = ws.np_fir
         infer = self.fused_eval and self._infer and not training and not split and S % 4 == 0
         if infer:
             # validate(): x -> block-1 output in ONE kernel (FIR -> firstBN -> ELU -> depthwiseConv -> depthwiseBN -> ELU ->
@@ -331,13 +349,19 @@ class EEGNet_tor(nn.Module):
             L("eav_absmax_scale", w1, 8 * K, 1.0, P(ws.part_amax), P(ws.scale_w), st)
             L("eav_eegnet_fir_fwd_split", P(x), w1, P(ws.scale_x), P(ws.scale_w), P(ws.y1), P(ws.part_fir), B, C, S, K,
               st)
+        elif self._use_fft():
+            np_fir = ws.np_fir_fft
+            if isinstance(x, IndexedBatch):
+                L("eav_eegnet_fir_fwd_fft", P(x.data), P(x.idx), w1, P(ws.y1), P(ws.part_fir), B, C, S, K, st)
+            else:
+                L("eav_eegnet_fir_fwd_fft", P(x), None, w1, P(ws.y1), P(ws.part_fir), B, C, S, K, st)
         else:
             if isinstance(x, IndexedBatch):
                 L("eav_eegnet_fir_fwd_indexed", P(x.data), P(x.idx), w1, P(ws.y1), P(ws.part_fir), B, C, S, K, st)
             else:
                 L("eav_eegnet_fir_fwd", P(x), w1, P(ws.y1), P(ws.part_fir), B, C, S, K, st)
         if not infer:
-            bnfin(ws.part_fir, ws.np_fir, 8, B * C * S, g1w, g1b, bn1, ws.bn1)
+            bnfin(ws.part_fir, np_fir, 8, B * C * S, g1w, g1b, bn1, ws.bn1)
             L("eav_eegnet_dw_fwd", P(ws.y1), P(ws.bn1), w2, P(ws.z), P(ws.part_dw), B, C, S, st)
             bnfin(ws.part_dw, B * ws.nchunk, 64, B * S, g2w, g2b, bn2, ws.bn2)
             L("eav_bn_elu_pool_fwd_absmax", P(ws.z), P(ws.bn2), P(ws.p2), P(ws.rowmax_p2) if split else None, B, 64, S, 4,
@@ -521,6 +545,13 @@ class EEGNet_tor(nn.Module):
             L("eav_eegnet_fir_wgrad_split", P(x), P(ws.y1), P(ws.g1), b1, P(ws.scale_x), P(ws.scale_dy),
               P(ws.part_fws), B, C, S, K, st)
             L("eav_reduce_partials", P(ws.part_fws), ws.np_fws, 8 * K, 8 * K, 1.0, P(g["firstConv.weight"]), st)
+        elif self._use_fft():
+            if ws.fft_ws is None:
+                ws.fft_ws = torch.empty(_lib.plain("eav_eegnet_fir_wgrad_fft_ws_floats", B, C, S), dtype=torch.float32,
+                                        device=ws.y1.device)
+            xi = isinstance(x, IndexedBatch)
+            L("eav_eegnet_fir_wgrad_fft", P(x.data) if xi else P(x), P(x.idx) if xi else None,
+              P(ws.y1) if training else None, P(ws.g1), b1, P(ws.fft_ws), P(g["firstConv.weight"]), B, C, S, K, st)
         else:
             # eval-mode training (every epoch after the first, Q4): BatchNorm backward is a plain scale, y1 is not needed
             if isinstance(x, IndexedBatch):

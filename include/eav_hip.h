@@ -64,6 +64,20 @@ int eav_eegnet_fir_wgrad(const float* x, const float* y1, const float* g1, const
 /* The same two kernels with the batch addressed in place: sample b of the batch = row xidx[b] of x [*,C,S] (the
  * trainer's HBM-resident data set) - the per-step batch copy (EEGNet_tor.py:100-101: a host->device copy in the
  * reference, a device gather otherwise) disappears.  xidx: device int64 [B]; NULL = x is the batch. */
+/* firstConv and its weight gradient by overlap-save FFT (csrc/eegnet_fir_fft.hip): the same exact-fp32 linear maps as
+ * eav_eegnet_fir_fwd / eav_eegnet_fir_wgrad (nn.Conv2d(1, 8, (1, kernLength), padding='same', bias=False) and autograd's
+ * weight gradient of it, CNN_torch/EEGNet_tor.py:24,51,109) in ~13 x fewer flops - HBM-bound instead of MFMA-bound; up to
+ * eav_eegnet_fir_fft_max_taps() = 321 taps, any C / S.  xidx (optional): the batch is x[xidx[0..B)].
+ * fwd: stat_part [eav_eegnet_fir_fwd_fft_nparts(B,C,S)][16] (8 sums, 8 sums of squares per row) for eav_bn_finalize.
+ * wgrad: dW [8, klen] is WRITTEN (no partials to reduce); ws: eav_eegnet_fir_wgrad_fft_ws_floats(B,C,S) floats;
+ * y1 = NULL selects BatchNorm in eval mode (dy = scale g).  Bit-reproducible run to run. */
+int eav_eegnet_fir_fft_max_taps(void);
+int eav_eegnet_fir_fwd_fft_nparts(int B, int C, int S);
+int eav_eegnet_fir_fwd_fft(const float* x, const int64_t* xidx, const float* w1, float* y1, float* stat_part, int B, int C,
+                           int S, int klen, void* stream);
+int64_t eav_eegnet_fir_wgrad_fft_ws_floats(int B, int C, int S);
+int eav_eegnet_fir_wgrad_fft(const float* x, const int64_t* xidx, const float* y1, const float* g1, const float* bn_params,
+                             float* ws, float* dW, int B, int C, int S, int klen, void* stream);
 int eav_eegnet_fir_fwd_indexed(const float* x, const int64_t* xidx, const float* w1, float* y1, float* stat_part, int B,
                                int C, int S, int klen, void* stream);
 int eav_eegnet_fir_wgrad_indexed(const float* x, const int64_t* xidx, const float* y1, const float* g1,

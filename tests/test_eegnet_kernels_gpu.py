@@ -551,3 +551,76 @@ def test_workspace_cache_is_bounded_for_eager_batch_sizes():
         for B in (1, 2, 3, 5, 7, 2, 9):
             m(torch.randn(B, 1, 30, 500, device="cuda"))
     assert len(m._wss) <= 2, list(m._wss)
+
+
+# ---------------------------------------------------------------------------------------------- firstConv by FFT
+# csrc/eegnet_fir_fft.hip: the same exact-fp32 linear maps as test_fir_fwd / test_fir_wgrad (nn.Conv2d(1, 8, (1, K),
+# padding='same'), EEGNet_tor.py:24,51 and its weight gradient) evaluated by overlap-save FFT blocks - SAME tolerances.
+# Shapes: the bench shape, one block exactly (704), one sample more, odd electrode counts (last pair half empty),
+# recordings shorter than a block, the longest supported kernel (321 taps), a short kernel.
+@pytest.mark.parametrize("B,C,S,K", [(1, 30, 10000, 300), (2, 30, 500, 300), (2, 5, 704, 300), (3, 3, 705, 300),
+                                     (2, 1, 1409, 321), (1, 7, 2100, 64), (2, 32, 130, 7)])
+@pytest.mark.parametrize("indexed", [False, True])
+def test_fir_fwd_fft(L, B, C, S, K, indexed):
+    N = B + 3 if indexed else B
+    xs = synth.normal(1, (N, C, S))
+    idx = np.array([(3 * i + 1) % N for i in range(B)], np.int64)
+    x = xs[idx] if indexed else xs
+    w = synth.uniform(2, (8, K), -0.1, 0.1)
+    xd, wd = dev(xs), dev(w)
+    y = torch.full((B, 8, C, S), float("nan"), device="cuda")
+    npart = L.plain("eav_eegnet_fir_fwd_fft_nparts", B, C, S)
+    part = torch.zeros(npart, 16, device="cuda")
+    L.call("eav_eegnet_fir_fwd_fft", xd.data_ptr(), dev(idx).data_ptr() if indexed else None, wd.data_ptr(), y.data_ptr(),
+           part.data_ptr(), B, C, S, K, None)
+    torch.cuda.synchronize()
+    xt = torch.from_numpy(x).unsqueeze(1)
+    left = (K - 1) // 2
+    ref = F.conv2d(F.pad(xt, (left, K - 1 - left)), torch.from_numpy(w).view(8, 1, 1, K))
+    close(y, ref, 1e-4, 2e-5, "y1")
+    st = part.sum(0).cpu().double().numpy()
+    close(st[:8], ref.double().sum((0, 2, 3)), 1e-5, 1e-3, "sum")
+    close(st[8:], (ref.double() ** 2).sum((0, 2, 3)), 1e-5, 1e-3, "sumsq")
+    # against float64 the FFT form must not be worse than the direct fp32 MFMA kernel
+    if K <= 300:
+        y2 = torch.empty(B, 8, C, S, device="cuda")
+        part2 = torch.zeros(L.plain("eav_eegnet_fir_fwd_nparts", B, C, S), 16, device="cuda")
+        L.call("eav_eegnet_fir_fwd", dev(x).data_ptr(), wd.data_ptr(), y2.data_ptr(), part2.data_ptr(), B, C, S, K, None)
+        ref64 = F.conv2d(F.pad(xt.double(), (left, K - 1 - left)), torch.from_numpy(w).double().view(8, 1, 1, K))
+        e_fft = float((y.double().cpu() - ref64).abs().max())
+        e_dir = float((y2.double().cpu() - ref64).abs().max())
+        print(f"fir_fwd_fft B={B} C={C} S={S} K={K}: max error vs float64 {e_fft:.2e} (direct fp32 MFMA kernel {e_dir:.2e})")
+        assert e_fft <= 4.0 * e_dir + 1e-6
+
+
+@pytest.mark.parametrize("B,C,S,K", [(1, 30, 10000, 300), (2, 30, 500, 300), (2, 4, 704, 300), (2, 3, 705, 300),
+                                     (3, 1, 1409, 321), (1, 3, 1100, 64)])
+@pytest.mark.parametrize("eval_mode", [False, True])
+def test_fir_wgrad_fft(L, B, C, S, K, eval_mode):
+    x = synth.normal(3, (B, C, S))
+    y1 = synth.normal(4, (B, 8, C, S))
+    g1 = synth.normal(5, (B, 8, C, S))
+    mean, invstd = synth.uniform(6, (8,), -0.2, 0.2), synth.uniform(7, (8,), 0.5, 2.0)
+    scale = synth.uniform(8, (8,), 0.5, 1.5)
+    m1, m2 = synth.uniform(9, (8,), -0.1, 0.1), synth.uniform(10, (8,), -0.1, 0.1)
+    if eval_mode:
+        m1, m2 = np.zeros(8, np.float32), np.zeros(8, np.float32)
+    bn = bn_buf(8, mean, invstd, scale, np.zeros(8, np.float32), m1, m2)
+    ws = torch.empty(L.plain("eav_eegnet_fir_wgrad_fft_ws_floats", B, C, S), device="cuda")
+    out = torch.full((8, K), float("nan"), device="cuda")
+    L.call("eav_eegnet_fir_wgrad_fft", dev(x).data_ptr(), None, None if eval_mode else dev(y1).data_ptr(),
+           dev(g1).data_ptr(), bn.data_ptr(), ws.data_ptr(), out.data_ptr(), B, C, S, K, None)
+    out2 = torch.full((8, K), float("nan"), device="cuda")
+    L.call("eav_eegnet_fir_wgrad_fft", dev(x).data_ptr(), None, None if eval_mode else dev(y1).data_ptr(),
+           dev(g1).data_ptr(), bn.data_ptr(), ws.data_ptr(), out2.data_ptr(), B, C, S, K, None)
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2), "the FFT weight gradient is not bit-reproducible"
+    bc = lambda v: torch.from_numpy(v).double()[None, :, None, None]  # noqa: E731
+    dy = bc(scale) * (torch.from_numpy(g1).double() - bc(m1) - (torch.from_numpy(y1).double() - bc(mean)) * bc(invstd) * bc(m2))
+    left = (K - 1) // 2
+    xp = F.pad(torch.from_numpy(x).double(), (left, K - 1 - left))
+    win = xp.unfold(2, S, 1)
+    ref = torch.einsum("bfcs,bcks->fk", dy, win)
+    close(out, ref, 2e-4, 2e-4 * float(ref.abs().max()), "dW1")
+    err = float((out.double().cpu() - ref).abs().max()) / float(ref.abs().max())
+    print(f"fir_wgrad_fft B={B} C={C} S={S} K={K} eval={eval_mode}: max error / max |dW| = {err:.2e}")

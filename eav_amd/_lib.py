@@ -12,7 +12,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libeav_hip.so")
+# (EAV_LIB_PATH: kernel-tuning runs load an alternative build of the same library - tools/ only, never set by the package)
+LIB_PATH = os.environ.get("EAV_LIB_PATH") or os.path.join(_HERE, "libeav_hip.so")
 
 
 class EavError(RuntimeError):

@@ -284,8 +284,8 @@ __global__ __launch_bounds__(512, 1) void fir_fft_wgrad_kernel(const float* __re
       }
     }
   };
+  if (blockIdx.x * 8 < nunits) fetch_raw(blockIdx.x * 8, cg, cy);
   for (int g = blockIdx.x; g < ngroups; g += gridDim.x) {
-    if (g * 8 < nunits) fetch_raw(g * 8, cg, cy);        // the group's first dy block travels under the Z transforms
     {
       const int u = g * 8 + wave;
       if (u < nunits) {
@@ -306,8 +306,11 @@ __global__ __launch_bounds__(512, 1) void fir_fft_wgrad_kernel(const float* __re
       const int blk = u % nblk, pr = (u / nblk) % npair;
       const int t0 = blk * LB;
       const bool has1 = 2 * pr + 1 < C;
+      // the next unit's rows (of this group, or the first of this workgroup's next group - they then travel under that
+      // group's Z transforms too) are in flight under this unit's transform; they are consumed one iteration later
       v2f ng[NROW], ny[NROW];
-      if (uu + 1 < 8 && u + 1 < nunits) fetch_raw(u + 1, ng, ny);      // in flight under this unit's transform
+      const int nu = (uu + 1 < 8) ? u + 1 : (g + (int)gridDim.x) * 8;
+      if (nu < nunits) fetch_raw(nu, ng, ny);
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         v2f d = (v2f){0.f, 0.f};
@@ -322,15 +325,15 @@ __global__ __launch_bounds__(512, 1) void fir_fft_wgrad_kernel(const float* __re
         }
         v[j] = d;
       }
-#pragma unroll
-      for (int j = 0; j < NROW; ++j) {
-        cg[j] = ng[j];
-        if (!PLAIN) cy[j] = ny[j];
-      }
       fft1024<false>(v, xb, lane, tw);
       const v2f* zp = zb + uu * NF + lane;
 #pragma unroll
       for (int j = 0; j < 16; ++j) acc[j] += cmulc(zp[64 * j], v[j]);
+#pragma unroll
+      for (int j = 0; j < NROW; ++j) {       // (after the transform: the copy is what waits for the loads)
+        cg[j] = ng[j];
+        if (!PLAIN) cy[j] = ny[j];
+      }
     }
     __syncthreads();
   }
@@ -383,6 +386,9 @@ int fft_units(int B, int C, int S, int* npair, int* nblk) {
 // more rounds than 256 workgroups would (14400 units = 1800 rounds-of-8: 225 workgroups x 8 rounds, no partial round)
 int fft_grid(int nunits, int per_wg) {
   const int items = cdiv(nunits, per_wg);
+#ifdef FFTV_G256
+  return std::max(1, std::min(256, items));
+#endif
   if (items <= 256) return std::max(1, items);
   const int rounds = cdiv(items, 256);
   return cdiv(items, rounds);

@@ -341,10 +341,10 @@ def bench_preprocess(dev, with_cpu=True):
     ab = n * (L * 4 + 1024 * 128 * 4)
     res["ast_log_mel"] = {"value": round(n / dt, 1), "unit": "clips/s", "ms_per_clip": round(dt / n * 1e3, 4),
                           "kernel": "eav_ast_fbank (float64 DFT up to the log, like the numpy reference)",
-                          "roofline": {"bound": "hbm", "algorithmic_bytes": ab, "achieved": round(ab / dt / 1e9, 1),
-                                       "peak": 8000.0, "unit": "GB/s", "frac": round(ab / dt / 8e12, 4),
-                                       "note": "arithmetic-bound in fp64 (498 frames x 512-point DFT per clip), far from the "
-                                               "HBM roof by construction"}}
+                          "bound": "fp64 arithmetic (498 frames x 512-point DFT per clip in float64, like the numpy reference) - "
+                                   "not an HBM-roofline kernel",
+                          "hbm_reference": {"algorithmic_bytes": ab, "achieved_gbps": round(ab / dt / 1e9, 1),
+                                            "frac_of_8_tb_per_s": round(ab / dt / 8e12, 4)}}
     # ---- ViT frames: uint8 [56,56,3] -> float32 [3,224,224]
     nf = 2500
     frames = torch.from_numpy((synth.uniform(32, (nf, 56, 56, 3), 0, 256)).astype(np.uint8)).to(dev)
@@ -352,6 +352,7 @@ def bench_preprocess(dev, with_cpu=True):
     ab = nf * (56 * 56 * 3 + 3 * 224 * 224 * 4)
     res["vit_frames"] = {"value": round(nf / dt, 1), "unit": "frames/s", "us_per_frame": round(dt / nf * 1e6, 3),
                          "kernel": "eav_resize_normalize_u8 (Pillow-exact 8-bit bilinear resize + rescale + normalise)",
+                         "bound": "hbm (one pass: 9.4 KB in, 602 KB out per frame)",
                          "roofline": {"bound": "hbm", "algorithmic_bytes": ab, "achieved": round(ab / dt / 1e9, 1),
                                       "peak": 8000.0, "unit": "GB/s", "frac": round(ab / dt / 8e12, 4)}}
     # ---- EEG: one subject's recording [30 ch, 10000 samples, 200 trials] float64: decimate by 5, Butterworth-5 band-pass
@@ -369,8 +370,10 @@ def bench_preprocess(dev, with_cpu=True):
     ab = ch * 8 * (t_ * tri + nd + 2 * nd)
     res["eeg_filters"] = {"value": round(dt, 5), "unit": "s/subject", "higher_is_better": False,
                           "kernel": "eav_decimate_fir_f64 + eav_sosfilt_f64 (exact chunk-parallel IIR), float64",
-                          "roofline": {"bound": "hbm", "algorithmic_bytes": ab, "achieved": round(ab / dt / 1e9, 1),
-                                       "peak": 8000.0, "unit": "GB/s", "frac": round(ab / dt / 8e12, 4)}}
+                          "bound": "latency / fp64 arithmetic (30 sequential order-10 IIR recurrences of 400 000 samples, made "
+                                   "chunk-parallel exactly) - not an HBM-roofline kernel",
+                          "hbm_reference": {"algorithmic_bytes": ab, "achieved_gbps": round(ab / dt / 1e9, 1),
+                                            "frac_of_8_tb_per_s": round(ab / dt / 8e12, 4)}}
     if with_cpu:
         from oracle import preprocess_oracle as po
         from scipy.signal import resample_poly, sosfilt

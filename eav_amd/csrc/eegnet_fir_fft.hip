@@ -24,9 +24,9 @@
 //   (1) radix-16 DFT over n1 in registers (lane = 4 n2 + n3), twiddle W^(lane k1)
 //   (2) exchange: slot 68 k1 + lane  ->  lane' = 4 k1 + n3 reads slots 68 k1 + 4 n2 + n3
 //   (3) radix-16 DFT over n2, twiddle W64^(n3 k2)
-//   (4) exchange: slot k1 + 16 k2 + 264 n3  ->  lane'' reads slots lane'' + 64 m + 264 n3 (m < 4)
+//   (4) exchange: slot k1 + 16 k2 + 260 n3  ->  lane'' reads slots lane'' + 64 m + 260 n3 (m < 4)
 //   (5) radix-4 DFT over n3: X[lane'' + 64 (m + 4 k3)]
-// Every ds_write_b64 / ds_read_b64 of both exchanges is bank-conflict free (pitches 68 and 264 slots; checked offline
+// Every ds_write_b64 / ds_read_b64 of both exchanges is bank-conflict free (pitches 68 and 260 slots - 264 has a 2-way conflict in the 16-lane groups of ds_write_b64; checked offline
 // against the lane groups of MI355X_MICROARCH.md section LDS).  No workgroup barrier inside the transform.
 #include <algorithm>
 
@@ -39,10 +39,25 @@ constexpr int F1 = 8;
 constexpr int NF = 1024;        // transform length
 constexpr int LB = 704;         // outputs per block: 11 rows of 64 (2816 B = 22 cache lines, so every block is line aligned)
 constexpr int NROW = LB / 64;   // 11
-constexpr int WBUF = 1088;      // float2 slots of a wave's exchange buffer: max(68 x 16, 264 x 4)
+constexpr int WBUF = 1088;      // float2 slots of a wave's exchange buffer: max(68 x 16, 260 x 3 + 256)
 constexpr int MAXK = NF - LB + 1;   // 321 taps
 
 typedef float v2f __attribute__((ext_vector_type(2)));
+
+// y1 / g1 are streamed exactly once by these kernels (614 MB each): non-temporal accesses keep them from evicting the
+// input segments that ARE re-used out of the L2 (-DFFTV_NO_NT: plain accesses, measured 2-4 % slower).
+// FFTV_ABL_NOLOAD / FFTV_ABL_NOFFT: timing-only ablations (results are garbage): the arithmetic side alone / the memory side
+// alone - forward 0.26 / 0.15 ms of 0.28, weight gradient 0.31 / 0.25 ms of 0.39: the transforms, not HBM, are the longer leg.
+#if defined(FFTV_ABL_NOLOAD)
+#define EAV_LDG(p) (1.0f)
+#define EAV_STG(p, v) asm volatile("" ::"v"(v))
+#elif !defined(FFTV_NO_NT)
+#define EAV_LDG(p) __builtin_nontemporal_load(p)
+#define EAV_STG(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define EAV_LDG(p) (*(p))
+#define EAV_STG(p, v) (*(p) = (v))
+#endif
 
 __device__ __forceinline__ v2f cmul(v2f a, v2f b) {       // a b
   return a.xx * b + a.yy * (v2f){-b.y, b.x};
@@ -118,6 +133,9 @@ __device__ __forceinline__ void make_twiddles(v2f* __restrict__ twl) {      // 5
 // In-wave 1024-point FFT: v[j] = x[lane + 64 j] -> v[j] = X[lane + 64 j].  INV: conjugate twiddles, no 1/N.
 template <bool INV>
 __device__ __forceinline__ void fft1024(v2f (&v)[16], v2f* __restrict__ xb, int lane, const v2f* __restrict__ twl) {
+#ifdef FFTV_ABL_NOFFT
+  return;
+#endif
   const v2f* t1 = twl + lane;
   const v2f* t2 = twl + 1024 + lane;
   dft16<INV>(v);
@@ -136,14 +154,14 @@ __device__ __forceinline__ void fft1024(v2f (&v)[16], v2f* __restrict__ xb, int 
 #pragma unroll
   for (int k = 1; k < 16; ++k) v[k] = twmul<INV>(v[k], t2[64 * k]);
   {
-    v2f* wp = xb + (lane >> 2) + 264 * (lane & 3);
+    v2f* wp = xb + (lane >> 2) + 260 * (lane & 3);
 #pragma unroll
     for (int k = 0; k < 16; ++k) wp[16 * k] = v[k];
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
-    v2f u0 = xb[lane + 64 * m], u1 = xb[lane + 64 * m + 264], u2 = xb[lane + 64 * m + 528], u3 = xb[lane + 64 * m + 792];
+    v2f u0 = xb[lane + 64 * m], u1 = xb[lane + 64 * m + 260], u2 = xb[lane + 64 * m + 520], u3 = xb[lane + 64 * m + 780];
     dft4<INV>(u0, u1, u2, u3);
     v[m] = u0; v[m + 4] = u1; v[m + 8] = u2; v[m + 12] = u3;
   }
@@ -226,11 +244,11 @@ __global__ __launch_bounds__(512, 1) void fir_fft_fwd_kernel(const float* __rest
 #pragma unroll
       for (int j = 0; j < NROW; ++j) {
         if (t0 + lane + 64 * j < S) {
-          dst[64 * j] = v[j].x;
+          EAV_STG(dst + 64 * j, v[j].x);
           a1 += v[j].x;
           a2 += v[j].x * v[j].x;
           if (has1) {
-            dst[S + 64 * j] = v[j].y;
+            EAV_STG(dst + S + 64 * j, v[j].y);
             a1 += v[j].y;
             a2 += v[j].y * v[j].y;
           }
@@ -276,11 +294,11 @@ __global__ __launch_bounds__(512, 1) void fir_fft_wgrad_kernel(const float* __re
 #pragma unroll
     for (int j = 0; j < NROW; ++j) {
       const bool ok = t0 + lane + 64 * j < S;
-      gr[j].x = ok ? g1[off + 64 * j] : 0.f;
-      gr[j].y = (ok && has1) ? g1[off + S + 64 * j] : 0.f;
+      gr[j].x = ok ? EAV_LDG(g1 + off + 64 * j) : 0.f;
+      gr[j].y = (ok && has1) ? EAV_LDG(g1 + off + S + 64 * j) : 0.f;
       if (!PLAIN) {
-        yr[j].x = ok ? y1[off + 64 * j] : 0.f;
-        yr[j].y = (ok && has1) ? y1[off + S + 64 * j] : 0.f;
+        yr[j].x = ok ? EAV_LDG(y1 + off + 64 * j) : 0.f;
+        yr[j].y = (ok && has1) ? EAV_LDG(y1 + off + S + 64 * j) : 0.f;
       }
     }
   };
@@ -342,33 +360,34 @@ __global__ __launch_bounds__(512, 1) void fir_fft_wgrad_kernel(const float* __re
   for (int j = 0; j < 16; ++j) *reinterpret_cast<v2f*>(out + 2 * (j * 64 + lane)) = acc[j];
 }
 
-// One workgroup per filter: sum the per-workgroup spectra in a fixed order (8 waves x nparts / 8 each, then the 8 wave
-// sums in wave order), inverse transform, keep the real parts of lags 0 .. klen - 1.
-__global__ __launch_bounds__(512, 1) void fir_fft_wgrad_finish_kernel(const float* __restrict__ spec, int nparts,
-                                                                      float* __restrict__ dW, int klen) {
-  __shared__ v2f smem[8 * NF + WBUF + TWSZ];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, f = blockIdx.x;
-  make_twiddles(smem + 8 * NF + WBUF);
-  v2f v[16];
-#pragma unroll
-  for (int j = 0; j < 16; ++j) v[j] = (v2f){0.f, 0.f};
-  for (int p = wave; p < nparts; p += 8) {
-    const float* src = spec + ((int64_t)p * F1 + f) * (2 * NF);
-#pragma unroll
-    for (int j = 0; j < 16; ++j) v[j] += *reinterpret_cast<const v2f*>(src + 2 * (j * 64 + lane));
-  }
-#pragma unroll
-  for (int j = 0; j < 16; ++j) smem[wave * NF + j * 64 + lane] = v[j];
+// Finish in two small launches.  (1) 64 workgroups = (filter, slice of 128 bins): 4 thread groups each sum every fourth
+// per-workgroup spectrum of their bins in order, the 4 group sums are added in group order - a fixed order, bit-reproducible -
+// and the total goes to row `nparts` of the workspace.  (2) One wave per filter transforms the total back and keeps the real
+// parts of lags 0 .. klen - 1.  (One workgroup per filter doing both took 30 us at 225 partials: 1.8 MB read by 8 waves.)
+__global__ __launch_bounds__(512) void fir_fft_wgrad_sum_kernel(float* __restrict__ spec, int nparts) {
+  __shared__ v2f red[512];
+  const int f = blockIdx.x >> 3, bin = (blockIdx.x & 7) * 128 + (threadIdx.x & 127), grp = threadIdx.x >> 7;
+  const v2f* src = reinterpret_cast<const v2f*>(spec) + (int64_t)f * NF + bin;
+  v2f a = (v2f){0.f, 0.f};
+  for (int p = grp; p < nparts; p += 4) a += src[(int64_t)p * F1 * NF];
+  red[threadIdx.x] = a;
   __syncthreads();
-  if (wave != 0) return;
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    v2f a = smem[j * 64 + lane];
-#pragma unroll
-    for (int w = 1; w < 8; ++w) a += smem[w * NF + j * 64 + lane];
-    v[j] = a;
+  if (grp == 0) {
+    a = (red[threadIdx.x] + red[threadIdx.x + 128]) + (red[threadIdx.x + 256] + red[threadIdx.x + 384]);
+    reinterpret_cast<v2f*>(spec)[((int64_t)nparts * F1 + f) * NF + bin] = a;
   }
-  fft1024<true>(v, smem + 8 * NF, lane, smem + 8 * NF + WBUF);
+}
+
+__global__ __launch_bounds__(64) void fir_fft_wgrad_finish_kernel(const float* __restrict__ spec, int nparts,
+                                                                  float* __restrict__ dW, int klen) {
+  __shared__ v2f smem[WBUF + TWSZ];
+  const int lane = threadIdx.x, f = blockIdx.x;
+  make_twiddles(smem + WBUF);
+  v2f v[16];
+  const v2f* src = reinterpret_cast<const v2f*>(spec) + ((int64_t)nparts * F1 + f) * NF + lane;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) v[j] = src[64 * j];
+  fft1024<true>(v, smem, lane, smem + WBUF);
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
     const int n = lane + 64 * j;
@@ -423,7 +442,7 @@ extern "C" int eav_eegnet_fir_fwd_fft(const float* x, const int64_t* xidx, const
 extern "C" int64_t eav_eegnet_fir_wgrad_fft_ws_floats(int B, int C, int S) {
   int npair, nblk;
   const int nunits = fft_units(B, C, S, &npair, &nblk);
-  return (int64_t)fft_grid(cdiv(nunits, 8), 1) * F1 * 2 * NF;
+  return ((int64_t)fft_grid(cdiv(nunits, 8), 1) + 1) * F1 * 2 * NF;      // + one row: the sum of the others
 }
 
 // dW [8, klen] = d loss / d firstConv.weight (written, not accumulated).  g1 = d loss / d(firstBN output) [B,8,C,S];
@@ -445,7 +464,9 @@ extern "C" int eav_eegnet_fir_wgrad_fft(const float* x, const int64_t* xidx, con
     hipLaunchKernelGGL(fir_fft_wgrad_kernel<true>, dim3(grid), dim3(512), 0, st, x, xidx, y1, g1, bn_params, ws, C, S,
                        (klen - 1) / 2, npair, nblk, nunits);
   EAV_CHECK_LAUNCH("eav_eegnet_fir_wgrad_fft");
-  hipLaunchKernelGGL(fir_fft_wgrad_finish_kernel, dim3(F1), dim3(512), 0, st, ws, grid, dW, klen);
+  hipLaunchKernelGGL(fir_fft_wgrad_sum_kernel, dim3(F1 * 8), dim3(512), 0, st, ws, grid);
+  EAV_CHECK_LAUNCH("eav_eegnet_fir_wgrad_fft(sum)");
+  hipLaunchKernelGGL(fir_fft_wgrad_finish_kernel, dim3(F1), dim3(64), 0, st, ws, grid, dW, klen);
   EAV_CHECK_LAUNCH("eav_eegnet_fir_wgrad_fft(finish)");
   return EAV_OK;
 }

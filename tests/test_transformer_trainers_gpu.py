@@ -145,3 +145,28 @@ def test_frozen_phase_feature_cache_changes_nothing(golden_dir, tmp_path, monkey
         assert np.abs(out1 - out0).max() < 2e-5
         assert all(float((head1[k] - head0[k]).abs().max()) < 2e-5 for k in head0)
         assert all(a[0] == b[0] for a, b in zip(st1, st0))
+
+
+@pytest.mark.parametrize("kind", ["ast", "vit"])
+def test_trainer_goldens_with_fp16_operand_gradients(kind, monkeypatch):
+    """The opt-in `grad_terms = 1` (backward GEMMs on the hi.hi term alone) on the two reference-trainer goldens: after the
+    frozen + unfrozen epoch `outputs_test` stays within 1e-4 of the unmodified reference trainer's (measured 2.5e-6 AST /
+    7.2e-6 ViT; three-term default 5e-7 / 1e-6) - far inside north_star's 1e-3.  It remains opt-in for what these two-step
+    goldens cannot show: over 40 AdamW steps the held-out logits drift by 1.6-2.1e-3 (tools/encoder_trajectory.py,
+    DESIGN.md Appendix B)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "gap_tool", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "trainer_grad_terms_gap.py"))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    env = {k: os.environ.get(k) for k in ("EAV_GRAD_TERMS", "EAV_ENCODER_PRECISION")}
+    try:
+        e1, _ = tool.run(kind, 1)
+    finally:
+        for k, v in env.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    print(f"{kind}: grad_terms = 1: max |outputs_test - reference| = {e1:.2e}")
+    assert e1 < 1e-4

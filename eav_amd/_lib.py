@@ -48,6 +48,7 @@ SIGNATURES = {
     "eav_conv64_prep_weights": [_p, _p, _p, _p],
     "eav_conv64_fwd": [_p, _p, _p, _p, _i, _i, _i, _p],
     "eav_conv64_wgrad": [_p, _p, _p, _i, _i, _i, _p],
+    "eav_conv64_fft_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _p],
     "eav_dense_softmax_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _p],
     "eav_dense_softmax_bwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     "eav_ce_fwd_bwd": [_p, _p, _p, _p, _p, _p, _i, _i, _p],
@@ -164,6 +165,8 @@ PLAIN = {
     "eav_sepconv_fwd_nparts": ([_i, _i], _i),
     "eav_pointwise_bwd_nparts": ([_i, _i], _i),
     "eav_conv64_fwd_nparts": ([_i, _i], _i),
+    "eav_conv64_fft_nparts": ([_i, _i], _i),
+    "eav_conv64_fft_ws_floats": ([_i, _i], _i64),
     "eav_conv64_wgrad_nparts": ([_i, _i], _i),
     "eav_layernorm_bwd_nparts": ([_i], _i),
     "eav_gemm_f32_splitk_plan": ([_i, _i, _i], _i),

@@ -624,3 +624,42 @@ def test_fir_wgrad_fft(L, B, C, S, K, eval_mode):
     close(out, ref, 2e-4, 2e-4 * float(ref.abs().max()), "dW1")
     err = float((out.double().cpu() - ref).abs().max()) / float(ref.abs().max())
     print(f"fir_wgrad_fft B={B} C={C} S={S} K={K} eval={eval_mode}: max error / max |dW| = {err:.2e}")
+
+
+# ---------------------------------------------------------------------------------------------- separableConv by FFT
+# csrc/eegnet_conv64_fft.hip: the same maps as test_conv64 (forward + BatchNorm sums, data gradient) in the frequency domain -
+# SAME tolerances.  T: the bench shape (2500 = 52 blocks of 49), the reference's own (125), one block (49), one block + 1, an
+# odd number of blocks (3 x 49: the last pair is half empty), a batch whose column count is not a multiple of 32.
+@pytest.mark.parametrize("B,T", [(1, 2500), (2, 125), (3, 49), (2, 50), (2, 147), (5, 300)])
+def test_conv64_fft(L, B, T):
+    x = synth.normal(31, (B, 64, T))
+    w = synth.uniform(32, (64, 64, 16), -0.05, 0.05)
+    wd, xd = dev(w), dev(x)
+    ws = torch.zeros(L.plain("eav_conv64_fft_ws_floats", B, T), device="cuda")
+    nt = L.plain("eav_conv64_fft_nparts", B, T)
+    out = torch.full((B, 64, T), float("nan"), device="cuda")
+    part = torch.zeros(nt, 128, device="cuda")
+    L.call("eav_conv64_fft_fwd", xd.data_ptr(), wd.data_ptr(), out.data_ptr(), part.data_ptr(), ws.data_ptr(), B, T, 0, None)
+    torch.cuda.synchronize()
+    xt = torch.from_numpy(x).double().requires_grad_(True)
+    wt = torch.from_numpy(w).double().requires_grad_(True)
+    ref = F.conv1d(F.pad(xt, (7, 8)), wt)
+    close(out, ref, 1e-4, 1e-5, "conv out")
+    st = part.sum(0).cpu().double().numpy()
+    close(st[:64], ref.detach().sum((0, 2)), 1e-4, 1e-3, "sum")
+    close(st[64:], (ref.detach() ** 2).sum((0, 2)), 1e-4, 1e-3, "sumsq")
+    du = synth.normal(33, (B, 64, T))
+    ref.backward(torch.from_numpy(du).double())
+    dx = torch.full((B, 64, T), float("nan"), device="cuda")
+    L.call("eav_conv64_fft_fwd", dev(du).data_ptr(), wd.data_ptr(), dx.data_ptr(), None, ws.data_ptr(), B, T, 1, None)
+    torch.cuda.synchronize()
+    close(dx, xt.grad, 1e-4, 1e-5, "dgrad")
+    # against float64, beside the direct fp32 MFMA kernel
+    wTf, wTb = torch.empty(1024, 64, device="cuda"), torch.empty(1024, 64, device="cuda")
+    L.call("eav_conv64_prep_weights", wd.data_ptr(), wTf.data_ptr(), wTb.data_ptr(), None)
+    out2 = torch.empty(B, 64, T, device="cuda")
+    L.call("eav_conv64_fwd", xd.data_ptr(), wTf.data_ptr(), out2.data_ptr(), None, B, T, 7, None)
+    e_fft = float((out.double().cpu() - ref.detach()).abs().max())
+    e_dir = float((out2.double().cpu() - ref.detach()).abs().max())
+    print(f"conv64_fft B={B} T={T}: max error vs float64 {e_fft:.2e} (direct fp32 MFMA kernel {e_dir:.2e})")
+    assert e_fft <= 4.0 * e_dir + 1e-6

@@ -49,6 +49,7 @@ SIGNATURES = {
     "eav_conv64_fwd": [_p, _p, _p, _p, _i, _i, _i, _p],
     "eav_conv64_wgrad": [_p, _p, _p, _i, _i, _i, _p],
     "eav_conv64_fft_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _p],
+    "eav_conv64_fft_wgrad": [_p, _p, _p, _i, _i, _p],
     "eav_dense_softmax_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _p],
     "eav_dense_softmax_bwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     "eav_ce_fwd_bwd": [_p, _p, _p, _p, _p, _p, _i, _i, _p],

@@ -77,7 +77,8 @@ __device__ __forceinline__ void fft64(v2f (&x)[64]) {
 }
 
 struct Geo {
-  int B, T, padl, nblk, npair, ncol, ncolp;      // ncolp = columns rounded up to the GEMM's 32-column tiles
+  int B, T, padl, nblk, npair, ncol, ncolp;      // ncolp = columns rounded up to 128: whole 32-column GEMM tiles and 8 equal
+                                                 // weight-gradient chunks of a multiple of 16 columns; columns >= ncol are ZERO
 };
 
 Geo geometry(int B, int T, int padl) {
@@ -86,15 +87,17 @@ Geo geometry(int B, int T, int padl) {
   g.nblk = cdiv(T, LV);
   g.npair = cdiv(g.nblk, 2);
   g.ncol = B * g.npair;
-  g.ncolp = cdiv(g.ncol, 32) * 32;
+  g.ncolp = cdiv(g.ncol, 128) * 128;
   return g;
 }
 
 // ---------------------------------------------------------------------------------------------------------- filter spectra
 // One workgroup (one wave) per output channel `out`, lane = input channel `in`.  bwd = 0: filter (out, in) = w[out][in][:];
 // bwd = 1 (data gradient: dp2[i] = sum_o w'[i][o] * du[o], w'[i][o][k'] = w[o][i][15 - k']): out = i, in = o.
-__global__ __launch_bounds__(64) void c64_spectra_kernel(const float* __restrict__ w, float* __restrict__ Bm, int bwd) {
+__global__ __launch_bounds__(64) void c64_spectra_kernel(const float* __restrict__ w, float* __restrict__ Bm0, int bwd0) {
   const int out = blockIdx.x, lane = threadIdx.x;
+  const int bwd = bwd0 + blockIdx.y;                      // grid.y = 2: the forward's table, then the data gradient's
+  float* Bm = Bm0 + (int64_t)blockIdx.y * 64 * 128 * 128;
   v2f x[64];
 #pragma unroll
   for (int n = 0; n < 64; ++n) {
@@ -119,29 +122,53 @@ __global__ __launch_bounds__(64) void c64_spectra_kernel(const float* __restrict
 // read back with lane = channel (bank (lane + n) mod 32: conflict-free); block A -> real parts, block B -> imaginary parts.
 constexpr int TS = 65;
 
-__global__ __launch_bounds__(256) void c64_pack_fft_kernel(const float* __restrict__ in, float* __restrict__ Z, Geo g) {
+// vonly: the block is its 49 valid samples, zero-padded (the du operand of the weight gradient), instead of 64 samples
+// starting padl before the block (forward / data gradient inputs).
+__global__ __launch_bounds__(256) void c64_pack_fft_kernel(const float* __restrict__ in, float* __restrict__ Z, Geo g,
+                                                           int vonly) {
   __shared__ float tiles[4][64 * TS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float* tile = tiles[wave];
   const int nwaves = gridDim.x * 4;
-  for (int col = blockIdx.x * 4 + wave; col < g.ncol; col += nwaves) {
+  for (int col = blockIdx.x * 4 + wave; col < g.ncolp; col += nwaves) {
+    if (col >= g.ncol) {                       // padding column: zero spectra (the weight gradient contracts over columns)
+      float* dz = Z + (int64_t)col * 128 + lane;
+#pragma unroll 8
+      for (int m = 0; m < 64; ++m) {
+        dz[(int64_t)m * g.ncolp * 128] = 0.f;
+        dz[(int64_t)m * g.ncolp * 128 + 64] = 0.f;
+      }
+      continue;
+    }
     const int b = col / g.npair, pr = col - b * g.npair;
     v2f x[64];
+    // all 128 row loads of the column are issued before the first one is consumed (8 at a time left the kernel waiting on
+    // HBM latency 16 times per column: 45 us; x[] doubles as the landing zone)
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       const int blk = 2 * pr + half;
-      const int t = blk * LV - g.padl + lane;
-      const bool ok = blk < g.nblk && t >= 0 && t < g.T;
+      const int t = blk * LV - (vonly ? 0 : g.padl) + lane;
+      const bool ok = blk < g.nblk && t >= 0 && t < g.T && (!vonly || lane < LV);
       const float* src = in + (int64_t)b * NCH * g.T + t;
-#pragma unroll 8
-      for (int ch = 0; ch < NCH; ++ch) tile[ch * TS + lane] = ok ? src[(int64_t)ch * g.T] : 0.f;
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch) {
+        const float v = ok ? src[(int64_t)ch * g.T] : 0.f;
+        if (half == 0) x[ch].x = v; else x[ch].y = v;
+      }
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch) tile[ch * TS + lane] = half == 0 ? x[ch].x : x[ch].y;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      float r[64];
+#pragma unroll
+      for (int n = 0; n < 64; ++n) r[n] = tile[lane * TS + n];
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
       for (int n = 0; n < 64; ++n) {
-        const float v = tile[lane * TS + n];
-        if (half == 0) x[n].x = v; else x[n].y = v;
+        if (half == 0) x[n].x = r[n]; else x[n].y = r[n];
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     fft64<false>(x);
     float* dst = Z + (int64_t)col * 128 + lane;
@@ -199,15 +226,25 @@ __global__ __launch_bounds__(256) void c64_bin_gemm_kernel(const float* __restri
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // the tile's 64 A operands are read before the first MFMA (left to itself hipcc reads them pairwise just in time:
+    // an LDS round trip in front of every second MFMA)
     const float* ap = xs[buf] + n * XS + kk;
+    float av[64];
 #pragma unroll
-    for (int ks = 0; ks < 64; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * ks], wreg[ks], acc, 0, 0, 0);
+    for (int ks = 0; ks < 64; ++ks) av[ks] = ap[2 * ks];
+    __builtin_amdgcn_sched_barrier(0);            // (the scheduler otherwise sinks the reads back between the MFMAs)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 64; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks], wreg[ks], acc, 0, 0, 0);
     // D[m = column][n = output]: lane holds output n, registers = columns (r & 3) + 8 (r >> 2) + 4 kk
     float* dst = cb + ((int64_t)tile * 32) * 128 + 32 * wave + n;
 #pragma unroll
     for (int r = 0; r < 16; ++r) dst[(int64_t)((r & 3) + 8 * (r >> 2) + 4 * kk) * 128] = acc[r];
     if (nxt < ntiles) commit(buf ^ 1);
-    __syncthreads();
+    // raw barrier: __syncthreads() would also wait for this tile's 16 global stores per lane (vmcnt(0)) at every tile
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     buf ^= 1;
   }
 }
@@ -261,15 +298,107 @@ __global__ __launch_bounds__(256) void c64_ifft_unpack_kernel(const float* __res
   }
 }
 
-int pack_grid(const Geo& g) { return std::max(1, std::min(512, cdiv(g.ncol, 4))); }
+
+// ------------------------------------------------------------------------------------------------------- weight gradient
+// dW[o][i][k] = sum_{b,t} du[b,o,t] in[b,i,t+k-7] = Re IFFT_m( sum_cols conj(D_o[m]) Z_i[m] )[k], D = spectra of the
+// zero-padded 49-sample blocks of du (two blocks per column: real + imaginary), Z = the forward's input spectra.  Per bin
+// one real [128 x cols]^T [cols x 128] product P[a][b] = sum_col D[col][a] Z[col][b] (a = (re|im, o), b = (re|im, i)):
+//   Re Acc[o][i] = P[(re,o)][(re,i)] + P[(im,o)][(im,i)],   Im Acc[o][i] = P[(re,o)][(im,i)] - P[(im,o)][(re,i)].
+// c64_bin_wgemm_kernel: grid (column chunks, 64 bins), 4 waves; wave w = rows a in [32 w, 32 w + 32), all 128 columns b
+// (four 32 x 32 accumulators); both operands are read straight from global memory - for a fixed column the 32 lanes of a
+// half-wave read 128 consecutive bytes - eight K-steps ahead; the chunk's partial product goes to Pp[chunk][bin].
+// c64_wfinish_kernel: lane = i, workgroup = o: sums the chunks in order, forms Acc, inverse FFT over the bins, taps 0..15.
+#ifndef C64V_WCH
+#define C64V_WCH 8
+#endif
+#ifndef C64V_PF
+#define C64V_PF 8
+#endif
+#ifndef C64V_GW
+#define C64V_GW 8
+#endif
+constexpr int WCH = C64V_WCH;      // column chunks (split-K) of the weight-gradient GEMM
+
+__global__ __launch_bounds__(256) void c64_bin_wgemm_kernel(const float* __restrict__ D, const float* __restrict__ Z,
+                                                            float* __restrict__ Pp, int ncolp, int cpc) {
+  const int bin = blockIdx.y, chunk = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = lane & 31, kk = lane >> 5;
+  const int c0 = chunk * cpc;                  // cpc: a multiple of 16 columns, all inside the zero-padded buffers
+  f32x16 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  const float* dp = D + ((int64_t)bin * ncolp + c0 + kk) * 128 + 32 * wave + n;
+  const float* zp = Z + ((int64_t)bin * ncolp + c0 + kk) * 128 + n;
+  const int nks = cpc >> 1;                    // K-steps of 2 columns: a multiple of PF
+  constexpr int PF = C64V_PF;
+  float ra[PF], rb[PF][4];
+#pragma unroll
+  for (int p = 0; p < PF; ++p) {
+    ra[p] = dp[(int64_t)p * 256];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rb[p][j] = zp[(int64_t)p * 256 + 32 * j];
+  }
+  for (int ks0 = 0; ks0 < nks; ks0 += PF) {
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+      const float a = ra[p];
+      const float b0 = rb[p][0], b1 = rb[p][1], b2 = rb[p][2], b3 = rb[p][3];
+      // unconditional reload, clamped to the chunk's last K-step (a branch here made hipcc copy the whole register window)
+      const int64_t o = (int64_t)min(ks0 + PF + p, nks - 1) * 256;
+      ra[p] = dp[o];
+      rb[p][0] = zp[o]; rb[p][1] = zp[o + 32]; rb[p][2] = zp[o + 64]; rb[p][3] = zp[o + 96];
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b2, acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b3, acc[3], 0, 0, 0);
+    }
+  }
+  // D-layout: lane holds column b = 32 j + n, rows a = 32 wave + (r & 3) + 8 (r >> 2) + 4 kk
+  float* out = Pp + (((int64_t)chunk * 64 + bin) * 128 + 32 * wave) * 128 + n;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[(int64_t)((r & 3) + 8 * (r >> 2) + 4 * kk) * 128 + 32 * j] = acc[j][r];
+}
+
+// (bin m, output o) per workgroup, lane = i: the chunk sums in a fixed order and the complex combination -> Acc[m][o][i]
+__global__ __launch_bounds__(64) void c64_wsum_kernel(const float* __restrict__ Pp, float* __restrict__ Acc, int nchunk) {
+  const int m = blockIdx.x, o = blockIdx.y, lane = threadIdx.x;
+  float prr = 0.f, pii = 0.f, pri = 0.f, pir = 0.f;
+  for (int c = 0; c < nchunk; ++c) {                // fixed order: bit-reproducible
+    const float* p = Pp + (((int64_t)c * 64 + m) * 128) * 128;
+    prr += p[(int64_t)o * 128 + lane];
+    pri += p[(int64_t)o * 128 + 64 + lane];
+    pir += p[(int64_t)(64 + o) * 128 + lane];
+    pii += p[(int64_t)(64 + o) * 128 + 64 + lane];
+  }
+  *reinterpret_cast<v2f*>(Acc + 2 * (((int64_t)m * 64 + o) * 64 + lane)) = (v2f){prr + pii, pri - pir};
+}
+
+// workgroup = o, lane = i: inverse FFT over the bins, real parts of lags 0 .. 15
+__global__ __launch_bounds__(64) void c64_wfinish_kernel(const float* __restrict__ Acc, float* __restrict__ dW) {
+  const int o = blockIdx.x, lane = threadIdx.x;
+  v2f x[64];
+#pragma unroll
+  for (int m = 0; m < 64; ++m) x[m] = *reinterpret_cast<const v2f*>(Acc + 2 * (((int64_t)m * 64 + o) * 64 + lane));
+  fft64<true>(x);
+#pragma unroll
+  for (int k = 0; k < KT; ++k) dW[((int64_t)o * NCH + lane) * KT + k] = x[pos64(k)].x * (1.0f / NB);
+}
+
+int pack_grid(const Geo& g) { return std::max(1, std::min(512, cdiv(g.ncolp, 4))); }
 
 }  // namespace
 
-// floats of the workspace of eav_conv64_fft_fwd: two filter-spectrum tables (forward, data gradient) + three spectra
-// buffers [64 bins][columns][128] (input of the forward, input of the data gradient, GEMM output)
+// floats of the workspace of eav_conv64_fft_*: two filter-spectrum tables (forward, data gradient), three spectra buffers
+// [64 bins][columns][128] (input of the forward - kept for the weight gradient -, input of the data gradient, a scratch one:
+// GEMM output / du blocks of the weight gradient) and the weight gradient's split-K partial products
 extern "C" int64_t eav_conv64_fft_ws_floats(int B, int T) {
   const Geo g = geometry(B, T, 7);
-  return (int64_t)2 * 64 * 128 * 128 + (int64_t)3 * 64 * g.ncolp * 128;
+  return (int64_t)2 * 64 * 128 * 128 + (int64_t)3 * 64 * g.ncolp * 128 + (int64_t)WCH * 64 * 128 * 128 +
+         (int64_t)64 * 64 * 64 * 2;
 }
 
 // rows of stat_part ([rows][128]: 64 sums, 64 sums of squares) eav_conv64_fft_fwd writes
@@ -279,23 +408,52 @@ extern "C" int eav_conv64_fft_nparts(int B, int T) {
 }
 
 // out [B,64,T] = separableConv(in) (bwd = 0, 'same' padding 7 / 8; stat_part as eav_conv64_fwd's, may be NULL) or its data
-// gradient (bwd = 1: in = d loss / d out, out = d loss / d in); w [64,64,16] = separableConv.weight.
+// gradient (bwd = 1: in = d loss / d out, out = d loss / d in; bwd = 2: the same, re-using the filter spectra the forward
+// call of this step prepared in ws - it prepares both tables); w [64,64,16] = separableConv.weight.
 extern "C" int eav_conv64_fft_fwd(const float* in, const float* w, float* out, float* stat_part, float* ws, int B, int T,
                                   int bwd, void* stream) {
   EAV_REQUIRE(in && w && out && ws && B > 0 && T > 0, "eav_conv64_fft_fwd: bad arguments");
   EAV_REQUIRE(((uintptr_t)ws & 15) == 0, "eav_conv64_fft_fwd: the workspace must be 16-byte aligned");
   const Geo g = geometry(B, T, bwd ? 8 : 7);
+  EAV_REQUIRE(bwd >= 0 && bwd <= 2, "eav_conv64_fft_fwd: bwd must be 0, 1 or 2");
   hipStream_t st = (hipStream_t)stream;
   float* Bm = ws + (bwd ? (int64_t)64 * 128 * 128 : 0);
+  const bool prepared = bwd == 2;                        // 2: the forward call of this step left the table in ws
+  if (bwd == 2) bwd = 1;
   float* Z = ws + (int64_t)2 * 64 * 128 * 128 + (bwd ? (int64_t)64 * g.ncolp * 128 : 0);
   float* Y = ws + (int64_t)2 * 64 * 128 * 128 + (int64_t)2 * 64 * g.ncolp * 128;
-  hipLaunchKernelGGL(c64_spectra_kernel, dim3(NCH), dim3(64), 0, st, w, Bm, bwd);
-  EAV_CHECK_LAUNCH("eav_conv64_fft_fwd(spectra)");
-  hipLaunchKernelGGL(c64_pack_fft_kernel, dim3(pack_grid(g)), dim3(256), 0, st, in, Z, g);
+  if (!prepared) {      // forward: both tables (weights do not change between the forward and the backward of a step)
+    hipLaunchKernelGGL(c64_spectra_kernel, dim3(NCH, bwd ? 1 : 2), dim3(64), 0, st, w, Bm, bwd);
+    EAV_CHECK_LAUNCH("eav_conv64_fft_fwd(spectra)");
+  }
+  hipLaunchKernelGGL(c64_pack_fft_kernel, dim3(pack_grid(g)), dim3(256), 0, st, in, Z, g, 0);
   EAV_CHECK_LAUNCH("eav_conv64_fft_fwd(fft)");
-  hipLaunchKernelGGL(c64_bin_gemm_kernel, dim3(std::min(8, g.ncolp / 32), 64), dim3(256), 0, st, Z, Bm, Y, g.ncolp);
+  hipLaunchKernelGGL(c64_bin_gemm_kernel, dim3(std::min(C64V_GW, g.ncolp / 32), 64), dim3(256), 0, st, Z, Bm, Y, g.ncolp);
   EAV_CHECK_LAUNCH("eav_conv64_fft_fwd(gemm)");
   hipLaunchKernelGGL(c64_ifft_unpack_kernel, dim3(pack_grid(g)), dim3(256), 0, st, Y, out, stat_part, g);
   EAV_CHECK_LAUNCH("eav_conv64_fft_fwd(ifft)");
+  return EAV_OK;
+}
+
+// dW [64,64,16] = d loss / d separableConv.weight (WRITTEN, no partials to reduce) from du = d loss / d(conv output)
+// [B,64,T].  The forward input's spectra must still be in `ws`: call after eav_conv64_fft_fwd(in, ..., ws, B, T, 0) of the
+// same step (a data-gradient call in between does not disturb them).  Bit-reproducible.
+extern "C" int eav_conv64_fft_wgrad(const float* du, float* dW, float* ws, int B, int T, void* stream) {
+  EAV_REQUIRE(du && dW && ws && B > 0 && T > 0, "eav_conv64_fft_wgrad: bad arguments");
+  const Geo g = geometry(B, T, 7);
+  hipStream_t st = (hipStream_t)stream;
+  float* Z = ws + (int64_t)2 * 64 * 128 * 128;
+  float* D = Z + (int64_t)2 * 64 * g.ncolp * 128;
+  float* Pp = Z + (int64_t)3 * 64 * g.ncolp * 128;
+  float* Acc = Pp + (int64_t)WCH * 64 * 128 * 128;
+  hipLaunchKernelGGL(c64_pack_fft_kernel, dim3(pack_grid(g)), dim3(256), 0, st, du, D, g, 1);
+  EAV_CHECK_LAUNCH("eav_conv64_fft_wgrad(fft)");
+  const int cpc = g.ncolp / WCH;                            // columns per chunk: a multiple of 16
+  hipLaunchKernelGGL(c64_bin_wgemm_kernel, dim3(WCH, 64), dim3(256), 0, st, D, Z, Pp, g.ncolp, cpc);
+  EAV_CHECK_LAUNCH("eav_conv64_fft_wgrad(gemm)");
+  hipLaunchKernelGGL(c64_wsum_kernel, dim3(64, 64), dim3(64), 0, st, Pp, Acc, WCH);
+  EAV_CHECK_LAUNCH("eav_conv64_fft_wgrad(sum)");
+  hipLaunchKernelGGL(c64_wfinish_kernel, dim3(NCH), dim3(64), 0, st, Acc, dW);
+  EAV_CHECK_LAUNCH("eav_conv64_fft_wgrad(finish)");
   return EAV_OK;
 }

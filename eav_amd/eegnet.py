@@ -58,7 +58,9 @@ class _Workspace:
         self.fft_ws = None         # spectrum partials of the FFT weight gradient, allocated on first use
         self.part_dw = f(B * nchunk, 128)
         self.np_c3 = _lib.plain("eav_conv64_fwd_nparts", B, T2)
-        self.part_c3 = f(self.np_c3, 128)
+        self.np_c3_fft = _lib.plain("eav_conv64_fft_nparts", B, T2)
+        self.part_c3 = f(max(self.np_c3, self.np_c3_fft), 128)
+        self.c64_ws = None         # spectra workspace of the frequency-domain separableConv, allocated on first use
         self.part_pb = f(B, 128)
         self.part_dst = f(B * nchunk, 16)
         self.part_dw2 = f(B * nchunk, 64 * C)
@@ -207,6 +209,7 @@ class EEGNet_tor(nn.Module):
         # (default): FFT for recordings of at least two 704-sample blocks and kernels of <= 321 taps, MFMA for short epochs
         # (the reference's own [B,1,30,500], where one FFT block would be mostly padding).  EAV_FIR_ALGO overrides.
         self.fir_algo = os.environ.get("EAV_FIR_ALGO", "auto")
+        self.conv_algo = os.environ.get("EAV_CONV_ALGO", "auto")      # separableConv: see _use_conv_fft
         self._fwd_counter = None               # device uint64: number of training forwards (dropout stream)
         self._infer = False                    # set per call: no-grad eval-mode forward
         # validate()'s forward with block 1 as ONE kernel (eav_eegnet_block1_infer: y1 / z never written).  Opt-in: at the
@@ -221,6 +224,17 @@ class EEGNet_tor(nn.Module):
         if self.fir_algo == "mfma" or self.kernLength > _lib.plain("eav_eegnet_fir_fft_max_taps"):
             return False
         return self.fir_algo == "fft" or self.Samples >= 1408
+
+    def _use_conv_fft(self, B):
+        """separableConv (forward, data and weight gradient) in the frequency domain (csrc/eegnet_conv64_fft.hip: per-bin
+        [128 x 128] GEMMs instead of a 1024-deep contraction, 6x fewer multiply-adds) when the batch is large enough to
+        amortise its extra launches; the direct fp32-MFMA kernels otherwise (the reference's own [32,1,30,500]).
+        `conv_algo` / EAV_CONV_ALGO: "auto" (default), "fft", "mfma"."""
+        if self.conv_algo not in ("auto", "fft", "mfma"):
+            raise ValueError(f"conv_algo {self.conv_algo!r}: expected 'auto', 'fft' or 'mfma'")
+        if self.conv_algo == "mfma" or self.fir_precision != "fp32":
+            return False
+        return self.conv_algo == "fft" or B * (self.Samples // 4) >= 40000
 
     def _ensure_flat(self):
         p0 = self.firstConv.weight
@@ -366,15 +380,23 @@ class EEGNet_tor(nn.Module):
             bnfin(ws.part_dw, B * ws.nchunk, 64, B * S, g2w, g2b, bn2, ws.bn2)
             L("eav_bn_elu_pool_fwd_absmax", P(ws.z), P(ws.bn2), P(ws.p2), P(ws.rowmax_p2) if split else None, B, 64, S, 4,
               drop, seed1, m1, cnt, st)
-        L("eav_conv64_prep_weights", w3, P(ws.wTf), P(ws.wTb), st)
+        if split or not self._use_conv_fft(B):       # (the frequency-domain path takes the weight tensor as it is)
+            L("eav_conv64_prep_weights", w3, P(ws.wTf), P(ws.wTb), st)
+        np_c3 = ws.np_c3
         if split:
             L("eav_absmax_finish", P(ws.rowmax_p2), B * 64, 1.0, P(ws.scale_p2), st)
             L("eav_absmax_scale", w3, 64 * 1024, 1.0, P(ws.part_amax), P(ws.scale_w3), st)
             L("eav_conv64_fwd_split", P(ws.p2), P(ws.wTf), P(ws.scale_p2), P(ws.scale_w3), P(ws.u3), P(ws.part_c3), B,
               ws.T2, 7, st)
+        elif self._use_conv_fft(B):
+            if ws.c64_ws is None:
+                ws.c64_ws = torch.zeros(_lib.plain("eav_conv64_fft_ws_floats", B, ws.T2), dtype=torch.float32,
+                                        device=ws.y1.device)
+            np_c3 = ws.np_c3_fft
+            L("eav_conv64_fft_fwd", P(ws.p2), w3, P(ws.u3), P(ws.part_c3), P(ws.c64_ws), B, ws.T2, 0, st)
         else:
             L("eav_conv64_fwd", P(ws.p2), P(ws.wTf), P(ws.u3), P(ws.part_c3), B, ws.T2, 7, st)
-        bnfin(ws.part_c3, ws.np_c3, 64, B * ws.T2, g3w, g3b, bn3, ws.bn3)
+        bnfin(ws.part_c3, np_c3, 64, B * ws.T2, g3w, g3b, bn3, ws.bn3)
         L("eav_bn_elu_pool_fwd", P(ws.u3), P(ws.bn3), P(ws.p3), B, 64, ws.T2, 8, drop, seed2, m2, cnt, st)
         probs = torch.empty(B, nb, dtype=torch.float32, device=x.device)   # fresh per forward: returned, kept for backward
         L("eav_dense_softmax_fwd", P(ws.p3), wd, bd, None, P(probs), B, ws.NF, nb, st)
@@ -512,14 +534,20 @@ class EEGNet_tor(nn.Module):
             L("eav_absmax_finish", P(ws.rowmax_du3), B * 64, 1.0, P(ws.scale_du3), st)
             L("eav_conv64_fwd_split", P(ws.du3), P(ws.wTb), P(ws.scale_du3), P(ws.scale_w3), P(ws.dp2), None, B, T2,
               8, st)
+        elif self._use_conv_fft(B):
+            # (bwd = 2: the filter spectra of the data gradient were prepared by this step's forward call)
+            L("eav_conv64_fft_fwd", P(ws.du3), P(self.separableConv.weight), P(ws.dp2), None, P(ws.c64_ws), B, T2, 2, st)
         else:
             L("eav_conv64_fwd", P(ws.du3), P(ws.wTb), P(ws.dp2), None, B, T2, 8, st)
         if split:
             L("eav_conv64_wgrad_split", P(ws.du3), P(ws.p2), P(ws.scale_du3), P(ws.scale_p2), P(ws.part_cw), B, T2, 7,
               st)
+            L("eav_reduce_partials", P(ws.part_cw), ws.np_cw, 65536, 65536, 1.0, P(g["separableConv.weight"]), st)
+        elif self._use_conv_fft(B):
+            L("eav_conv64_fft_wgrad", P(ws.du3), P(g["separableConv.weight"]), P(ws.c64_ws), B, T2, st)
         else:
             L("eav_conv64_wgrad", P(ws.du3), P(ws.p2), P(ws.part_cw), B, T2, 7, st)
-        L("eav_reduce_partials", P(ws.part_cw), ws.np_cw, 65536, 65536, 1.0, P(g["separableConv.weight"]), st)
+            L("eav_reduce_partials", P(ws.part_cw), ws.np_cw, 65536, 65536, 1.0, P(g["separableConv.weight"]), st)
         # block 1 tail: Dropout <- AvgPool4 <- ELU <- depthwiseBN
         b2 = P(ws.bn2)
         L("eav_bn_elu_pool_bwd_reduce", P(ws.dp2), P(ws.z), b2, P(ws.part_pb), B, 64, S, 4, drop, seed1, m1, cnt, st)

@@ -150,12 +150,15 @@ int eav_conv64_fwd(const float* in, const float* wT, float* out, float* stat_par
  * and autograd's input gradient of it) by overlap-save blocks of 64 samples: per frequency bin the channel mixing is one
  * [128 x 128] real matrix - 6 x fewer multiply-adds than the 1024-deep direct contraction.  w = separableConv.weight
  * [64,64,16] (no prepared copy needed); bwd = 0 forward (stat_part [eav_conv64_fft_nparts(B,T)][128] or NULL), bwd = 1 data
- * gradient; ws: eav_conv64_fft_ws_floats(B,T) floats, 16-byte aligned (it keeps the input spectra of both calls for the
+ * gradient, bwd = 2 data gradient re-using the filter spectra the forward call of the same step prepared in ws; ws: eav_conv64_fft_ws_floats(B,T) floats, 16-byte aligned (it keeps the input spectra of both calls for the
  * weight gradient). */
 int64_t eav_conv64_fft_ws_floats(int B, int T);
 int eav_conv64_fft_nparts(int B, int T);
 int eav_conv64_fft_fwd(const float* in, const float* w, float* out, float* stat_part, float* ws, int B, int T, int bwd,
                        void* stream);
+/* dW [64,64,16] = d loss / d separableConv.weight, WRITTEN (replaces eav_conv64_wgrad + eav_reduce_partials); needs the
+ * forward input's spectra of the same step in ws (eav_conv64_fft_fwd with bwd = 0 was called on it). */
+int eav_conv64_fft_wgrad(const float* du, float* dW, float* ws, int B, int T, void* stream);
 int eav_conv64_wgrad_nparts(int B, int T);
 /* part [nparts][64*64*16]; sum over parts = dL/dW[o,i,k]. */
 int eav_conv64_wgrad(const float* du, const float* in, float* part, int B, int T, int padl, void* stream);

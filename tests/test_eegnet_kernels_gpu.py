@@ -651,9 +651,24 @@ def test_conv64_fft(L, B, T):
     du = synth.normal(33, (B, 64, T))
     ref.backward(torch.from_numpy(du).double())
     dx = torch.full((B, 64, T), float("nan"), device="cuda")
-    L.call("eav_conv64_fft_fwd", dev(du).data_ptr(), wd.data_ptr(), dx.data_ptr(), None, ws.data_ptr(), B, T, 1, None)
+    # (bwd = 2: the data gradient on the filter spectra the forward call left in ws - the model's sequence; it must leave the
+    # forward's input spectra alone: the weight gradient below reads them)
+    L.call("eav_conv64_fft_fwd", dev(du).data_ptr(), wd.data_ptr(), dx.data_ptr(), None, ws.data_ptr(), B, T, 2, None)
+    dx1 = torch.full((B, 64, T), float("nan"), device="cuda")
+    ws1 = torch.zeros_like(ws)
+    L.call("eav_conv64_fft_fwd", dev(du).data_ptr(), wd.data_ptr(), dx1.data_ptr(), None, ws1.data_ptr(), B, T, 1, None)
     torch.cuda.synchronize()
     close(dx, xt.grad, 1e-4, 1e-5, "dgrad")
+    assert torch.equal(dx, dx1), "bwd = 1 (own filter spectra) and bwd = 2 (the forward's) differ"
+    dw = torch.full((64, 64, 16), float("nan"), device="cuda")
+    L.call("eav_conv64_fft_wgrad", dev(du).data_ptr(), dw.data_ptr(), ws.data_ptr(), B, T, None)
+    dw2 = torch.full((64, 64, 16), float("nan"), device="cuda")
+    L.call("eav_conv64_fft_wgrad", dev(du).data_ptr(), dw2.data_ptr(), ws.data_ptr(), B, T, None)
+    torch.cuda.synchronize()
+    close(dw, wt.grad, 1e-4, 1e-4 * float(wt.grad.abs().max()), "wgrad")
+    assert torch.equal(dw, dw2), "the frequency-domain weight gradient is not bit-reproducible"
+    print(f"conv64_fft wgrad B={B} T={T}: max error / max |dW| = "
+          f"{float((dw.double().cpu() - wt.grad).abs().max() / wt.grad.abs().max()):.2e}")
     # against float64, beside the direct fp32 MFMA kernel
     wTf, wTb = torch.empty(1024, 64, device="cuda"), torch.empty(1024, 64, device="cuda")
     L.call("eav_conv64_prep_weights", wd.data_ptr(), wTf.data_ptr(), wTb.data_ptr(), None)

@@ -39,6 +39,18 @@ def main():
         t_m = timeit(lambda: L.call("eav_conv64_fwd", P(x), P(wT), P(y_m), P(pm) if not bwd else None, B, T, padl, None))
         print(f"{name} fft {t_f:.3f} ms   mfma {t_m:.3f} ms   max |diff| {float((y_f - y_m).abs().max()):.2e} "
               f"(max |y| {float(y_m.abs().max()):.2f})")
+    du = torch.randn(B, 64, T, device="cuda")
+    L.call("eav_conv64_fft_fwd", P(x), P(w), P(y_f), None, P(ws), B, T, 0, None)        # leaves the input spectra in ws
+    d_f, d_m = torch.empty(64, 64, 16, device="cuda"), torch.empty(64, 64, 16, device="cuda")
+    npw = L.plain("eav_conv64_wgrad_nparts", B, T)
+    pw = torch.empty(npw, 65536, device="cuda")
+    t_f = timeit(lambda: L.call("eav_conv64_fft_wgrad", P(du), P(d_f), P(ws), B, T, None))
+
+    def mf():
+        L.call("eav_conv64_wgrad", P(du), P(x), P(pw), B, T, 7, None)
+        L.call("eav_reduce_partials", P(pw), npw, 65536, 65536, 1.0, P(d_m), None)
+    t_m = timeit(mf)
+    print(f"wgrad fft {t_f:.3f} ms   mfma {t_m:.3f} ms   max |diff| / max |dW| {float((d_f - d_m).abs().max() / d_m.abs().max()):.2e}")
 
 
 if __name__ == "__main__":

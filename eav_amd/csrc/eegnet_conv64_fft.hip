@@ -11,7 +11,7 @@
 // imaginary): every step - FFT, complex-linear mixing, inverse FFT - keeps them apart (real filters), no unpacking.
 //
 // Three kernels + the filter spectra:
-//   c64_spectra_kernel   Bm[bin][(ri_o, o)][(ri_i, i)] = [[Gr, -Gi], [Gi, Gr]], G = conj(W) / 64 (forward), or the
+//   c64_spectra_kernel   BmT[bin][(ri_i, i)][(ri_o, o)] = the transpose of [[Gr, -Gi], [Gi, Gr]], G = conj(W) / 64 (forward), or the
 //                        flipped / transposed filters of the data gradient
 //   c64_pack_fft_kernel  a wave per column (sample b, block pair): coalesced row loads -> LDS transpose -> lane = channel,
 //                        64-point complex FFT entirely in registers (8 x 8, no exchange) -> Z[bin][col][re | im][64 ch]
@@ -92,17 +92,19 @@ Geo geometry(int B, int T, int padl) {
 }
 
 // ---------------------------------------------------------------------------------------------------------- filter spectra
-// One workgroup (one wave) per output channel `out`, lane = input channel `in`.  bwd = 0: filter (out, in) = w[out][in][:];
-// bwd = 1 (data gradient: dp2[i] = sum_o w'[i][o] * du[o], w'[i][o][k'] = w[o][i][15 - k']): out = i, in = o.
+// BmT[bin][k = (ri_i, in)][n = (ri_o, out)] (contraction index major: the GEMM's weight-stationary waves then load their
+// operand registers as whole 128-byte rows).  One workgroup (one wave) per input channel `in`, lane = output channel `out`.
+// Table 0 (forward): filter (out, in) = w[out][in][:]; table 1 (data gradient: dp2[i] = sum_o w'[i][o] * du[o],
+// w'[i][o][k'] = w[o][i][15 - k']): out = i, in = o.
 __global__ __launch_bounds__(64) void c64_spectra_kernel(const float* __restrict__ w, float* __restrict__ Bm0, int bwd0) {
-  const int out = blockIdx.x, lane = threadIdx.x;
+  const int in = blockIdx.x, lane = threadIdx.x;
   const int bwd = bwd0 + blockIdx.y;                      // grid.y = 2: the forward's table, then the data gradient's
   float* Bm = Bm0 + (int64_t)blockIdx.y * 64 * 128 * 128;
   v2f x[64];
 #pragma unroll
   for (int n = 0; n < 64; ++n) {
     float t = 0.f;
-    if (n < KT) t = bwd ? w[((int64_t)lane * NCH + out) * KT + (KT - 1 - n)] : w[((int64_t)out * NCH + lane) * KT + n];
+    if (n < KT) t = bwd ? w[((int64_t)in * NCH + lane) * KT + (KT - 1 - n)] : w[((int64_t)lane * NCH + in) * KT + n];
     x[n] = (v2f){t, 0.f};
   }
   fft64<false>(x);
@@ -110,10 +112,10 @@ __global__ __launch_bounds__(64) void c64_spectra_kernel(const float* __restrict
   for (int m = 0; m < 64; ++m) {
     const v2f W = x[pos64(m)];
     const float gr = W.x * (1.0f / NB), gi = -W.y * (1.0f / NB);      // G = conj(W) / 64
-    float* row0 = Bm + ((int64_t)m * 128 + out) * 128;                // output row (re, out)
-    float* row1 = Bm + ((int64_t)m * 128 + 64 + out) * 128;           // output row (im, out)
-    row0[lane] = gr;  row0[64 + lane] = -gi;
-    row1[lane] = gi;  row1[64 + lane] = gr;
+    float* row0 = Bm + ((int64_t)m * 128 + in) * 128;                 // contraction row (re, in)
+    float* row1 = Bm + ((int64_t)m * 128 + 64 + in) * 128;            // contraction row (im, in)
+    row0[lane] = gr;   row0[64 + lane] = gi;                          // y_re += gr z_re,  y_im += gi z_re
+    row1[lane] = -gi;  row1[64 + lane] = gr;                          // y_re -= gi z_im,  y_im += gr z_im
   }
 }
 
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(256) void c64_pack_fft_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------------------------------------------- per-bin GEMM
-// C[bin][col][n] = sum_k Z[bin][col][k] Bm[bin][n][k], n, k in [0,128).  grid (wgs per bin, 64 bins), 4 waves; wave w owns
+// C[bin][col][n] = sum_k Z[bin][col][k] BmT[bin][k][n], n, k in [0,128).  grid (wgs per bin, 64 bins), 4 waves; wave w owns
 // outputs [32 w, 32 w + 32): its Bm rows stay in 64 VGPRs (B operand of v_mfma_f32_32x32x2_f32: lane = (k & 1, n)).  Column
 // tiles of 32 are staged into LDS (row stride 129: the A-operand reads hit 32 banks), next tile prefetched in registers.
 constexpr int XS = 129;
@@ -193,9 +195,9 @@ __global__ __launch_bounds__(256) void c64_bin_gemm_kernel(const float* __restri
   const int n = lane & 31, kk = lane >> 5;
   float wreg[64];
   {
-    const float* bp = Bm + ((int64_t)bin * 128 + 32 * wave + n) * 128 + kk;
+    const float* bp = Bm + ((int64_t)bin * 128 + kk) * 128 + 32 * wave + n;      // BmT[bin][k][n]: 128-byte rows per half-wave
 #pragma unroll
-    for (int ks = 0; ks < 64; ++ks) wreg[ks] = bp[2 * ks];
+    for (int ks = 0; ks < 64; ++ks) wreg[ks] = bp[(int64_t)2 * ks * 128];
   }
   const int ntiles = ncolp >> 5;
   const float* zb = Z + (int64_t)bin * ncolp * 128;
@@ -239,6 +241,9 @@ __global__ __launch_bounds__(256) void c64_bin_gemm_kernel(const float* __restri
     for (int ks = 0; ks < 64; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks], wreg[ks], acc, 0, 0, 0);
     // D[m = column][n = output]: lane holds output n, registers = columns (r & 3) + 8 (r >> 2) + 4 kk
     float* dst = cb + ((int64_t)tile * 32) * 128 + 32 * wave + n;
+#ifdef C64V_ABL_NOSTORE      // (timing-only ablation)
+    if (acc[0] == 12345.f)
+#endif
 #pragma unroll
     for (int r = 0; r < 16; ++r) dst[(int64_t)((r & 3) + 8 * (r >> 2) + 4 * kk) * 128] = acc[r];
     if (nxt < ntiles) commit(buf ^ 1);
@@ -309,7 +314,7 @@ __global__ __launch_bounds__(256) void c64_ifft_unpack_kernel(const float* __res
 // half-wave read 128 consecutive bytes - eight K-steps ahead; the chunk's partial product goes to Pp[chunk][bin].
 // c64_wfinish_kernel: lane = i, workgroup = o: sums the chunks in order, forms Acc, inverse FFT over the bins, taps 0..15.
 #ifndef C64V_WCH
-#define C64V_WCH 8
+#define C64V_WCH 4
 #endif
 #ifndef C64V_PF
 #define C64V_PF 8
@@ -346,9 +351,11 @@ __global__ __launch_bounds__(256) void c64_bin_wgemm_kernel(const float* __restr
       const float a = ra[p];
       const float b0 = rb[p][0], b1 = rb[p][1], b2 = rb[p][2], b3 = rb[p][3];
       // unconditional reload, clamped to the chunk's last K-step (a branch here made hipcc copy the whole register window)
+#ifndef C64V_ABL_NOLOAD      // (timing-only ablation: the MFMA side alone)
       const int64_t o = (int64_t)min(ks0 + PF + p, nks - 1) * 256;
       ra[p] = dp[o];
       rb[p][0] = zp[o]; rb[p][1] = zp[o + 32]; rb[p][2] = zp[o + 64]; rb[p][3] = zp[o + 96];
+#endif
       acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
       acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
       acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b2, acc[2], 0, 0, 0);

@@ -81,9 +81,13 @@ def avg(name):
 
 
 parts = [("FIR forward (FFT)", avg("fir_fft_fwd_kernel")),
-         ("FIR weight gradient (FFT) + finish", avg("fir_fft_wgrad_kernel<false>") + avg("fir_fft_wgrad_finish_kernel")),
+         ("FIR weight gradient (FFT) + sum + finish", avg("fir_fft_wgrad_kernel<false>") + avg("fir_fft_wgrad_sum_kernel")
+          + avg("fir_fft_wgrad_finish_kernel")),
          ("dw_fwd", avg("dw_fwd_kernel")), ("dw_bwd (fused)", avg("dw_bwd_kernel<true>")),
-         ("conv64 fwd + dgrad", 2 * avg("conv64_fwd_kernel<128>")), ("conv64 wgrad", avg("conv64_wgrad_kernel")),
+         ("separableConv fwd + dgrad (spectra, FFT, per-bin GEMM, IFFT)",
+          avg("c64_spectra_kernel") + 2 * (avg("c64_bin_gemm_kernel") + avg("c64_ifft_unpack_kernel")) + 2 * avg("c64_pack_fft_kernel")),
+         ("separableConv wgrad (FFT, per-bin GEMM, sum, IFFT)",
+          avg("c64_pack_fft_kernel") + avg("c64_bin_wgemm_kernel") + avg("c64_wsum_kernel") + avg("c64_wfinish_kernel")),
          ("pool fwd / bwd (P = 4, 8)", avg("pool_fwd_kernel<4>") + avg("pool_bwd_reduce_kernel<4>") + avg("pool_fwd_kernel<8>")
           + avg("pool_bwd_reduce_kernel<8>") + avg("pool_bwd_apply_kernel<8>"))]
 known = sum(p[1] for p in parts)

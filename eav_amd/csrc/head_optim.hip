@@ -24,14 +24,36 @@ __global__ __launch_bounds__(1024) void dense_softmax_fwd_kernel(const float* __
   for (int j = 0; j < NCMAX; ++j) acc[j] = 0.f;
   if ((NF & 3) == 0) {      // 16 B per lane: the kernel is pure load latency (one block per sample)
     const int nq = NF >> 2;
-    for (int i = threadIdx.x; i < nq; i += 1024) {
-      const float4 v = reinterpret_cast<const float4*>(src)[i];
+    if (NC <= 5) {
+      // the reference's 5 classes: four strides of the feature vector at a time, all 4 + 20 loads in flight before the first
+      // product (one stride per trip left a 64-block launch waiting on memory five times over: 19 us at NF = 19 968)
+      for (int i0 = threadIdx.x; i0 < nq; i0 += 4096) {
+        float4 v[4], wv[4][5];
 #pragma unroll
-      for (int j = 0; j < NCMAX; ++j)
-        if (j < NC) {
-          const float4 wv = reinterpret_cast<const float4*>(w + (int64_t)j * NF)[i];
-          acc[j] += (wv.x * v.x + wv.y * v.y) + (wv.z * v.z + wv.w * v.w);
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + 1024 * u;
+          const bool ok = i < nq;
+          v[u] = ok ? reinterpret_cast<const float4*>(src)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+          for (int j = 0; j < 5; ++j)
+            wv[u][j] = (ok && j < NC) ? reinterpret_cast<const float4*>(w + (int64_t)j * NF)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int j = 0; j < 5; ++j)
+            acc[j] += (wv[u][j].x * v[u].x + wv[u][j].y * v[u].y) + (wv[u][j].z * v[u].z + wv[u][j].w * v[u].w);
+      }
+    } else {
+      for (int i = threadIdx.x; i < nq; i += 1024) {
+        const float4 v = reinterpret_cast<const float4*>(src)[i];
+#pragma unroll
+        for (int j = 0; j < NCMAX; ++j)
+          if (j < NC) {
+            const float4 wv = reinterpret_cast<const float4*>(w + (int64_t)j * NF)[i];
+            acc[j] += (wv.x * v.x + wv.y * v.y) + (wv.z * v.z + wv.w * v.w);
+          }
+      }
     }
   } else {
     for (int i = threadIdx.x; i < NF; i += 1024) {

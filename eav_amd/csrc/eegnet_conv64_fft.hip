@@ -224,7 +224,9 @@ __global__ __launch_bounds__(256) void c64_bin_gemm_kernel(const float* __restri
   __syncthreads();
   for (; tile < ntiles; tile += gridDim.x) {
     const int nxt = tile + gridDim.x;
+#ifndef C64V_ABL_NOFETCH
     if (nxt < ntiles) fetch(nxt);
+#endif
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -233,7 +235,11 @@ __global__ __launch_bounds__(256) void c64_bin_gemm_kernel(const float* __restri
     const float* ap = xs[buf] + n * XS + kk;
     float av[64];
 #pragma unroll
+#ifdef C64V_ABL_NOLDS
+    for (int ks = 0; ks < 64; ++ks) av[ks] = 1.0f + ks;
+#else
     for (int ks = 0; ks < 64; ++ks) av[ks] = ap[2 * ks];
+#endif
     __builtin_amdgcn_sched_barrier(0);            // (the scheduler otherwise sinks the reads back between the MFMAs)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
@@ -246,7 +252,9 @@ __global__ __launch_bounds__(256) void c64_bin_gemm_kernel(const float* __restri
 #endif
 #pragma unroll
     for (int r = 0; r < 16; ++r) dst[(int64_t)((r & 3) + 8 * (r >> 2) + 4 * kk) * 128] = acc[r];
+#ifndef C64V_ABL_NOFETCH
     if (nxt < ntiles) commit(buf ^ 1);
+#endif
     // raw barrier: __syncthreads() would also wait for this tile's 16 global stores per lane (vmcnt(0)) at every tile
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();

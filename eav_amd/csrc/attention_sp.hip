@@ -21,6 +21,8 @@
 // layout every lane owns one stationary row and its registers 8s..8s+7 are 8 CONSECUTIVE streamed rows - exactly one
 // B-operand fragment of the next product (no shuffles, no LDS round trip for P / dS), and softmax row statistics are
 // register-local plus one exchange with lane^32.
+#include <type_traits>
+
 #include "eav_common.h"
 #include "../../include/eav_hip.h"
 
@@ -55,6 +57,9 @@ __device__ __forceinline__ void split_frag(const float* t, float lomul, f16x8& h
   }
 }
 
+#ifndef ATTN_ABL
+#define ATTN_ABL 0     // timing-only ablations of the forward loop (results are garbage): 1 no softmax arithmetic, 2 no MFMAs, 4 no streaming
+#endif
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
 
 // ---- LDS images -----------------------------------------------------------------------------------------------
@@ -199,6 +204,12 @@ __device__ __forceinline__ void attn_block_map(int ntile, int nbh, int& tile, in
   }
 }
 
+#if ATTN_ABL & 2
+#define FMF(a, b, c) fake_mfma(a, b, c)
+__device__ __forceinline__ f32x16 fake_mfma(f16x8 a, f16x8 b, f32x16 c) { c[0] += (float)a[0] * (float)b[0]; return c; }
+#else
+#define FMF(a, b, c) MFMA16(a, b, c)
+#endif
 template <int NW>
 __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_sp_kernel(const u8* __restrict__ rowp, const u8* __restrict__ tp,
                                                                  const float* __restrict__ slot, float* __restrict__ ao,
@@ -243,9 +254,15 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_sp_kernel(const u8* __res
     const int buf = kt & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+#if !(ATTN_ABL & 4)
     if (kt + 1 < nkt) issue(kt + 1, buf ^ 1);
+#endif
     if (q0 >= N) continue;                 // wave-uniform: a wave without a valid row only helps to stage the tiles
+#if ATTN_ABL & 4
+    const u8* kt_ = smem;
+#else
     const u8* kt_ = smem + buf * STAGE;
+#endif
     const u8* vt_ = kt_ + 8192;
     f32x16 s;
 #pragma unroll
@@ -253,9 +270,9 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_sp_kernel(const u8* __res
 #pragma unroll
     for (int st = 0; st < 4; ++st) {       // S^T[key][q] = K-tile . Q^T
       const f16x8 kh = frag_row(kt_, prow, st, h2, 0), kl = frag_row(kt_, prow, st, h2, 1);
-      s = MFMA16(kh, qh[st], s);
-      s = MFMA16(kl, qh[st], s);
-      s = MFMA16(kh, ql[st], s);
+      s = FMF(kh, qh[st], s);
+      s = FMF(kl, qh[st], s);
+      s = FMF(kh, ql[st], s);
     }
     // register r <-> key 32 kt + (r&7) + 8 h2 + 16 (r>>3)
 #pragma unroll
@@ -265,6 +282,11 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_sp_kernel(const u8* __res
       for (int r = 0; r < 16; ++r)
         if (32 * kt + (r & 7) + 8 * h2 + 16 * (r >> 3) >= N) s[r] = -INFINITY;
     }
+    f16x8 ph[2], pl[2];
+#if ATTN_ABL & 1
+    for (int e = 0; e < 8; ++e) { ph[0][e] = (_Float16)s[e]; ph[1][e] = (_Float16)s[8 + e]; pl[0][e] = ph[1][e]; pl[1][e] = ph[0][e]; }
+    l += 1.f; m = 0.f;
+#else
     float mx = s[0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
@@ -284,19 +306,19 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_sp_kernel(const u8* __res
     m = mn;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
-    f16x8 ph[2], pl[2];
     split_frag(pt, 1.f, ph[0], pl[0]);
     split_frag(pt + 8, 1.f, ph[1], pl[1]);
+#endif
 #pragma unroll
     for (int st = 0; st < 2; ++st) {       // O^T[d][q] += V^T[d][key] . P^T[key][q]
       const f16x8 v0h = frag_tr(vt_, 0, st, 0, lane), v0l = frag_tr(vt_, 0, st, 1, lane);
       const f16x8 v1h = frag_tr(vt_, 32, st, 0, lane), v1l = frag_tr(vt_, 32, st, 1, lane);
-      o0 = MFMA16(v0h, ph[st], o0);
-      o1 = MFMA16(v1h, ph[st], o1);
-      o0 = MFMA16(v0l, ph[st], o0);
-      o1 = MFMA16(v1l, ph[st], o1);
-      o0 = MFMA16(v0h, pl[st], o0);
-      o1 = MFMA16(v1h, pl[st], o1);
+      o0 = FMF(v0h, ph[st], o0);
+      o1 = FMF(v1h, ph[st], o1);
+      o0 = FMF(v0l, ph[st], o0);
+      o1 = FMF(v1l, ph[st], o1);
+      o0 = FMF(v0h, pl[st], o0);
+      o1 = FMF(v1h, pl[st], o1);
     }
   }
   const float inv = l > 0.f ? isg / (l * SP) : 0.f;
@@ -310,6 +332,353 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_sp_kernel(const u8* __res
     slot_ao[EAV_SLOT_ISIGMA] = isg;
   }
   const float vmax = store_rows_T(reinterpret_cast<float*>(smem) + wave * (32 * 33), o0, o1, inv,
+                                  ao ? ao + (int64_t)b * N * D + h * 64 : nullptr, D, q0, N, lane,
+                                  aop ? aop + (int64_t)b * N * (D * 4) + h * 256 : nullptr, (int64_t)D * 4, psig);
+  emit_amax(amax, vmax, lane, (int)blockIdx.x * NW + wave, q0 < N ? b * N + q0 : -1);
+}
+
+// ------------------------------------------------------------------------------------------------ forward, pipelined
+// The same arithmetic as attn_fwd_sp_kernel with the tile loop software-pipelined INSIDE a wave (long sequences: the
+// launcher picks it above g_fwd2_above keys).  Per key tile t two regions:
+//   R1  the twelve score MFMAs of tile t + 1   ||  exponentials, row sums and hi / lo split of the probabilities of tile t
+//   R2  the twelve P.V MFMAs of tile t         ||  row maxima of the scores of tile t + 1
+// so the matrix pipe has work while the wave's VALU slots carry the softmax.  The running maximum is a REFERENCE m, moved
+// (O and l rescaled) only when some row of the wave sees a score more than 1 (log2 units) above it - probabilities are
+// then at most 2, times 2^14 still fp16 - which on all but the first tiles skips the 32-register rescale.  K and V rows
+// stream through two rings of three 8-KB tiles (K two tiles ahead of its score product, V two ahead of its P.V product;
+// LDS-DMA issued from asm with counted vmcnt waits, one barrier per tile); every LDS fragment address is a per-lane
+// register + an immediate (the loop is unrolled over the three ring positions).  Row sums stay per lane half (keys
+// 8 h2 .. of every 16) until the end.  Compiled with -fno-slp-vectorize (Makefile): the split of a probability pair is
+// then v_cvt_pk_f16_f32 + v_fma_mixlo_f16 + v_fma_mixhi_f16, three instructions instead of seven.
+struct FwdSt {
+  f16x8 qh[4], ql[4];
+  f32x16 o0, o1, s;
+  float m, l;
+};
+
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// 8 fp32 -> hi and lo fragments; neg1 = -1.0f held in a register the optimiser cannot see through (fma(hi, -1, t) would be
+// rewritten as a subtraction of a converted value; as an fma it is one v_fma_mix*_f16 reading the packed hi directly)
+__device__ __forceinline__ void split_frag_mix(const float* t, float neg1, f16x8& hi, f16x8& lo) {
+#pragma unroll
+  for (int e = 0; e < 8; e += 2) {
+    const f32x2 tt = {t[e], t[e + 1]};
+    const f16x2 h = __builtin_convertvector(tt, f16x2);
+    hi[e] = h[0];
+    hi[e + 1] = h[1];
+    lo[e] = (_Float16)__builtin_fmaf((float)h[0], neg1, t[e]);
+    lo[e + 1] = (_Float16)__builtin_fmaf((float)h[1], neg1, t[e + 1]);
+  }
+}
+
+#define SBAR() __builtin_amdgcn_sched_barrier(0)
+#define ATTN_DMA(voff, base, dst) \
+  asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(dst) : "memory")
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 2) void attn_fwd_sp2_kernel(const u8* __restrict__ rowp, const float* __restrict__ slot,
+                                                                  float* __restrict__ ao, float* __restrict__ lse,
+                                                                  unsigned* __restrict__ amax, int N, int H, float scale,
+                                                                  int ntile, int nbh, u8* __restrict__ aop,
+                                                                  float* __restrict__ slot_ao) {
+  constexpr int TILE = 8192, CH = 8 / NW;
+  __shared__ __attribute__((aligned(1024))) u8 smem[6 * TILE];   // K ring [0, 3), V ring [3, 6) (48 KB >= the epilogue patches)
+  static_assert(6 * TILE >= NW * 32 * 33 * 4, "epilogue patches alias the rings");
+  const int D = H * 64;
+  const int ldrow = 3 * D * 4;
+  int tile_, bh;
+  attn_block_map(ntile, nbh, tile_, bh);
+  const int b = bh / H, h = bh - b * H;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 31, h2 = lane >> 5;
+  const int q0 = tile_ * 32 * NW + wave * 32;
+  const bool active = q0 < N;                 // (wave-uniform) a wave without a valid row only helps to stage the tiles
+  const u8* rows_b = rowp + (int64_t)b * N * ldrow;
+  FwdSt f;
+  load_row_frags(rows_b + (int64_t)min(q0 + j, N - 1) * ldrow + h * 256, h2, f.qh, f.ql);
+  const u8* kbase = rows_b + (int64_t)(D + h * 64) * 4;
+  const u8* vbase = rows_b + (int64_t)(2 * D + h * 64) * 4;
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)smem;
+  const int nkt = (N + 31) / 32;
+  float neg1;
+  asm volatile("s_mov_b32 %0, 0xbf800000" : "=s"(neg1));
+  // chunk c of a tile = rows 4c .. 4c+3; this lane's row and 16-byte piece (source side of the XOR swizzle)
+  int crow[CH];
+  unsigned cpo[CH];
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    const int c = wave + NW * i;
+    crow[i] = 4 * c + (lane >> 4);
+    cpo[i] = (unsigned)(((lane & 15) ^ (crow[i] & 15)) * 16);
+  }
+  auto issue_k = [&](int t) {                   // K rows of tile t -> K ring position t % 3
+    const unsigned dst = lds0 + (unsigned)(t % 3) * TILE;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const unsigned vo = (unsigned)min(32 * t + crow[i], N - 1) * (unsigned)ldrow + cpo[i];
+      ATTN_DMA(vo, kbase, dst + (unsigned)(wave + NW * i) * 1024u);
+    }
+  };
+  auto issue_v = [&](int t) {
+    const unsigned dst = lds0 + (unsigned)(3 + t % 3) * TILE;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const unsigned vo = (unsigned)min(32 * t + crow[i], N - 1) * (unsigned)ldrow + cpo[i];
+      ATTN_DMA(vo, vbase, dst + (unsigned)(wave + NW * i) * 1024u);
+    }
+  };
+  // fragment addresses inside a tile (per lane; ring position and token step are immediates)
+  const int prow = pi_row(j);
+  int kofs[4][2];                               // K row fragment [head_dim step][hl]
+#pragma unroll
+  for (int st = 0; st < 4; ++st)
+#pragma unroll
+    for (int hl = 0; hl < 2; ++hl) kofs[st][hl] = prow * 256 + (((4 * st + 2 * h2 + hl) ^ (prow & 15)) << 4);
+  int vofs[2][2][2];                            // V transposing reads: [dbase / 32][hl][token + 4]
+  {
+    const int G = lane >> 4, r = (lane >> 2) & 3, q = lane & 3;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int hl = 0; hl < 2; ++hl)
+#pragma unroll
+        for (int ab = 0; ab < 2; ++ab) {
+          const int piece = 2 * (4 * db + 2 * (G & 1) + (q >> 1)) + hl;
+          const int tok = 8 * (G >> 1) + r + 4 * ab;
+          vofs[db][hl][ab] = tok * 256 + ((piece ^ (tok & 15)) << 4) + ((q & 1) << 3);
+        }
+  }
+  const float isg = slot[EAV_SLOT_ISIGMA];
+  const float c1 = scale * LOG2E * isg * isg;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { f.o0[r] = 0.f; f.o1[r] = 0.f; f.s[r] = 0.f; }
+  f.m = -INFINITY;
+  f.l = 0.f;
+
+  auto scores = [&](const u8* kt_, f32x16& s) {      // s = K-tile . Q^T (raw operand units)
+    f16x8 kh[4], kl[4];
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      kh[st] = *reinterpret_cast<const f16x8*>(kt_ + kofs[st][0]);
+      kl[st] = *reinterpret_cast<const f16x8*>(kt_ + kofs[st][1]);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      s = FMF(kh[st], f.qh[st], s);
+      s = FMF(kl[st], f.qh[st], s);
+      s = FMF(kh[st], f.ql[st], s);
+    }
+  };
+  // row maximum (log2 units) of a score tile.  The ragged last tile needs no mask here: its rows beyond N are copies of
+  // key N - 1 (the DMA clamps the row index), which cannot raise the maximum; their probabilities are zeroed in the last step.
+  auto tile_max = [&](const f32x16& s) {
+    float mx = fmaxf(fmaxf(s[0], s[1]), s[2]);
+#pragma unroll
+    for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, s[r]), s[r + 1]);
+    mx = fmaxf(mx, s[15]);
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+    return fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1])) * c1;
+  };
+  // move the reference maximum when some row of the wave needs it (wave-uniform branch)
+  auto rebase = [&](float mx) {
+    if (__builtin_amdgcn_ballot_w64(mx > f.m + 1.0f) != 0) {
+      const float mn = fmaxf(f.m, mx);
+      const float alpha = ex2(f.m - mn);
+      f.m = mn;
+      f.l *= alpha;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { f.o0[r] *= alpha; f.o1[r] *= alpha; }
+    }
+  };
+
+  // one tile.  RP = ring position of tile kt; MORE: a tile kt + 1 exists (else: the last, possibly ragged, tile).
+  // The order below is the issue order (sched_barrier after every MFMA group pins it): one MFMA, then its fillers.
+  auto step = [&](auto RPc, auto MOREc, int kt) {
+    constexpr int RP = decltype(RPc)::value;
+    constexpr bool MORE = decltype(MOREc)::value;
+    const u8* kn_ = smem + ((RP + 1) % 3) * TILE;
+    const u8* vt_ = smem + (3 + RP) * TILE;
+    f32x16 sn;
+    f16x8 kh[4], kl[4];
+    f16x8 v[2][2][2];                            // V^T fragments [token step][dbase][hl]
+    f16x8 ph[2], pl[2];
+    float pt[16];
+    float rs = 0.f;
+    const float sh = 14.f - f.m;                 // probabilities leave the exponential already scaled by 2^14 (SP)
+    SBAR();
+    if constexpr (MORE) {
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        kh[st] = *reinterpret_cast<const f16x8*>(kn_ + kofs[st][0]);
+        kl[st] = *reinterpret_cast<const f16x8*>(kn_ + kofs[st][1]);
+      }
+    }
+    auto expo = [&](int r) {
+#if ATTN_ABL & 1
+      pt[r] = f.s[r];
+#else
+      pt[r] = ex2(fmaf(f.s[r], c1, sh));
+      if constexpr (!MORE) {
+        if (32 * kt + (r & 7) + 8 * h2 + 16 * (r >> 3) >= N) pt[r] = 0.f;
+      }
+      rs += pt[r];
+#endif
+    };
+    auto split2 = [&](int pr) {                  // probabilities 2 pr, 2 pr + 1 -> their halves of the hi / lo fragments
+      const int e = (2 * pr) & 7, fr = pr >> 2;
+      const f32x2 tt = {pt[2 * pr], pt[2 * pr + 1]};
+      const f16x2 hh = __builtin_convertvector(tt, f16x2);
+      ph[fr][e] = hh[0];
+      ph[fr][e + 1] = hh[1];
+      pl[fr][e] = (_Float16)__builtin_fmaf((float)hh[0], neg1, pt[2 * pr]);
+      pl[fr][e + 1] = (_Float16)__builtin_fmaf((float)hh[1], neg1, pt[2 * pr + 1]);
+    };
+    auto vread = [&](int i) {                    // i = 4 st + 2 db + hl
+      const int st = i >> 2, db = (i >> 1) & 1, hl = i & 1;
+      const f16x4 a = __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (lds_s16x4_ptr)(vt_ + vofs[db][hl][0] + st * 4096)));
+      const f16x4 c = __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (lds_s16x4_ptr)(vt_ + vofs[db][hl][1] + st * 4096)));
+      v[st][db][hl].lo = a;
+      v[st][db][hl].hi = c;
+    };
+    // head: the first exponentials cover the latency of the K fragment reads
+#pragma unroll
+    for (int r = 0; r < 6; ++r) expo(r);
+    SBAR();
+    // R1: scores of tile kt + 1 || exponentials 6 .. 15, split, V fragments of token step 0
+#pragma unroll
+    for (int g = 0; g < 12; ++g) {
+      if constexpr (MORE) {
+        const int st = g / 3, term = g - 3 * st;
+        if (g == 0) {
+          const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          sn = FMF(kh[0], f.qh[0], zero);
+        } else if (term == 0) sn = FMF(kh[st], f.qh[st], sn);
+        else if (term == 1) sn = FMF(kl[st], f.qh[st], sn);
+        else sn = FMF(kh[st], f.ql[st], sn);
+      }
+      if (g < 10) expo(6 + g);
+      if (g <= 4) split2(g);
+      else if (g == 6) split2(5);
+      else if (g == 8) split2(6);
+      else if (g == 10) split2(7);
+      if (g >= 4 && g < 8) vread(g - 4);
+      SBAR();
+    }
+    f.l += rs;
+    // R2: P.V of tile kt || V fragments of token step 1, row maxima of the scores of tile kt + 1
+    float mxa = 0.f, mxb = 0.f;
+#pragma unroll
+    for (int g = 0; g < 12; ++g) {
+      const int st = g / 6, i = g - 6 * st;
+      if (i == 0) f.o0 = FMF(v[st][0][0], ph[st], f.o0);
+      else if (i == 1) f.o1 = FMF(v[st][1][0], ph[st], f.o1);
+      else if (i == 2) f.o0 = FMF(v[st][0][1], ph[st], f.o0);
+      else if (i == 3) f.o1 = FMF(v[st][1][1], ph[st], f.o1);
+      else if (i == 4) f.o0 = FMF(v[st][0][0], pl[st], f.o0);
+      else f.o1 = FMF(v[st][1][0], pl[st], f.o1);
+      if (g < 4) vread(4 + g);
+      if constexpr (MORE) {
+#if !(ATTN_ABL & 1)
+        if (g == 3) { mxa = fmaxf(fmaxf(sn[0], sn[1]), sn[2]); mxb = fmaxf(fmaxf(sn[3], sn[4]), sn[5]); }
+        if (g == 4) { mxa = fmaxf(fmaxf(mxa, sn[6]), sn[7]); mxb = fmaxf(fmaxf(mxb, sn[8]), sn[9]); }
+        if (g == 5) { mxa = fmaxf(fmaxf(mxa, sn[10]), sn[11]); mxb = fmaxf(fmaxf(mxb, sn[12]), sn[13]); }
+        if (g == 6) { mxa = fmaxf(fmaxf(mxa, sn[14]), sn[15]); mxa = fmaxf(mxa, mxb); }
+        if (g == 7) {
+          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mxa), __float_as_uint(mxa), false, false);
+          mxa = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1])) * c1;
+        }
+#endif
+      }
+      SBAR();
+    }
+    if constexpr (MORE) {
+      f.s = sn;
+#if !(ATTN_ABL & 1)
+      rebase(mxa);
+#endif
+    }
+  };
+
+  // ---- prologue: K(0), V(0), K(1) | K(2), V(1); scores of tile 0
+  issue_k(0);
+  issue_v(0);
+  if (nkt > 1) issue_k(1);
+  if (nkt > 2) issue_k(2);
+  if (nkt > 1) issue_v(1);
+  if (nkt > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * CH) : "memory");
+  else if (nkt > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CH) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  // ---- tiles.  At the top of tile kt everything but the newest group (K(kt+2), V(kt+1)) has landed: K(kt+1), V(kt).
+  auto top = [&](int kt) {
+#if !(ATTN_ABL & 4)
+    if (kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * CH) : "memory");
+    else if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CH) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+#if !(ATTN_ABL & 8)
+    __builtin_amdgcn_s_barrier();
+#endif
+#if !(ATTN_ABL & 4)
+    if (kt + 3 < nkt) issue_k(kt + 3);          // into the ring position of K(kt): its scores were formed in tile kt - 1
+    if (kt + 2 < nkt) issue_v(kt + 2);          // into the position of V(kt - 1)
+#endif
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using T = std::true_type;
+  using F = std::false_type;
+  if (!active) {                                 // (wave-uniform) no valid row: this wave only stages its share of the tiles
+    for (int kt = 0; kt < nkt; ++kt) top(kt);
+  } else {
+    scores(smem, f.s);
+    f.m = tile_max(f.s);                         // (O and l are still zero: nothing to rescale)
+    int kt = 0;
+    for (; kt + 3 < nkt; kt += 3) {              // ring position of tile kt is 0 at the top of every round
+      top(kt);
+      step(I0{}, T{}, kt);
+      top(kt + 1);
+      step(I1{}, T{}, kt + 1);
+      top(kt + 2);
+      step(I2{}, T{}, kt + 2);
+    }
+    const int rem = nkt - kt;                    // 1 .. 3 tiles left, the last one without a successor
+    if (rem > 1) {
+      top(kt);
+      step(I0{}, T{}, kt);
+      ++kt;
+    }
+    if (rem > 2) {
+      top(kt);
+      step(I1{}, T{}, kt);
+      ++kt;
+    }
+    top(kt);
+    if (rem == 1) step(I0{}, F{}, kt);
+    else if (rem == 2) step(I1{}, F{}, kt);
+    else step(I2{}, F{}, kt);
+  }
+  float l = f.l;
+  {
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l), __float_as_uint(l), false, false);
+    l = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+  }
+  const float inv = l > 0.f ? isg / l : 0.f;     // l carries the 2^14 of the probabilities
+  if (h2 == 0 && q0 + j < N) lse[(int64_t)bh * N + q0 + j] = (f.m + log2f(l) - 14.f) * LN2;
+  __syncthreads();   // every wave is done with the tiles before the patch area is reused
+  const float psig = aop ? slot[EAV_SLOT_SIGMA] : 0.f;
+  if (aop && blockIdx.x == 0 && threadIdx.x == 0) {
+    slot_ao[EAV_SLOT_SIGMA] = psig;
+    slot_ao[EAV_SLOT_ISIGMA] = isg;
+  }
+  const float vmax = store_rows_T(reinterpret_cast<float*>(smem) + wave * (32 * 33), f.o0, f.o1, inv,
                                   ao ? ao + (int64_t)b * N * D + h * 64 : nullptr, D, q0, N, lane,
                                   aop ? aop + (int64_t)b * N * (D * 4) + h * 256 : nullptr, (int64_t)D * 4, psig);
   emit_amax(amax, vmax, lane, (int)blockIdx.x * NW + wave, q0 < N ? b * N + q0 : -1);
@@ -672,7 +1041,12 @@ extern "C" int eav_attn_sp_prep(const float* src, float* slot, void* rowp, void*
 // backward 418 -> 379 us with 4 waves (half as many re-reads of a head's K / V planes, one idle wave instead of one idle
 // half-block); tuning hook
 int g_nw4_above = 128;
-extern "C" int eav_attn_sp_set_nw4_above(int n) { g_nw4_above = n; return 0; }
+int g_fwd2_from = 512;        // forward: the software-pipelined kernel from this sequence length on (negative argument of the hook)
+extern "C" int eav_attn_sp_set_nw4_above(int n) {
+  if (n < 0) g_fwd2_from = -n;
+  else g_nw4_above = n;
+  return 0;
+}
 
 // ao_planes (optional): the output as the GEMM operand planes [B*N][D/8][2][8] of the o-proj products, scaled with qkv's own
 // sigma (|O| <= max|V|), which the kernel copies into ao_slot; ao may then be null (no fp32 copy: forward-only passes).
@@ -684,6 +1058,14 @@ extern "C" int eav_attn_fwd_sp_planes(const void* rowp, const void* tp, const fl
   EAV_REQUIRE(head_dim == 64, "eav_attn_fwd_sp: head_dim %d unsupported (needs 64)", head_dim);
   const int Npad = eav_attn_sp_npad(N);
   hipStream_t st = (hipStream_t)stream;
+  // long sequences (AST: 1214 tokens): the software-pipelined kernel, 152 -> 120 us per layer at B = 8; short ones (ViT: 197
+  // tokens, 7 key tiles, bound by its HBM traffic and its per-workgroup prologue) stay on the plain loop (86 against 105 us)
+  if (N >= g_fwd2_from) {
+    hipLaunchKernelGGL(attn_fwd_sp2_kernel<4>, dim3(cdiv(N, 128) * B * H), dim3(256), 0, st, (const u8*)rowp, slot, ao, lse,
+                       (unsigned*)amax_slot, N, H, scale, cdiv(N, 128), B * H, (u8*)ao_planes, ao_slot);
+    EAV_CHECK_LAUNCH("eav_attn_fwd_sp");
+    return EAV_OK;
+  }
   if (N > g_nw4_above) {
     hipLaunchKernelGGL(attn_fwd_sp_kernel<4>, dim3(cdiv(N, 128) * B * H), dim3(256), 0, st, (const u8*)rowp,
                        (const u8*)tp, slot, ao, lse, (unsigned*)amax_slot, N, Npad, H, scale, cdiv(N, 128), B * H,

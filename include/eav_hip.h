@@ -388,7 +388,7 @@ int eav_sp_set_convert_blocks(int n);  /* resident-block cap of eav_sp_convert (
  * tmask, per-head transposed planes [B][ncols/64][64][Npad/8][2][8] (Npad = eav_attn_sp_npad(N), zero beyond N); here
  * lo = fp16(sigma x - hi) without the 2^11 lift of the GEMM planes.  amax_slot (optional) receives max|output| shards. */
 int eav_attn_sp_npad(int N);
-int eav_attn_sp_set_nw4_above(int n);   /* TEST / TUNING ONLY (as eav_gemm_sp_set_tile): 128-row (4-wave) workgroups for N > n (default 128) */
+int eav_attn_sp_set_nw4_above(int n);   /* TEST / TUNING ONLY (as eav_gemm_sp_set_tile): 128-row (4-wave) workgroups for N > n (default 128); n < 0: the software-pipelined forward from N >= -n (default 512) */
 int eav_attn_sp_prep(const float* src, float* slot, void* rowp, void* tp, int B, int N, int ncols, int secw,
                      unsigned tmask, void* stream);
 /* Since round 3 the three attention kernels take their token-contracting operands (V in the forward, K in the dQ kernel,

@@ -1,0 +1,18 @@
+#!/bin/bash
+# ON THE GPU BOX: SQ counters of the split-operand attention kernels (tools/attn_sp_time.py); per-kernel means by tools/rocpd_pmc.py
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
+OUT=$R/gpurun_out/attn_pmc
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+WHAT=${1:-fwd}
+SHAPE=$2
+i=0
+for PMC in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY"; do
+  i=$((i+1))
+  rm -rf $OUT/p$i
+  timeout 300 rocprofv3 --kernel-trace --pmc $PMC -d $OUT/p$i -o p -- python3 $R/tools/attn_sp_time.py $WHAT $SHAPE > $OUT/p$i.log 2>&1
+  DB=$(find $OUT/p$i -name "*.db" | head -1)
+  echo "== $PMC"
+  if [ -n "$DB" ]; then python3 $R/tools/rocpd_pmc.py $DB attn_ | grep -v "^    launches" ; else tail -3 $OUT/p$i.log; fi
+done
+find $OUT -name "*.db" -delete

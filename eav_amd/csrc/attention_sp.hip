@@ -67,6 +67,21 @@ __device__ __forceinline__ void split_frag(const float* t, float lomul, f16x8& h
 // "T tile"  : 64 head_dim rows x 32 tokens = 64 x 128 B (8 pieces per row), slot = d*8 + (p ^ ((d >> 1) & 7))
 // both 8 KB = 8 global_load_lds instructions of 1 KB.  src_row: pointer to the row's first byte of this tile.
 // chunk c of a row tile = rows 4c..4c+3; of a T tile = rows 8c..8c+7.
+// The LDS-DMA is issued from inline asm (wave-uniform 64-bit base + a 32-bit per-lane offset), not through
+// __builtin_amdgcn_global_load_lds: hipcc puts an `s_waitcnt vmcnt(0)` in front of the first LDS read that follows a DMA
+// builtin it cannot disambiguate - in these loops right after the prefetch of the NEXT tile was issued, i.e. the prefetch
+// was waited for before the current tile's products (no overlap at all).  An asm DMA is invisible to that pass; the waits
+// that order DMA and fragment reads are the explicit ones at the top of every tile.
+#define SBAR() __builtin_amdgcn_sched_barrier(0)
+#define ATTN_DMA(voff, base, dst) \
+  asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(dst) : "memory")
+// chunk c (rows 4c .. 4c+3) of a 32-row tile whose first row is row0 (clamped to max_row) -> the row-tile image at lds_tile
+__device__ __forceinline__ void dma_row_chunk(unsigned lds_tile, int c, const u8* base, unsigned row_stride, int row0,
+                                              int max_row, int lane) {
+  const int r = 4 * c + (lane >> 4);
+  const unsigned vo = (unsigned)min(row0 + r, max_row) * row_stride + (unsigned)(((lane & 15) ^ (r & 15)) * 16);
+  ATTN_DMA(vo, base, lds_tile + (unsigned)c * 1024u);
+}
 __device__ __forceinline__ void glds_row_chunk(u8* lds_tile, int c, const u8* base, int64_t row_stride, int row0,
                                                int max_row, int lane) {
   const int r = 4 * c + (lane >> 4);
@@ -232,13 +247,14 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_sp_kernel(const u8* __res
   load_row_frags(rows_b + (int64_t)min(q0 + j, N - 1) * ldrow + h * 256, h2, qh, ql);
   const u8* kbase = rows_b + (int64_t)(D + h * 64) * 4;
   const u8* vbase = rows_b + (int64_t)(2 * D + h * 64) * 4;
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)smem;
   auto issue = [&](int kt, int buf) {
-    u8* st = smem + buf * STAGE;
+    const unsigned st = lds0 + buf * STAGE;
 #pragma unroll
     for (int i = 0; i < 8 / NW; ++i) {
       const int c = wave + NW * i;
-      glds_row_chunk(st, c, kbase, ldrow, 32 * kt, N - 1, lane);
-      glds_row_chunk(st + 8192, c, vbase, ldrow, 32 * kt, N - 1, lane);      // V ROWS: read transposed (frag_tr)
+      dma_row_chunk(st, c, kbase, (unsigned)ldrow, 32 * kt, N - 1, lane);
+      dma_row_chunk(st + 8192, c, vbase, (unsigned)ldrow, 32 * kt, N - 1, lane);      // V ROWS: read transposed (frag_tr)
     }
   };
   const float isg = slot[EAV_SLOT_ISIGMA];
@@ -372,17 +388,30 @@ __device__ __forceinline__ void split_frag_mix(const float* t, float neg1, f16x8
   }
 }
 
-#define SBAR() __builtin_amdgcn_sched_barrier(0)
-#define ATTN_DMA(voff, base, dst) \
-  asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(dst) : "memory")
 
 template <int NW>
-__global__ __launch_bounds__(64 * NW, 2) void attn_fwd_sp2_kernel(const u8* __restrict__ rowp, const float* __restrict__ slot,
+__global__ __launch_bounds__(64 * NW, 1) void attn_fwd_sp2_kernel(const u8* __restrict__ rowp, const float* __restrict__ slot,
                                                                   float* __restrict__ ao, float* __restrict__ lse,
                                                                   unsigned* __restrict__ amax, int N, int H, float scale,
                                                                   int ntile, int nbh, u8* __restrict__ aop,
                                                                   float* __restrict__ slot_ao) {
   constexpr int TILE = 8192, CH = 8 / NW;
+#ifdef ATTN_TRACE
+  unsigned long long trc_last = __builtin_readcyclecounter();
+  unsigned trc_sum[5] = {0, 0, 0, 0, 0};       // cycles ending at marker i: 0 = rebase/loop -> top, 1 = top, 2 = R1, 3 = R2, 4 = rebase
+#define TRC(i) { const unsigned long long n_ = __builtin_readcyclecounter(); trc_sum[i] += (unsigned)(n_ - trc_last); trc_last = n_; }
+#else
+#define TRC(i)
+#endif
+#ifdef ATTN_TRACE     // debug build: per-workgroup start / end wall clock and hardware id behind the lse rows (tools/probes/attn_trace.py)
+  unsigned long long trace_t0 = 0;
+  unsigned trace_hw = 0, trace_xcc = 0;
+  if (threadIdx.x == 0) {
+    trace_t0 = wall_clock64();
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(trace_hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(trace_xcc));
+  }
+#endif
   __shared__ __attribute__((aligned(1024))) u8 smem[6 * TILE];   // K ring [0, 3), V ring [3, 6) (48 KB >= the epilogue patches)
   static_assert(6 * TILE >= NW * 32 * 33 * 4, "epilogue patches alias the rings");
   const int D = H * 64;
@@ -546,6 +575,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_sp2_kernel(const u8* __re
       v[st][db][hl].lo = a;
       v[st][db][hl].hi = c;
     };
+    TRC(1);
     // head: the first exponentials cover the latency of the K fragment reads
 #pragma unroll
     for (int r = 0; r < 6; ++r) expo(r);
@@ -571,6 +601,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_sp2_kernel(const u8* __re
       SBAR();
     }
     f.l += rs;
+    TRC(2);
     // R2: P.V of tile kt || V fragments of token step 1, row maxima of the scores of tile kt + 1
     float mxa = 0.f, mxb = 0.f;
 #pragma unroll
@@ -597,12 +628,14 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_sp2_kernel(const u8* __re
       }
       SBAR();
     }
+    TRC(3);
     if constexpr (MORE) {
       f.s = sn;
 #if !(ATTN_ABL & 1)
       rebase(mxa);
 #endif
     }
+    TRC(4);
   };
 
   // ---- prologue: K(0), V(0), K(1) | K(2), V(1); scores of tile 0
@@ -617,6 +650,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_sp2_kernel(const u8* __re
   __builtin_amdgcn_s_barrier();
   // ---- tiles.  At the top of tile kt everything but the newest group (K(kt+2), V(kt+1)) has landed: K(kt+1), V(kt).
   auto top = [&](int kt) {
+    TRC(0);
 #if !(ATTN_ABL & 4)
     if (kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * CH) : "memory");
     else if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CH) : "memory");
@@ -682,6 +716,18 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_sp2_kernel(const u8* __re
                                   ao ? ao + (int64_t)b * N * D + h * 64 : nullptr, D, q0, N, lane,
                                   aop ? aop + (int64_t)b * N * (D * 4) + h * 256 : nullptr, (int64_t)D * 4, psig);
   emit_amax(amax, vmax, lane, (int)blockIdx.x * NW + wave, q0 < N ? b * N + q0 : -1);
+#ifdef ATTN_TRACE
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long* tr = reinterpret_cast<unsigned long long*>(lse + (((int64_t)nbh * N + 3) & ~3ll)) + 8 * (int64_t)blockIdx.x;
+    tr[0] = trace_t0;
+    tr[1] = wall_clock64();
+    tr[2] = trace_hw | ((unsigned long long)trc_sum[0] << 32);
+    tr[3] = trace_xcc | ((unsigned long long)trc_sum[1] << 32);
+    tr[4] = trc_sum[2] | ((unsigned long long)trc_sum[3] << 32);
+    tr[5] = trc_sum[4];
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dQ
@@ -713,13 +759,14 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_q_sp_kernel(
   load_row_frags(dorow + ((int64_t)b * N + q) * lddo + h * 256, h2, gh, gl);
   const u8* kbase = rows_b + (int64_t)(D + h * 64) * 4;
   const u8* vrbase = rows_b + (int64_t)(2 * D + h * 64) * 4;
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)smem;
   auto issue = [&](int kt, int buf) {
-    u8* st = smem + buf * STAGE;
+    const unsigned st = lds0 + buf * STAGE;
 #pragma unroll
     for (int i = 0; i < 8 / NW; ++i) {
       const int c = wave + NW * i;
-      glds_row_chunk(st, c, kbase, ldrow, 32 * kt, N - 1, lane);
-      glds_row_chunk(st + 8192, c, vrbase, ldrow, 32 * kt, N - 1, lane);
+      dma_row_chunk(st, c, kbase, (unsigned)ldrow, 32 * kt, N - 1, lane);
+      dma_row_chunk(st + 8192, c, vrbase, (unsigned)ldrow, 32 * kt, N - 1, lane);
     }
   };
   const float isg = slot[EAV_SLOT_ISIGMA], isd = slot_do[EAV_SLOT_ISIGMA];
@@ -837,17 +884,19 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_kv_sp_kernel(
   const u8* gbase = dorow + (int64_t)b * N * lddo + (int64_t)(h * 64) * 4;
   const float* lse_b = lse + (int64_t)bh * N;
   const float* del_b = delta + (int64_t)bh * N;
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)smem;
   auto issue = [&](int qt, int buf) {
-    u8* st = smem + buf * STAGE;
+    const unsigned st = lds0 + buf * STAGE;
 #pragma unroll
     for (int i = 0; i < 8 / NW; ++i) {
       const int c = wave + NW * i;
-      glds_row_chunk(st, c, qbase, ldrow, 32 * qt, N - 1, lane);
-      glds_row_chunk(st + 8192, c, gbase, lddo, 32 * qt, N - 1, lane);
+      dma_row_chunk(st, c, qbase, (unsigned)ldrow, 32 * qt, N - 1, lane);
+      dma_row_chunk(st + 8192, c, gbase, (unsigned)lddo, 32 * qt, N - 1, lane);
     }
-    if (wave == 0) {   // through LDS as well: an ordinary load here would make hipcc drain the LDS-DMA queue at its use
-      const float* src = (lane < 32 ? lse_b : del_b) + min(32 * qt + (lane & 31), N - 1);
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(st + 16384), 4, 0, 0);
+    if (wave == 0) {   // lse | delta of the query tile through LDS as well (lanes 0-31 | 32-63: two wave-uniform bases)
+      const unsigned vo = (unsigned)min(32 * qt + (lane & 31), N - 1) * 4u;
+      const float* sb = lane < 32 ? lse_b : del_b;
+      asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dword %0, off" ::"v"(reinterpret_cast<const u8*>(sb) + vo), "s"(st + 16384u) : "memory");
     }
   };
   const float isg = slot[EAV_SLOT_ISIGMA], isd = slot_do[EAV_SLOT_ISIGMA];
@@ -1061,6 +1110,12 @@ extern "C" int eav_attn_fwd_sp_planes(const void* rowp, const void* tp, const fl
   // long sequences (AST: 1214 tokens): the software-pipelined kernel, 152 -> 120 us per layer at B = 8; short ones (ViT: 197
   // tokens, 7 key tiles, bound by its HBM traffic and its per-workgroup prologue) stay on the plain loop (86 against 105 us)
   if (N >= g_fwd2_from) {
+#ifdef ATTN_FWD2_NW8
+    hipLaunchKernelGGL(attn_fwd_sp2_kernel<8>, dim3(cdiv(N, 256) * B * H), dim3(512), 0, st, (const u8*)rowp, slot, ao, lse,
+                       (unsigned*)amax_slot, N, H, scale, cdiv(N, 256), B * H, (u8*)ao_planes, ao_slot);
+    EAV_CHECK_LAUNCH("eav_attn_fwd_sp");
+    return EAV_OK;
+#endif
     hipLaunchKernelGGL(attn_fwd_sp2_kernel<4>, dim3(cdiv(N, 128) * B * H), dim3(256), 0, st, (const u8*)rowp, slot, ao, lse,
                        (unsigned*)amax_slot, N, H, scale, cdiv(N, 128), B * H, (u8*)ao_planes, ao_slot);
     EAV_CHECK_LAUNCH("eav_attn_fwd_sp");

@@ -390,7 +390,7 @@ __device__ __forceinline__ void split_frag_mix(const float* t, float neg1, f16x8
 
 
 template <int NW>
-__global__ __launch_bounds__(64 * NW, 1) void attn_fwd_sp2_kernel(const u8* __restrict__ rowp, const float* __restrict__ slot,
+__global__ __launch_bounds__(64 * NW, 2) void attn_fwd_sp2_kernel(const u8* __restrict__ rowp, const float* __restrict__ slot,
                                                                   float* __restrict__ ao, float* __restrict__ lse,
                                                                   unsigned* __restrict__ amax, int N, int H, float scale,
                                                                   int ntile, int nbh, u8* __restrict__ aop,
@@ -705,7 +705,7 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_fwd_sp2_kernel(const u8* __re
     l = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
   }
   const float inv = l > 0.f ? isg / l : 0.f;     // l carries the 2^14 of the probabilities
-  if (h2 == 0 && q0 + j < N) lse[(int64_t)bh * N + q0 + j] = (f.m + log2f(l) - 14.f) * LN2;
+  if (h2 == 0 && q0 + j < N) lse[(int64_t)bh * N + q0 + j] = (f.m + log2f(l * (1.f / 16384.f))) * LN2;
   __syncthreads();   // every wave is done with the tiles before the patch area is reused
   const float psig = aop ? slot[EAV_SLOT_SIGMA] : 0.f;
   if (aop && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -798,51 +798,124 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_q_sp_kernel(
   float tmax = 0.f;
   const int nkt = (N + 31) / 32;
   const int prow = pi_row(j);
-  issue(0, 0);
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int buf = kt & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (kt + 1 < nkt) issue(kt + 1, buf ^ 1);
-    if (q0 >= N) continue;
-    const u8* kt_ = smem + buf * STAGE;
+  float neg2048;
+  asm volatile("s_mov_b32 %0, 0xc5000000" : "=s"(neg2048));      // -2048.0f, opaque to the optimiser (see split_frag_mix)
+  // fragment addresses inside a 32-row tile (per lane); the stage is an immediate (tile<BUF>)
+  int kofs[4][2];
+#pragma unroll
+  for (int st = 0; st < 4; ++st)
+#pragma unroll
+    for (int hl = 0; hl < 2; ++hl) kofs[st][hl] = prow * 256 + (((4 * st + 2 * h2 + hl) ^ (prow & 15)) << 4);
+  int tofs[2][2][2];                            // transposing reads of the K rows: [dbase / 32][hl][token + 4]
+  {
+    const int G = lane >> 4, r = (lane >> 2) & 3, qq = lane & 3;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int hl = 0; hl < 2; ++hl)
+#pragma unroll
+        for (int ab = 0; ab < 2; ++ab) {
+          const int piece = 2 * (4 * db + 2 * (G & 1) + (qq >> 1)) + hl;
+          const int tok = 8 * (G >> 1) + r + 4 * ab;
+          tofs[db][hl][ab] = tok * 256 + ((piece ^ (tok & 15)) << 4) + ((qq & 1) << 3);
+        }
+  }
+  const float dqs = dq_ * DS_DOWN;              // t = p . [(dP - delta) 2^-22]: the down-scale rides on the fma of the bracket
+                                                // (folded into the exponent it would cost the probability 2e-6 of relative accuracy)
+  // one key tile.  LAST: the (possibly ragged) last tile - keys beyond N contribute nothing
+  auto tile = [&](auto BUFc, auto LASTc, int kt) {
+    constexpr int BUF = decltype(BUFc)::value;
+    constexpr bool LAST = decltype(LASTc)::value;
+    const u8* kt_ = smem + BUF * STAGE;
     const u8* vr_ = kt_ + 8192;
     f32x16 s, dp;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
-      const f16x8 kh = frag_row(kt_, prow, st, h2, 0), kl = frag_row(kt_, prow, st, h2, 1);
-      const f16x8 vh = frag_row(vr_, prow, st, h2, 0), vl = frag_row(vr_, prow, st, h2, 1);
+      const f16x8 kh = *reinterpret_cast<const f16x8*>(kt_ + kofs[st][0]), kl = *reinterpret_cast<const f16x8*>(kt_ + kofs[st][1]);
+      const f16x8 vh = *reinterpret_cast<const f16x8*>(vr_ + kofs[st][0]), vl = *reinterpret_cast<const f16x8*>(vr_ + kofs[st][1]);
       s = MFMA16(kh, qh[st], s);          // S^T = K . Q^T
       dp = MFMA16(vh, gh[st], dp);        // dP^T = V . dO^T
       s = MFMA16(kl, qh[st], s);
       dp = MFMA16(vl, gh[st], dp);
       s = MFMA16(kh, ql[st], s);
       dp = MFMA16(vh, gl[st], dp);
+      if (st & 1) SBAR();                 // (at most two steps' fragments in flight: the kernel sits at 256 registers)
     }
     float t[16];
-    const bool ragged = 32 * kt + 32 > N;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      float p = ex2(s[r] * c1 - lq);
-      if (ragged && 32 * kt + (r & 7) + 8 * h2 + 16 * (r >> 3) >= N) p = 0.f;
-      t[r] = p * (dp[r] - dq_) * DS_DOWN;
+      float p = ex2(fmaf(s[r], c1, -lq));
+      if constexpr (LAST) {
+        if (32 * kt + (r & 7) + 8 * h2 + 16 * (r >> 3) >= N) p = 0.f;
+      }
+      t[r] = p * fmaf(dp[r], DS_DOWN, -dqs);
       tmax = fmaxf(tmax, fabsf(t[r]));
     }
     f16x8 th[2], tl[2];
-    split_frag(t, 2048.f, th[0], tl[0]);
-    split_frag(t + 8, 2048.f, th[1], tl[1]);
+#pragma unroll
+    for (int fr = 0; fr < 2; ++fr)
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) {          // hi = fp16(t), lo = fp16((t - hi) 2^11): one v_cvt_pk + two v_mul + two v_fma_mix
+        const float t0 = t[8 * fr + e], t1 = t[8 * fr + e + 1];
+        const f32x2 tt = {t0, t1};
+        const f16x2 hh = __builtin_convertvector(tt, f16x2);
+        th[fr][e] = hh[0];
+        th[fr][e + 1] = hh[1];
+        tl[fr][e] = (_Float16)__builtin_fmaf((float)hh[0], neg2048, t0 * 2048.f);
+        tl[fr][e + 1] = (_Float16)__builtin_fmaf((float)hh[1], neg2048, t1 * 2048.f);
+      }
 #pragma unroll
     for (int st = 0; st < 2; ++st) {       // dQ^T[d][q] += K^T[d][key] . dS^T[key][q]
-      const f16x8 k0h = frag_tr(kt_, 0, st, 0, lane), k0l = frag_tr(kt_, 0, st, 1, lane);
-      const f16x8 k1h = frag_tr(kt_, 32, st, 0, lane), k1l = frag_tr(kt_, 32, st, 1, lane);
-      g0 = MFMA16(k0h, th[st], g0);
-      g1 = MFMA16(k1h, th[st], g1);
-      g0 = MFMA16(k0l, th[st], g0);
-      g1 = MFMA16(k1l, th[st], g1);
-      x0 = MFMA16(k0h, tl[st], x0);
-      x1 = MFMA16(k1h, tl[st], x1);
+      f16x8 kf[2][2];                      // [dbase][hl]
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int hl = 0; hl < 2; ++hl) {
+          const f16x4 a = __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (lds_s16x4_ptr)(kt_ + tofs[db][hl][0] + st * 4096)));
+          const f16x4 c = __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (lds_s16x4_ptr)(kt_ + tofs[db][hl][1] + st * 4096)));
+          kf[db][hl].lo = a;
+          kf[db][hl].hi = c;
+        }
+      g0 = MFMA16(kf[0][0], th[st], g0);
+      g1 = MFMA16(kf[1][0], th[st], g1);
+      g0 = MFMA16(kf[0][1], th[st], g0);
+      g1 = MFMA16(kf[1][1], th[st], g1);
+      x0 = MFMA16(kf[0][0], tl[st], x0);
+      x1 = MFMA16(kf[1][0], tl[st], x1);
+    }
+  };
+  auto top = [&](int kt, int buf) {             // tile kt has landed in stage buf; prefetch tile kt + 1 into the other one
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + 1 < nkt) issue(kt + 1, buf ^ 1);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using T = std::true_type;
+  using F = std::false_type;
+  issue(0, 0);
+  if (q0 >= N) {                                 // (wave-uniform) no valid row: this wave only stages its share of the tiles
+    for (int kt = 0; kt < nkt; ++kt) top(kt, kt & 1);
+  } else {
+    int kt = 0;
+    for (; kt + 2 < nkt; kt += 2) {
+      top(kt, 0);
+      tile(I0{}, F{}, kt);
+      top(kt + 1, 1);
+      tile(I1{}, F{}, kt + 1);
+    }
+    if (kt + 1 < nkt) {
+      top(kt, 0);
+      tile(I0{}, F{}, kt);
+      top(kt + 1, 1);
+      tile(I1{}, T{}, kt + 1);
+    } else {
+      top(kt, 0);
+      tile(I0{}, T{}, kt);
     }
   }
 #pragma unroll
@@ -908,74 +981,128 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_kv_sp_kernel(
   for (int r = 0; r < 16; ++r) { gk0[r] = 0.f; gk1[r] = 0.f; gv0[r] = 0.f; gv1[r] = 0.f; }
   const int nqt = (N + 31) / 32;
   const int prow = pi_row(j);
-  issue(0, 0);
-  for (int qt = 0; qt < nqt; ++qt) {
-    const int buf = qt & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (qt + 1 < nqt) issue(qt + 1, buf ^ 1);
-    if (k0 >= N) continue;
-    const u8* qr_ = smem + buf * STAGE;
+  float neg1;
+  asm volatile("s_mov_b32 %0, 0xbf800000" : "=s"(neg1));
+  // fragment addresses inside a tile: the hi pieces; the lo piece of the same fragment is the address ^ 16 (the hl bit is
+  // bit 0 of the XOR-swizzled piece index) - one v_xor at the read instead of eight more live registers (this kernel sits at
+  // the 256-register limit of two waves per SIMD; with both tables resident hipcc spilled eight of them to scratch)
+  int rofs[4];                                  // row fragments of the Q / dO tiles, per head_dim step
+#pragma unroll
+  for (int st = 0; st < 4; ++st) rofs[st] = prow * 256 + (((4 * st + 2 * h2) ^ (prow & 15)) << 4);
+  int tofs[2][2];                               // transposing reads: [dbase / 32][token + 4]
+  {
+    const int G = lane >> 4, r = (lane >> 2) & 3, qq = lane & 3;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int ab = 0; ab < 2; ++ab) {
+        const int piece = 2 * (4 * db + 2 * (G & 1) + (qq >> 1));
+        const int tok = 8 * (G >> 1) + r + 4 * ab;
+        tofs[db][ab] = tok * 256 + ((piece ^ (tok & 15)) << 4) + ((qq & 1) << 3);
+      }
+  }
+  // t = dS 2^-22 s2 in operand units = p . [(dP - delta dsc) kq], kq = 2^-22 s2 (a power of two: exact)
+  const float kq = DS_DOWN * s2, dk = dsc * kq;
+  // one query tile (queries beyond N in the ragged last tile: their lse entry is +inf - see top - so p = 0 without a mask)
+  auto tile = [&](auto BUFc, int qt) {
+    constexpr int BUF = decltype(BUFc)::value;
+    const u8* qr_ = smem + BUF * STAGE;
     const u8* gr_ = qr_ + 8192;
     f32x16 s, dp;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
-      const f16x8 ah = frag_row(qr_, prow, st, h2, 0), al = frag_row(qr_, prow, st, h2, 1);
-      const f16x8 bh_ = frag_row(gr_, prow, st, h2, 0), bl_ = frag_row(gr_, prow, st, h2, 1);
+      const f16x8 ah = *reinterpret_cast<const f16x8*>(qr_ + rofs[st]), al = *reinterpret_cast<const f16x8*>(qr_ + (rofs[st] ^ 16));
+      const f16x8 bh_ = *reinterpret_cast<const f16x8*>(gr_ + rofs[st]), bl_ = *reinterpret_cast<const f16x8*>(gr_ + (rofs[st] ^ 16));
       s = MFMA16(ah, kh[st], s);          // S[q][key] = Q . K^T
       dp = MFMA16(bh_, vh[st], dp);       // dP[q][key] = dO . V^T
       s = MFMA16(al, kh[st], s);
       dp = MFMA16(bl_, vh[st], dp);
       s = MFMA16(ah, kl[st], s);
       dp = MFMA16(bh_, vl[st], dp);
+      if (st & 1) SBAR();                 // (at most two steps' fragments in flight: the kernel sits at 256 registers)
     }
-    float pt[16], t[16];
+    auto tfrag = [&](const u8* tile_, int st, int db, int hl) {
+      f16x8 out;
+      out.lo = __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (lds_s16x4_ptr)(tile_ + (tofs[db][0] ^ (16 * hl)) + st * 4096)));
+      out.hi = __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (lds_s16x4_ptr)(tile_ + (tofs[db][1] ^ (16 * hl)) + st * 4096)));
+      return out;
+    };
     const float* ls = reinterpret_cast<const float*>(qr_ + 16384);
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
+    for (int g = 0; g < 2; ++g) {       // sixteen queries at a time (token step g of the second products): their probabilities
+                                        // and dS leave as fragments and go straight into the twelve MFMAs of the step
       const int ql = 16 * g + 8 * h2;                    // 8 consecutive queries <-> registers 8g .. 8g+7
       const float4 l0 = *reinterpret_cast<const float4*>(ls + ql), l1 = *reinterpret_cast<const float4*>(ls + ql + 4);
       const float4 d0 = *reinterpret_cast<const float4*>(ls + 32 + ql);
       const float4 d1 = *reinterpret_cast<const float4*>(ls + 36 + ql);
       const float lqv[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
       const float dlv[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+      float pt[8], t[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int r = 8 * g + e;
-        const float p = (32 * qt + ql + e < N) ? ex2(s[r] * c1 - lqv[e] * LOG2E) : 0.f;
-        pt[r] = p * SP;
-        t[r] = p * (dp[r] - dlv[e] * dsc) * (DS_DOWN * s2);
+        // (the 2^14 of the probability and the 2^-22 s2 of dS are NOT folded into the exponent: an argument near 14 instead
+        // of near 0 costs the exponential 7e-7 of relative accuracy - the spike case of test_attention_sp_is_fp32_grade)
+        const float p = ex2(fmaf(s[r], c1, -lqv[e] * LOG2E));
+        pt[e] = p * SP;
+        t[e] = p * fmaf(dp[r], kq, -dlv[e] * dk);
       }
-    }
-    f16x8 ph[2], pl[2], th[2], tl[2];
-    split_frag(pt, 1.f, ph[0], pl[0]);
-    split_frag(pt + 8, 1.f, ph[1], pl[1]);
-    split_frag(t, 1.f, th[0], tl[0]);
-    split_frag(t + 8, 1.f, th[1], tl[1]);
-#pragma unroll
-    for (int st = 0; st < 2; ++st) {
+      f16x8 ph, pl, th, tl;
+      split_frag_mix(pt, neg1, ph, pl);
+      split_frag_mix(t, neg1, th, tl);
       {                                    // dV^T[d][key] += dO^T[d][q] . P[q][key]
-        const f16x8 a0h = frag_tr(gr_, 0, st, 0, lane), a0l = frag_tr(gr_, 0, st, 1, lane);
-        const f16x8 a1h = frag_tr(gr_, 32, st, 0, lane), a1l = frag_tr(gr_, 32, st, 1, lane);
-        gv0 = MFMA16(a0h, ph[st], gv0);
-        gv1 = MFMA16(a1h, ph[st], gv1);
-        gv0 = MFMA16(a0l, ph[st], gv0);
-        gv1 = MFMA16(a1l, ph[st], gv1);
-        gv0 = MFMA16(a0h, pl[st], gv0);
-        gv1 = MFMA16(a1h, pl[st], gv1);
+        const f16x8 a0h = tfrag(gr_, g, 0, 0), a0l = tfrag(gr_, g, 0, 1);
+        const f16x8 a1h = tfrag(gr_, g, 1, 0), a1l = tfrag(gr_, g, 1, 1);
+        gv0 = MFMA16(a0h, ph, gv0);
+        gv1 = MFMA16(a1h, ph, gv1);
+        gv0 = MFMA16(a0l, ph, gv0);
+        gv1 = MFMA16(a1l, ph, gv1);
+        gv0 = MFMA16(a0h, pl, gv0);
+        gv1 = MFMA16(a1h, pl, gv1);
       }
       {                                    // dK^T[d][key] += Q^T[d][q] . dS[q][key]
-        const f16x8 a0h = frag_tr(qr_, 0, st, 0, lane), a0l = frag_tr(qr_, 0, st, 1, lane);
-        const f16x8 a1h = frag_tr(qr_, 32, st, 0, lane), a1l = frag_tr(qr_, 32, st, 1, lane);
-        gk0 = MFMA16(a0h, th[st], gk0);
-        gk1 = MFMA16(a1h, th[st], gk1);
-        gk0 = MFMA16(a0l, th[st], gk0);
-        gk1 = MFMA16(a1l, th[st], gk1);
-        gk0 = MFMA16(a0h, tl[st], gk0);
-        gk1 = MFMA16(a1h, tl[st], gk1);
+        const f16x8 a0h = tfrag(qr_, g, 0, 0), a0l = tfrag(qr_, g, 0, 1);
+        const f16x8 a1h = tfrag(qr_, g, 1, 0), a1l = tfrag(qr_, g, 1, 1);
+        gk0 = MFMA16(a0h, th, gk0);
+        gk1 = MFMA16(a1h, th, gk1);
+        gk0 = MFMA16(a0l, th, gk0);
+        gk1 = MFMA16(a1l, th, gk1);
+        gk0 = MFMA16(a0h, tl, gk0);
+        gk1 = MFMA16(a1h, tl, gk1);
       }
+      SBAR();
+    }
+  };
+  auto top = [&](int qt, int buf) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (wave == 0 && 32 * qt + 32 > N) {         // ragged last tile: lse = +inf for the queries beyond N (wave 0 staged the
+      if (lane < 32 && 32 * qt + lane >= N)      // entries - its own DMA has landed - and every wave reads them after the barrier)
+        reinterpret_cast<float*>(smem + buf * STAGE + 16384)[lane] = INFINITY;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (qt + 1 < nqt) issue(qt + 1, buf ^ 1);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  issue(0, 0);
+  if (k0 >= N) {                                 // (wave-uniform) no valid key: this wave only stages its share of the tiles
+    for (int qt = 0; qt < nqt; ++qt) top(qt, qt & 1);
+  } else {
+    int qt = 0;
+    for (; qt + 2 <= nqt; qt += 2) {
+      top(qt, 0);
+      tile(I0{}, qt);
+      top(qt + 1, 1);
+      tile(I1{}, qt + 1);
+    }
+    if (qt < nqt) {
+      top(qt, 0);
+      tile(I0{}, qt);
     }
   }
   __syncthreads();
@@ -1110,12 +1237,6 @@ extern "C" int eav_attn_fwd_sp_planes(const void* rowp, const void* tp, const fl
   // long sequences (AST: 1214 tokens): the software-pipelined kernel, 152 -> 120 us per layer at B = 8; short ones (ViT: 197
   // tokens, 7 key tiles, bound by its HBM traffic and its per-workgroup prologue) stay on the plain loop (86 against 105 us)
   if (N >= g_fwd2_from) {
-#ifdef ATTN_FWD2_NW8
-    hipLaunchKernelGGL(attn_fwd_sp2_kernel<8>, dim3(cdiv(N, 256) * B * H), dim3(512), 0, st, (const u8*)rowp, slot, ao, lse,
-                       (unsigned*)amax_slot, N, H, scale, cdiv(N, 256), B * H, (u8*)ao_planes, ao_slot);
-    EAV_CHECK_LAUNCH("eav_attn_fwd_sp");
-    return EAV_OK;
-#endif
     hipLaunchKernelGGL(attn_fwd_sp2_kernel<4>, dim3(cdiv(N, 128) * B * H), dim3(256), 0, st, (const u8*)rowp, slot, ao, lse,
                        (unsigned*)amax_slot, N, H, scale, cdiv(N, 128), B * H, (u8*)ao_planes, ao_slot);
     EAV_CHECK_LAUNCH("eav_attn_fwd_sp");

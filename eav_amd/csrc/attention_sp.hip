@@ -843,49 +843,49 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_q_sp_kernel(
       dp = MFMA16(vh, gl[st], dp);
       if (st & 1) SBAR();                 // (at most two steps' fragments in flight: the kernel sits at 256 registers)
     }
-    float t[16];
+    // per token step (16 keys): dS and its hi / lo split, then the six dQ MFMAs of the step - the second step's
+    // arithmetic is independent of the first step's MFMAs and fills their issue slots
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float p = ex2(fmaf(s[r], c1, -lq));
-      if constexpr (LAST) {
-        if (32 * kt + (r & 7) + 8 * h2 + 16 * (r >> 3) >= N) p = 0.f;
+    for (int fr = 0; fr < 2; ++fr) {
+      float t[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int r = 8 * fr + e;
+        float p = ex2(fmaf(s[r], c1, -lq));
+        if constexpr (LAST) {
+          if (32 * kt + (r & 7) + 8 * h2 + 16 * (r >> 3) >= N) p = 0.f;
+        }
+        t[e] = p * fmaf(dp[r], DS_DOWN, -dqs);
+        tmax = fmaxf(tmax, fabsf(t[e]));
       }
-      t[r] = p * fmaf(dp[r], DS_DOWN, -dqs);
-      tmax = fmaxf(tmax, fabsf(t[r]));
-    }
-    f16x8 th[2], tl[2];
-#pragma unroll
-    for (int fr = 0; fr < 2; ++fr)
+      f16x8 th, tl;
 #pragma unroll
       for (int e = 0; e < 8; e += 2) {          // hi = fp16(t), lo = fp16((t - hi) 2^11): one v_cvt_pk + two v_mul + two v_fma_mix
-        const float t0 = t[8 * fr + e], t1 = t[8 * fr + e + 1];
-        const f32x2 tt = {t0, t1};
+        const f32x2 tt = {t[e], t[e + 1]};
         const f16x2 hh = __builtin_convertvector(tt, f16x2);
-        th[fr][e] = hh[0];
-        th[fr][e + 1] = hh[1];
-        tl[fr][e] = (_Float16)__builtin_fmaf((float)hh[0], neg2048, t0 * 2048.f);
-        tl[fr][e + 1] = (_Float16)__builtin_fmaf((float)hh[1], neg2048, t1 * 2048.f);
+        th[e] = hh[0];
+        th[e + 1] = hh[1];
+        tl[e] = (_Float16)__builtin_fmaf((float)hh[0], neg2048, t[e] * 2048.f);
+        tl[e + 1] = (_Float16)__builtin_fmaf((float)hh[1], neg2048, t[e + 1] * 2048.f);
       }
-#pragma unroll
-    for (int st = 0; st < 2; ++st) {       // dQ^T[d][q] += K^T[d][key] . dS^T[key][q]
-      f16x8 kf[2][2];                      // [dbase][hl]
+      f16x8 kf[2][2];                      // K^T fragments [dbase][hl]
 #pragma unroll
       for (int db = 0; db < 2; ++db)
 #pragma unroll
         for (int hl = 0; hl < 2; ++hl) {
-          const f16x4 a = __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (lds_s16x4_ptr)(kt_ + tofs[db][hl][0] + st * 4096)));
-          const f16x4 c = __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (lds_s16x4_ptr)(kt_ + tofs[db][hl][1] + st * 4096)));
-          kf[db][hl].lo = a;
-          kf[db][hl].hi = c;
+          const f16x4 a_ = __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (lds_s16x4_ptr)(kt_ + tofs[db][hl][0] + fr * 4096)));
+          const f16x4 c_ = __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (lds_s16x4_ptr)(kt_ + tofs[db][hl][1] + fr * 4096)));
+          kf[db][hl].lo = a_;
+          kf[db][hl].hi = c_;
         }
-      g0 = MFMA16(kf[0][0], th[st], g0);
-      g1 = MFMA16(kf[1][0], th[st], g1);
-      g0 = MFMA16(kf[0][1], th[st], g0);
-      g1 = MFMA16(kf[1][1], th[st], g1);
-      x0 = MFMA16(kf[0][0], tl[st], x0);
-      x1 = MFMA16(kf[1][0], tl[st], x1);
+      g0 = MFMA16(kf[0][0], th, g0);       // dQ^T[d][q] += K^T[d][key] . dS^T[key][q]
+      g1 = MFMA16(kf[1][0], th, g1);
+      g0 = MFMA16(kf[0][1], th, g0);
+      g1 = MFMA16(kf[1][1], th, g1);
+      x0 = MFMA16(kf[0][0], tl, x0);
+      x1 = MFMA16(kf[1][0], tl, x1);
     }
   };
   auto top = [&](int kt, int buf) {             // tile kt has landed in stage buf; prefetch tile kt + 1 into the other one

@@ -167,7 +167,8 @@ class _HeadFn(torch.autograd.Function):
         ctx.model, ctx.B = model, feat.shape[0]
         hw = model._head_ws(feat.shape[0], feat.device)
         hw.feat.copy_(feat)
-        model._st = _lib.stream_ptr()
+        model._main = torch.cuda.current_stream()
+        model._st = model._main.cuda_stream
         model._head_forward(hw.feat, hw, feat.shape[0])
         hw.token = model._token = model._token + 1
         ctx.token = hw.token
@@ -179,7 +180,8 @@ class _HeadFn(torch.autograd.Function):
         hw = model._head_ws(ctx.B, dlogits.device)
         if hw.token != ctx.token:
             raise _lib.EavError("Encoder.head backward: activations were overwritten by a later head forward")
-        model._st = _lib.stream_ptr()
+        model._main = torch.cuda.current_stream()
+        model._st = model._main.cuda_stream
         model._head_backward(dlogits.contiguous(), hw.feat, hw, ctx.B, False)
         offs, gflat = model._flat[2], model._flat[1]
         out = []
@@ -589,10 +591,16 @@ class Encoder(nn.Module):
                     self._wready[k] = ev
         self._wplanes_key = key
 
+    def _cur_stream(self):
+        """The stream the current launch sequence runs on (cached by _launch_forward / _launch_backward / the head functions:
+        torch.cuda.current_stream() costs tens of microseconds per call, and the step waits on ~50 events)."""
+        m = getattr(self, "_main", None)
+        return m if m is not None else torch.cuda.current_stream()
+
     def _wp(self, key, transposed=False):
         ev = self._wready.pop(key, None)
         if ev is not None:
-            torch.cuda.current_stream().wait_event(ev)
+            self._cur_stream().wait_event(ev)
         pl, plT, n = self._wplanes[key]
         return _lib.ptr(plT if transposed else pl), self._wplanes["_slots"].data_ptr() + 4 * self.SLOT * n
 
@@ -612,7 +620,7 @@ class Encoder(nn.Module):
         self._ring_pos[pool] = i = i % len(ring)
         ev = self._part_busy.pop(ring[i].data_ptr(), None)
         if ev is not None:
-            torch.cuda.current_stream().wait_event(ev)
+            self._cur_stream().wait_event(ev)
         return ring[i]
 
     def _reduce_async(self, buf, off_bytes, nparts, stride, n, out):
@@ -688,14 +696,14 @@ class Encoder(nn.Module):
         finished before the next conversion overwrites it."""
         ev = self._wgrad_done.pop(buf.data_ptr(), None) if buf is not None else None
         if ev is not None:
-            torch.cuda.current_stream().wait_event(ev)
+            self._cur_stream().wait_event(ev)
 
     def _join_wgrads(self):
         if self._side is not None and self._wgrad_done:
-            torch.cuda.current_stream().wait_stream(self._side)
+            self._cur_stream().wait_stream(self._side)
             self._wgrad_done.clear()
         if self._aux is not None and self._part_busy:
-            torch.cuda.current_stream().wait_stream(self._aux)
+            self._cur_stream().wait_stream(self._aux)
             self._part_busy.clear()
 
     # ------------------------------------------------------------------ classification head (shared by the full path
@@ -765,7 +773,8 @@ class Encoder(nn.Module):
     def _launch_forward(self, x):
         c = self.cfg
         P, L = _lib.ptr, self._call
-        self._st = st = _lib.stream_ptr()
+        self._main = torch.cuda.current_stream()      # (looked up once per launch sequence: ~50 event waits per step use it)
+        self._st = st = self._main.cuda_stream
         self._phase = "fwd"
         B = x.shape[0]
         D, FF, N, H = c.hidden, c.ff, c.ntok, c.heads
@@ -875,7 +884,7 @@ class Encoder(nn.Module):
         if any(r != rel[0] for r in rel) or any(first(i) - first(0) != i * stride for i in range(c.layers)):
             return
         if self._wnorm_ready is not None:              # the row norms come from the side-stream weight refresh
-            torch.cuda.current_stream().wait_event(self._wnorm_ready)
+            self._cur_stream().wait_event(self._wnorm_ready)
         o = rel[0]
         qkvp = self.fused_qkv and ws.fused
         self._call("eav_tf_forward_scales_qkv", _lib.ptr(self._flat[0]) + 4 * first(0), stride, c.layers, o[0], o[1], o[2],
@@ -1089,7 +1098,8 @@ class Encoder(nn.Module):
             raise _lib.EavError("Encoder.backward: activations were overwritten by a later forward")
         c = self.cfg
         P, L = _lib.ptr, self._call
-        st = self._st = _lib.stream_ptr()
+        self._main = torch.cuda.current_stream()
+        st = self._st = self._main.cuda_stream
         self._phase = "bwd"
         _, x, full, _ = self._saved
         ws = self._ws

@@ -152,9 +152,11 @@ __device__ __forceinline__ uint4 gemm_plane_piece4(float t0, float t1, float t2,
 // out[(row0 + r) * ld + 32*half + ..] = acc^T: lane = row, registers = 32 columns per accumulator; through an LDS patch.
 // out may be null; planes (optional): the same rows also leave as GEMM operand planes scaled by psig - planes points at the
 // first row's piece of column 0 of this head (row pitch ldp bytes).
+// cs (optional): the sums of the wave's valid rows, per column, go to cs[0 .. 63] (a bias-gradient partial; fixed order).
 __device__ __forceinline__ float store_rows_T(float* __restrict__ patch, const f32x16& a0, const f32x16& a1, float mul,
                                               float* __restrict__ out, int ld, int row0, int nrows, int lane,
-                                              u8* __restrict__ planes = nullptr, int64_t ldp = 0, float psig = 0.f) {
+                                              u8* __restrict__ planes = nullptr, int64_t ldp = 0, float psig = 0.f,
+                                              float* __restrict__ cs = nullptr) {
   const int j = lane & 31, h2 = lane >> 5;
   float vmax = 0.f;
 #pragma unroll
@@ -167,6 +169,12 @@ __device__ __forceinline__ float store_rows_T(float* __restrict__ patch, const f
       if (row0 + j < nrows) vmax = fmaxf(vmax, fabsf(v));
     }
     __syncthreads();
+    if (cs && lane < 32) {                  // column `lane` of this half over the valid rows, rows in order
+      float t = 0.f;
+      const int nv = min(32, nrows - row0);
+      for (int r = 0; r < nv; ++r) t += patch[r * 33 + lane];
+      cs[32 * half + lane] = t;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int idx = lane + 64 * i;
@@ -740,7 +748,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_q_sp_kernel(
     const u8* __restrict__ rowp, const u8* __restrict__ tp, const u8* __restrict__ dorow, const float* __restrict__ slot,
     const float* __restrict__ slot_do, const float* __restrict__ lse, const float* __restrict__ ao,
     const float* __restrict__ dout, float* __restrict__ delta, float* __restrict__ dqkv,
-    unsigned* __restrict__ amax_ds, unsigned* __restrict__ amax_out, int N, int Npad, int H, float scale, int ntile, int nbh) {
+    unsigned* __restrict__ amax_ds, unsigned* __restrict__ amax_out, int N, int Npad, int H, float scale, int ntile, int nbh,
+    u8* __restrict__ gplanes, const float* __restrict__ gslot, float* __restrict__ cs_part) {
   constexpr int STAGE = 16384;   // K rows | V rows (K^T for the last product is read transposed from the K rows: frag_tr)
   __shared__ __attribute__((aligned(1024))) u8 smem[2 * STAGE > NW * 32 * 33 * 4 ? 2 * STAGE : NW * 32 * 33 * 4];
   const int D = H * 64;
@@ -923,8 +932,15 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_q_sp_kernel(
   emit_amax(amax_ds, tmax, lane, (int)blockIdx.x * NW + wave);
   __syncthreads();
   const float mul = scale * (1.f / DS_DOWN) * isd * isg * isg;
+  // gplanes (optional): dQ also (or only: dqkv = null) leaves as its section of the operand planes of the q/k/v projection's
+  // gradient products, scaled by gslot's sigma - a BOUND of |dqkv| set before the launch (eav_attn_dqkv_bound) - and the
+  // column sums of the wave's rows (bias-gradient partials) go to cs_part[(b, row tile)][3 D]
+  const int nrb = (N + 31) / 32;
   const float vmax = store_rows_T(reinterpret_cast<float*>(smem) + wave * (32 * 33), g0, g1, mul,
-                                  dqkv + (int64_t)b * N * 3 * D + h * 64, 3 * D, q0, N, lane);
+                                  dqkv ? dqkv + (int64_t)b * N * 3 * D + h * 64 : nullptr, 3 * D, q0, N, lane,
+                                  gplanes ? gplanes + (int64_t)b * N * (3 * D * 4) + h * 256 : nullptr, (int64_t)3 * D * 4,
+                                  gplanes ? gslot[EAV_SLOT_SIGMA] : 0.f,
+                                  cs_part && q0 < N ? cs_part + ((int64_t)b * nrb + q0 / 32) * (3 * D) + h * 64 : nullptr);
   emit_amax(amax_out, vmax, lane, (int)blockIdx.x * NW + wave, q0 < N ? b * N + q0 : -1);
 }
 
@@ -936,7 +952,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_kv_sp_kernel(
     const u8* __restrict__ rowp, const u8* __restrict__ tp, const u8* __restrict__ dorow, const u8* __restrict__ dotp,
     const float* __restrict__ slot, const float* __restrict__ slot_do, const float* __restrict__ slot_ds,
     const float* __restrict__ lse, const float* __restrict__ delta, float* __restrict__ dqkv,
-    unsigned* __restrict__ amax_out, int N, int Npad, int H, float scale, int ntile, int nbh) {
+    unsigned* __restrict__ amax_out, int N, int Npad, int H, float scale, int ntile, int nbh,
+    u8* __restrict__ gplanes, const float* __restrict__ gslot, float* __restrict__ cs_part) {
   constexpr int STAGE = 16384 + 256;   // Q rows | dO rows | lse[32], delta[32] of the query tile (Q^T, dO^T: frag_tr)
   __shared__ __attribute__((aligned(1024))) u8 smem[2 * STAGE];
   const int D = H * 64;
@@ -1106,12 +1123,18 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_kv_sp_kernel(
     }
   }
   __syncthreads();
-  float* base = dqkv + (int64_t)b * N * 3 * D + h * 64;
+  float* base = dqkv ? dqkv + (int64_t)b * N * 3 * D + h * 64 : nullptr;
   float* patch = reinterpret_cast<float*>(smem) + wave * (32 * 33);
   const float mk = scale * (1.f / DS_DOWN) / s2 * isd * isg * isg;
   const float mv = isd / SP;
-  float vmax = store_rows_T(patch, gk0, gk1, mk, base + D, 3 * D, k0, N, lane);
-  vmax = fmaxf(vmax, store_rows_T(patch, gv0, gv1, mv, base + 2 * D, 3 * D, k0, N, lane));
+  const int nrb = (N + 31) / 32;
+  u8* gp_ = gplanes ? gplanes + (int64_t)b * N * (3 * D * 4) + h * 256 : nullptr;     // (see attn_bwd_q_sp_kernel)
+  float* cs_ = cs_part && k0 < N ? cs_part + ((int64_t)b * nrb + k0 / 32) * (3 * D) + h * 64 : nullptr;
+  const float gsig = gplanes ? gslot[EAV_SLOT_SIGMA] : 0.f;
+  float vmax = store_rows_T(patch, gk0, gk1, mk, base ? base + D : nullptr, 3 * D, k0, N, lane, gp_ ? gp_ + D * 4 : nullptr,
+                            (int64_t)3 * D * 4, gsig, cs_ ? cs_ + D : nullptr);
+  vmax = fmaxf(vmax, store_rows_T(patch, gv0, gv1, mv, base ? base + 2 * D : nullptr, 3 * D, k0, N, lane,
+                                  gp_ ? gp_ + 2 * D * 4 : nullptr, (int64_t)3 * D * 4, gsig, cs_ ? cs_ + 2 * D : nullptr));
   emit_amax(amax_out, vmax, lane, (int)blockIdx.x * NW + wave, k0 < N ? b * N + k0 : -1);
 }
 
@@ -1197,6 +1220,27 @@ __global__ __launch_bounds__(256) void attn_sp_prep_kernel(const float* __restri
   }
 }
 
+// sigma / 1 / sigma of slot_out from a BOUND of |dqkv| (the scale of the planes eav_attn_bwd_sp_planes writes): with
+// m = max|dO| (slot_do's shards) and q = max|qkv| (measured: slot_qkv's shards; or the bound 2^15 / sigma_qkv):  |dP|, |delta| <= 64 m q, hence
+// |dS_ij| <= 128 P_ij m q;  |dQ_i| <= scale 128 m q^2 (row sums of P are 1), |dK_j| <= N scale 128 m q^2, |dV_j| <= N m.
+// The bound is loose (by N and more); the planes keep fp32-grade ABSOLUTE accuracy regardless: fp16 denormal operands
+// are honoured by the MFMA (tools/probes/mfma_denorm.hip), so an element far below the scale loses relative, not absolute,
+// precision (error <= 2^-50 of the bound).
+__global__ __launch_bounds__(64) void attn_dqkv_bound_kernel(float* __restrict__ slot_out, const float* __restrict__ slot_do,
+                                                             const float* __restrict__ slot_qkv, int N, float scale) {
+  const unsigned bits = eav_slot_bits(slot_do);
+  if (threadIdx.x == 0) {
+    // q: the measured maximum when the producer of qkv left it in the slot's shards (the fused projection does), else the
+    // bound its scale stands for (2^15 / sigma)
+    const unsigned qb = eav_slot_bits(slot_qkv);
+    const float m = __uint_as_float(bits), q = qb ? __uint_as_float(qb) : 32768.f * slot_qkv[EAV_SLOT_ISIGMA];
+    const float bound = (float)N * m * fmaxf(1.f, 128.f * scale * q * q) * 1.0001f;
+    const float sg = sigma_from_bits(__float_as_uint(bound));
+    slot_out[EAV_SLOT_SIGMA] = sg;
+    slot_out[EAV_SLOT_ISIGMA] = 1.f / sg;
+  }
+}
+
 }  // namespace
 
 extern "C" int eav_attn_sp_npad(int N) { return (N + 31) / 32 * 32; }
@@ -1261,13 +1305,25 @@ extern "C" int eav_attn_fwd_sp(const void* rowp, const void* tp, const float* sl
   return eav_attn_fwd_sp_planes(rowp, tp, slot, ao, lse, amax_slot, nullptr, nullptr, B, H, N, head_dim, scale, stream);
 }
 
-// delta: scratch [B*H, N].  slot_ds: scratch slot (zeroed by the caller).  dqkv [B*N, 3*H*64] fp32.
-extern "C" int eav_attn_bwd_sp(const void* rowp, const void* tp, const void* dorow, const void* dotp, const float* slot,
-                               const float* slot_do, float* slot_ds, const float* ao, const float* dout,
-                               const float* lse, float* delta, float* dqkv, float* amax_slot, int B, int H, int N,
-                               int head_dim, float scale, void* stream) {
-  EAV_REQUIRE(rowp && dorow && slot && slot_do && slot_ds && ao && dout && lse && delta && dqkv && B > 0 &&
-                  H > 0 && N > 0, "eav_attn_bwd_sp: bad arguments");
+extern "C" int eav_attn_dqkv_bound(float* slot_out, const float* slot_do, const float* slot_qkv, int N, float scale,
+                                   void* stream) {
+  EAV_REQUIRE(slot_out && slot_do && slot_qkv && N > 0 && scale > 0.f, "eav_attn_dqkv_bound: bad arguments");
+  hipLaunchKernelGGL(attn_dqkv_bound_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, slot_out, slot_do, slot_qkv, N, scale);
+  EAV_CHECK_LAUNCH("eav_attn_dqkv_bound");
+  return EAV_OK;
+}
+
+// delta: scratch [B*H, N].  slot_ds: scratch slot (zeroed by the caller).  dqkv [B*N, 3*H*64] fp32 (optional with planes).
+// planes (optional): dqkv also (or only) leaves as the operand planes [B*N][3D/8][2][8] of the q/k/v projection's gradient
+// products, scaled by planes_slot's sigma (eav_attn_dqkv_bound, launched before); colsum_part (optional)
+// [B * ceil(N / 32)][3 D]: per 32-row tile the column sums of dqkv (finish the bias gradient with eav_reduce_partials).
+extern "C" int eav_attn_bwd_sp_planes(const void* rowp, const void* tp, const void* dorow, const void* dotp,
+                                      const float* slot, const float* slot_do, float* slot_ds, const float* ao,
+                                      const float* dout, const float* lse, float* delta, float* dqkv, float* amax_slot,
+                                      void* planes, const float* planes_slot, float* colsum_part, int B, int H, int N,
+                                      int head_dim, float scale, void* stream) {
+  EAV_REQUIRE(rowp && dorow && slot && slot_do && slot_ds && ao && dout && lse && delta && (dqkv || planes) && B > 0 &&
+                  H > 0 && N > 0 && (!planes || planes_slot), "eav_attn_bwd_sp: bad arguments");
   EAV_REQUIRE(head_dim == 64, "eav_attn_bwd_sp: head_dim %d unsupported (needs 64)", head_dim);
   const int Npad = eav_attn_sp_npad(N);
   hipStream_t st = (hipStream_t)stream;
@@ -1275,19 +1331,28 @@ extern "C" int eav_attn_bwd_sp(const void* rowp, const void* tp, const void* dor
   if (N > g_nw4_above) {
     hipLaunchKernelGGL(attn_bwd_q_sp_kernel<4>, dim3(nt128 * nbh), dim3(256), 0, st, (const u8*)rowp, (const u8*)tp,
                        (const u8*)dorow, slot, slot_do, lse, ao, dout, delta, dqkv, (unsigned*)slot_ds,
-                       (unsigned*)amax_slot, N, Npad, H, scale, nt128, nbh);
+                       (unsigned*)amax_slot, N, Npad, H, scale, nt128, nbh, (u8*)planes, planes_slot, colsum_part);
     EAV_CHECK_LAUNCH("eav_attn_bwd_sp(dQ)");
   } else {
     hipLaunchKernelGGL(attn_bwd_q_sp_kernel<2>, dim3(nt64 * nbh), dim3(128), 0, st, (const u8*)rowp, (const u8*)tp,
                        (const u8*)dorow, slot, slot_do, lse, ao, dout, delta, dqkv, (unsigned*)slot_ds,
-                       (unsigned*)amax_slot, N, Npad, H, scale, nt64, nbh);
+                       (unsigned*)amax_slot, N, Npad, H, scale, nt64, nbh, (u8*)planes, planes_slot, colsum_part);
     EAV_CHECK_LAUNCH("eav_attn_bwd_sp(dQ)");
   }
   // the dK,dV kernel holds 66 KB of tiles per block: 4-wave blocks keep 2 waves per SIMD at every N (a wave past the last
   // key only stages tiles)
   hipLaunchKernelGGL(attn_bwd_kv_sp_kernel<4>, dim3(nt128 * nbh), dim3(256), 0, st, (const u8*)rowp, (const u8*)tp,
                      (const u8*)dorow, (const u8*)dotp, slot, slot_do, slot_ds, lse, delta, dqkv, (unsigned*)amax_slot, N,
-                     Npad, H, scale, nt128, nbh);
+                     Npad, H, scale, nt128, nbh, (u8*)planes, planes_slot, colsum_part);
   EAV_CHECK_LAUNCH("eav_attn_bwd_sp(dK,dV)");
   return EAV_OK;
+}
+
+extern "C" int eav_attn_bwd_sp(const void* rowp, const void* tp, const void* dorow, const void* dotp, const float* slot,
+                               const float* slot_do, float* slot_ds, const float* ao, const float* dout,
+                               const float* lse, float* delta, float* dqkv, float* amax_slot, int B, int H, int N,
+                               int head_dim, float scale, void* stream) {
+  EAV_REQUIRE(dqkv, "eav_attn_bwd_sp: bad arguments");
+  return eav_attn_bwd_sp_planes(rowp, tp, dorow, dotp, slot, slot_do, slot_ds, ao, dout, lse, delta, dqkv, amax_slot,
+                                nullptr, nullptr, nullptr, B, H, N, head_dim, scale, stream);
 }

@@ -242,6 +242,10 @@ class Encoder(nn.Module):
         # split mode, forward: the fused q/k/v projection writes the attention kernels' row planes itself (scale from a bound of
         # |qkv|), the per-head transposes are made from those planes - no fp32 qkv tensor (EAV_FUSED_QKV=0 for A/B runs)
         self.fused_qkv = os.environ.get("EAV_FUSED_QKV", "1") != "0"
+        # split mode, backward: the attention backward writes dqkv as the planes of the q/k/v projection's gradient products
+        # itself (scale from a rigorous bound of |dqkv|, eav_attn_dqkv_bound) and leaves the bias-gradient partials - no fp32
+        # dqkv, no conversion pass (EAV_FUSED_DQKV=0 for A/B runs)
+        self.fused_dqkv = os.environ.get("EAV_FUSED_DQKV", "1") != "0"
         self._side, self._aux, self._wgrad_done, self._wready, self._wnorm_ready = None, None, {}, {}, None
         self._part_busy, self._ring_pos = {}, {}
         self._wplanes = None          # split mode: {weight key: (planes, planes of the transpose, slot index)}
@@ -459,6 +463,8 @@ class Encoder(nn.Module):
             ws.np_cs2 = _lib.plain("eav_sp_convert_colsum_nparts", M)
             ws.part_cs2 = torch.empty(ws.np_cs2, max(FF, 3 * D), dtype=torch.float32, device=dev)
             ws.part_cs2_pool = [ws.part_cs2] + [torch.empty_like(ws.part_cs2) for _ in range(3)]
+            ws.np_attn = ws.B * ((c.ntok + 31) // 32)          # bias-gradient partials of the attention backward: one row per 32-token tile
+            ws.part_attn_pool = [torch.zeros(ws.np_attn, 3 * D, dtype=torch.float32, device=dev) for _ in range(4)]
             ws.bslots = torch.zeros(2 + self.BS * Lr, self.SLOT, dtype=torch.float32, device=dev)
             if ws.fused:
                 ws.dorow = torch.empty(M, 2 * D, dtype=torch.float16, device=dev)
@@ -933,8 +939,9 @@ class Encoder(nn.Module):
             # scale = the bound eav_tf_forward_scales_qkv put into s_qkv); the per-head transposes (V^T for the forward; Q^T,
             # K^T for the backward) are a pure fp16 transposition of those planes
             L("eav_gemm_sp_ex", P(ws.y1p[j]), wpl, None, s_y1, wsl, M, 3 * D, D, 3 * D, 1, 0, 0, 1.0,
-              w(f"{Lk}.attention.q_proj.bias"), 0, None, None, 0, 0, None, P(ws.qkvrow[j]), s_qkv, None,
-              4 | (1 if self.fwd_terms == 1 else 0), st)
+              w(f"{Lk}.attention.q_proj.bias"), 0, None, None, 0, 0, s_qkv, P(ws.qkvrow[j]), s_qkv, None,
+              4 | 8 | (1 if self.fwd_terms == 1 else 0), st)      # (+ the MEASURED max|qkv| into the slot's shards: the
+            #                                                         backward's bound of |dqkv| uses it, eav_attn_dqkv_bound)
         else:
             self._gemm_sp(P(ws.y1p[j]), s_y1, wpl, wsl, qkv, M, 3 * D, D, 3 * D, bias=w(f"{Lk}.attention.q_proj.bias"),
                           amax=s_qkv if ws.fused else None)
@@ -1043,8 +1050,17 @@ class Encoder(nn.Module):
         # attention core
         if ws.fused:
             L("eav_attn_sp_prep", dao, b_dao, P(ws.dorow), None, ws.B, N, D, D, 0, st)
-            L("eav_attn_bwd_sp", P(ws.qkvrow[i]), None, P(ws.dorow), None, s_qkv, b_dao, b_ds,
-              P(ws.ao[i]), dao, P(ws.lse[i]), P(ws.delta), dqkv, b_dqkv, ws.B, H, N, hd, scale, st)
+            if self.fused_dqkv and self.grad_terms != 1:      # (hi.hi-only gradient products need the tight measured scale)
+                L("eav_attn_dqkv_bound", b_dqkv, b_dao, s_qkv, N, scale, st)
+                self._before_overwrite(ws.dqkvp)
+                part = self._part_buf("part_attn_pool")
+                L("eav_attn_bwd_sp_planes", P(ws.qkvrow[i]), None, P(ws.dorow), None, s_qkv, b_dao, b_ds,
+                  P(ws.ao[i]), dao, P(ws.lse[i]), P(ws.delta), None, None, P(ws.dqkvp), b_dqkv, P(part), ws.B, H, N, hd,
+                  scale, st)
+                self._reduce_async(part, 0, ws.np_attn, 3 * D, 3 * D, gp(f"{Lk}.attention.q_proj.bias"))
+            else:
+                L("eav_attn_bwd_sp", P(ws.qkvrow[i]), None, P(ws.dorow), None, s_qkv, b_dao, b_ds,
+                  P(ws.ao[i]), dao, P(ws.lse[i]), P(ws.delta), dqkv, b_dqkv, ws.B, H, N, hd, scale, st)
         else:
             qkv = P(ws.qkv[i])
             ldn = ws.ldn
@@ -1061,7 +1077,8 @@ class Encoder(nn.Module):
         # fused q/k/v projection
         if not ws.fused:
             self._call("eav_sp_absmax", dqkv, M, 3 * D, 3 * D, b_dqkv, st)
-        self._to_planes_bias(dqkv, M, 3 * D, b_dqkv, ws.dqkvp, gp(f"{Lk}.attention.q_proj.bias"))
+        if not (ws.fused and self.fused_dqkv and self.grad_terms != 1):
+            self._to_planes_bias(dqkv, M, 3 * D, b_dqkv, ws.dqkvp, gp(f"{Lk}.attention.q_proj.bias"))
         self._wgrad_sp(ws.dqkvp, b_dqkv, ws.y1p[i], s_y1, gp(f"{Lk}.attention.q_proj.weight"), 3 * D, D, M)
         wpl, wsl = self._wp(f"qkv{i}", transposed=True)
         self._gemm_sp(P(ws.dqkvp), b_dqkv, wpl, wsl, dy, M, D, 3 * D, D)

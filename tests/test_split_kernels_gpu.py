@@ -277,6 +277,33 @@ def test_attention_sp_is_fp32_grade(cfg):
               0.125, None)
     assert torch.equal(aop3[:B * N], aop[:B * N])
 
+    # the backward writing dqkv as the operand planes of the q/k/v projection's gradient products (eav_attn_bwd_sp_planes):
+    # scale from the rigorous bound (eav_attn_dqkv_bound) >= max|dqkv|; planes == the fp32 dqkv of the plain call to split
+    # precision in ABSOLUTE terms (2^-21 of the scale's range: the bound is loose, small elements sit far below it); the
+    # column sums of every 32-row tile add up to the bias gradient; the fp32 copy is optional; pad rows untouched
+    s_g = torch.zeros(SLOT, device="cuda")
+    _lib.call("eav_attn_dqkv_bound", P(s_g), P(s_do), P(s_qkv), N, 0.125, None)
+    gsig = float(s_g[2048])
+    assert float(dqkv.abs().max()) * gsig < 2.0 ** 15 and float(s_g[2049]) == 1.0 / gsig
+    nrb = (N + 31) // 32
+    gpl = torch.full(((B * N + 31) // 32 * 32, 2 * kpad(3 * D)), 7.0, dtype=torch.float16, device="cuda")
+    cs = torch.zeros(B * nrb, 3 * D, device="cuda")
+    s_ds2, delta2 = torch.zeros(SLOT, device="cuda"), torch.empty(B * H, N, device="cuda")
+    dq2 = torch.empty_like(dqkv)
+    _lib.call("eav_attn_bwd_sp_planes", P(rowp), P(tp), P(dorow), P(dotp), P(s_qkv), P(s_do), P(s_ds2), P(ao), P(dO), P(lse),
+              P(delta2), P(dq2), None, P(gpl), P(s_g), P(cs), B, H, N, 64, 0.125, None)
+    assert torch.equal(dq2, dqkv)
+    got = decode_planes(gpl, B * N, 3 * D, gsig)
+    assert (got - dqkv.double()).abs().max().item() <= 2.0 ** -21 * (2.0 ** 15 / gsig) * 2.0 ** -10 + \
+        2.0 ** -21 * float(dqkv.abs().max())
+    assert (gpl[B * N:] == 7).all()
+    want_cs = dqkv.double().sum(0)
+    assert (cs.double().sum(0) - want_cs).abs().max().item() <= 1e-5 * float(dqkv.abs().max()) * (B * N) ** 0.5
+    gpl3 = torch.zeros_like(gpl)
+    _lib.call("eav_attn_bwd_sp_planes", P(rowp), P(tp), P(dorow), P(dotp), P(s_qkv), P(s_do), P(s_ds2), P(ao), P(dO), P(lse),
+              P(delta2), None, None, P(gpl3), P(s_g), None, B, H, N, 64, 0.125, None)
+    assert torch.equal(gpl3[:B * N], gpl[:B * N])
+
     def rel(a, r):
         return ((a.double() - r).abs().max() / r.abs().max()).item()
     assert rel(ao, ro) <= 1.5 * rel(ao32, ro) + 2e-7

@@ -41,11 +41,11 @@ import contextlib
 hp = os.environ.get("HIGH_PRIO")
 ctx = torch.cuda.stream(torch.cuda.Stream(priority=-1)) if hp else contextlib.nullcontext()
 with ctx:
-    for _ in range(2):
+    for _ in range(4):                   # (lazy allocations, first launches of every kernel, event / stream pools)
         step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    n = 4
+    n = int(os.environ.get("STEPS", "12"))
     for _ in range(n):
         step()
     torch.cuda.synchronize()

@@ -81,6 +81,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
   if (lane == 0) {
     if (mean_o) mean_o[row] = mean;
     if (rstd_o) rstd_o[row] = rstd;
+    // max over the rows of rstd, for the bound of the backward's output (eav_layernorm_bwd_bound): word 1 of the row's shard
+    // line in whichever scale slot this launch has (the line is this row's atomic target anyway / unused in a-priori mode)
+    unsigned* rs = amax ? amax : reinterpret_cast<unsigned*>(const_cast<float*>(pslot));
+    if (rs && rstd == rstd) atomicMax(rs + EAV_SLOT_SHARD(row) + 1, __float_as_uint(rstd));
   }
   if (amax) {   // max |y| of the row into one of the 64 shards of the operand-scale slot (gemm_sp.hip)
 #pragma unroll
@@ -96,8 +100,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             const float* __restrict__ mean_i,
                                                             const float* __restrict__ rstd_i, float* __restrict__ dx,
                                                             int accumulate, float* __restrict__ part, int M, int D,
-                                                            unsigned* __restrict__ amax) {
-  extern __shared__ float sh[];  // [4][2*D]
+                                                            unsigned* __restrict__ amax, unsigned char* __restrict__ planes,
+                                                            int64_t ldp, float lomul) {
+  // planes (optional): the STORED value (dx, after the accumulation) also leaves as row planes scaled by the sigma in the
+  // amax slot - a bound set before the launch (eav_layernorm_bwd_bound) - and its column sums (the bias gradient of the
+  // linear layer that produced the residual branch) as a third section of the partials: part[blk][3*D]
+  extern __shared__ float sh[];  // [4][2*D] (planes: [4][3*D])
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nq = D >> 2;
   const float4* g4 = reinterpret_cast<const float4*>(gamma);
@@ -109,6 +117,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     ag[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     ab[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
+  float4 ac[LN_MAXQ];              // planes: column sums of the stored value
+#pragma unroll
+  for (int i = 0; i < LN_MAXQ; ++i) ac[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float psg = planes ? reinterpret_cast<const float*>(amax)[EAV_SLOT_SIGMA] : 0.f;
   float vmax = 0.f;
   // the rows of a wave are independent: the NEXT row's x, dy (and dx when accumulating) are loaded before the current
   // row's reductions, so a wave always has a row in flight (in the encoder step this kernel runs beside a weight-gradient
@@ -179,9 +191,27 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         }
         dst[q] = o;
         rmax = fmaxf(rmax, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
+        if (planes) {     // (as layernorm_fwd_kernel: lanes 2p, 2p + 1 swap halves, each stores one whole 16-byte piece)
+          ac[i].x += o.x; ac[i].y += o.y; ac[i].z += o.z; ac[i].w += o.w;
+          const float t[4] = {o.x * psg, o.y * psg, o.z * psg, o.w * psg};
+          _Float16 h[4], l[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            h[e] = (_Float16)t[e];
+            l[e] = (_Float16)((t[e] - (float)h[e]) * lomul);
+          }
+          const uint2 hh = *reinterpret_cast<const uint2*>(h), ll = *reinterpret_cast<const uint2*>(l);
+          const bool first = (q & 1) == 0;
+          const uint2 send = first ? ll : hh;
+          uint2 recv;
+          recv.x = __shfl_xor(send.x, 1, 64);
+          recv.y = __shfl_xor(send.y, 1, 64);
+          *reinterpret_cast<uint4*>(planes + (int64_t)row * ldp + (int64_t)(q >> 1) * 32 + (first ? 0 : 16)) =
+              first ? make_uint4(hh.x, hh.y, recv.x, recv.y) : make_uint4(recv.x, recv.y, ll.x, ll.y);
+        }
       }
     }
-    if (amax) {       // the group's maximum into its 32-row block's entry (per-row-block operand scales, eav_common.h)
+    if (amax && !planes) {       // the group's maximum into its 32-row block's entry (per-row-block operand scales, eav_common.h)
       gmax = fmaxf(gmax, rmax);
       if (((row + 1) & (RG - 1)) == 0 || row + 1 >= M) {
 #pragma unroll
@@ -191,23 +221,29 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         gmax = 0.f;
       }
     }
+    if (planes) vmax = fmaxf(vmax, rmax);      // (a-priori scale: no block entries, the tensor-wide measured maximum only -
+                                               // the next bound starts from it)
   }
   if (amax) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
     if (lane == 0 && vmax == vmax) atomicMax(amax + EAV_SLOT_SHARD(blockIdx.x * 4 + wave), __float_as_uint(vmax));
   }
   if (!part) return;
-  float4* shw = reinterpret_cast<float4*>(sh + wave * 2 * D);
+  const int NS = planes ? 3 : 2;
+  float4* shw = reinterpret_cast<float4*>(sh + wave * NS * D);
 #pragma unroll
   for (int i = 0; i < LN_MAXQ; ++i) {
     const int q = lane + 64 * i;
     if (q < nq) {
       shw[q] = ag[i];
       shw[nq + q] = ab[i];
+      if (planes) shw[2 * nq + q] = ac[i];
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * D; i += 256)
-    part[(int64_t)blockIdx.x * 2 * D + i] = (sh[i] + sh[2 * D + i]) + (sh[4 * D + i] + sh[6 * D + i]);
+  for (int i = threadIdx.x; i < NS * D; i += 256)
+    part[(int64_t)blockIdx.x * NS * D + i] = (sh[i] + sh[NS * D + i]) + (sh[2 * NS * D + i] + sh[3 * NS * D + i]);
 }
 
 // ------------------------------------------------------------------------------------ softmax
@@ -610,7 +646,8 @@ extern "C" int eav_layernorm_bwd(const float* dy, const float* x, const float* g
   EAV_REQUIRE(dy && x && gamma && mean && rstd && dx && M > 0 && D > 0 && (D & 3) == 0 && D <= 1024,
               "eav_layernorm_bwd: need D %% 4 == 0 and D <= 1024");
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(eav_layernorm_bwd_nparts(M)), dim3(256), 8 * D * sizeof(float),
-                     (hipStream_t)stream, dy, x, gamma, mean, rstd, dx, accumulate, part, M, D, (unsigned*)nullptr);
+                     (hipStream_t)stream, dy, x, gamma, mean, rstd, dx, accumulate, part, M, D, (unsigned*)nullptr,
+                     (unsigned char*)nullptr, (int64_t)0, 0.f);
   EAV_CHECK_LAUNCH("eav_layernorm_bwd");
   return EAV_OK;
 }
@@ -622,10 +659,28 @@ extern "C" int eav_layernorm_bwd_amax(const float* dy, const float* x, const flo
               "eav_layernorm_bwd_amax: need D %% 4 == 0 and D <= 1024");
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(eav_layernorm_bwd_nparts(M)), dim3(256), 8 * D * sizeof(float),
                      (hipStream_t)stream, dy, x, gamma, mean, rstd, dx, accumulate, part, M, D,
-                     reinterpret_cast<unsigned*>(amax_slot));
+                     reinterpret_cast<unsigned*>(amax_slot), (unsigned char*)nullptr, (int64_t)0, 0.f);
   EAV_CHECK_LAUNCH("eav_layernorm_bwd_amax");
   return EAV_OK;
 }
+
+// eav_layernorm_bwd_amax whose stored value (dx, after the accumulation) ALSO leaves as the row planes [M][Dp/8][2][8] of the
+// products that consume it - no conversion pass - scaled by slot's sigma, which eav_layernorm_bwd_bound sets beforehand; part is
+// [nparts][3*D]: dgamma | dbeta | column sums of the stored value (the bias gradient of the layer that fed the residual).
+// slot's shards receive the measured tensor-wide maximum (no 32-row block entries: the scale is a-priori).
+extern "C" int eav_layernorm_bwd_planes(const float* dy, const float* x, const float* gamma, const float* mean,
+                                        const float* rstd, float* dx, int accumulate, float* part, int M, int D,
+                                        float* slot, void* planes, void* stream) {
+  EAV_REQUIRE(dy && x && gamma && mean && rstd && dx && part && slot && planes && M > 0 && D > 0 && (D & 7) == 0 &&
+                  D <= 1024 && ((uintptr_t)planes & 15) == 0,
+              "eav_layernorm_bwd_planes: need D %% 8 == 0, D <= 1024, 16-byte aligned planes");
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(eav_layernorm_bwd_nparts(M)), dim3(256), 12 * D * sizeof(float),
+                     (hipStream_t)stream, dy, x, gamma, mean, rstd, dx, accumulate, part, M, D,
+                     reinterpret_cast<unsigned*>(slot), (unsigned char*)planes, (int64_t)eav_sp_kpad(D) * 4, 2048.f);
+  EAV_CHECK_LAUNCH("eav_layernorm_bwd_planes");
+  return EAV_OK;
+}
+
 
 extern "C" int eav_softmax_fwd(float* s, int64_t rows, int N, int ld, void* stream) {
   EAV_REQUIRE(s && rows > 0 && N > 0 && ld >= N && N <= 2048, "eav_softmax_fwd: need N <= 2048");
@@ -737,6 +792,44 @@ extern "C" int eav_colnorm_max(const float* w, int R, int C, int64_t ld, float* 
   return EAV_OK;
 }
 
+// sigma / 1 / sigma of slot_out from a bound of the tensor eav_layernorm_bwd_planes is about to store,
+//   |dx_old + LN'(dy)| <= max|dx_old| + (2 + sqrt(D)) max|gamma| max_rows(rstd) max|dy|
+// (dx = rstd (g - mean g - xhat mean(g xhat)), g = gamma o dy: |g - mean g| <= 2 max|g|, |xhat| <= sqrt(D), mean|xhat| <= 1).
+// slot_old: the slot whose shards hold the MEASURED max|dx_old| (0: no accumulation); slot_dy: shards of max|dy|.  One block.
+__global__ __launch_bounds__(256) void layernorm_bwd_bound_kernel(float* __restrict__ slot_out, const float* __restrict__ slot_old,
+                                                                  const float* __restrict__ slot_dy,
+                                                                  const float* __restrict__ gamma,
+                                                                  const float* __restrict__ rstd, int M, int D,
+                                                                  const float* __restrict__ slot_rstd) {
+  __shared__ float red[8];
+  float gmx = 0.f, rmx = 0.f;
+  for (int i = threadIdx.x; i < D; i += 256) gmx = fmaxf(gmx, fabsf(gamma[i]));
+  // max rstd: from the forward's slot (word 1 of the 64 shard lines, layernorm_fwd_kernel) when there is one - a walk over the
+  // M-long rstd array by one block cost 69 us per launch at M = 25216
+  if (slot_rstd) {
+    if (threadIdx.x < 64) rmx = slot_rstd[32 * threadIdx.x + 1];
+  } else {
+    for (int i = threadIdx.x; i < M; i += 256) rmx = fmaxf(rmx, rstd[i]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    gmx = fmaxf(gmx, __shfl_xor(gmx, o, 64));
+    rmx = fmaxf(rmx, __shfl_xor(rmx, o, 64));
+  }
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = gmx; red[4 + (threadIdx.x >> 6)] = rmx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    gmx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    rmx = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+    const float old = slot_old ? __uint_as_float(eav_slot_bits(slot_old)) : 0.f;
+    const float dy = __uint_as_float(eav_slot_bits(slot_dy));
+    const float bound = (old + (2.f + sqrtf((float)D)) * gmx * rmx * dy) * 1.0001f;
+    const float sg = sigma_of_bound(bound);
+    slot_out[EAV_SLOT_SIGMA] = sg;
+    slot_out[EAV_SLOT_ISIGMA] = 1.f / sg;
+  }
+}
+
 // sigma / 1 / sigma of slot_out from the bound factor * max|x| * *norm, max|x| = the maximum in amax_slot's shards: the
 // operand scale of a tensor that is about to be produced, from a bound of its magnitude (e.g. the MLP's hidden-state
 // gradient dact = (dh W2) o gelu'(pre): |dact| <= 1.13 sqrt(D) max|dh| max_j ||W2[:, j]||_2) - its producer then writes
@@ -750,6 +843,15 @@ __global__ __launch_bounds__(64) void bound_scale_kernel(float* __restrict__ slo
     slot_out[EAV_SLOT_SIGMA] = sg;
     slot_out[EAV_SLOT_ISIGMA] = 1.f / sg;
   }
+}
+
+extern "C" int eav_layernorm_bwd_bound(float* slot_out, const float* slot_old, const float* slot_dy, const float* gamma,
+                                       const float* rstd, int M, int D, const float* slot_rstd, void* stream) {
+  EAV_REQUIRE(slot_out && slot_dy && gamma && (rstd || slot_rstd) && M > 0 && D > 0, "eav_layernorm_bwd_bound: bad arguments");
+  hipLaunchKernelGGL(layernorm_bwd_bound_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, slot_out, slot_old, slot_dy, gamma,
+                     rstd, M, D, slot_rstd);
+  EAV_CHECK_LAUNCH("eav_layernorm_bwd_bound");
+  return EAV_OK;
 }
 
 extern "C" int eav_sp_bound_scale(float* slot_out, const float* amax_slot, const float* norm, float factor, void* stream) {

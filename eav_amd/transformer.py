@@ -246,6 +246,10 @@ class Encoder(nn.Module):
         # itself (scale from a rigorous bound of |dqkv|, eav_attn_dqkv_bound) and leaves the bias-gradient partials - no fp32
         # dqkv, no conversion pass (EAV_FUSED_DQKV=0 for A/B runs)
         self.fused_dqkv = os.environ.get("EAV_FUSED_DQKV", "1") != "0"
+        # split mode, backward: the LayerNorm backward kernels write the residual-stream gradient they produce as operand
+        # planes as well (scale from a rigorous bound, eav_layernorm_bwd_bound) and leave the bias-gradient partials of the
+        # linear layer that consumes it - two conversion passes per layer disappear (EAV_FUSED_DH=0 for A/B runs)
+        self.fused_dh = os.environ.get("EAV_FUSED_DH", "1") != "0"
         self._side, self._aux, self._wgrad_done, self._wready, self._wnorm_ready = None, None, {}, {}, None
         self._part_busy, self._ring_pos = {}, {}
         self._wplanes = None          # split mode: {weight key: (planes, planes of the transpose, slot index)}
@@ -418,6 +422,7 @@ class Encoder(nn.Module):
             ws.np_ln = _lib.plain("eav_layernorm_bwd_nparts", M)
             ws.part_ln = f(ws.np_ln, 2 * D)
             ws.part_ln_pool = [ws.part_ln, f(ws.np_ln, 2 * D)]     # split path: see _part_buf
+            ws.part_ln3_pool = [f(ws.np_ln, 3 * D) for _ in range(4)]   # ... with the bias-gradient section (fused_dh)
             ws.np_cs = _lib.plain("eav_colsum_nparts", M)
             ws.part_cs = f(ws.np_cs, max(FF, 3 * D))
             shapes = [(D, FF, M), (FF, D, M), (3 * D, D, M), (D, D, M), (D, c.kp, B * c.npatch)]
@@ -431,7 +436,7 @@ class Encoder(nn.Module):
 
     # ------------------------------------------------------------------ split-operand (fp16 hi/lo planes) plumbing
     SLOT = 4128   # floats per scale slot (include/eav_hip.h EAV_SP_SLOT)
-    FS, BS = 5, 6   # slots per layer: forward y1, qkv, ao, y2, act; backward dh(fc2), dact, dh(o), dao, dS, dqkv
+    FS, BS = 5, 8   # slots per layer: forward y1, qkv, ao, y2, act; backward dh(fc2), dact, dh(o), dao, dS, dqkv, dy(fc1), dy(qkv)
 
     def _alloc_split(self, ws, dev, nsave):
         c = self.cfg
@@ -1011,10 +1016,13 @@ class Encoder(nn.Module):
         w = lambda k: P(self._pmap[k])  # noqa: E731
         dh, dy, dao, dact, dqkv = P(ws.dh), P(ws.dy), P(ws.dao), P(ws.dact), P(ws.dqkv)
         s_y1, s_qkv, s_ao, s_y2, s_act = (fslot(1 + self.FS * i + k) for k in range(5))
-        b_dh2, b_dact, b_dh1, b_dao, b_ds, b_dqkv = (bslot(1 + self.BS * i + k) for k in range(6))
+        b_dh2, b_dact, b_dh1, b_dao, b_ds, b_dqkv, b_dy2, b_dy1 = (bslot(1 + self.BS * i + k) for k in range(8))
+        fdh = self.fused_dh and self.grad_terms != 1      # (hi.hi-only gradient products need the tight measured scales)
         # fc2: h_out = h_mid + act.W2^T + b2.  max|dh| is already in b_dh2 (left there by the producer of dh); every
-        # conversion pass also yields the bias gradient of its tensor
-        self._to_planes_bias(dh, M, D, b_dh2, ws.dhp, gp(f"{Lk}.mlp.fc2.bias"))
+        # conversion pass also yields the bias gradient of its tensor.  (fused_dh: the layer above's LayerNorm backward
+        # already wrote these planes and the bias-gradient partials - only the top layer's dh comes from the head)
+        if not (fdh and i < c.layers - 1):
+            self._to_planes_bias(dh, M, D, b_dh2, ws.dhp, gp(f"{Lk}.mlp.fc2.bias"))
         self._wgrad_sp(ws.dhp, b_dh2, ws.actp[i], s_act, gp(f"{Lk}.mlp.fc2.weight"), D, FF, M)
         wpl, wsl = self._wp(f"fc2{i}", transposed=True)
         if self.fused_dact and FF % 8 == 0:
@@ -1036,13 +1044,19 @@ class Encoder(nn.Module):
         # fc1
         self._wgrad_sp(ws.dactp, b_dact, ws.y2p[i], s_y2, gp(f"{Lk}.mlp.fc1.weight"), FF, D, M)
         wpl, wsl = self._wp(f"fc1{i}", transposed=True)
-        self._gemm_sp(P(ws.dactp), b_dact, wpl, wsl, dy, M, D, FF, D)
-        part = self._part_buf("part_ln_pool")
-        L("eav_layernorm_bwd_amax", dy, P(ws.hmid[i]), w(f"{Lk}.layernorm_after.weight"), stp + 8 * M, stp + 12 * M, dh,
-          1, P(part), M, D, b_dh1, st)
-        self._reduce_ln(part, gp(f"{Lk}.layernorm_after.weight"), gp(f"{Lk}.layernorm_after.bias"))
-        # o_proj
-        self._to_planes_bias(dh, M, D, b_dh1, ws.dhp2, gp(f"{Lk}.attention.o_proj.bias"))
+        if fdh:
+            self._gemm_sp(P(ws.dactp), b_dact, wpl, wsl, dy, M, D, FF, D, amax=b_dy2, blockmax=False)
+            self._ln_bwd_planes(dy, P(ws.hmid[i]), w(f"{Lk}.layernorm_after.weight"), stp + 8 * M, stp + 12 * M, dh, b_dh1,
+                                b_dh2, b_dy2, ws.dhp2, gp(f"{Lk}.layernorm_after.weight"), gp(f"{Lk}.layernorm_after.bias"),
+                                gp(f"{Lk}.attention.o_proj.bias"), s_y2)
+        else:
+            self._gemm_sp(P(ws.dactp), b_dact, wpl, wsl, dy, M, D, FF, D)
+            part = self._part_buf("part_ln_pool")
+            L("eav_layernorm_bwd_amax", dy, P(ws.hmid[i]), w(f"{Lk}.layernorm_after.weight"), stp + 8 * M, stp + 12 * M, dh,
+              1, P(part), M, D, b_dh1, st)
+            self._reduce_ln(part, gp(f"{Lk}.layernorm_after.weight"), gp(f"{Lk}.layernorm_after.bias"))
+            # o_proj
+            self._to_planes_bias(dh, M, D, b_dh1, ws.dhp2, gp(f"{Lk}.attention.o_proj.bias"))
         self._wgrad_sp(ws.dhp2, b_dh1, ws.aop[i], s_ao, gp(f"{Lk}.attention.o_proj.weight"), D, D, M)
         wpl, wsl = self._wp(f"o{i}", transposed=True)
         # (dao goes to the attention operand preparation: one scale per tensor, no row-block maxima needed)
@@ -1081,12 +1095,37 @@ class Encoder(nn.Module):
             self._to_planes_bias(dqkv, M, 3 * D, b_dqkv, ws.dqkvp, gp(f"{Lk}.attention.q_proj.bias"))
         self._wgrad_sp(ws.dqkvp, b_dqkv, ws.y1p[i], s_y1, gp(f"{Lk}.attention.q_proj.weight"), 3 * D, D, M)
         wpl, wsl = self._wp(f"qkv{i}", transposed=True)
-        self._gemm_sp(P(ws.dqkvp), b_dqkv, wpl, wsl, dy, M, D, 3 * D, D)
         # the gradient w.r.t. this layer's input is the next (lower) layer's dh: leave its max in that layer's slot
-        part = self._part_buf("part_ln_pool")
-        L("eav_layernorm_bwd_amax", dy, P(ws.hs[i]), w(f"{Lk}.layernorm_before.weight"), stp, stp + 4 * M, dh, 1,
-          P(part), M, D, bslot(1 + self.BS * (i - 1)) if i > 0 else bslot(0), st)
-        self._reduce_ln(part, gp(f"{Lk}.layernorm_before.weight"), gp(f"{Lk}.layernorm_before.bias"))
+        if fdh and i > 0:
+            self._gemm_sp(P(ws.dqkvp), b_dqkv, wpl, wsl, dy, M, D, 3 * D, D, amax=b_dy1, blockmax=False)
+            below = Lk.rsplit(".", 1)[0] + f".{i - 1}"
+            self._ln_bwd_planes(dy, P(ws.hs[i]), w(f"{Lk}.layernorm_before.weight"), stp, stp + 4 * M, dh,
+                                bslot(1 + self.BS * (i - 1)), b_dh1, b_dy1, ws.dhp, gp(f"{Lk}.layernorm_before.weight"),
+                                gp(f"{Lk}.layernorm_before.bias"), gp(f"{below}.mlp.fc2.bias"), s_y1)
+        else:
+            self._gemm_sp(P(ws.dqkvp), b_dqkv, wpl, wsl, dy, M, D, 3 * D, D)
+            part = self._part_buf("part_ln_pool")
+            L("eav_layernorm_bwd_amax", dy, P(ws.hs[i]), w(f"{Lk}.layernorm_before.weight"), stp, stp + 4 * M, dh, 1,
+              P(part), M, D, bslot(1 + self.BS * (i - 1)) if i > 0 else bslot(0), st)
+            self._reduce_ln(part, gp(f"{Lk}.layernorm_before.weight"), gp(f"{Lk}.layernorm_before.bias"))
+
+    def _ln_bwd_planes(self, dy, x, gamma, mean, rstd, dh, slot_out, slot_old, slot_dy, planes, g_gamma, g_beta, g_bias,
+                       slot_fwd):
+        """LayerNorm backward, accumulated into dh, whose result ALSO leaves as the operand planes of the next gradient
+        products (scale: the bound eav_layernorm_bwd_bound derives from the measured max|dh| before, max|dy|, max|gamma| and
+        max rstd), with the bias-gradient partials of the linear layer that consumes dh: no conversion pass."""
+        ws, D, M = self._ws, self.cfg.hidden, self._ws.M
+        L, P = self._call, _lib.ptr
+        L("eav_layernorm_bwd_bound", slot_out, slot_old, slot_dy, gamma, rstd, M, D, slot_fwd, self._st)
+        self._before_overwrite(planes)
+        part = self._part_buf("part_ln3_pool")
+        L("eav_layernorm_bwd_planes", dy, x, gamma, mean, rstd, dh, 1, P(part), M, D, slot_out, P(planes), self._st)
+        if g_beta == g_gamma + 4 * D:
+            self._reduce_async(part, 0, ws.np_ln, 3 * D, 2 * D, g_gamma)
+        else:
+            self._reduce_async(part, 0, ws.np_ln, 3 * D, D, g_gamma)
+            self._reduce_async(part, 4 * D, ws.np_ln, 3 * D, D, g_beta)
+        self._reduce_async(part, 8 * D, ws.np_ln, 3 * D, D, g_bias)
 
     def _wgrad(self, A, B, C, M, N, K, lda, ldb):
         """C[M,N] = A^T.B for A stored [K,M], B stored [K,N] (weight gradient: contraction over tokens)."""

@@ -390,6 +390,49 @@ def decode_planes(pl, R, C, sigma):
     return ((v[:, :, 0, :] + v[:, :, 1, :] / 2048.0).reshape(R, -1)[:, :C]) / sigma
 
 
+@pytest.mark.parametrize("M,D", [(37, 64), (1214, 768), (300, 1024), (70, 8)])
+def test_layernorm_backward_writes_the_operand_planes_itself(M, D):
+    """eav_layernorm_bwd_planes: dx (accumulated) bit-equal to eav_layernorm_bwd_amax, dgamma / dbeta partials identical, the
+    third section of the partials sums to the column sums of the stored value, the planes hold the stored value to split
+    precision under the scale of eav_layernorm_bwd_bound (>= the measured maximum, which lands in the slot's shards)."""
+    torch.manual_seed(3 * M + D)
+    x = torch.randn(M, D, device="cuda") * 2 + 0.3
+    x[M // 3] = 0.467                                   # a constant row: rstd = 1e6
+    dy = torch.randn(M, D, device="cuda") * 1e-3
+    g = torch.rand(D, device="cuda") * 3 + 0.2
+    b = torch.randn(D, device="cuda")
+    old = torch.randn(M, D, device="cuda") * 1e-2
+    y, mean, rstd = torch.empty_like(x), torch.empty(M, device="cuda"), torch.empty(M, device="cuda")
+    _lib.call("eav_layernorm_fwd", P(x), P(g), P(b), P(y), P(mean), P(rstd), M, D, 1e-12, None)
+    npart = _lib.plain("eav_layernorm_bwd_nparts", M)
+    dx1, part1, s1 = old.clone(), torch.zeros(npart, 2 * D, device="cuda"), torch.zeros(SLOT, device="cuda")
+    _lib.call("eav_layernorm_bwd_amax", P(dy), P(x), P(g), P(mean), P(rstd), P(dx1), 1, P(part1), M, D, P(s1), None)
+    s_old, s_dy, s2 = (torch.zeros(SLOT, device="cuda") for _ in range(3))
+    _lib.call("eav_sp_absmax", P(old), M, D, D, P(s_old), None)
+    _lib.call("eav_sp_absmax", P(dy), M, D, D, P(s_dy), None)
+    _lib.call("eav_layernorm_bwd_bound", P(s2), P(s_old), P(s_dy), P(g), P(rstd), M, D, None, None)
+    sig = float(s2[2048])
+    # the same bound from the forward's slot: eav_layernorm_fwd_amax leaves max(rstd) in word 1 of the shard lines
+    s_f, s3 = torch.zeros(SLOT, device="cuda"), torch.zeros(SLOT, device="cuda")
+    _lib.call("eav_layernorm_fwd_amax", P(x), P(g), P(b), P(y), P(mean), P(rstd), M, D, 1e-12, P(s_f), None)
+    assert float(s_f[1:2048:32].max()) == float(rstd.max())
+    _lib.call("eav_layernorm_bwd_bound", P(s3), P(s_old), P(s_dy), P(g), None, M, D, P(s_f), None)
+    assert float(s3[2048]) == sig
+    dx2, part2 = old.clone(), torch.zeros(npart, 3 * D, device="cuda")
+    pl = torch.full(((M + 31) // 32 * 32, 2 * kpad(D)), 7.0, dtype=torch.float16, device="cuda")
+    _lib.call("eav_layernorm_bwd_planes", P(dy), P(x), P(g), P(mean), P(rstd), P(dx2), 1, P(part2), M, D, P(s2), P(pl), None)
+    assert torch.equal(dx2, dx1)
+    assert torch.equal(part2[:, :2 * D], part1)
+    mx = float(dx1.abs().max())
+    assert mx * sig < 2.0 ** 15
+    assert float(s2[:2048:32].view(torch.int32).max().view(torch.float32)) == mx
+    want = dx1.double().sum(0)
+    assert (part2[:, 2 * D:].double().sum(0) - want).abs().max().item() <= 1e-5 * mx * M ** 0.5 + 1e-12
+    got = decode_planes(pl, M, D, sig)
+    assert (got - dx1.double()).abs().max().item() <= 2.0 ** -21 * mx + 2.0 ** -35 / sig
+    assert (pl[M:] == 7).all() and (pl[:M, 2 * D:] == 7).all()
+
+
 @pytest.mark.parametrize("M,D", [(37, 64), (1214, 768), (300, 1024), (5, 8)])
 def test_layernorm_writes_the_operand_planes_itself(M, D):
     """eav_layernorm_fwd_planes: the LayerNorm output as row planes scaled by a slot's sigma (no fp32 copy, no

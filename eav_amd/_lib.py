@@ -71,7 +71,7 @@ SIGNATURES = {
     "eav_sp_convert_colsum": [_p, _i, _i, _i64, _p, _p, _p, _p, _p],
     "eav_layernorm_fwd_amax": [_p, _p, _p, _p, _p, _p, _i, _i, _f, _p, _p],
     "eav_layernorm_bwd_amax": [_p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _p, _p],
-    "eav_layernorm_bwd_planes": [_p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _p, _p, _p],
+    "eav_layernorm_bwd_planes": [_p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p],
     "eav_layernorm_bwd_bound": [_p, _p, _p, _p, _p, _i, _i, _p, _p],
     "eav_gelu_bwd_amax": [_p, _p, _i64, _p, _p],
     "eav_gemm_sp": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i64, _i64, _f, _p, _i, _p, _p, _i, _i, _p, _p],

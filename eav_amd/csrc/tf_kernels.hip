@@ -93,6 +93,16 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
   }
 }
 
+__device__ __forceinline__ float sigma_of_bound(float b) {
+  // the power of two that puts b in [2^14, 2^15) (as sigma_from_bits in gemm_sp.hip); 1 for 0 / non-finite
+  const unsigned bits = __float_as_uint(b);
+  const int e = (int)((bits >> 23) & 0xff);
+  if (b <= 0.f || e == 0xff) return 1.f;
+  int se = 14 - (e - 127);
+  se = max(-126, min(126, se));
+  return __uint_as_float((unsigned)(se + 127) << 23);
+}
+
 // dx = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat));  dgamma += dy*xhat, dbeta += dy per column.
 // Persistent blocks; part[blk][2*D] = (dgamma, dbeta) partials of the rows this block handled.
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
@@ -101,7 +111,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             const float* __restrict__ rstd_i, float* __restrict__ dx,
                                                             int accumulate, float* __restrict__ part, int M, int D,
                                                             unsigned* __restrict__ amax, unsigned char* __restrict__ planes,
-                                                            int64_t ldp, float lomul) {
+                                                            int64_t ldp, float lomul, const float* __restrict__ slot_old,
+                                                            const float* __restrict__ slot_dy,
+                                                            const float* __restrict__ slot_rstd) {
   // planes (optional): the STORED value (dx, after the accumulation) also leaves as row planes scaled by the sigma in the
   // amax slot - a bound set before the launch (eav_layernorm_bwd_bound) - and its column sums (the bias gradient of the
   // linear layer that produced the residual branch) as a third section of the partials: part[blk][3*D]
@@ -120,7 +132,36 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   float4 ac[LN_MAXQ];              // planes: column sums of the stored value
 #pragma unroll
   for (int i = 0; i < LN_MAXQ; ++i) ac[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  const float psg = planes ? reinterpret_cast<const float*>(amax)[EAV_SLOT_SIGMA] : 0.f;
+  // planes: the scale.  slot_dy given: the bound of eav_layernorm_bwd_bound formed HERE, by every wave from the same numbers
+  // (max|gamma| over the lanes' own gains, the three slots' shard words - bit-identical in every wave), and published by
+  // block 0 for the consumers; a separate one-block launch waited 15-40 us per call for a CU between the persistent GEMMs
+  // of the two streams.  slot_dy NULL: the sigma already in the slot.
+  float psg = 0.f;
+  if (planes) {
+    if (slot_dy) {
+      float gmx = 0.f;
+#pragma unroll
+      for (int i = 0; i < LN_MAXQ; ++i)
+        gmx = fmaxf(gmx, fmaxf(fmaxf(fabsf(gm[i].x), fabsf(gm[i].y)), fmaxf(fabsf(gm[i].z), fabsf(gm[i].w))));
+      float rmx = slot_rstd[32 * lane + 1];
+      float old = slot_old ? slot_old[32 * lane] : 0.f, dmx = slot_dy[32 * lane];      // (non-negative floats: bit order = value order)
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        gmx = fmaxf(gmx, __shfl_xor(gmx, o, 64));
+        rmx = fmaxf(rmx, __shfl_xor(rmx, o, 64));
+        old = fmaxf(old, __shfl_xor(old, o, 64));
+        dmx = fmaxf(dmx, __shfl_xor(dmx, o, 64));
+      }
+      const float bound = (old + (2.f + sqrtf((float)D)) * gmx * rmx * dmx) * 1.0001f;
+      psg = sigma_of_bound(bound);
+      if (blockIdx.x == 0 && threadIdx.x == 0) {
+        reinterpret_cast<float*>(amax)[EAV_SLOT_SIGMA] = psg;
+        reinterpret_cast<float*>(amax)[EAV_SLOT_ISIGMA] = 1.f / psg;
+      }
+    } else {
+      psg = reinterpret_cast<const float*>(amax)[EAV_SLOT_SIGMA];
+    }
+  }
   float vmax = 0.f;
   // the rows of a wave are independent: the NEXT row's x, dy (and dx when accumulating) are loaded before the current
   // row's reductions, so a wave always has a row in flight (in the encoder step this kernel runs beside a weight-gradient
@@ -513,15 +554,6 @@ __global__ __launch_bounds__(256) void colnorm_max_kernel(const float* __restric
   }
 }
 
-__device__ __forceinline__ float sigma_of_bound(float b) {
-  // the power of two that puts b in [2^14, 2^15) (as sigma_from_bits in gemm_sp.hip); 1 for 0 / non-finite
-  const unsigned bits = __float_as_uint(b);
-  const int e = (int)((bits >> 23) & 0xff);
-  if (b <= 0.f || e == 0xff) return 1.f;
-  int se = 14 - (e - 127);
-  se = max(-126, min(126, se));
-  return __uint_as_float((unsigned)(se + 127) << 23);
-}
 
 // Operand scales of one encoder layer's forward from RIGOROUS bounds of the tensors, so that their producers can emit
 // the fp16 hi / lo planes directly (no measured maximum, no conversion pass).  With xhat the normalised row of a
@@ -647,7 +679,8 @@ extern "C" int eav_layernorm_bwd(const float* dy, const float* x, const float* g
               "eav_layernorm_bwd: need D %% 4 == 0 and D <= 1024");
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(eav_layernorm_bwd_nparts(M)), dim3(256), 8 * D * sizeof(float),
                      (hipStream_t)stream, dy, x, gamma, mean, rstd, dx, accumulate, part, M, D, (unsigned*)nullptr,
-                     (unsigned char*)nullptr, (int64_t)0, 0.f);
+                     (unsigned char*)nullptr, (int64_t)0, 0.f, (const float*)nullptr, (const float*)nullptr,
+                     (const float*)nullptr);
   EAV_CHECK_LAUNCH("eav_layernorm_bwd");
   return EAV_OK;
 }
@@ -659,24 +692,29 @@ extern "C" int eav_layernorm_bwd_amax(const float* dy, const float* x, const flo
               "eav_layernorm_bwd_amax: need D %% 4 == 0 and D <= 1024");
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(eav_layernorm_bwd_nparts(M)), dim3(256), 8 * D * sizeof(float),
                      (hipStream_t)stream, dy, x, gamma, mean, rstd, dx, accumulate, part, M, D,
-                     reinterpret_cast<unsigned*>(amax_slot), (unsigned char*)nullptr, (int64_t)0, 0.f);
+                     reinterpret_cast<unsigned*>(amax_slot), (unsigned char*)nullptr, (int64_t)0, 0.f, (const float*)nullptr,
+                     (const float*)nullptr, (const float*)nullptr);
   EAV_CHECK_LAUNCH("eav_layernorm_bwd_amax");
   return EAV_OK;
 }
 
 // eav_layernorm_bwd_amax whose stored value (dx, after the accumulation) ALSO leaves as the row planes [M][Dp/8][2][8] of the
-// products that consume it - no conversion pass - scaled by slot's sigma, which eav_layernorm_bwd_bound sets beforehand; part is
+// products that consume it - no conversion pass - scaled by slot's sigma: with slot_dy the kernel forms the bound of
+// eav_layernorm_bwd_bound itself (slot_old / slot_dy / slot_rstd as there) and publishes it in slot; slot_dy NULL: the sigma
+// already in slot.  part is
 // [nparts][3*D]: dgamma | dbeta | column sums of the stored value (the bias gradient of the layer that fed the residual).
 // slot's shards receive the measured tensor-wide maximum (no 32-row block entries: the scale is a-priori).
 extern "C" int eav_layernorm_bwd_planes(const float* dy, const float* x, const float* gamma, const float* mean,
                                         const float* rstd, float* dx, int accumulate, float* part, int M, int D,
-                                        float* slot, void* planes, void* stream) {
+                                        float* slot, void* planes, const float* slot_old, const float* slot_dy,
+                                        const float* slot_rstd, void* stream) {
   EAV_REQUIRE(dy && x && gamma && mean && rstd && dx && part && slot && planes && M > 0 && D > 0 && (D & 7) == 0 &&
-                  D <= 1024 && ((uintptr_t)planes & 15) == 0,
+                  D <= 1024 && ((uintptr_t)planes & 15) == 0 && (!slot_dy || slot_rstd) && slot_old != slot,
               "eav_layernorm_bwd_planes: need D %% 8 == 0, D <= 1024, 16-byte aligned planes");
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(eav_layernorm_bwd_nparts(M)), dim3(256), 12 * D * sizeof(float),
                      (hipStream_t)stream, dy, x, gamma, mean, rstd, dx, accumulate, part, M, D,
-                     reinterpret_cast<unsigned*>(slot), (unsigned char*)planes, (int64_t)eav_sp_kpad(D) * 4, 2048.f);
+                     reinterpret_cast<unsigned*>(slot), (unsigned char*)planes, (int64_t)eav_sp_kpad(D) * 4, 2048.f, slot_old,
+                     slot_dy, slot_rstd);
   EAV_CHECK_LAUNCH("eav_layernorm_bwd_planes");
   return EAV_OK;
 }

@@ -1112,14 +1112,14 @@ class Encoder(nn.Module):
     def _ln_bwd_planes(self, dy, x, gamma, mean, rstd, dh, slot_out, slot_old, slot_dy, planes, g_gamma, g_beta, g_bias,
                        slot_fwd):
         """LayerNorm backward, accumulated into dh, whose result ALSO leaves as the operand planes of the next gradient
-        products (scale: the bound eav_layernorm_bwd_bound derives from the measured max|dh| before, max|dy|, max|gamma| and
-        max rstd), with the bias-gradient partials of the linear layer that consumes dh: no conversion pass."""
+        products (scale: the bound of eav_layernorm_bwd_bound - measured max|dh| before, max|dy|, max|gamma|, the forward's max
+        rstd - formed inside the launch), with the bias-gradient partials of the linear layer that consumes dh: no conversion pass."""
         ws, D, M = self._ws, self.cfg.hidden, self._ws.M
         L, P = self._call, _lib.ptr
-        L("eav_layernorm_bwd_bound", slot_out, slot_old, slot_dy, gamma, rstd, M, D, slot_fwd, self._st)
         self._before_overwrite(planes)
         part = self._part_buf("part_ln3_pool")
-        L("eav_layernorm_bwd_planes", dy, x, gamma, mean, rstd, dh, 1, P(part), M, D, slot_out, P(planes), self._st)
+        L("eav_layernorm_bwd_planes", dy, x, gamma, mean, rstd, dh, 1, P(part), M, D, slot_out, P(planes), slot_old, slot_dy,
+          slot_fwd, self._st)
         if g_beta == g_gamma + 4 * D:
             self._reduce_async(part, 0, ws.np_ln, 3 * D, 2 * D, g_gamma)
         else:

@@ -306,13 +306,16 @@ int eav_layernorm_bwd_amax(const float* dy, const float* x, const float* gamma, 
 /* eav_layernorm_bwd_amax whose stored value (dx after the accumulation) also leaves as the row planes [M][Dp/8][2][8] of the
  * gradient products that consume it - no conversion pass over the residual-stream gradient (modeling_vit.py /
  * modeling_audio_spectrogram_transformer.py layernorm_before / layernorm_after backward through HF autograd) - scaled by
- * slot's sigma, which eav_layernorm_bwd_bound sets BEFORE from the rigorous bound
+ * slot's sigma = the rigorous bound of eav_layernorm_bwd_bound, which the kernel forms itself when slot_dy is given (every
+ * workgroup from the same slot words, published in slot by the first; a separate one-block launch queued 15-40 us behind the
+ * persistent GEMMs) or which a call of eav_layernorm_bwd_bound put there before (slot_dy NULL):
  * max|dx_old| + (2 + sqrt(D)) max|gamma| max(rstd) max|dy| (slot_old: shards of the measured max|dx_old| or NULL; slot_dy:
  * shards of max|dy|; max(rstd) from slot_rstd - the scale slot the forward LayerNorm launch had, whose shard lines carry it in
  * word 1 - or, slot_rstd NULL, from a walk over rstd[M]).  part is [nparts][3 D]: dgamma | dbeta | column sums of the stored value (a bias gradient).  slot's
  * shards receive the measured maximum of the stored value. */
 int eav_layernorm_bwd_planes(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
-                             float* dx, int accumulate, float* part, int M, int D, float* slot, void* planes, void* stream);
+                             float* dx, int accumulate, float* part, int M, int D, float* slot, void* planes,
+                             const float* slot_old, const float* slot_dy, const float* slot_rstd, void* stream);
 int eav_layernorm_bwd_bound(float* slot_out, const float* slot_old, const float* slot_dy, const float* gamma,
                             const float* rstd, int M, int D, const float* slot_rstd, void* stream);
 int eav_gelu_bwd_amax(float* dact, const float* pre, int64_t n, float* amax_slot, void* stream);

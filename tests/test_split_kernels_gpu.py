@@ -420,8 +420,15 @@ def test_layernorm_backward_writes_the_operand_planes_itself(M, D):
     assert float(s3[2048]) == sig
     dx2, part2 = old.clone(), torch.zeros(npart, 3 * D, device="cuda")
     pl = torch.full(((M + 31) // 32 * 32, 2 * kpad(D)), 7.0, dtype=torch.float16, device="cuda")
-    _lib.call("eav_layernorm_bwd_planes", P(dy), P(x), P(g), P(mean), P(rstd), P(dx2), 1, P(part2), M, D, P(s2), P(pl), None)
+    _lib.call("eav_layernorm_bwd_planes", P(dy), P(x), P(g), P(mean), P(rstd), P(dx2), 1, P(part2), M, D, P(s2), P(pl), None,
+              None, None, None)
+    # the bound formed inside the launch (slots given) = the one of the stand-alone call, same planes
+    s4, dx4, part4, pl4 = torch.zeros(SLOT, device="cuda"), old.clone(), torch.zeros(npart, 3 * D, device="cuda"), torch.zeros_like(pl)
+    _lib.call("eav_layernorm_bwd_planes", P(dy), P(x), P(g), P(mean), P(rstd), P(dx4), 1, P(part4), M, D, P(s4), P(pl4), P(s_old),
+              P(s_dy), P(s_f), None)
+    assert float(s4[2048]) == sig and float(s4[2049]) == 1.0 / sig and torch.equal(dx4, dx2) and torch.equal(part4, part2)
     assert torch.equal(dx2, dx1)
+    assert torch.equal(pl4[:M, :2 * D], pl[:M, :2 * D])
     assert torch.equal(part2[:, :2 * D], part1)
     mx = float(dx1.abs().max())
     assert mx * sig < 2.0 ** 15

@@ -738,6 +738,21 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_sp2_kernel(const u8* __re
 #endif
 }
 
+// sigma of the planes the backward kernels write dqkv as: the bound of eav_attn_dqkv_bound (see there), formed by every wave
+// from the same slot words - one more one-block launch on the main stream waited ~12 us for a CU between the persistent GEMMs
+__device__ __forceinline__ float dqkv_sigma(const float* __restrict__ slot_do, const float* __restrict__ slot_qkv, int N,
+                                            float scale, int lane) {
+  float m = slot_do[32 * lane], q = slot_qkv[32 * lane];          // shard words (non-negative floats)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    m = fmaxf(m, __shfl_xor(m, o, 64));
+    q = fmaxf(q, __shfl_xor(q, o, 64));
+  }
+  if (q == 0.f) q = 32768.f * slot_qkv[EAV_SLOT_ISIGMA];
+  const float bound = (float)N * m * fmaxf(1.f, 128.f * scale * q * q) * 1.0001f;
+  return sigma_from_bits(__float_as_uint(bound));
+}
+
 // ------------------------------------------------------------------------------------------------ backward: dQ
 // Query tile stationary.  Streams K rows, V rows and K^T.  dS^T = P^T o (dP^T - delta) in operand units
 // (sigma_do sigma_qkv dS) is bounded by 2^37: |dP| <= 64 * 2^15 * 2^15 and |delta| = |dO . O| <= the same because O is
@@ -749,7 +764,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_q_sp_kernel(
     const float* __restrict__ slot_do, const float* __restrict__ lse, const float* __restrict__ ao,
     const float* __restrict__ dout, float* __restrict__ delta, float* __restrict__ dqkv,
     unsigned* __restrict__ amax_ds, unsigned* __restrict__ amax_out, int N, int Npad, int H, float scale, int ntile, int nbh,
-    u8* __restrict__ gplanes, const float* __restrict__ gslot, float* __restrict__ cs_part) {
+    u8* __restrict__ gplanes, float* __restrict__ gslot, float* __restrict__ cs_part) {
   constexpr int STAGE = 16384;   // K rows | V rows (K^T for the last product is read transposed from the K rows: frag_tr)
   __shared__ __attribute__((aligned(1024))) u8 smem[2 * STAGE > NW * 32 * 33 * 4 ? 2 * STAGE : NW * 32 * 33 * 4];
   const int D = H * 64;
@@ -936,10 +951,15 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_q_sp_kernel(
   // gradient products, scaled by gslot's sigma - a BOUND of |dqkv| set before the launch (eav_attn_dqkv_bound) - and the
   // column sums of the wave's rows (bias-gradient partials) go to cs_part[(b, row tile)][3 D]
   const int nrb = (N + 31) / 32;
+  const float gsig = gplanes ? dqkv_sigma(slot_do, slot, N, scale, lane) : 0.f;
+  if (gplanes && blockIdx.x == 0 && threadIdx.x == 0) {          // published for the consumers of the planes
+    gslot[EAV_SLOT_SIGMA] = gsig;
+    gslot[EAV_SLOT_ISIGMA] = 1.f / gsig;
+  }
   const float vmax = store_rows_T(reinterpret_cast<float*>(smem) + wave * (32 * 33), g0, g1, mul,
                                   dqkv ? dqkv + (int64_t)b * N * 3 * D + h * 64 : nullptr, 3 * D, q0, N, lane,
                                   gplanes ? gplanes + (int64_t)b * N * (3 * D * 4) + h * 256 : nullptr, (int64_t)3 * D * 4,
-                                  gplanes ? gslot[EAV_SLOT_SIGMA] : 0.f,
+                                  gsig,
                                   cs_part && q0 < N ? cs_part + ((int64_t)b * nrb + q0 / 32) * (3 * D) + h * 64 : nullptr);
   emit_amax(amax_out, vmax, lane, (int)blockIdx.x * NW + wave, q0 < N ? b * N + q0 : -1);
 }
@@ -1130,7 +1150,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_kv_sp_kernel(
   const int nrb = (N + 31) / 32;
   u8* gp_ = gplanes ? gplanes + (int64_t)b * N * (3 * D * 4) + h * 256 : nullptr;     // (see attn_bwd_q_sp_kernel)
   float* cs_ = cs_part && k0 < N ? cs_part + ((int64_t)b * nrb + k0 / 32) * (3 * D) + h * 64 : nullptr;
-  const float gsig = gplanes ? gslot[EAV_SLOT_SIGMA] : 0.f;
+  const float gsig = gplanes ? dqkv_sigma(slot_do, slot, N, scale, lane) : 0.f;     // (= what the dQ kernel published)
   float vmax = store_rows_T(patch, gk0, gk1, mk, base ? base + D : nullptr, 3 * D, k0, N, lane, gp_ ? gp_ + D * 4 : nullptr,
                             (int64_t)3 * D * 4, gsig, cs_ ? cs_ + D : nullptr);
   vmax = fmaxf(vmax, store_rows_T(patch, gv0, gv1, mv, base ? base + 2 * D : nullptr, 3 * D, k0, N, lane,
@@ -1315,12 +1335,13 @@ extern "C" int eav_attn_dqkv_bound(float* slot_out, const float* slot_do, const 
 
 // delta: scratch [B*H, N].  slot_ds: scratch slot (zeroed by the caller).  dqkv [B*N, 3*H*64] fp32 (optional with planes).
 // planes (optional): dqkv also (or only) leaves as the operand planes [B*N][3D/8][2][8] of the q/k/v projection's gradient
-// products, scaled by planes_slot's sigma (eav_attn_dqkv_bound, launched before); colsum_part (optional)
+// products, scaled by the bound of eav_attn_dqkv_bound, which the kernels form themselves from slot_do's and slot's shard
+// words and publish in planes_slot (sigma, 1 / sigma); colsum_part (optional)
 // [B * ceil(N / 32)][3 D]: per 32-row tile the column sums of dqkv (finish the bias gradient with eav_reduce_partials).
 extern "C" int eav_attn_bwd_sp_planes(const void* rowp, const void* tp, const void* dorow, const void* dotp,
                                       const float* slot, const float* slot_do, float* slot_ds, const float* ao,
                                       const float* dout, const float* lse, float* delta, float* dqkv, float* amax_slot,
-                                      void* planes, const float* planes_slot, float* colsum_part, int B, int H, int N,
+                                      void* planes, float* planes_slot, float* colsum_part, int B, int H, int N,
                                       int head_dim, float scale, void* stream) {
   EAV_REQUIRE(rowp && dorow && slot && slot_do && slot_ds && ao && dout && lse && delta && (dqkv || planes) && B > 0 &&
                   H > 0 && N > 0 && (!planes || planes_slot), "eav_attn_bwd_sp: bad arguments");

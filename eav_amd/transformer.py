@@ -1065,7 +1065,6 @@ class Encoder(nn.Module):
         if ws.fused:
             L("eav_attn_sp_prep", dao, b_dao, P(ws.dorow), None, ws.B, N, D, D, 0, st)
             if self.fused_dqkv and self.grad_terms != 1:      # (hi.hi-only gradient products need the tight measured scale)
-                L("eav_attn_dqkv_bound", b_dqkv, b_dao, s_qkv, N, scale, st)
                 self._before_overwrite(ws.dqkvp)
                 part = self._part_buf("part_attn_pool")
                 L("eav_attn_bwd_sp_planes", P(ws.qkvrow[i]), None, P(ws.dorow), None, s_qkv, b_dao, b_ds,

@@ -79,6 +79,7 @@ SIGNATURES = {
     "eav_gemm_sp_splitk_x1": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "eav_gemm_sp_ex": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i64, _i64, _f, _p, _i, _p, _p, _i, _i, _p, _p, _p, _p, _i, _p],
     "eav_colnorm_max": [_p, _i, _i, _i64, _p, _p],
+    "eav_norm_max_multi": [_p, _i, _i, _p],
     "eav_sp_bound_scale": [_p, _p, _p, _f, _p],
     "eav_gemm_sp_planes": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i64, _i64, _f, _p, _i, _p, _p, _i, _i, _p, _p, _p, _p],
     "eav_layernorm_fwd_planes": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p],

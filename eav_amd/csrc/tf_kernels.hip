@@ -477,13 +477,13 @@ int grid_for(int64_t n) { return (int)(n < 1 ? 1 : (cdiv64(n, 256) > 4096 ? 4096
 // max over the rows of ||w_r||_2 (bits, atomicMax - zero `out` first): one wave per row at a time, 16-byte loads, all
 // loads of a row in flight at once for rows of up to 1024 floats; a few persistent blocks and ONE atomic per block (one
 // atomic per row to the same address serialised in the L2: 34 us for 3072 rows)
-__global__ __launch_bounds__(256) void rownorm_max_kernel(const float* __restrict__ w, int R, int C, int64_t ld,
-                                                          unsigned* __restrict__ out) {
+__device__ __forceinline__ void rownorm_max_body(const float* __restrict__ w, int R, int C, int64_t ld,
+                                                 unsigned* __restrict__ out, int bx, int nbx) {
   __shared__ float red[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bool vec = (C & 3) == 0 && (ld & 3) == 0 && ((uintptr_t)w & 15) == 0;
   float best = 0.f;
-  for (int r = blockIdx.x * 4 + wave; r < R; r += gridDim.x * 4) {
+  for (int r = bx * 4 + wave; r < R; r += nbx * 4) {
     const float* src = w + (int64_t)r * ld;
     float s = 0.f;
     if (vec) {
@@ -511,15 +511,19 @@ __global__ __launch_bounds__(256) void rownorm_max_kernel(const float* __restric
     if (best == best) atomicMax(out, __float_as_uint(best));
   }
 }
+__global__ __launch_bounds__(256) void rownorm_max_kernel(const float* __restrict__ w, int R, int C, int64_t ld,
+                                                          unsigned* __restrict__ out) {
+  rownorm_max_body(w, R, C, ld, out, blockIdx.x, gridDim.x);
+}
 
 // max over the COLUMNS of ||w[:, c]||_2 (bits, atomicMax - zero `out` first).  A block owns 64 columns: thread (rs, cq)
 // sums the squares of columns 4 cq .. + 3 over the rows rs, rs + 16, ... (a row segment = 256 contiguous bytes per 16
 // threads), the 16 row slices are added through LDS, one atomic per block.
-__global__ __launch_bounds__(256) void colnorm_max_kernel(const float* __restrict__ w, int R, int C, int64_t ld,
-                                                          unsigned* __restrict__ out) {
+__device__ __forceinline__ void colnorm_max_body(const float* __restrict__ w, int R, int C, int64_t ld,
+                                                 unsigned* __restrict__ out, int bx) {
   __shared__ float4 part[16][17];
   const int cq = threadIdx.x & 15, rs = threadIdx.x >> 4;
-  const int c = blockIdx.x * 64 + 4 * cq;
+  const int c = bx * 64 + 4 * cq;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (c < C) {
     int r = rs;
@@ -551,6 +555,24 @@ __global__ __launch_bounds__(256) void colnorm_max_kernel(const float* __restric
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) best = fmaxf(best, __shfl_xor(best, o, 64));
     if (threadIdx.x == 0 && best == best) atomicMax(out, __float_as_uint(best));
+  }
+}
+__global__ __launch_bounds__(256) void colnorm_max_kernel(const float* __restrict__ w, int R, int C, int64_t ld,
+                                                          unsigned* __restrict__ out) {
+  colnorm_max_body(w, R, C, ld, out, blockIdx.x);
+}
+
+// A table of row / column norm maxima in ONE launch (eav_norm_max_multi): job y = blockIdx.y, its blocks blockIdx.x <
+// (row job: min(ceil(R / 4), 128); column job: ceil(C / 64)).  The weight refresh after an optimiser step issued 36 such
+// launches of ~10 us on the side stream before the forward's a-priori scales could be formed.
+struct NormJob { const float* w; int64_t ld; unsigned* out; int R, C, cols, pad; };
+__global__ __launch_bounds__(256) void norm_max_multi_kernel(const NormJob* __restrict__ jobs) {
+  const NormJob j = jobs[blockIdx.y];
+  if (j.cols) {
+    if ((int)blockIdx.x < (j.C + 63) / 64) colnorm_max_body(j.w, j.R, j.C, j.ld, j.out, blockIdx.x);
+  } else {
+    const int nb = min((j.R + 3) / 4, 128);
+    if ((int)blockIdx.x < nb) rownorm_max_body(j.w, j.R, j.C, j.ld, j.out, blockIdx.x, nb);
   }
 }
 
@@ -827,6 +849,16 @@ extern "C" int eav_colnorm_max(const float* w, int R, int C, int64_t ld, float* 
   hipLaunchKernelGGL(colnorm_max_kernel, dim3(cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, w, R, C, ld,
                      reinterpret_cast<unsigned*>(out));
   EAV_CHECK_LAUNCH("eav_colnorm_max");
+  return EAV_OK;
+}
+
+// jobs: device table of njobs rows of 5 int64 {w, ld, out, R | C << 32, cols (0: row norms, 1: column norms)} (the outputs
+// zeroed by the caller, as for eav_rownorm_max / eav_colnorm_max); max_blocks >= the largest job's block count
+extern "C" int eav_norm_max_multi(const void* jobs, int njobs, int max_blocks, void* stream) {
+  EAV_REQUIRE(jobs && njobs > 0 && max_blocks > 0, "eav_norm_max_multi: bad arguments");
+  static_assert(sizeof(NormJob) == 40, "EavNormJob layout");
+  hipLaunchKernelGGL(norm_max_multi_kernel, dim3(max_blocks, njobs), dim3(256), 0, (hipStream_t)stream, (const NormJob*)jobs);
+  EAV_CHECK_LAUNCH("eav_norm_max_multi");
   return EAV_OK;
 }
 

@@ -556,16 +556,28 @@ class Encoder(nn.Module):
                     wp["_jobs_key"] = key[0]
                 _lib.call("eav_sp_refresh_planes", _lib.ptr(jobs), len(stale), max(o for _, _, o, _ in stale),
                           max(i for _, _, _, i in stale), st)
-                for k, src, out, inn in stale:
-                    if k.startswith("fc1"):
-                        _lib.call("eav_rownorm_max", src, out, inn, inn, wp["_wnorm_fc1"].data_ptr() + 4 * int(k[3:]), st)
-                    elif k.startswith("fc2") and wp["_T"]:
-                        # (keyed on the planes HAVING transposes, not on this call's need_T: a no_grad forward right after an
-                        # optimiser step refreshes everything with need_T = False, and the next training step finds nothing
-                        # stale - its backward must still see the norms of the CURRENT weights)
-                        _lib.call("eav_colnorm_max", src, out, inn, inn, wp["_wcolnorm_fc2"].data_ptr() + 4 * int(k[3:]), st)
-                    elif k.startswith("qkv"):
-                        _lib.call("eav_rownorm_max", src, out, inn, inn, wp["_wnorm_qkv"].data_ptr() + 4 * int(k[3:]), st)
+                # the row / column norms behind the a-priori scales: one launch for the whole table (36 launches of ~10 us
+                # stood between the optimiser step and the first scales of the next forward)
+                njobs = wp.get("_njobs")
+                if njobs is None or wp["_njobs_key"] != (key[0], wp["_T"]):
+                    rows, mb = [], 1
+                    for k, src, out, inn in stale:
+                        if k.startswith("fc1"):
+                            rows.append([src, inn, wp["_wnorm_fc1"].data_ptr() + 4 * int(k[3:]), out | (inn << 32), 0])
+                            mb = max(mb, min((out + 3) // 4, 128))
+                        elif k.startswith("fc2") and wp["_T"]:
+                            # (keyed on the planes HAVING transposes, not on this call's need_T: a no_grad forward right after
+                            # an optimiser step refreshes everything with need_T = False, and the next training step finds
+                            # nothing stale - its backward must still see the norms of the CURRENT weights)
+                            rows.append([src, inn, wp["_wcolnorm_fc2"].data_ptr() + 4 * int(k[3:]), out | (inn << 32), 1])
+                            mb = max(mb, (inn + 63) // 64)
+                        elif k.startswith("qkv"):
+                            rows.append([src, inn, wp["_wnorm_qkv"].data_ptr() + 4 * int(k[3:]), out | (inn << 32), 0])
+                            mb = max(mb, min((out + 3) // 4, 128))
+                    njobs = wp["_njobs"] = (torch.tensor(rows, dtype=torch.int64).to(dev), len(rows), mb)
+                    wp["_njobs_key"] = (key[0], wp["_T"])
+                if njobs[1]:
+                    _lib.call("eav_norm_max_multi", _lib.ptr(njobs[0]), njobs[1], njobs[2], st)
                 if side is not None:
                     ev = torch.cuda.Event()
                     ev.record(side)

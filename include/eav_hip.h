@@ -344,6 +344,11 @@ int eav_layernorm_fwd_planes(const float* x, const float* gamma, const float* be
 int eav_rownorm_max(const float* w, int R, int C, int64_t ld, float* out, void* stream);
 /* the same over the COLUMNS of w [R, C] (C, ld multiples of 4) */
 int eav_colnorm_max(const float* w, int R, int C, int64_t ld, float* out, void* stream);
+/* A table of eav_rownorm_max / eav_colnorm_max jobs in one launch: jobs = device array of njobs rows of 5 int64
+ * {w, ld, out, R | C << 32, cols} (cols 0: max row norm, 1: max column norm; outputs zeroed by the caller), max_blocks >=
+ * the largest job's block count (rows: min(ceil(R / 4), 128); columns: ceil(C / 64)).  The weight refresh after an optimiser
+ * step forms all the norms behind the a-priori operand scales with it. */
+int eav_norm_max_multi(const void* jobs, int njobs, int max_blocks, void* stream);
 /* sigma, 1/sigma of slot_out from the bound  factor * max|x| * *norm  (max|x| = the maximum held by amax_slot's shards, norm a
  * device scalar): the operand scale of a tensor BEFORE it is produced, so that its producer can write planes directly.
  * Used for the MLP hidden-state gradient dact = (dh W2) o gelu'(pre): |dact| <= 1.13 sqrt(D) max|dh| max_j ||W2[:,j]||_2. */

@@ -554,10 +554,9 @@ class Encoder(nn.Module):
                                      wp["_slots"].data_ptr() + 4 * self.SLOT * n, out | (inn << 32)])     # EavPlaneJob
                     jobs = wp["_jobs"] = torch.tensor(rows, dtype=torch.int64).to(dev)
                     wp["_jobs_key"] = key[0]
-                _lib.call("eav_sp_refresh_planes", _lib.ptr(jobs), len(stale), max(o for _, _, o, _ in stale),
-                          max(i for _, _, _, i in stale), st)
-                # the row / column norms behind the a-priori scales: one launch for the whole table (36 launches of ~10 us
-                # stood between the optimiser step and the first scales of the next forward)
+                # the row / column norms behind the a-priori scales FIRST (their own event: the forward's scales wait for
+                # nothing else) and in one launch for the whole table (36 launches of ~10 us stood between the optimiser step
+                # and the first scales of the next forward)
                 njobs = wp.get("_njobs")
                 if njobs is None or wp["_njobs_key"] != (key[0], wp["_T"]):
                     rows, mb = [], 1
@@ -579,10 +578,14 @@ class Encoder(nn.Module):
                 if njobs[1]:
                     _lib.call("eav_norm_max_multi", _lib.ptr(njobs[0]), njobs[1], njobs[2], st)
                 if side is not None:
+                    self._wnorm_ready = torch.cuda.Event()
+                    self._wnorm_ready.record(side)
+                _lib.call("eav_sp_refresh_planes", _lib.ptr(jobs), len(stale), max(o for _, _, o, _ in stale),
+                          max(i for _, _, _, i in stale), st)
+                if side is not None:
                     ev = torch.cuda.Event()
                     ev.record(side)
                     self._wready = {k: ev for k, _, _, _ in stale}
-                    self._wnorm_ready = ev
                 stale = []
             # some matrices are stale (a partial update): the row / column norms first - the a-priori scales of EVERY layer
             # are computed by one launch before layer 0 and wait for ONE event (`_wnorm_ready`), not for the conversions -

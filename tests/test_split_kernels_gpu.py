@@ -231,7 +231,10 @@ def _attn_prep(x, B, N, ncols, secw, tmask):
 # N = 128 / 129: either side of the 64-row / 128-row workgroup switch
 @pytest.mark.parametrize("cfg", [(1, 2, 64, 1.0, False), (2, 3, 197, 1.0, False), (1, 2, 1214, 1.0, False),
                                  (2, 2, 300, 3.0, True), (1, 1, 33, 1.0, False), (3, 4, 129, 1.0, False),
-                                 (3, 3, 128, 1.0, False), (4, 4, 70, 1.0, False)])
+                                 (3, 3, 128, 1.0, False), (4, 4, 70, 1.0, False),
+                                 # the software-pipelined forward (N >= 512): 16 / 18 / 17 key tiles = every tail of its
+                                 # three-way unrolled tile loop, the last one ragged
+                                 (1, 2, 512, 1.0, False), (2, 1, 576, 1.0, False), (1, 3, 530, 2.0, True)])
 def test_attention_sp_is_fp32_grade(cfg):
     B, H, N, qs, spike = cfg
     D = H * 64
@@ -307,7 +310,9 @@ def test_attention_sp_is_fp32_grade(cfg):
     def rel(a, r):
         return ((a.double() - r).abs().max() / r.abs().max()).item()
     assert rel(ao, ro) <= 1.5 * rel(ao32, ro) + 2e-7
-    assert (lse.double() - rl).abs().max().item() <= 1.5 * (lse32.double() - rl).abs().max().item() + 1e-6
+    # (+ 3 ulp of the largest lse: with a spike it reaches 64, one fp32 ulp there is 7.6e-6)
+    assert (lse.double() - rl).abs().max().item() <= 1.5 * (lse32.double() - rl).abs().max().item() + 1e-6 + \
+        3 * 2.0 ** -24 * rl.abs().max().item()
     for i in range(3):
         sl = slice(i * D, (i + 1) * D)
         assert rel(dqkv[:, sl], rg[:, sl]) <= 1.5 * rel(dq32[:, sl], rg[:, sl]) + 3e-7, i

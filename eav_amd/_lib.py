@@ -96,7 +96,7 @@ SIGNATURES = {
     "eav_tf_forward_scales_qkv": [_p, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _i64, _i, _i, _i, _i, _p],
     "eav_attn_fwd_sp_planes": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
     "eav_attn_bwd_sp": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
-    "eav_attn_bwd_sp_planes": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
+    "eav_attn_bwd_sp_planes": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
     "eav_attn_dqkv_bound": [_p, _p, _p, _i, _f, _p],
     "eav_attn_fwd": [_p, _p, _p, _i, _i, _i, _i, _f, _p],
     "eav_attn_bwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],

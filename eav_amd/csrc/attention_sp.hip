@@ -764,7 +764,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_q_sp_kernel(
     const float* __restrict__ slot_do, const float* __restrict__ lse, const float* __restrict__ ao,
     const float* __restrict__ dout, float* __restrict__ delta, float* __restrict__ dqkv,
     unsigned* __restrict__ amax_ds, unsigned* __restrict__ amax_out, int N, int Npad, int H, float scale, int ntile, int nbh,
-    u8* __restrict__ gplanes, float* __restrict__ gslot, float* __restrict__ cs_part) {
+    u8* __restrict__ gplanes, float* __restrict__ gslot, float* __restrict__ cs_part, const u8* __restrict__ aop,
+    const float* __restrict__ slot_ao) {
   constexpr int STAGE = 16384;   // K rows | V rows (K^T for the last product is read transposed from the K rows: frag_tr)
   __shared__ __attribute__((aligned(1024))) u8 smem[2 * STAGE > NW * 32 * 33 * 4 ? 2 * STAGE : NW * 32 * 33 * 4];
   const int D = H * 64;
@@ -799,7 +800,29 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_q_sp_kernel(
   // delta[q] = dO[q, head] . O[q, head] (fp32): this lane's half of the row, the other half from lane ^ 32; published
   // for the dK,dV kernel, which runs after this one
   float dsum = 0.f;
-  {
+  if (aop) {
+    // ... from the planes: dO's row fragments are already in registers (gh / gl, unlifted lo), O's come from the o-proj
+    // operand planes the forward wrote (same 16-byte pieces, lo lifted by 2^11) - no fp32 O tensor exists in the training
+    // step and neither fp32 tensor is read (ViT: 154 of this kernel's 557 MB).  Products of two 22-bit values, fp32 sums.
+    const u8* orow = aop + ((int64_t)b * N + q) * ((int64_t)D * 4) + h * 256;
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const uint4 ph = *reinterpret_cast<const uint4*>(orow + 64 * s + 32 * h2);
+      const uint4 pl = *reinterpret_cast<const uint4*>(orow + 64 * s + 32 * h2 + 16);
+      const f16x8 oh = *reinterpret_cast<const f16x8*>(&ph), ol = *reinterpret_cast<const f16x8*>(&pl);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float ov = fmaf((float)ol[e], 1.f / 2048.f, (float)oh[e]);
+        const float gv = (float)gh[s][e] + (float)gl[s][e];
+        if (e & 1) a1 = fmaf(ov, gv, a1);
+        else a0 = fmaf(ov, gv, a0);
+      }
+    }
+    dsum = (a0 + a1) * (slot_ao[EAV_SLOT_ISIGMA] * isd);
+    dsum += __shfl_xor(dsum, 32, 64);
+    if (h2 == 0 && q0 + j < N) delta[(int64_t)bh * N + q] = dsum;
+  } else {
     const float4* o4 = reinterpret_cast<const float4*>(ao + ((int64_t)b * N + q) * D + h * 64 + 32 * h2);
     const float4* g4 = reinterpret_cast<const float4*>(dout + ((int64_t)b * N + q) * D + h * 64 + 32 * h2);
     float4 ov[8], gv[8];
@@ -1338,13 +1361,15 @@ extern "C" int eav_attn_dqkv_bound(float* slot_out, const float* slot_do, const 
 // products, scaled by the bound of eav_attn_dqkv_bound, which the kernels form themselves from slot_do's and slot's shard
 // words and publish in planes_slot (sigma, 1 / sigma); colsum_part (optional)
 // [B * ceil(N / 32)][3 D]: per 32-row tile the column sums of dqkv (finish the bias gradient with eav_reduce_partials).
+// ao_planes + ao_slot (optional): the attention output as the forward's o-proj operand planes (eav_attn_fwd_sp_planes) - the
+// row sums delta = dO . O are then formed from them and from dO's planes, and ao / dout (fp32) are not read and may be NULL.
 extern "C" int eav_attn_bwd_sp_planes(const void* rowp, const void* tp, const void* dorow, const void* dotp,
                                       const float* slot, const float* slot_do, float* slot_ds, const float* ao,
                                       const float* dout, const float* lse, float* delta, float* dqkv, float* amax_slot,
-                                      void* planes, float* planes_slot, float* colsum_part, int B, int H, int N,
-                                      int head_dim, float scale, void* stream) {
-  EAV_REQUIRE(rowp && dorow && slot && slot_do && slot_ds && ao && dout && lse && delta && (dqkv || planes) && B > 0 &&
-                  H > 0 && N > 0 && (!planes || planes_slot), "eav_attn_bwd_sp: bad arguments");
+                                      void* planes, float* planes_slot, float* colsum_part, const void* ao_planes,
+                                      const float* ao_slot, int B, int H, int N, int head_dim, float scale, void* stream) {
+  EAV_REQUIRE(rowp && dorow && slot && slot_do && slot_ds && ((ao && dout) || (ao_planes && ao_slot)) && lse && delta &&
+                  (dqkv || planes) && B > 0 && H > 0 && N > 0 && (!planes || planes_slot), "eav_attn_bwd_sp: bad arguments");
   EAV_REQUIRE(head_dim == 64, "eav_attn_bwd_sp: head_dim %d unsupported (needs 64)", head_dim);
   const int Npad = eav_attn_sp_npad(N);
   hipStream_t st = (hipStream_t)stream;
@@ -1352,12 +1377,14 @@ extern "C" int eav_attn_bwd_sp_planes(const void* rowp, const void* tp, const vo
   if (N > g_nw4_above) {
     hipLaunchKernelGGL(attn_bwd_q_sp_kernel<4>, dim3(nt128 * nbh), dim3(256), 0, st, (const u8*)rowp, (const u8*)tp,
                        (const u8*)dorow, slot, slot_do, lse, ao, dout, delta, dqkv, (unsigned*)slot_ds,
-                       (unsigned*)amax_slot, N, Npad, H, scale, nt128, nbh, (u8*)planes, planes_slot, colsum_part);
+                       (unsigned*)amax_slot, N, Npad, H, scale, nt128, nbh, (u8*)planes, planes_slot, colsum_part,
+                       (const u8*)ao_planes, ao_slot);
     EAV_CHECK_LAUNCH("eav_attn_bwd_sp(dQ)");
   } else {
     hipLaunchKernelGGL(attn_bwd_q_sp_kernel<2>, dim3(nt64 * nbh), dim3(128), 0, st, (const u8*)rowp, (const u8*)tp,
                        (const u8*)dorow, slot, slot_do, lse, ao, dout, delta, dqkv, (unsigned*)slot_ds,
-                       (unsigned*)amax_slot, N, Npad, H, scale, nt64, nbh, (u8*)planes, planes_slot, colsum_part);
+                       (unsigned*)amax_slot, N, Npad, H, scale, nt64, nbh, (u8*)planes, planes_slot, colsum_part,
+                       (const u8*)ao_planes, ao_slot);
     EAV_CHECK_LAUNCH("eav_attn_bwd_sp(dQ)");
   }
   // the dK,dV kernel holds 66 KB of tiles per block: 4-wave blocks keep 2 waves per SIMD at every N (a wave past the last
@@ -1375,5 +1402,5 @@ extern "C" int eav_attn_bwd_sp(const void* rowp, const void* tp, const void* dor
                                int head_dim, float scale, void* stream) {
   EAV_REQUIRE(dqkv, "eav_attn_bwd_sp: bad arguments");
   return eav_attn_bwd_sp_planes(rowp, tp, dorow, dotp, slot, slot_do, slot_ds, ao, dout, lse, delta, dqkv, amax_slot,
-                                nullptr, nullptr, nullptr, B, H, N, head_dim, scale, stream);
+                                nullptr, nullptr, nullptr, nullptr, nullptr, B, H, N, head_dim, scale, stream);
 }

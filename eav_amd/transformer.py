@@ -972,7 +972,9 @@ class Encoder(nn.Module):
             if fusedp and self.fused_ao:
                 # the attention output leaves as the planes of the o-proj products (scale: qkv's own, |O| <= max|V|); its
                 # fp32 copy is written only when a backward will read it
-                L("eav_attn_fwd_sp_planes", P(ws.qkvrow[j]), None, s_qkv, P(ao) if ws.full else None,
+                # (... and only by the unfused gradient flow: the fused one forms delta = dO . O from these planes)
+                need_ao = ws.full and not (self.fused_dqkv and self.grad_terms != 1)
+                L("eav_attn_fwd_sp_planes", P(ws.qkvrow[j]), None, s_qkv, P(ao) if need_ao else None,
                   P(ws.lse[j]), None, P(ws.aop[j]), s_ao, ws.B, H, N, hd, scale, st)
             else:
                 L("eav_attn_fwd_sp", P(ws.qkvrow[j]), None, s_qkv, P(ao), P(ws.lse[j]), s_ao, ws.B, H, N, hd,
@@ -1082,9 +1084,10 @@ class Encoder(nn.Module):
             if self.fused_dqkv and self.grad_terms != 1:      # (hi.hi-only gradient products need the tight measured scale)
                 self._before_overwrite(ws.dqkvp)
                 part = self._part_buf("part_attn_pool")
+                # (delta = dO . O from the planes of dO and of the attention output: no fp32 attention output in the step)
                 L("eav_attn_bwd_sp_planes", P(ws.qkvrow[i]), None, P(ws.dorow), None, s_qkv, b_dao, b_ds,
-                  P(ws.ao[i]), dao, P(ws.lse[i]), P(ws.delta), None, None, P(ws.dqkvp), b_dqkv, P(part), ws.B, H, N, hd,
-                  scale, st)
+                  None, None, P(ws.lse[i]), P(ws.delta), None, None, P(ws.dqkvp), b_dqkv, P(part), P(ws.aop[i]), s_ao,
+                  ws.B, H, N, hd, scale, st)
                 self._reduce_async(part, 0, ws.np_attn, 3 * D, 3 * D, gp(f"{Lk}.attention.q_proj.bias"))
             else:
                 L("eav_attn_bwd_sp", P(ws.qkvrow[i]), None, P(ws.dorow), None, s_qkv, b_dao, b_ds,

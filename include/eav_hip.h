@@ -432,13 +432,16 @@ int eav_attn_bwd_sp(const void* rowp, const void* tp, const void* dorow, const v
  * projection's gradient products - no fp32 dqkv, no conversion pass - scaled by a sigma the kernels form themselves and
  * publish in planes_slot (eav_attn_dqkv_bound computes the same number stand-alone) from a rigorous bound |dqkv| <= N max|dO| max(1, 128 scale max|qkv|^2) (slot_do: the
  * shards of max|dO|; slot_qkv: the forward's qkv slot); colsum_part (optional) [B * ceil(N/32)][3D] receives the column sums
- * of every 32-row tile (bias-gradient partials: finish with eav_reduce_partials).  Replaces, in the split step, the
+ * of every 32-row tile (bias-gradient partials: finish with eav_reduce_partials).  ao_planes + ao_slot (optional): the attention
+ * output as the planes eav_attn_fwd_sp_planes wrote - delta = dO . O then comes from planes and ao / dout may be NULL (the
+ * training step keeps no fp32 attention output).  Replaces, in the split step, the
  * eav_sp_convert_colsum pass over dqkv (Transformer_Audio.py:72 / Transformer_Vision.py:92 through HF's backward). */
 int eav_attn_dqkv_bound(float* slot_out, const float* slot_do, const float* slot_qkv, int N, float scale, void* stream);
 int eav_attn_bwd_sp_planes(const void* rowp, const void* tp, const void* dorow, const void* dotp, const float* slot,
                            const float* slot_do, float* slot_ds, const float* ao, const float* dout, const float* lse,
                            float* delta, float* dqkv, float* amax_slot, void* planes, float* planes_slot,
-                           float* colsum_part, int B, int H, int N, int head_dim, float scale, void* stream);
+                           float* colsum_part, const void* ao_planes, const float* ao_slot, int B, int H, int N,
+                           int head_dim, float scale, void* stream);
 /* Fused multi-head self-attention (head_dim 64), exact fp32 MFMA, flash-style: softmax(Q K^T scale) V per
  * (image, head) of qkv [B*N, 3*H*64] (HF eager_attention_forward).  ao [B*N, H*64]; lse [B*H, N] saved for
  * the backward. */

@@ -294,7 +294,7 @@ def test_attention_sp_is_fp32_grade(cfg):
     s_ds2, delta2 = torch.zeros(SLOT, device="cuda"), torch.empty(B * H, N, device="cuda")
     dq2 = torch.empty_like(dqkv)
     _lib.call("eav_attn_bwd_sp_planes", P(rowp), P(tp), P(dorow), P(dotp), P(s_qkv), P(s_do), P(s_ds2), P(ao), P(dO), P(lse),
-              P(delta2), P(dq2), None, P(gpl), P(s_g), P(cs), B, H, N, 64, 0.125, None)
+              P(delta2), P(dq2), None, P(gpl), P(s_g), P(cs), None, None, B, H, N, 64, 0.125, None)
     assert torch.equal(dq2, dqkv)
     got = decode_planes(gpl, B * N, 3 * D, gsig)
     assert (got - dqkv.double()).abs().max().item() <= 2.0 ** -21 * (2.0 ** 15 / gsig) * 2.0 ** -10 + \
@@ -304,8 +304,17 @@ def test_attention_sp_is_fp32_grade(cfg):
     assert (cs.double().sum(0) - want_cs).abs().max().item() <= 1e-5 * float(dqkv.abs().max()) * (B * N) ** 0.5
     gpl3 = torch.zeros_like(gpl)
     _lib.call("eav_attn_bwd_sp_planes", P(rowp), P(tp), P(dorow), P(dotp), P(s_qkv), P(s_do), P(s_ds2), P(ao), P(dO), P(lse),
-              P(delta2), None, None, P(gpl3), P(s_g), None, B, H, N, 64, 0.125, None)
+              P(delta2), None, None, P(gpl3), P(s_g), None, None, None, B, H, N, 64, 0.125, None)
     assert torch.equal(gpl3[:B * N], gpl[:B * N])
+    # delta = dO . O from the planes of dO and of the attention output (no fp32 O, dO read): the row sums to 2^-20 of
+    # |dO| |O| sqrt(64), dqkv to the same bounds as the fp32-delta run
+    delta3, dq3 = torch.empty_like(delta2), torch.empty_like(dqkv)
+    _lib.call("eav_attn_bwd_sp_planes", P(rowp), P(tp), P(dorow), P(dotp), P(s_qkv), P(s_do), P(s_ds2), None, None, P(lse),
+              P(delta3), P(dq3), None, None, None, None, P(aop), P(s_ao), B, H, N, 64, 0.125, None)
+    assert (delta3 - delta2).abs().max().item() <= 2.0 ** -20 * 8 * float(dO.abs().max()) * float(ao.abs().max()) + 1e-30
+    for i in range(3):
+        sl = slice(i * D, (i + 1) * D)
+        assert ((dq3[:, sl] - dqkv[:, sl]).abs().max() / dqkv[:, sl].abs().max()).item() <= 2e-6, i
 
     def rel(a, r):
         return ((a.double() - r).abs().max() / r.abs().max()).item()

@@ -33,6 +33,8 @@ SIGNATURES = {
     "eav_bn_finalize": [_p, _i, _i, _d, _p, _p, _p, _p, _i, _f, _f, _p, _p, _p, _p, _p],
     "eav_bn_bwd_finalize": [_p, _i, _i, _d, _i, _p, _p, _p, _p, _p],
     "eav_renorm_rows": [_p, _i, _i, _f, _p],
+    "eav_renorm_rows2": [_p, _i, _i, _p, _i, _i, _f, _p],
+    "eav_eegnet_step_prologue": [_p, _p, _p, _p, _p, _p, _p, _p],
     "eav_eegnet_fir_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
     "eav_eegnet_fir_wgrad": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "eav_eegnet_fir_fwd_indexed": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],

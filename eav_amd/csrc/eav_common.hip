@@ -222,9 +222,16 @@ extern "C" int eav_bn_bwd_finalize(const float* part, int nparts, int nch, doubl
 // ---------------------------------------------------------------------------------------------
 // Tensor.renorm_(p=2, dim=0, maxnorm) on a [rows, cols] matrix (EEGNet_tor.py:34,48):
 // rows with ||w||_2 > maxnorm are scaled by maxnorm / (norm + 1e-7).
-__global__ void renorm_rows_kernel(float* __restrict__ w, int rows, int cols, float maxnorm) {
+// (second matrix w_b [rows_b, cols_b]: blocks rows .. rows + rows_b - 1; eav_renorm_rows2)
+__global__ void renorm_rows_kernel(float* __restrict__ w, int rows, int cols, float maxnorm, float* __restrict__ w_b,
+                                   int cols_b) {
   __shared__ float red[8];
   int r = blockIdx.x;
+  if (r >= rows) {
+    r -= rows;
+    w = w_b;
+    cols = cols_b;
+  }
   float* row = w + (int64_t)r * cols;
   float v[1] = {0.f};
   for (int i = threadIdx.x; i < cols; i += 256) v[0] += row[i] * row[i];
@@ -242,7 +249,17 @@ __global__ void renorm_rows_kernel(float* __restrict__ w, int rows, int cols, fl
 
 extern "C" int eav_renorm_rows(float* w, int rows, int cols, float maxnorm, void* stream) {
   EAV_REQUIRE(w && rows > 0 && cols > 0, "eav_renorm_rows: bad arguments");
-  hipLaunchKernelGGL(renorm_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, w, rows, cols, maxnorm);
+  hipLaunchKernelGGL(renorm_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, w, rows, cols, maxnorm,
+                     (float*)nullptr, 0);
   EAV_CHECK_LAUNCH("eav_renorm_rows");
+  return EAV_OK;
+}
+
+extern "C" int eav_renorm_rows2(float* w_a, int rows_a, int cols_a, float* w_b, int rows_b, int cols_b, float maxnorm,
+                                void* stream) {
+  EAV_REQUIRE(w_a && rows_a > 0 && cols_a > 0 && w_b && rows_b > 0 && cols_b > 0, "eav_renorm_rows2: bad arguments");
+  hipLaunchKernelGGL(renorm_rows_kernel, dim3(rows_a + rows_b), dim3(256), 0, (hipStream_t)stream, w_a, rows_a, cols_a,
+                     maxnorm, w_b, cols_b);
+  EAV_CHECK_LAUNCH("eav_renorm_rows2");
   return EAV_OK;
 }

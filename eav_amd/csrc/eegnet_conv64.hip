@@ -204,9 +204,16 @@ __global__ __launch_bounds__(256, 3) void conv64_wgrad_kernel(const float* __res
 }
 
 // wT_fwd[(i*16+k)][o] = W[o][i][k];  wT_bwd[(o*16+k')][i] = W[o][i][15-k']
+// c0..c3 (optional): step counters incremented by one thread of the launch (eav_eegnet_step_prologue)
 __global__ void conv64_prep_kernel(const float* __restrict__ w, float* __restrict__ wT_fwd,
-                                   float* __restrict__ wT_bwd) {
+                                   float* __restrict__ wT_bwd, int64_t* c0, int64_t* c1, int64_t* c2, int64_t* c3) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx == 0) {
+    if (c0) *c0 += 1;
+    if (c1) *c1 += 1;
+    if (c2) *c2 += 1;
+    if (c3) *c3 += 1;
+  }
   if (idx >= NCH * KD) return;
   const int o = idx / KD, rem = idx - o * KD, i = rem >> 4, k = rem & 15;
   const float v = w[idx];
@@ -218,8 +225,15 @@ __global__ void conv64_prep_kernel(const float* __restrict__ w, float* __restric
 
 extern "C" int eav_conv64_prep_weights(const float* w, float* wT_fwd, float* wT_bwd, void* stream) {
   EAV_REQUIRE(w && wT_fwd && wT_bwd, "eav_conv64_prep_weights: bad arguments");
-  hipLaunchKernelGGL(conv64_prep_kernel, dim3(NCH * KD / 256), dim3(256), 0, (hipStream_t)stream, w, wT_fwd, wT_bwd);
-  EAV_CHECK_LAUNCH("eav_conv64_prep_weights");
+  return eav_eegnet_step_prologue(w, wT_fwd, wT_bwd, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int eav_eegnet_step_prologue(const float* w, float* wT_fwd, float* wT_bwd, int64_t* c0, int64_t* c1,
+                                        int64_t* c2, int64_t* c3, void* stream) {
+  EAV_REQUIRE(w && wT_fwd && wT_bwd, "eav_eegnet_step_prologue: bad arguments");
+  hipLaunchKernelGGL(conv64_prep_kernel, dim3(NCH * KD / 256), dim3(256), 0, (hipStream_t)stream, w, wT_fwd, wT_bwd,
+                     c0, c1, c2, c3);
+  EAV_CHECK_LAUNCH("eav_eegnet_step_prologue");
   return EAV_OK;
 }
 

@@ -331,11 +331,6 @@ class EEGNet_tor(nn.Module):
             if self._fwd_counter is None or self._fwd_counter.device != x.device:
                 self._fwd_counter = torch.zeros((), dtype=torch.int64, device=x.device)
             cnt = P(self._fwd_counter)
-        if cnt is not None or training:
-            # one launch for the dropout step counter and the three BatchNorm step counters (nn.BatchNorm2d's
-            # num_batches_tracked): library kernels, no torch op inside a captured step
-            L("eav_counter_inc4", cnt, *([P(bn.num_batches_tracked) for bn in (bn1, bn2, bn3)] if training else [None] * 3),
-              st)
         m1 = P(masks[0]) if masks is not None else None
         m2 = P(masks[1]) if masks is not None else None
 
@@ -347,6 +342,14 @@ class EEGNet_tor(nn.Module):
         if self.fir_precision not in ("fp32", "split"):
             raise ValueError(f"fir_precision {self.fir_precision!r}: expected 'fp32' or 'split'")
         split = self.fir_precision == "split"
+        counters = [cnt] + ([P(bn.num_batches_tracked) for bn in (bn1, bn2, bn3)] if training else [None] * 3)
+        if split or not self._use_conv_fft(B):    # (the frequency-domain separableConv takes the weight tensor as it is)
+            # per-step prologue, one launch: the transposed separableConv weights of the direct kernels + the dropout step
+            # counter and the three BatchNorm step counters (nn.BatchNorm2d's num_batches_tracked)
+            L("eav_eegnet_step_prologue", w3, P(ws.wTf), P(ws.wTb), *counters, st)
+        elif cnt is not None or training:
+            # library kernels, no torch op inside a captured step
+            L("eav_counter_inc4", *counters, st)
         np_fir = ws.np_fir
         infer = self.fused_eval and self._infer and not training and not split and S % 4 == 0
         if infer:
@@ -380,8 +383,6 @@ class EEGNet_tor(nn.Module):
             bnfin(ws.part_dw, B * ws.nchunk, 64, B * S, g2w, g2b, bn2, ws.bn2)
             L("eav_bn_elu_pool_fwd_absmax", P(ws.z), P(ws.bn2), P(ws.p2), P(ws.rowmax_p2) if split else None, B, 64, S, 4,
               drop, seed1, m1, cnt, st)
-        if split or not self._use_conv_fft(B):       # (the frequency-domain path takes the weight tensor as it is)
-            L("eav_conv64_prep_weights", w3, P(ws.wTf), P(ws.wTb), st)
         np_c3 = ws.np_c3
         if split:
             L("eav_absmax_finish", P(ws.rowmax_p2), B * 64, 1.0, P(ws.scale_p2), st)
@@ -400,9 +401,8 @@ class EEGNet_tor(nn.Module):
         L("eav_bn_elu_pool_fwd", P(ws.u3), P(ws.bn3), P(ws.p3), B, 64, ws.T2, 8, drop, seed2, m2, cnt, st)
         probs = torch.empty(B, nb, dtype=torch.float32, device=x.device)   # fresh per forward: returned, kept for backward
         L("eav_dense_softmax_fwd", P(ws.p3), wd, bd, None, P(probs), B, ws.NF, nb, st)
-        if self.apply_max_norm:  # the forward hooks of the reference (:33-34, :47-48), intended meaning
-            L("eav_renorm_rows", w2, 64, C, self.norm_rate, st)
-            L("eav_renorm_rows", wd, nb, ws.NF, self.norm_rate, st)
+        if self.apply_max_norm:  # the forward hooks of the reference (:33-34, :47-48), intended meaning: one launch
+            L("eav_renorm_rows2", w2, 64, C, wd, nb, ws.NF, self.norm_rate, st)
         self._saved = (self._token, x, training, drop, seed1, seed2, masks, cnt, split, ws, probs)
         return self._token
 

@@ -41,6 +41,9 @@ int eav_bn_bwd_finalize(const float* part, int nparts, int nch, double count, in
                         float* dbeta, float* m1, float* m2, void* stream);
 /* weight.data.renorm_(p=2, dim=0, maxnorm) - the max-norm hooks, EEGNet_tor.py:33-34,47-48. */
 int eav_renorm_rows(float* w, int rows, int cols, float maxnorm, void* stream);
+/* both hooks of EEGNet_tor.forward (depthwiseConv.weight, dense.weight) in one launch */
+int eav_renorm_rows2(float* w_a, int rows_a, int cols_a, float* w_b, int rows_b, int cols_b, float maxnorm,
+                     void* stream);
 
 /* ---- EEGNet block 1 ----------------------------------------------------------------------- */
 /* firstConv forward: nn.Conv2d(1,8,(1,K<=300),padding='same',bias=False), EEGNet_tor.py:24,51.
@@ -140,6 +143,10 @@ int eav_bn_elu_pool_bwd_apply(const float* dp, const float* u, const float* bn, 
 
 /* ---- separableConv: dense 64->64, 16 taps, 'same' (EEGNet_tor.py:37,59) ------------------- */
 int eav_conv64_prep_weights(const float* w /*[64,64,16]*/, float* wT_fwd /*[1024,64]*/, float* wT_bwd, void* stream);
+/* eav_conv64_prep_weights and eav_counter_inc4 (the dropout / num_batches_tracked step counters; NULL = skip) in one
+ * launch: the per-step prologue of EEGNet_tor.forward when the direct separableConv kernels run */
+int eav_eegnet_step_prologue(const float* w, float* wT_fwd, float* wT_bwd, int64_t* c0, int64_t* c1, int64_t* c2,
+                             int64_t* c3, void* stream);
 int eav_conv64_ntiles(int T);
 /* out[b,o,t] = sum wT[(i*16+k)][o]*in[b,i,t+k-padl]; stat_part (may be NULL) [eav_conv64_fwd_nparts()][128]. */
 int eav_conv64_fwd_nparts(int B, int T);

@@ -678,3 +678,33 @@ def test_conv64_fft(L, B, T):
     e_dir = float((out2.double().cpu() - ref.detach()).abs().max())
     print(f"conv64_fft B={B} T={T}: max error vs float64 {e_fft:.2e} (direct fp32 MFMA kernel {e_dir:.2e})")
     assert e_fft <= 4.0 * e_dir + 1e-6
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Launch mergers of the launch-bound shapes: same results as the separate launches they replace.
+def test_renorm_rows2_is_the_two_hooks_in_one_launch(L):
+    a, b = synth.uniform(52, (64, 30), -0.5, 0.5), synth.uniform(53, (5, 960), -0.1, 0.1)
+    a[::2] *= 0.1
+    b[1] *= 0.01
+    a1, b1, a2, b2 = dev(a), dev(b), dev(a), dev(b)
+    L.call("eav_renorm_rows", a1.data_ptr(), 64, 30, 0.25, None)
+    L.call("eav_renorm_rows", b1.data_ptr(), 5, 960, 0.25, None)
+    L.call("eav_renorm_rows2", a2.data_ptr(), 64, 30, b2.data_ptr(), 5, 960, 0.25, None)
+    torch.cuda.synchronize()
+    assert torch.equal(a1, a2) and torch.equal(b1, b2)
+    assert not torch.equal(a1.cpu(), torch.from_numpy(a)) and not torch.equal(b1.cpu(), torch.from_numpy(b))
+
+
+def test_step_prologue_is_prep_weights_plus_the_step_counters(L):
+    w = dev(synth.normal(54, (64, 64, 16)))
+    ref_f, ref_b = torch.empty(1024, 64, device="cuda"), torch.empty(1024, 64, device="cuda")
+    got_f, got_b = torch.empty(1024, 64, device="cuda"), torch.empty(1024, 64, device="cuda")
+    cnt = torch.tensor([5, 0, 41, 7], dtype=torch.int64, device="cuda")
+    c = cnt.data_ptr()
+    L.call("eav_conv64_prep_weights", w.data_ptr(), ref_f.data_ptr(), ref_b.data_ptr(), None)
+    for _ in range(3):
+        L.call("eav_eegnet_step_prologue", w.data_ptr(), got_f.data_ptr(), got_b.data_ptr(), c, None, c + 16, c + 24, None)
+    torch.cuda.synchronize()
+    assert torch.equal(got_f, ref_f) and torch.equal(got_b, ref_b)
+    assert cnt.tolist() == [8, 0, 44, 10]
+    assert torch.equal(ref_f.view(64, 16, 64), w.permute(1, 2, 0))        # wT_fwd[(i*16+k)][o] = W[o][i][k]

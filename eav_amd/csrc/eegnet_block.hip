@@ -52,21 +52,52 @@ __device__ __forceinline__ void st4(float* p, int i, int n, bool vec, const floa
   }
 }
 
+// block_sum_256 for NT-thread blocks (NT / 64 waves; the wave sums are added in wave order)
+template <int NT, int NV>
+__device__ __forceinline__ void block_sum_nt(float (&v)[NV], float* red) {
+  if constexpr (NT == 256) {
+    block_sum_256<NV>(v, red);
+  } else {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const float s = wave_sum(v[k]);
+      if (lane == 0) red[wave * NV + k] = s;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < NV) {
+      float t = red[threadIdx.x];
+#pragma unroll
+      for (int w = 1; w < NT / 64; ++w) t += red[w * NV + threadIdx.x];
+      v[0] = t;
+    }
+    __syncthreads();
+  }
+}
+
 // ------------------------------------------------------------------------------------- dw_fwd
 // grid (nchunk, F1, B); block 256 threads x 4 samples = 1024 samples of one (b, f).
 // z[b, f*8+d, t] = sum_c w2[f*8+d, c] * ELU(scale1[f]*y1[b,f,c,t] + shift1[f])
 // part[(b*nchunk+chunk)][2*64]: per-channel sum z / sum z^2 (slots of this block's 8 channels).
-__global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ y1, const float* __restrict__ bn1,
+// CG = channel groups, NT = threads: for short rows (S <= 4 NT / CG, one chunk - the reference's own S = 500) the block is
+// CG groups of NT / CG threads, group j walks channels j, j + CG, ... and the groups' partial sums meet in LDS (fixed
+// order): every wave works instead of half of them idling past the row's end, and the serial channel loop - a chain of
+// exposed instruction latencies when a CU holds one block - is CG times shorter.
+template <int CG, int NT>
+__global__ __launch_bounds__(NT) void dw_fwd_kernel(const float* __restrict__ y1, const float* __restrict__ bn1,
                                                      const float* __restrict__ w2, float* __restrict__ z,
                                                      float* __restrict__ part, int C, int S) {
   __shared__ float wsh[DD * CHMAX];
-  __shared__ float red[4 * 16];
+  __shared__ float red[NT / 64 * 16];
+  __shared__ float xsum[CG > 1 ? (CG - 1) * DD * 4 * (NT / CG) : 1];
+  constexpr int TPG = NT / CG;            // threads per channel group
   const int chunk = blockIdx.x, f = blockIdx.y, b = blockIdx.z;
-  for (int i = threadIdx.x; i < DD * C; i += 256) wsh[i] = w2[f * DD * C + i];
+  const int cg = CG > 1 ? threadIdx.x / TPG : 0, tl = CG > 1 ? threadIdx.x % TPG : threadIdx.x;
+  for (int i = threadIdx.x; i < DD * C; i += NT) wsh[i] = w2[f * DD * C + i];
   __syncthreads();
   const float sc = bn1[16 + f], sh = bn1[24 + f];  // layout: mean, invstd, scale, shift (8 each)
   const bool vec = (S & 3) == 0;
-  const int t = chunk * 1024 + threadIdx.x * 4;
+  const int t = chunk * (4 * TPG) + tl * 4;
   float acc[DD][4];
 #pragma unroll
   for (int d = 0; d < DD; ++d)
@@ -75,13 +106,13 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ y
   if (t < S) {
     const float* src = y1 + ((int64_t)b * F1 + f) * C * S;
     float nx[2][4];                       // two channel rows in flight ahead of the one being consumed
-    ld4s(src, t, S, vec, nx[0]);
-    ld4s(src + (int64_t)min(1, C - 1) * S, t, S, vec, nx[1]);
-    for (int c = 0; c < C; ++c) {
+    ld4s(src + (int64_t)(CG > 1 ? min(cg, C - 1) : 0) * S, t, S, vec, nx[0]);
+    ld4s(src + (int64_t)min(cg + CG, C - 1) * S, t, S, vec, nx[1]);
+    for (int c = cg; c < C; c += CG) {
       float v[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) { v[e] = nx[0][e]; nx[0][e] = nx[1][e]; }
-      ld4s(src + (int64_t)min(c + 2, C - 1) * S, t, S, vec, nx[1]);
+      ld4s(src + (int64_t)min(c + 2 * CG, C - 1) * S, t, S, vec, nx[1]);
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = elu_f(sc * v[e] + sh);
 #pragma unroll
@@ -92,21 +123,37 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ y
       }
     }
   }
+  if (CG > 1) {                           // group 0 collects the other groups' partial sums, in group order
+    if (cg > 0)
+#pragma unroll
+      for (int d = 0; d < DD; ++d)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xsum[(((cg - 1) * DD + d) * 4 + e) * TPG + tl] = acc[d][e];
+    __syncthreads();
+    if (cg == 0)
+#pragma unroll
+      for (int g = 1; g < CG; ++g)
+#pragma unroll
+        for (int d = 0; d < DD; ++d)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[d][e] += xsum[(((g - 1) * DD + d) * 4 + e) * TPG + tl];
+  }
+  const bool mine = CG == 1 || cg == 0;   // the group that holds the sums writes z and the statistics
   float st[16];
 #pragma unroll
   for (int d = 0; d < DD; ++d) {
     float s = 0.f, q = 0.f;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      float v = (t + e < S) ? acc[d][e] : 0.f;
+      float v = (mine && t + e < S) ? acc[d][e] : 0.f;
       s += v;
       q += v * v;
     }
     st[d] = s;
     st[8 + d] = q;
-    if (t < S) st4s(z + ((int64_t)b * F1 * DD + f * DD + d) * S, t, S, vec, acc[d]);
+    if (mine && t < S) st4s(z + ((int64_t)b * F1 * DD + f * DD + d) * S, t, S, vec, acc[d]);
   }
-  block_sum_256<16>(st, red);
+  block_sum_nt<NT, 16>(st, red);
   if (threadIdx.x < 16) {
     const int nch = F1 * DD;
     float* dst = part + ((int64_t)b * gridDim.x + chunk) * 2 * nch;
@@ -249,21 +296,28 @@ struct DwFuse {
   float drop_p; uint64_t seed; const uint8_t* mask; const uint64_t* seed_dev;
 };
 
-template <bool FUSED>
-__global__ __launch_bounds__(256) void dw_bwd_kernel(const float* __restrict__ y1, const float* __restrict__ dz,
+// CG: channel groups for short rows, as in dw_fwd_kernel - every group forms dz for the row's samples (the same loads: L1
+// hits), group j walks channels j, j + CG, ...; g1 and the depthwise weight gradient are per channel, the two statistics
+// are block sums anyway.
+template <bool FUSED, int CG, int NT>
+__global__ __launch_bounds__(NT) void dw_bwd_kernel(const float* __restrict__ y1, const float* __restrict__ dz,
                                                      const float* __restrict__ bn1, const float* __restrict__ w2,
                                                      float* __restrict__ g1, float* __restrict__ part_st,
                                                      float* __restrict__ part_w, int C, int S, DwFuse fu) {
   __shared__ float wsh[DD * CHMAX];
-  __shared__ float red[4 * 8];
-  __shared__ float wacc[4 * DD * CHMAX];
+  __shared__ float red[NT / 64 * 8];
+  __shared__ float wacc[NT / 64 * DD * CHMAX];
+  constexpr int TPG = NT / CG;            // threads per channel group (a multiple of the wave size)
   const int chunk = blockIdx.x, f = blockIdx.y, b = blockIdx.z;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int i = threadIdx.x; i < DD * C; i += 256) wsh[i] = w2[f * DD * C + i];
+  const int cg = CG > 1 ? threadIdx.x / TPG : 0, tl = CG > 1 ? threadIdx.x % TPG : threadIdx.x;
+  for (int i = threadIdx.x; i < DD * C; i += NT) wsh[i] = w2[f * DD * C + i];
+  if (CG > 1)                             // a wave only fills its own group's channels of its wacc slot
+    for (int i = threadIdx.x; i < NT / 64 * DD * CHMAX; i += NT) wacc[i] = 0.f;
   __syncthreads();
   const float mean = bn1[f], invstd = bn1[8 + f], sc = bn1[16 + f], sh = bn1[24 + f];
   const bool vec = (S & 3) == 0;
-  const int t = chunk * 1024 + threadIdx.x * 4;
+  const int t = chunk * (4 * TPG) + tl * 4;
   float dzv[DD][4];
   if (FUSED) {
     const uint64_t seed = dropout_seed(fu.seed, fu.seed_dev);
@@ -295,13 +349,13 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const float* __restrict__ y
   float st[2] = {0.f, 0.f};
   const int64_t base = ((int64_t)b * F1 + f) * C * S;
   float nx[2][4];
-  ld4s(y1 + base, t < S ? t : S, S, vec, nx[0]);
-  ld4s(y1 + base + (int64_t)min(1, C - 1) * S, t < S ? t : S, S, vec, nx[1]);
-  for (int c = 0; c < C; ++c) {
+  ld4s(y1 + base + (int64_t)(CG > 1 ? min(cg, C - 1) : 0) * S, t < S ? t : S, S, vec, nx[0]);
+  ld4s(y1 + base + (int64_t)min(cg + CG, C - 1) * S, t < S ? t : S, S, vec, nx[1]);
+  for (int c = cg; c < C; c += CG) {
     float v[4], g[4], a[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) { v[e] = nx[0][e]; nx[0][e] = nx[1][e]; }
-    ld4s(y1 + base + (int64_t)min(c + 2, C - 1) * S, t < S ? t : S, S, vec, nx[1]);
+    ld4s(y1 + base + (int64_t)min(c + 2 * CG, C - 1) * S, t < S ? t : S, S, vec, nx[1]);
     float wd[DD];
 #pragma unroll
     for (int d = 0; d < DD; ++d) wd[d] = wsh[d * C + c];
@@ -354,12 +408,16 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const float* __restrict__ y
       wacc[wave * DD * CHMAX + d * C + c] = r1;  // one slot per wave: summed in a fixed order below
     }
   }
-  block_sum_256<2>(st, red);
+  block_sum_nt<NT, 2>(st, red);
   if (threadIdx.x < 2) part_st[((int64_t)b * gridDim.x + chunk) * 16 + threadIdx.x * 8 + f] = st[0];
   __syncthreads();
   float* dst = part_w + ((int64_t)b * gridDim.x + chunk) * (F1 * DD * C) + f * DD * C;
-  for (int i = threadIdx.x; i < DD * C; i += 256)
-    dst[i] = (wacc[i] + wacc[DD * CHMAX + i]) + (wacc[2 * DD * CHMAX + i] + wacc[3 * DD * CHMAX + i]);
+  for (int i = threadIdx.x; i < DD * C; i += NT) {
+    float w = (wacc[i] + wacc[DD * CHMAX + i]) + (wacc[2 * DD * CHMAX + i] + wacc[3 * DD * CHMAX + i]);
+    if constexpr (NT == 512)
+      w += (wacc[4 * DD * CHMAX + i] + wacc[5 * DD * CHMAX + i]) + (wacc[6 * DD * CHMAX + i] + wacc[7 * DD * CHMAX + i]);
+    dst[i] = w;
+  }
 }
 
 }  // namespace
@@ -369,7 +427,12 @@ extern "C" int eav_eegnet_dw_fwd(const float* y1, const float* bn1, const float*
   EAV_REQUIRE(y1 && bn1 && w2 && z && stat_part && B > 0 && C > 0 && C <= CHMAX && S > 0,
               "eav_eegnet_dw_fwd: bad arguments (Chans must be <= %d)", CHMAX);
   dim3 grid(cdiv(S, 1024), F1, B);
-  hipLaunchKernelGGL(dw_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, y1, bn1, w2, z, stat_part, C, S);
+  if (S <= 256)         // short rows: channel groups (see the kernel)
+    hipLaunchKernelGGL((dw_fwd_kernel<4, 256>), grid, dim3(256), 0, (hipStream_t)stream, y1, bn1, w2, z, stat_part, C, S);
+  else if (S <= 512)
+    hipLaunchKernelGGL((dw_fwd_kernel<4, 512>), grid, dim3(512), 0, (hipStream_t)stream, y1, bn1, w2, z, stat_part, C, S);
+  else
+    hipLaunchKernelGGL((dw_fwd_kernel<1, 256>), grid, dim3(256), 0, (hipStream_t)stream, y1, bn1, w2, z, stat_part, C, S);
   EAV_CHECK_LAUNCH("eav_eegnet_dw_fwd");
   return EAV_OK;
 }
@@ -379,8 +442,8 @@ extern "C" int eav_eegnet_dw_bwd(const float* y1, const float* dz, const float* 
   EAV_REQUIRE(y1 && dz && bn1 && w2 && g1 && stat_part && w_part && B > 0 && C > 0 && C <= CHMAX && S > 0,
               "eav_eegnet_dw_bwd: bad arguments (Chans must be <= %d)", CHMAX);
   dim3 grid(cdiv(S, 1024), F1, B);
-  hipLaunchKernelGGL(dw_bwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, y1, dz, bn1, w2, g1, stat_part,
-                     w_part, C, S, DwFuse{});
+  hipLaunchKernelGGL((dw_bwd_kernel<false, 1, 256>), grid, dim3(256), 0, (hipStream_t)stream, y1, dz, bn1, w2, g1,
+                     stat_part, w_part, C, S, DwFuse{});
   EAV_CHECK_LAUNCH("eav_eegnet_dw_bwd");
   return EAV_OK;
 }
@@ -396,8 +459,15 @@ extern "C" int eav_eegnet_dw_bwd_fused(const float* y1, const float* z, const fl
   EAV_REQUIRE(drop_p > -1.f && drop_p < 1.f, "eav_eegnet_dw_bwd_fused: dropout %f outside (-1,1)", drop_p);
   dim3 grid(cdiv(S, 1024), F1, B);
   DwFuse fu{z, dp2, bn2, drop_p, seed, mask, seed_dev};
-  hipLaunchKernelGGL(dw_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, y1, nullptr, bn1, w2, g1, stat_part,
-                     w_part, C, S, fu);
+  if (S <= 256)
+    hipLaunchKernelGGL((dw_bwd_kernel<true, 4, 256>), grid, dim3(256), 0, (hipStream_t)stream, y1, nullptr, bn1, w2, g1,
+                       stat_part, w_part, C, S, fu);
+  else if (S <= 512)
+    hipLaunchKernelGGL((dw_bwd_kernel<true, 4, 512>), grid, dim3(512), 0, (hipStream_t)stream, y1, nullptr, bn1, w2, g1,
+                       stat_part, w_part, C, S, fu);
+  else
+    hipLaunchKernelGGL((dw_bwd_kernel<true, 1, 256>), grid, dim3(256), 0, (hipStream_t)stream, y1, nullptr, bn1, w2, g1,
+                       stat_part, w_part, C, S, fu);
   EAV_CHECK_LAUNCH("eav_eegnet_dw_bwd_fused");
   return EAV_OK;
 }

@@ -89,7 +89,9 @@ def test_fir_wgrad(L, B, C, S, K):
     close(out, ref, 2e-4, 2e-4 * float(ref.abs().max()), "dW1")
 
 
-@pytest.mark.parametrize("B,C,S", [(2, 30, 500), (1, 30, 2050), (2, 7, 333)])
+# (S <= 512 / <= 256: the two- / four-channel-group forms of dw_fwd for short rows)
+@pytest.mark.parametrize("B,C,S", [(2, 30, 500), (1, 30, 2050), (2, 7, 333), (3, 30, 200), (2, 5, 256), (2, 30, 512),
+                                   (2, 3, 130), (1, 30, 513)])
 def test_dw_fwd_bwd(L, B, C, S):
     y1 = synth.normal(11, (B, 8, C, S))
     w2 = synth.uniform(12, (64, C), -0.3, 0.3)
@@ -708,3 +710,44 @@ def test_step_prologue_is_prep_weights_plus_the_step_counters(L):
     assert torch.equal(got_f, ref_f) and torch.equal(got_b, ref_b)
     assert cnt.tolist() == [8, 0, 44, 10]
     assert torch.equal(ref_f.view(64, 16, 64), w.permute(1, 2, 0))        # wT_fwd[(i*16+k)][o] = W[o][i][k]
+
+
+@pytest.mark.parametrize("B,C,S,drop", [(2, 30, 500, 0.5), (3, 30, 200, 0.25), (2, 7, 132, 0.0), (1, 30, 2052, 0.5),
+                                        (2, 3, 512, -0.5), (2, 30, 256, 0.5), (1, 5, 516, 0.0)])
+def test_dw_bwd_fused_matches_apply_then_dw_bwd(L, B, C, S, drop):
+    """eav_eegnet_dw_bwd_fused (dz formed in the prologue; two / four channel groups for S <= 512 / 256) against
+    eav_bn_elu_pool_bwd_apply -> eav_eegnet_dw_bwd (checked against torch autograd above)."""
+    y1, z = synth.normal(21, (B, 8, C, S)), synth.normal(22, (B, 64, S))
+    dp2 = synth.normal(23, (B, 64, S // 4))
+    w2 = synth.uniform(24, (64, C), -0.3, 0.3)
+
+    def bn(seed, nch):
+        mean, invstd = synth.uniform(seed, (nch,), -0.2, 0.2), synth.uniform(seed + 1, (nch,), 0.5, 2.0)
+        gamma, beta = synth.uniform(seed + 2, (nch,), 0.5, 1.5), synth.uniform(seed + 3, (nch,), -0.2, 0.2)
+        m1, m2 = synth.uniform(seed + 4, (nch,), -0.01, 0.01), synth.uniform(seed + 5, (nch,), -0.01, 0.01)
+        return bn_buf(nch, mean, invstd, gamma * invstd, beta - mean * gamma * invstd, m1, m2)
+
+    b1, b2 = bn(30, 8), bn(40, 64)
+    nchunk = (S + 1023) // 1024
+    y1d, zd, dpd, w2d = dev(y1), dev(z), dev(dp2), dev(w2)
+    dz = torch.empty(B, 64, S, device="cuda")
+    L.call("eav_bn_elu_pool_bwd_apply", dpd.data_ptr(), zd.data_ptr(), b2.data_ptr(), b2.data_ptr() + 4 * 256,
+           dz.data_ptr(), B, 64, S, 4, drop, 77, None, None, None)
+    outs = []
+    for fused in (False, True):
+        g1 = torch.full((B, 8, C, S), float("nan"), device="cuda")
+        pst = torch.full((B * nchunk, 16), float("nan"), device="cuda")
+        pw = torch.full((B * nchunk, 64 * C), float("nan"), device="cuda")
+        if fused:
+            L.call("eav_eegnet_dw_bwd_fused", y1d.data_ptr(), zd.data_ptr(), dpd.data_ptr(), b2.data_ptr(), b1.data_ptr(),
+                   w2d.data_ptr(), g1.data_ptr(), pst.data_ptr(), pw.data_ptr(), B, C, S, drop, 77, None, None, None)
+        else:
+            L.call("eav_eegnet_dw_bwd", y1d.data_ptr(), dz.data_ptr(), b1.data_ptr(), w2d.data_ptr(), g1.data_ptr(),
+                   pst.data_ptr(), pw.data_ptr(), B, C, S, None)
+        torch.cuda.synchronize()
+        outs.append((g1, pst.double().sum(0), pw.double().sum(0)))
+    (ga, sa, wa), (gb, sb, wb) = outs
+    assert torch.isfinite(gb).all()
+    close(gb, ga, 1e-5, 1e-6 * float(ga.abs().max()), "g1")
+    close(sb, sa, 1e-4, 1e-5 * float(sa.abs().max()), "sum g, sum g*yhat")
+    close(wb, wa, 1e-4, 1e-5 * float(wa.abs().max()), "dW2")

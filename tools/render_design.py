@@ -83,7 +83,7 @@ def avg(name):
 parts = [("FIR forward (FFT)", avg("fir_fft_fwd_kernel")),
          ("FIR weight gradient (FFT) + sum + finish", avg("fir_fft_wgrad_kernel<false>") + avg("fir_fft_wgrad_sum_kernel")
           + avg("fir_fft_wgrad_finish_kernel")),
-         ("dw_fwd", avg("dw_fwd_kernel")), ("dw_bwd (fused)", avg("dw_bwd_kernel<true>")),
+         ("dw_fwd", avg("dw_fwd_kernel<1, 256>")), ("dw_bwd (fused)", avg("dw_bwd_kernel<true, 1, 256>")),
          ("separableConv fwd + dgrad (spectra, FFT, per-bin GEMM, IFFT)",
           avg("c64_spectra_kernel") + 2 * (avg("c64_bin_gemm_kernel") + avg("c64_ifft_unpack_kernel")) + 2 * avg("c64_pack_fft_kernel")),
          ("separableConv wgrad (FFT, per-bin GEMM, sum, IFFT)",

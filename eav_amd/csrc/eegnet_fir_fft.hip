@@ -59,29 +59,59 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #define EAV_STG(p, v) (*(p) = (v))
 #endif
 
+__device__ __forceinline__ v2f swp(v2f a) { return __builtin_shufflevector(a, a, 1, 0); }      // (y, x): an op_sel, no move
+__device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+// Complex products in forms hipcc maps to v_pk_mul_f32 / v_pk_fma_f32 with op_sel operands only - written as
+// a.xx * b + a.yy * (-b.y, b.x) it builds the swapped / negated pair with a v_xor + v_mov per product (124 of the 454 VALU
+// instructions of one inverse transform + filter product).
+#ifdef FFTV_OLD_ARITH
+__device__ __forceinline__ v2f cmul(v2f a, v2f b) { return a.xx * b + a.yy * (v2f){-b.y, b.x}; }
+__device__ __forceinline__ v2f cmulc(v2f a, v2f b) { return a.xx * (v2f){b.x, -b.y} + a.yy * (v2f){b.y, b.x}; }
+#else
 __device__ __forceinline__ v2f cmul(v2f a, v2f b) {       // a b
-  return a.xx * b + a.yy * (v2f){-b.y, b.x};
+  return fma2(a.yy * (v2f){-1.f, 1.f}, swp(b), a.xx * b);
 }
 __device__ __forceinline__ v2f cmulc(v2f a, v2f b) {      // a conj(b)
-  return a.xx * (v2f){b.x, -b.y} + a.yy * (v2f){b.y, b.x};
+  return fma2(a.yy, swp(b), (a.xx * (v2f){1.f, -1.f}) * b);
 }
+#endif
+// a w (forward) / a conj(w) (inverse) for a twiddle w: the w-only factors are loop invariants the compiler keeps in
+// registers, which leaves two instructions per product
 template <bool INV>
-__device__ __forceinline__ v2f twmul(v2f a, v2f w) {      // forward: a w; inverse: a conj(w)
+__device__ __forceinline__ v2f twmul(v2f a, v2f w) {
+#ifdef FFTV_OLD_ARITH
   return INV ? cmulc(a, w) : cmul(a, w);
+#else
+  return fma2(w.yy * (INV ? (v2f){1.f, -1.f} : (v2f){-1.f, 1.f}), swp(a), w.xx * a);
+#endif
 }
 // multiply by -i (forward) / +i (inverse)
 template <bool INV>
 __device__ __forceinline__ v2f rot(v2f a) {
+#ifdef FFTV_OLD_ARITH
   return INV ? (v2f){-a.y, a.x} : (v2f){a.y, -a.x};
+#else
+  return swp(a) * (INV ? (v2f){-1.f, 1.f} : (v2f){1.f, -1.f});
+#endif
 }
 
 template <bool INV>
 __device__ __forceinline__ void dft4(v2f& a0, v2f& a1, v2f& a2, v2f& a3) {
+#ifdef FFTV_OLD_ARITH
   const v2f t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, t3 = rot<INV>(a1 - a3);
   a0 = t0 + t2;
   a1 = t1 + t3;
   a2 = t0 - t2;
   a3 = t1 - t3;
+#else
+  // t1 +- rot(d) = fma(swap(d), (1, -1), t1): the rotation rides on the add (exact: the factors are +-1)
+  const v2f t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, d = swp(a1 - a3);
+  const v2f c = INV ? (v2f){-1.f, 1.f} : (v2f){1.f, -1.f};
+  a0 = t0 + t2;
+  a1 = fma2(d, c, t1);
+  a2 = t0 - t2;
+  a3 = fma2(d, -c, t1);
+#endif
 }
 
 // 16-point DFT in registers: n = 4 a + b, k = c + 4 d; X[c + 4 d] = sum_b W16^(b c) W4^(b d) sum_a v[4 a + b] W4^(a c)
@@ -130,6 +160,17 @@ __device__ __forceinline__ void make_twiddles(v2f* __restrict__ twl) {      // 5
   __syncthreads();
 }
 
+// The exchanges need no hardware wait between a wave's writes and its own reads: the LDS executes one wave's DS
+// instructions in issue order, and the transform is private to the wave.  What is needed is that the COMPILER keeps the
+// order (a "memory" clobber); it then places counted lgkmcnt waits in front of the first use of each read by itself, so the
+// butterflies start on the first rows while the last ones are still in flight (-DFFTV_HWWAIT: the round-4 form, a full
+// lgkmcnt(0) drain after the writes and again after the reads).
+#ifdef FFTV_HWWAIT
+#define FFT_ORDER() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#else
+#define FFT_ORDER() asm volatile("" ::: "memory")
+#endif
+
 // In-wave 1024-point FFT: v[j] = x[lane + 64 j] -> v[j] = X[lane + 64 j].  INV: conjugate twiddles, no 1/N.
 template <bool INV>
 __device__ __forceinline__ void fft1024(v2f (&v)[16], v2f* __restrict__ xb, int lane, const v2f* __restrict__ twl) {
@@ -143,13 +184,13 @@ __device__ __forceinline__ void fft1024(v2f (&v)[16], v2f* __restrict__ xb, int 
   for (int k = 1; k < 16; ++k) v[k] = twmul<INV>(v[k], t1[64 * k]);
 #pragma unroll
   for (int k = 0; k < 16; ++k) xb[68 * k + lane] = v[k];
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  FFT_ORDER();
   {
     const v2f* rp = xb + 68 * (lane >> 2) + (lane & 3);
 #pragma unroll
     for (int n2 = 0; n2 < 16; ++n2) v[n2] = rp[4 * n2];
   }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  FFT_ORDER();
   dft16<INV>(v);
 #pragma unroll
   for (int k = 1; k < 16; ++k) v[k] = twmul<INV>(v[k], t2[64 * k]);
@@ -158,25 +199,43 @@ __device__ __forceinline__ void fft1024(v2f (&v)[16], v2f* __restrict__ xb, int 
 #pragma unroll
     for (int k = 0; k < 16; ++k) wp[16 * k] = v[k];
   }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  FFT_ORDER();
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
     v2f u0 = xb[lane + 64 * m], u1 = xb[lane + 64 * m + 260], u2 = xb[lane + 64 * m + 520], u3 = xb[lane + 64 * m + 780];
     dft4<INV>(u0, u1, u2, u3);
     v[m] = u0; v[m + 4] = u1; v[m + 8] = u2; v[m + 12] = u3;
   }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  FFT_ORDER();
 }
 
-__device__ __forceinline__ float wave_sum(float a) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
-  return a;
+// Sum of a over the wave as a wave-uniform value: in-row inclusive scan (row_shr 1, 2, 4, 8), row totals carried by the
+// two row broadcasts, total read from lane 63 - DPP operands only.  (__shfl_xor butterflies compile to six DEPENDENT
+// ds_bpermute round trips, ~600 cycles of LDS latency at the end of every filter iteration of the forward kernel.)
+template <int CTRL, int ROW_MASK, bool BOUND>
+__device__ __forceinline__ float dpp_mov(float src) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(src), CTRL, ROW_MASK, 0xf, BOUND));
+}
+__device__ __forceinline__ float wave_total(float a) {
+  a += dpp_mov<0x111, 0xf, true>(a);      // row_shr:1
+  a += dpp_mov<0x112, 0xf, true>(a);      // row_shr:2
+  a += dpp_mov<0x114, 0xf, true>(a);      // row_shr:4
+  a += dpp_mov<0x118, 0xf, true>(a);      // row_shr:8
+  a += dpp_mov<0x142, 0xa, false>(a);     // row_bcast:15 into rows 1 and 3
+  a += dpp_mov<0x143, 0xc, false>(a);     // row_bcast:31 into rows 2 and 3
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), 63));
 }
 
-// segment of one electrode pair: v[j] = x[c0][t0 - padl + lane + 64 j] + i x[c0 + 1][...]
+// segment of one electrode pair: v[j] = x[c0][t0 - padl + lane + 64 j] + i x[c0 + 1][...].  Interior segments of a full
+// pair (12 of the 15 blocks of a 10000-sample row) take 32 unpredicated loads; the others one exec-masked load per element.
 __device__ __forceinline__ void load_segment(v2f (&v)[16], const float* __restrict__ xrow, bool has1, int S, int tbase,
                                              int lane) {
+  if (has1 && tbase >= 0 && tbase + NF <= S) {
+    const float* p = xrow + tbase + lane;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = (v2f){p[64 * j], p[S + 64 * j]};
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
     const int t = tbase + lane + 64 * j;
@@ -195,7 +254,7 @@ __global__ __launch_bounds__(512, 1) void fir_fft_fwd_kernel(const float* __rest
                                                              int npair, int nblk, int nunits) {
   __shared__ v2f smem[F1 * NF + 8 * WBUF + TWSZ];
   v2f* Hs = smem;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave id as a scalar
   v2f* xb = smem + F1 * NF + wave * WBUF;
   const v2f* tw = smem + F1 * NF + 8 * WBUF;
   make_twiddles(smem + F1 * NF + 8 * WBUF);
@@ -240,22 +299,36 @@ __global__ __launch_bounds__(512, 1) void fir_fft_fwd_kernel(const float* __rest
       for (int j = 0; j < 16; ++j) v[j] = cmul(z[j], hp[64 * j]);
       fft1024<true>(v, xb, lane, tw);
       float* dst = y1 + (((int64_t)b * F1 + f) * C + c0) * S + t0 + lane;
-      float a1 = 0.f, a2 = 0.f;
+      float a1, a2;
+      if (has1 && t0 + LB <= S) {      // a whole block of a full pair (14 of 15): no predicates
+        v2f s1 = (v2f){0.f, 0.f}, s2 = (v2f){0.f, 0.f};
 #pragma unroll
-      for (int j = 0; j < NROW; ++j) {
-        if (t0 + lane + 64 * j < S) {
+        for (int j = 0; j < NROW; ++j) {
           EAV_STG(dst + 64 * j, v[j].x);
-          a1 += v[j].x;
-          a2 += v[j].x * v[j].x;
-          if (has1) {
-            EAV_STG(dst + S + 64 * j, v[j].y);
-            a1 += v[j].y;
-            a2 += v[j].y * v[j].y;
+          EAV_STG(dst + S + 64 * j, v[j].y);
+          s1 += v[j];
+          s2 = fma2(v[j], v[j], s2);
+        }
+        a1 = s1.x + s1.y;
+        a2 = s2.x + s2.y;
+      } else {
+        a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NROW; ++j) {
+          if (t0 + lane + 64 * j < S) {
+            EAV_STG(dst + 64 * j, v[j].x);
+            a1 += v[j].x;
+            a2 += v[j].x * v[j].x;
+            if (has1) {
+              EAV_STG(dst + S + 64 * j, v[j].y);
+              a1 += v[j].y;
+              a2 += v[j].y * v[j].y;
+            }
           }
         }
       }
-      a1 = wave_sum(a1);
-      a2 = wave_sum(a2);
+      a1 = wave_total(a1);
+      a2 = wave_total(a2);
       if (lane == f) sacc += a1;
       if (lane == 8 + f) sacc += a2;
     }
@@ -274,7 +347,7 @@ __global__ __launch_bounds__(512, 1) void fir_fft_wgrad_kernel(const float* __re
                                                                int C, int S, int padl, int npair, int nblk, int nunits) {
   __shared__ v2f smem[8 * NF + 8 * WBUF + TWSZ];
   v2f* zb = smem;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, f = wave;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), f = wave;
   v2f* xb = smem + 8 * NF + wave * WBUF;
   const v2f* tw = smem + 8 * NF + 8 * WBUF;
   make_twiddles(smem + 8 * NF + 8 * WBUF);
@@ -291,6 +364,14 @@ __global__ __launch_bounds__(512, 1) void fir_fft_wgrad_kernel(const float* __re
     const int c0 = 2 * pr, t0 = blk * LB;
     const bool has1 = c0 + 1 < C;
     const int64_t off = (((int64_t)b * F1 + f) * C + c0) * S + t0 + lane;
+    if (has1 && t0 + LB <= S) {      // a whole block of a full pair: no predicates
+#pragma unroll
+      for (int j = 0; j < NROW; ++j) {
+        gr[j] = (v2f){EAV_LDG(g1 + off + 64 * j), EAV_LDG(g1 + off + S + 64 * j)};
+        if (!PLAIN) yr[j] = (v2f){EAV_LDG(y1 + off + 64 * j), EAV_LDG(y1 + off + S + 64 * j)};
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < NROW; ++j) {
       const bool ok = t0 + lane + 64 * j < S;
@@ -330,19 +411,22 @@ __global__ __launch_bounds__(512, 1) void fir_fft_wgrad_kernel(const float* __re
       const int nu = (uu + 1 < 8) ? u + 1 : (g + (int)gridDim.x) * 8;
       if (nu < nunits) fetch_raw(nu, ng, ny);
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        v2f d = (v2f){0.f, 0.f};
-        if (j < NROW && t0 + lane + 64 * j < S) {
-          if (PLAIN) {
-            d = sc * cg[j < NROW ? j : 0];
-          } else {
-            const v2f gg = cg[j < NROW ? j : 0], yy = cy[j < NROW ? j : 0];
-            d = sc * (gg - m1 - (yy - mean) * invstd * m2);
-          }
-          if (!has1) d.y = 0.f;
+      for (int j = 0; j < NROW; ++j) {
+        if (PLAIN) {
+          v[j] = sc * cg[j];
+        } else {
+          v[j] = sc * (cg[j] - m1 - (cy[j] - mean) * invstd * m2);
         }
-        v[j] = d;
       }
+      if (!(has1 && t0 + LB <= S)) {      // ragged last block / odd electrode count: zero what lies outside
+#pragma unroll
+        for (int j = 0; j < NROW; ++j) {
+          if (t0 + lane + 64 * j >= S) v[j] = (v2f){0.f, 0.f};
+          if (!has1) v[j].y = 0.f;
+        }
+      }
+#pragma unroll
+      for (int j = NROW; j < 16; ++j) v[j] = (v2f){0.f, 0.f};
       fft1024<false>(v, xb, lane, tw);
       const v2f* zp = zb + uu * NF + lane;
 #pragma unroll

@@ -39,7 +39,12 @@ constexpr int F1 = 8;
 constexpr int NF = 1024;        // transform length
 constexpr int LB = 704;         // outputs per block: 11 rows of 64 (2816 B = 22 cache lines, so every block is line aligned)
 constexpr int NROW = LB / 64;   // 11
+#ifdef FFTV_LDSX2
 constexpr int WBUF = 1088;      // float2 slots of a wave's exchange buffer: max(68 x 16, 260 x 3 + 256)
+#else
+constexpr int XP = 66;          // pitch of the exchange rows: reads 66 k1 + n3 (+ 4 n2) cover 32 distinct 8-byte banks
+constexpr int WBUF = 1056;      // float2 slots of a wave's exchange buffer: 66 x 15 + 64, rounded to 128 bytes
+#endif
 constexpr int MAXK = NF - LB + 1;   // 321 taps
 
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -147,18 +152,37 @@ __device__ __forceinline__ void dft16(v2f (&v)[16]) {
 
 // Twiddle tables of a workgroup in LDS (16 KB): t1[k][lane] = W1024^(lane k), t2[k][lane] = W64^((lane & 3) k) - one
 // conflict-free ds_read_b64 per use instead of 64 resident VGPRs (with them the forward kernel spilled 68 registers).
+#ifdef FFTV_LDSX2
 constexpr int TWSZ = 2 * 16 * 64;
+#else
+constexpr int TWSZ = 16 * 64 + 16 * 4;
+#endif
 
 __device__ __forceinline__ void make_twiddles(v2f* __restrict__ twl) {      // 512 threads: one entry each, twice
   for (int i = threadIdx.x; i < TWSZ; i += blockDim.x) {
-    const int which = i >> 10, k = (i >> 6) & 15, lane = i & 63;
     float s, c;
+#ifdef FFTV_LDSX2
+    const int which = i >> 10, k = (i >> 6) & 15, lane = i & 63;
     if (which == 0) sincospif((float)(lane * k) * (1.0f / 512.0f), &s, &c);      // 2 pi m / 1024 = pi (m / 512), m exact
     else sincospif((float)((lane & 3) * k) * (1.0f / 32.0f), &s, &c);            // 2 pi m / 64
+#else
+    if (i < 1024) sincospif((float)((i & 63) * (i >> 6)) * (1.0f / 512.0f), &s, &c);      // t1[k][lane] = W1024^(lane k)
+    else sincospif((float)(((i - 1024) & 3) * ((i - 1024) >> 2)) * (1.0f / 32.0f), &s, &c);      // t2[k][n3] = W64^(n3 k)
+#endif
     twl[i] = (v2f){c, -s};
   }
   __syncthreads();
 }
+
+// LDS reads as single ds_read_b64 (2 LDS cycles per wave-instruction): left alone, hipcc pairs them into ds_read2_b64 /
+// ds_read2st64_b64, which the LDS serves as two 4 x 16-lane accesses = 8 cycles for the same 16 bytes per lane
+// (MI355X_MICROARCH.md, LDS table).  A volatile access is the one form its load-store optimiser leaves alone.
+#ifdef FFTV_READ2
+__device__ __forceinline__ v2f lds_ld(const v2f* p) { return *p; }
+#else
+typedef const volatile __attribute__((address_space(3))) v2f* lds_cvp;
+__device__ __forceinline__ v2f lds_ld(const v2f* p) { return *(lds_cvp)p; }
+#endif
 
 // The exchanges need no hardware wait between a wave's writes and its own reads: the LDS executes one wave's DS
 // instructions in issue order, and the transform is private to the wave.  What is needed is that the COMPILER keeps the
@@ -172,6 +196,7 @@ __device__ __forceinline__ void make_twiddles(v2f* __restrict__ twl) {      // 5
 #endif
 
 // In-wave 1024-point FFT: v[j] = x[lane + 64 j] -> v[j] = X[lane + 64 j].  INV: conjugate twiddles, no 1/N.
+#ifdef FFTV_LDSX2
 template <bool INV>
 __device__ __forceinline__ void fft1024(v2f (&v)[16], v2f* __restrict__ xb, int lane, const v2f* __restrict__ twl) {
 #ifdef FFTV_ABL_NOFFT
@@ -181,19 +206,19 @@ __device__ __forceinline__ void fft1024(v2f (&v)[16], v2f* __restrict__ xb, int 
   const v2f* t2 = twl + 1024 + lane;
   dft16<INV>(v);
 #pragma unroll
-  for (int k = 1; k < 16; ++k) v[k] = twmul<INV>(v[k], t1[64 * k]);
+  for (int k = 1; k < 16; ++k) v[k] = twmul<INV>(v[k], lds_ld(t1 + 64 * k));
 #pragma unroll
   for (int k = 0; k < 16; ++k) xb[68 * k + lane] = v[k];
   FFT_ORDER();
   {
     const v2f* rp = xb + 68 * (lane >> 2) + (lane & 3);
 #pragma unroll
-    for (int n2 = 0; n2 < 16; ++n2) v[n2] = rp[4 * n2];
+    for (int n2 = 0; n2 < 16; ++n2) v[n2] = lds_ld(rp + 4 * n2);
   }
   FFT_ORDER();
   dft16<INV>(v);
 #pragma unroll
-  for (int k = 1; k < 16; ++k) v[k] = twmul<INV>(v[k], t2[64 * k]);
+  for (int k = 1; k < 16; ++k) v[k] = twmul<INV>(v[k], lds_ld(t2 + 64 * k));
   {
     v2f* wp = xb + (lane >> 2) + 260 * (lane & 3);
 #pragma unroll
@@ -202,12 +227,67 @@ __device__ __forceinline__ void fft1024(v2f (&v)[16], v2f* __restrict__ xb, int 
   FFT_ORDER();
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
-    v2f u0 = xb[lane + 64 * m], u1 = xb[lane + 64 * m + 260], u2 = xb[lane + 64 * m + 520], u3 = xb[lane + 64 * m + 780];
+    v2f u0 = lds_ld(xb + lane + 64 * m), u1 = lds_ld(xb + lane + 64 * m + 260), u2 = lds_ld(xb + lane + 64 * m + 520),
+        u3 = lds_ld(xb + lane + 64 * m + 780);
     dft4<INV>(u0, u1, u2, u3);
     v[m] = u0; v[m + 4] = u1; v[m + 8] = u2; v[m + 12] = u3;
   }
   FFT_ORDER();
 }
+#else
+// exchange a[lanes 32-63] with b[lanes 0-31] / a[lanes 16-31, 48-63] with b[lanes 0-15, 32-47]: one step of a transpose
+// between a lane bit and a register-index bit, both directions in ONE instruction, no LDS
+__device__ __forceinline__ void swap32(v2f& a, v2f& b) {
+  const auto rx = __builtin_amdgcn_permlane32_swap(__float_as_uint(a.x), __float_as_uint(b.x), false, false);
+  const auto ry = __builtin_amdgcn_permlane32_swap(__float_as_uint(a.y), __float_as_uint(b.y), false, false);
+  a = (v2f){__uint_as_float(rx[0]), __uint_as_float(ry[0])};
+  b = (v2f){__uint_as_float(rx[1]), __uint_as_float(ry[1])};
+}
+__device__ __forceinline__ void swap16(v2f& a, v2f& b) {
+  const auto rx = __builtin_amdgcn_permlane16_swap(__float_as_uint(a.x), __float_as_uint(b.x), false, false);
+  const auto ry = __builtin_amdgcn_permlane16_swap(__float_as_uint(a.y), __float_as_uint(b.y), false, false);
+  a = (v2f){__uint_as_float(rx[0]), __uint_as_float(ry[0])};
+  b = (v2f){__uint_as_float(rx[1]), __uint_as_float(ry[1])};
+}
+
+template <bool INV>
+__device__ __forceinline__ void fft1024(v2f (&v)[16], v2f* __restrict__ xb, int lane, const v2f* __restrict__ twl) {
+#ifdef FFTV_ABL_NOFFT
+  return;
+#endif
+  const v2f* t1 = twl + lane;
+  const v2f* t2 = twl + 1024 + (lane >> 4);
+  dft16<INV>(v);
+#pragma unroll
+  for (int k = 1; k < 16; ++k) v[k] = twmul<INV>(v[k], lds_ld(t1 + 64 * k));
+#pragma unroll
+  for (int k = 0; k < 16; ++k) xb[XP * k + lane] = v[k];
+  FFT_ORDER();
+  {
+    const v2f* rp = xb + XP * (lane & 15) + (lane >> 4);
+#pragma unroll
+    for (int n2 = 0; n2 < 16; ++n2) v[n2] = lds_ld(rp + 4 * n2);
+  }
+  FFT_ORDER();
+  dft16<INV>(v);
+#pragma unroll
+  for (int k = 1; k < 16; ++k) v[k] = twmul<INV>(v[k], lds_ld(t2 + 4 * k));
+  // lane 16 n3 + k1 holds k2 = 4 m + r in register 4 m + r; the 4 x 4 transposes put n3 into the register index:
+  // lane 16 r + k1, register 4 m + n3
+  v2f o[16];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    swap32(v[4 * m], v[4 * m + 2]);
+    swap32(v[4 * m + 1], v[4 * m + 3]);
+    swap16(v[4 * m], v[4 * m + 1]);
+    swap16(v[4 * m + 2], v[4 * m + 3]);
+    dft4<INV>(v[4 * m], v[4 * m + 1], v[4 * m + 2], v[4 * m + 3]);
+    o[m] = v[4 * m]; o[m + 4] = v[4 * m + 1]; o[m + 8] = v[4 * m + 2]; o[m + 12] = v[4 * m + 3];
+  }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) v[k] = o[k];
+}
+#endif
 
 // Sum of a over the wave as a wave-uniform value: in-row inclusive scan (row_shr 1, 2, 4, 8), row totals carried by the
 // two row broadcasts, total read from lane 63 - DPP operands only.  (__shfl_xor butterflies compile to six DEPENDENT
@@ -246,20 +326,29 @@ __device__ __forceinline__ void load_segment(v2f (&v)[16], const float* __restri
 }
 
 // ------------------------------------------------------------------------------------------------------------------ fwd
-// Work unit = (sample b, electrode pair, block of 704 outputs), one wave each; 8 waves per workgroup share the 8 filter
-// spectra H_f = conj(FFT(w_f)) / 1024 (computed by the workgroup itself: wave f transforms filter f).
-__global__ __launch_bounds__(512, 1) void fir_fft_fwd_kernel(const float* __restrict__ x, const int64_t* __restrict__ xidx,
-                                                             const float* __restrict__ w1, float* __restrict__ y1,
-                                                             float* __restrict__ part, int C, int S, int klen, int padl,
-                                                             int npair, int nblk, int nunits) {
-  __shared__ v2f smem[F1 * NF + 8 * WBUF + TWSZ];
+// Work unit = (sample b, electrode pair, block of 704 outputs), one wave each; the NWF = 12 waves of a workgroup (3 per
+// SIMD) share the 8 filter spectra H_f = conj(FFT(w_f)) / 1024, computed by the workgroup itself (wave f < 8 transforms
+// filter f).  The filters are real, so H_f[1024 - k] = conj(H_f[k]): only bins 0 .. 512 are kept (33 KB instead of 64 KB -
+// what makes room for the exchange buffers of 12 waves), rows j >= 8 of a lane read the mirrored bin and conjugate.
+#ifdef FFTV_W8
+constexpr int NWF = 8;
+#else
+constexpr int NWF = 12;
+#endif
+constexpr int HB = 520;         // float2 slots per filter: bins 0 .. 512, padded to a multiple of 64 bytes
+
+__global__ __launch_bounds__(64 * NWF, 1) void fir_fft_fwd_kernel(const float* __restrict__ x, const int64_t* __restrict__ xidx,
+                                                                  const float* __restrict__ w1, float* __restrict__ y1,
+                                                                  float* __restrict__ part, int C, int S, int klen, int padl,
+                                                                  int npair, int nblk, int nunits) {
+  __shared__ v2f smem[F1 * HB + NWF * WBUF + TWSZ];
   v2f* Hs = smem;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave id as a scalar
-  v2f* xb = smem + F1 * NF + wave * WBUF;
-  const v2f* tw = smem + F1 * NF + 8 * WBUF;
-  make_twiddles(smem + F1 * NF + 8 * WBUF);
+  v2f* xb = smem + F1 * HB + wave * WBUF;
+  const v2f* tw = smem + F1 * HB + NWF * WBUF;
+  make_twiddles(smem + F1 * HB + NWF * WBUF);
   v2f v[16];
-  {
+  if (wave < F1) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       const int n = lane + 64 * j;
@@ -267,11 +356,12 @@ __global__ __launch_bounds__(512, 1) void fir_fft_fwd_kernel(const float* __rest
     }
     fft1024<false>(v, xb, lane, tw);
 #pragma unroll
-    for (int j = 0; j < 16; ++j) Hs[wave * NF + j * 64 + lane] = (v2f){v[j].x, -v[j].y} * (1.0f / NF);
+    for (int j = 0; j < 8; ++j) Hs[wave * HB + j * 64 + lane] = (v2f){v[j].x, -v[j].y} * (1.0f / NF);
+    if (lane == 0) Hs[wave * HB + 512] = (v2f){v[8].x, -v[8].y} * (1.0f / NF);
   }
   __syncthreads();
   float sacc = 0.f;      // lane f: sum of filter f's outputs, lane 8 + f: sum of their squares (this wave's share)
-  const int wgid = blockIdx.x * 8 + wave, nwaves = gridDim.x * 8;
+  const int wgid = blockIdx.x * NWF + wave, nwaves = gridDim.x * NWF;
   // the NEXT unit's input segment is fetched into registers before the eight inverse transforms of the current one
   v2f nx[16];
   auto fetch = [&](int u, v2f (&dst)[16]) {
@@ -294,9 +384,12 @@ __global__ __launch_bounds__(512, 1) void fir_fft_fwd_kernel(const float* __rest
     for (int j = 0; j < 16; ++j) z[j] = v[j];
 #pragma unroll 1
     for (int f = 0; f < F1; ++f) {
-      const v2f* hp = Hs + f * NF + lane;
+      const v2f* hp = Hs + f * HB + lane;       // bins lane + 64 j, j < 8
+      const v2f* hm = Hs + f * HB - lane;       // bins 1024 - (lane + 64 j), j >= 8: the conjugates
 #pragma unroll
-      for (int j = 0; j < 16; ++j) v[j] = cmul(z[j], hp[64 * j]);
+      for (int j = 0; j < 8; ++j) v[j] = cmul(z[j], lds_ld(hp + 64 * j));
+#pragma unroll
+      for (int j = 8; j < 16; ++j) v[j] = cmulc(z[j], lds_ld(hm + (NF - 64 * j)));
       fft1024<true>(v, xb, lane, tw);
       float* dst = y1 + (((int64_t)b * F1 + f) * C + c0) * S + t0 + lane;
       float a1, a2;
@@ -333,7 +426,7 @@ __global__ __launch_bounds__(512, 1) void fir_fft_fwd_kernel(const float* __rest
       if (lane == 8 + f) sacc += a2;
     }
   }
-  if (lane < 16) part[wgid * 16 + lane] = sacc;
+  if (lane < 16) part[wgid * 16 + lane] = sacc;      // (a wave without units writes its zeros)
 }
 
 // ---------------------------------------------------------------------------------------------------------------- wgrad
@@ -384,18 +477,25 @@ __global__ __launch_bounds__(512, 1) void fir_fft_wgrad_kernel(const float* __re
     }
   };
   if (blockIdx.x * 8 < nunits) fetch_raw(blockIdx.x * 8, cg, cy);
+  // input segment of this wave's unit of a group: fetched one group ahead, so that the Z transforms that open a group
+  // find their data in registers (the loads travel under the previous group's eight dy transforms)
+  v2f nx[16];
+  auto fetch_x = [&](int u, v2f (&dst)[16]) {
+    const int blk = u % nblk, pr = (u / nblk) % npair, b = u / (nblk * npair);
+    const int c0 = 2 * pr;
+    const float* xrow = x + ((xidx ? xidx[b] : (int64_t)b) * C + c0) * S;
+    load_segment(dst, xrow, c0 + 1 < C, S, blk * LB - padl, lane);
+  };
+  if (blockIdx.x * 8 + wave < nunits) fetch_x(blockIdx.x * 8 + wave, nx);
   for (int g = blockIdx.x; g < ngroups; g += gridDim.x) {
-    {
-      const int u = g * 8 + wave;
-      if (u < nunits) {
-        const int blk = u % nblk, pr = (u / nblk) % npair, b = u / (nblk * npair);
-        const int c0 = 2 * pr;
-        const float* xrow = x + ((xidx ? xidx[b] : (int64_t)b) * C + c0) * S;
-        load_segment(v, xrow, c0 + 1 < C, S, blk * LB - padl, lane);
-        fft1024<false>(v, xb, lane, tw);
+    if (g * 8 + wave < nunits) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) zb[wave * NF + j * 64 + lane] = v[j];
-      }
+      for (int j = 0; j < 16; ++j) v[j] = nx[j];
+      const int un = (g + (int)gridDim.x) * 8 + wave;
+      if (un < nunits) fetch_x(un, nx);
+      fft1024<false>(v, xb, lane, tw);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) zb[wave * NF + j * 64 + lane] = v[j];
     }
     __syncthreads();
 #pragma unroll 1
@@ -430,7 +530,7 @@ __global__ __launch_bounds__(512, 1) void fir_fft_wgrad_kernel(const float* __re
       fft1024<false>(v, xb, lane, tw);
       const v2f* zp = zb + uu * NF + lane;
 #pragma unroll
-      for (int j = 0; j < 16; ++j) acc[j] += cmulc(zp[64 * j], v[j]);
+      for (int j = 0; j < 16; ++j) acc[j] += cmulc(lds_ld(zp + 64 * j), v[j]);
 #pragma unroll
       for (int j = 0; j < NROW; ++j) {       // (after the transform: the copy is what waits for the loads)
         cg[j] = ng[j];
@@ -505,7 +605,7 @@ extern "C" int eav_eegnet_fir_fft_max_taps(void) { return MAXK; }
 extern "C" int eav_eegnet_fir_fwd_fft_nparts(int B, int C, int S) {
   int npair, nblk;
   const int nunits = fft_units(B, C, S, &npair, &nblk);
-  return fft_grid(nunits, 8) * 8;
+  return fft_grid(nunits, NWF) * NWF;
 }
 
 // y1 [B,8,C,S] = firstConv(x) for the batch x[xidx[0..B)] (xidx NULL: x itself), 'same' padding, klen <= 321 taps;
@@ -516,7 +616,7 @@ extern "C" int eav_eegnet_fir_fwd_fft(const float* x, const int64_t* xidx, const
   EAV_REQUIRE(klen >= 1 && klen <= MAXK, "eav_eegnet_fir_fwd_fft: kernLength %d outside [1,%d]", klen, MAXK);
   int npair, nblk;
   const int nunits = fft_units(B, C, S, &npair, &nblk);
-  hipLaunchKernelGGL(fir_fft_fwd_kernel, dim3(fft_grid(nunits, 8)), dim3(512), 0, (hipStream_t)stream, x, xidx, w1, y1,
+  hipLaunchKernelGGL(fir_fft_fwd_kernel, dim3(fft_grid(nunits, NWF)), dim3(64 * NWF), 0, (hipStream_t)stream, x, xidx, w1, y1,
                      stat_part, C, S, klen, (klen - 1) / 2, npair, nblk, nunits);
   EAV_CHECK_LAUNCH("eav_eegnet_fir_fwd_fft");
   return EAV_OK;

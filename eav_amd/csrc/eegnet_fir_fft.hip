@@ -452,8 +452,18 @@ __global__ __launch_bounds__(512, 1) void fir_fft_wgrad_kernel(const float* __re
   const int ngroups = (nunits + 7) >> 3;
   // raw g1 (and y1) rows of a unit for this wave's filter: .x = electrode c0, .y = electrode c0 + 1 (0 outside)
   v2f cg[NROW], cy[NROW];
-  auto fetch_raw = [&](int u, v2f (&gr)[NROW], v2f (&yr)[NROW]) {
-    const int blk = u % nblk, pr = (u / nblk) % npair, b = u / (nblk * npair);
+  // (block, pair, sample) of a unit: one set of integer divisions per GROUP (they compile to ~60 scalar instructions each);
+  // inside a group the position is advanced
+  struct Pos { int blk, pr, b; };
+  auto decode = [&](int u) { return Pos{u % nblk, (u / nblk) % npair, u / (nblk * npair)}; };
+  auto advance = [&](Pos& q) {
+    if (++q.blk == nblk) {
+      q.blk = 0;
+      if (++q.pr == npair) q.pr = 0, ++q.b;
+    }
+  };
+  auto fetch_raw = [&](const Pos& q, v2f (&gr)[NROW], v2f (&yr)[NROW]) {
+    const int blk = q.blk, pr = q.pr, b = q.b;
     const int c0 = 2 * pr, t0 = blk * LB;
     const bool has1 = c0 + 1 < C;
     const int64_t off = (((int64_t)b * F1 + f) * C + c0) * S + t0 + lane;
@@ -476,7 +486,8 @@ __global__ __launch_bounds__(512, 1) void fir_fft_wgrad_kernel(const float* __re
       }
     }
   };
-  if (blockIdx.x * 8 < nunits) fetch_raw(blockIdx.x * 8, cg, cy);
+  Pos cur = decode(blockIdx.x * 8);      // the unit whose rows are in cg / cy
+  if (blockIdx.x * 8 < nunits) fetch_raw(cur, cg, cy);
   // input segment of this wave's unit of a group: fetched one group ahead, so that the Z transforms that open a group
   // find their data in registers (the loads travel under the previous group's eight dy transforms)
   v2f nx[16];
@@ -502,14 +513,15 @@ __global__ __launch_bounds__(512, 1) void fir_fft_wgrad_kernel(const float* __re
     for (int uu = 0; uu < 8; ++uu) {
       const int u = g * 8 + uu;
       if (u >= nunits) break;
-      const int blk = u % nblk, pr = (u / nblk) % npair;
-      const int t0 = blk * LB;
-      const bool has1 = 2 * pr + 1 < C;
+      const int t0 = cur.blk * LB;
+      const bool has1 = 2 * cur.pr + 1 < C;
       // the next unit's rows (of this group, or the first of this workgroup's next group - they then travel under that
       // group's Z transforms too) are in flight under this unit's transform; they are consumed one iteration later
       v2f ng[NROW], ny[NROW];
       const int nu = (uu + 1 < 8) ? u + 1 : (g + (int)gridDim.x) * 8;
-      if (nu < nunits) fetch_raw(nu, ng, ny);
+      if (uu + 1 < 8) advance(cur);
+      else cur = decode(nu);
+      if (nu < nunits) fetch_raw(cur, ng, ny);
 #pragma unroll
       for (int j = 0; j < NROW; ++j) {
         if (PLAIN) {

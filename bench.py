@@ -38,14 +38,16 @@ ENC = {"ast": dict(B=8, gflop_fwd=261.03, gemm_share=8.592 / 10.856, cpu_B=8, cp
 
 
 # ---------------------------------------------------------------------------------------------- CPU baselines (oracle)
-def cpu_baseline_eegnet(steps=2, batch=B_PER_GPU):
+def cpu_baseline_eegnet(steps=3, batch=B_PER_GPU):
     """The oracle (pure fp32 torch CPU restatement, validated against the imported reference) timed on this box's
     host cores on a bounded sample of the same workload, same batch size."""
     import torch
     from eav_amd import synth
     from oracle import eegnet_oracle as orc
     from tests.golden_util import eegnet_weights
-    torch.set_num_threads(min(os.cpu_count() or 1, 64))   # torch CPU conv kernels stop scaling well before 256 threads
+    # (SURVEY 8d asks os.cpu_count() threads; torch's CPU convolutions stop scaling well before the box's 256 hardware
+    # threads and get slower beyond ~64 - the count used is reported as `cores`)
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
     sd = eegnet_weights(31, SAMPLES)
     P = {k: torch.from_numpy(sd[k].copy()) for k in orc.PARAM_NAMES}
     Bf = {k: torch.from_numpy(sd[k].copy()) for k in orc.BUFFER_NAMES}
@@ -53,14 +55,16 @@ def cpu_baseline_eegnet(steps=2, batch=B_PER_GPU):
     x, y = synth.eeg_batch(99, batch, CHANS, SAMPLES)
     xt, yt = torch.from_numpy(x), torch.from_numpy(y)
     st.step(xt, yt, True, None)                     # warm-up
-    t0 = time.perf_counter()
+    per = []
     for _ in range(steps):
+        t0 = time.perf_counter()
         st.step(xt, yt, True, None)
-    dt = time.perf_counter() - t0
-    return {"value": round(steps * batch / dt, 3), "unit": "samples/s", "cores": torch.get_num_threads(),
+        per.append(time.perf_counter() - t0)
+    med = statistics.median(per)
+    return {"value": round(batch / med, 3), "unit": "samples/s", "cores": torch.get_num_threads(),
             "kind": "port",
-            "sample": f"{steps} train steps (fwd+CE+bwd+Adam) of the oracle on [{batch},1,{CHANS},{SAMPLES}] fp32 "
-                      f"after 1 warm-up, {dt:.1f} s"}
+            "sample": f"median of {steps} train steps (fwd+CE+bwd+Adam) of the oracle on [{batch},1,{CHANS},{SAMPLES}] "
+                      f"fp32 after 1 warm-up, {sum(per):.1f} s"}
 
 
 def cpu_baseline_encoder(kind):
@@ -133,9 +137,12 @@ def bench_encoder(kind, dev, world, sync_factory, steps=4, warmup=2, blocks=3, b
         if global_batch:
             sync.set_batch(B, global_batch)
     res = {}
-    runs = runs or (("unfrozen", False, "split"), ("frozen", True, "split"), ("unfrozen_fp32", False, "fp32"),
-                    ("frozen_fp32", True, "fp32"), ("unfrozen_fp16_gradients", False, "split_g1"),
-                    ("unfrozen_fp16", False, "split_11"), ("unfrozen_bf16", False, "bf16"))
+    from eav_amd import _lib as _eavlib
+    runs = runs or ((("unfrozen", False, "split"), ("frozen", True, "split"), ("unfrozen_fp32", False, "fp32"),
+                     ("frozen_fp32", True, "fp32"), ("unfrozen_fp16_gradients", False, "split_g1"),
+                     ("unfrozen_fp16", False, "split_11")) +
+                    # literal bf16 operands: a comparison-only kernel (`make -C eav_amd/csrc BENCH_EXTRAS=1`)
+                    ((("unfrozen_bf16", False, "bf16"),) if _eavlib.have_extras() else ()))
     notes = {"split": "fp16 MFMA, operands split into hi + lo fp16 planes, 3 MFMAs per product, fp32 accumulate: "
                       "fp32-grade (not worse than the exact-fp32 kernels against float64; logits within 1e-4 of HF)",
              "fp32": "exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)",
@@ -246,14 +253,51 @@ def _pmc_traffic(kind, prec, freeze):
 
 
 
+def _subject_job_record(sched, world, n_subjects, steps, batch, times, have, dev, hybrid):
+    """Common tail of the subject-sharded legs: max over ranks of (whole region, solo part, tail part), the gathered
+    per-subject results, the rates and the speed-up against this run's own one-GPU step rate."""
+    import torch
+    import torch.distributed as dist
+    from eav_amd import dist as eav_dist
+    times = torch.tensor(times, dtype=torch.float64, device=dev)
+    if world > 1:
+        gathered = [torch.empty_like(have) for _ in range(world)]
+        dist.all_gather(gathered, have)                      # the job's only whole-world collective: its results
+        have = torch.stack(gathered).max(0).values
+        dist.all_reduce(times, op=dist.ReduceOp.MAX)
+    dt, t_solo, t_tail = (float(v) for v in times.tolist())
+    nsolo = max(len(v) for v in sched.solo)
+    solo_ms = t_solo / max(nsolo * steps, 1) * 1e3
+    value = n_subjects * steps * batch / dt
+    one_gpu = batch / (solo_ms * 1e-3) if nsolo else None
+    rec = {"value": round(value, 2), "unit": "samples/s", "seconds": round(dt, 4), "subjects": n_subjects,
+           "steps_per_subject": steps, "batch": batch,
+           "job_step_ms": round(dt / steps * 1e3, 4),
+           "schedule": {"rounds": sched.rounds, "hybrid": hybrid,
+                        "groups": [[s_, r_] for s_, r_ in sched.groups], "group_size": sched.group_size},
+           "solo_ms_per_step": round(solo_ms, 4),
+           "tail_ms_per_step": round(t_tail / steps * 1e3, 4) if sched.groups else None,
+           "ideal_speedup": round(sched.ideal_speedup(), 3),
+           "ideal_speedup_round_robin": round(eav_dist.subject_schedule(sched.world, n_subjects, hybrid=False).ideal_speedup(), 3),
+           "speedup_vs_one_gpu_rate_of_this_run": round(value / one_gpu, 3) if one_gpu else None,
+           "all_subjects_reported": bool((have > 0).all().item()),
+           "scaling": "strong (total work fixed: every subject once)",
+           "note": "independent per-subject trainings; no collective on the data path of the whole rounds, gradient "
+                   "all-reduce only inside the tail groups, one all_gather of the results"}
+    if one_gpu:
+        rec["speedup_vs_ideal"] = round(value / one_gpu / sched.ideal_speedup(), 3)
+    return rec
+
+
 # ---------------------------------------------------------------------------------------------- encoders, N > 1 legs
-def bench_encoder_multi(kind, dev, rank, world, steps=3, warmup=1):
+def bench_encoder_multi(kind, dev, rank, world, steps=3, warmup=1, ks_frozen=5, ks_unfrozen=5):
     """The data-parallel legs of the AST / ViT fine-tune beyond the weak-scaling phases of bench_encoder:
     `strong` - fixed GLOBAL batch (AST 32, ViT 128: the reference drivers' batch sizes times 4 / 1) split over the ranks,
     per-layer gradient buckets all-reduced from inside the backward (345 MB per step);
     `subject_sharded` - the 42 independent per-subject fine-tunes (Dataload_audio.py:82-115, Transformer_Vision.py:136-152)
-    round-robin over the ranks, each a fresh head + AdamW state, two frozen and two unfrozen steps at the reference batch
-    size, no data-path collective, one all_gather of a per-subject result at the end."""
+    in whole rounds one per rank plus the tail on groups of ranks (eav_amd.dist.SubjectSchedule), each a fresh model + AdamW
+    state, ks_frozen frozen and ks_unfrozen unfrozen steps at the reference batch size; no data-path collective in the whole
+    rounds, per-layer gradient buckets inside the tail groups, one all_gather of a per-subject result at the end."""
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -270,43 +314,64 @@ def bench_encoder_multi(kind, dev, rank, world, steps=3, warmup=1):
                                                              T.param_shapes(T.make_config(kind)).values()),
                          "note": "unfrozen step, fixed global batch; gradient buckets (one per layer) all-reduced from "
                                  "inside the backward"}
-    # ---- Mode S
+    # ---- Mode S: whole rounds solo, the tail on groups (eav_amd.dist.SubjectSchedule)
     cfg = T.make_config(kind)
     torch.manual_seed(0)
     model = T.Encoder(cfg).to(dev).train()
+    model._ensure_flat()
     B = ENC[kind]["B"]
     x, y = (synth.mel_batch(5, B) if kind == "ast" else synth.frame_batch(5, B))
     x, y = torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
     crit = CrossEntropyLoss()
     init = {k: v.detach().clone() for k, v in model.state_dict().items()}
-    subs = eav_dist.subjects_for_rank(rank, world)
-    mine = torch.zeros(42, device=dev)
+    sched = eav_dist.subject_schedule(world)
+    groups = sched.make_groups()
+    mine = sched.group_of(rank)
+    gsync, gx, gy = None, x, y
+    if mine and len(mine[1]) > 1 and B % len(mine[1]) == 0:
+        i, n = mine[1].index(rank), len(mine[1])
+        gsync = eav_dist.GradSync([model._flat[1]], group=groups[mine[0]])
+        gsync.set_batch(B // n, B)
+        gx, gy = x[i * (B // n):(i + 1) * (B // n)].contiguous(), y[i * (B // n):(i + 1) * (B // n)].contiguous()
+    phases = (True,) * ks_frozen + (False,) * ks_unfrozen
+
+    def train_subject(xb, yb, sync):
+        model.load_state_dict(init)                                   # a fresh model per subject
+        model.grad_ready_hook = sync.bucket if sync is not None else None
+        opt = FusedAdam(model.parameters(), lr=5e-4, weight_decay=0.01, decoupled=True)
+        for freeze in phases:
+            for k, p in model.named_parameters():
+                p.requires_grad = (not freeze) or k.startswith("classifier.")
+            if sync is not None:
+                sync.set_active(model.head_grad_ranges() if freeze else None)
+            opt.zero_grad()
+            loss = crit(model(xb).logits, yb)
+            loss.backward()
+            if sync is not None:
+                sync()
+            opt.step()
+        return loss.detach()
+
+    for xb, yb, sy in ((x, y, None),) + (((gx, gy, gsync),) if gsync is not None else ()):     # untimed: workspaces, planes
+        train_subject(xb, yb, sy)
+    have = torch.zeros(42, device=dev)
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for s_ in subs:
-        model.load_state_dict(init)                                   # a fresh model per subject
-        opt = FusedAdam(model.parameters(), lr=5e-4, weight_decay=0.01, decoupled=True)
-        for freeze in (True, True, False, False):
-            for k, p in model.named_parameters():
-                p.requires_grad = (not freeze) or k.startswith("classifier.")
-            opt.zero_grad()
-            loss = crit(model(x).logits, y)
-            loss.backward()
-            opt.step()
-        mine[s_ - 1] = loss.detach()
+    for s_ in sched.solo[rank]:
+        have[s_ - 1] = train_subject(x, y, None)
     torch.cuda.synchronize()
-    ds = time.perf_counter() - t0
-    gathered = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(gathered, mine)
-    t = torch.tensor([ds], dtype=torch.float64, device=dev)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    ds = float(t.item())
-    out["subject_sharded"] = {"value": round(42 * 4 * B / ds, 2), "unit": "samples/s", "seconds": round(ds, 4),
-                              "subjects": 42, "steps_per_subject": "2 frozen + 2 unfrozen", "batch": B,
-                              "subjects_on_busiest_rank": len(eav_dist.subjects_for_rank(0, world)),
-                              "scaling": "strong (total work fixed: 42 subjects; ideal speed-up 42 / ceil(42/N))",
-                              "all_subjects_reported": bool((torch.stack(gathered).sum(0) > 0).all().item())}
+    t_solo = time.perf_counter() - t0
+    if mine:
+        have[mine[0] - 1] = train_subject(gx, gy, gsync)
+    torch.cuda.synchronize()
+    t_all = time.perf_counter() - t0
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    out["subject_sharded"] = _subject_job_record(sched, world, 42, len(phases), B, [dt, t_solo, t_all - t_solo], have, dev,
+                                                 True)
+    out["subject_sharded"]["steps_per_subject_detail"] = f"{ks_frozen} frozen + {ks_unfrozen} unfrozen"
+    model.grad_ready_hook = None
     del model
     torch.cuda.empty_cache()
     return out
@@ -730,6 +795,9 @@ def compact_headline(out):
     line["roofline"]["flop_per_launch"] = out["roofline"].get("flop_per_launch")
     line["roofline"]["avg_kernel_ms"] = out["roofline"].get("avg_kernel_ms", {}).get(
         out["roofline"]["kernel"].replace("_kernel", ""))
+    line["roofline"]["traffic_source"] = out["roofline"].get("traffic_source")
+    if out["roofline"].get("step"):
+        line["roofline"]["step"] = {k: v for k, v in out["roofline"]["step"].items() if k != "source"}
     if out["roofline"].get("fir_kernels"):
         line["roofline"]["fir_kernels"] = out["roofline"]["fir_kernels"]
     if out.get("cpu_baseline"):
@@ -752,15 +820,25 @@ def compact_headline(out):
         for leg in ("strong", "weak", "subject_sharded"):
             if leg in mg:
                 short["eegnet_" + leg] = mg[leg]["value"]
+        ss = mg.get("subject_sharded") or {}
+        for k in ("ideal_speedup", "ideal_speedup_round_robin", "speedup_vs_one_gpu_rate_of_this_run", "speedup_vs_ideal",
+                  "solo_ms_per_step", "tail_ms_per_step", "steps_per_subject"):
+            if ss.get(k) is not None:
+                short["eegnet_subjects_" + k] = ss[k]
         for kind in ("ast", "vit"):
             for leg in ("strong", "subject_sharded"):
                 if kind in mg and leg in mg[kind]:
                     short[f"{kind}_{leg}"] = mg[kind][leg]["value"]
+            e = (mg.get(kind) or {}).get("subject_sharded") or {}
+            if e.get("speedup_vs_ideal") is not None:
+                short[f"{kind}_subjects_speedup_vs_ideal"] = e["speedup_vs_ideal"]
         line["multi_gpu"] = short
-    pss = out.get("predicted_strong_scaling")
-    if pss:
-        line["predicted_strong_scaling_at_8"] = {k: v["predicted_speedup"].get("8") for k, v in pss.items()
-                                                 if isinstance(v, dict) and "predicted_speedup" in v}
+    for k in ("ideal_speedup", "speedup_vs_ideal"):
+        if out.get(k) is not None:
+            line[k] = out[k]
+    if out.get("subject_loop_check"):
+        line["subject_loop_vs_plain_step_rate"] = out["subject_loop_check"]["ratio_to_plain_step_rate"]
+    # (the single-GPU proxy of the Mode-G scaling curve is a prediction, not a measurement: detail file only)
     line["detail"] = "bench_detail.json"
     return line
 
@@ -811,7 +889,10 @@ class EEGRun:
     full batches replay a captured hipGraph (GraphStep: batch gather, forward, CE, backward[, all-reduce], fused Adam);
     `eager_step` issues the same launches one by one (used for the per-kernel HIP-event timing)."""
 
-    def __init__(self, dev, rank, world, batch, nsteps, seed=0, subject=None, data=None):
+    def __init__(self, dev, rank, world, batch, nsteps, seed=0, subject=None, data=None, group=None, shard=None):
+        """world > 1: replicas of ONE training, `batch` samples per rank, gradient all-reduce over `group` (default: every
+        rank).  shard = (i, n): this rank takes slice i of n of every global batch of n * batch indices drawn from a
+        generator all members seed alike (a Mode-G group must see one data set and one batch sequence)."""
         import torch
         from eav_amd import dist as eav_dist, synth
         from eav_amd.eegnet import EEGNet_tor
@@ -829,9 +910,15 @@ class EEGRun:
         self.crit = CrossEntropyLoss()
         self.opt = FusedAdam(self.model.parameters(), lr=1e-5, capturable=True)      # as Trainer_uni builds it
         self.model._ensure_flat()
-        self.sync = eav_dist.GradSync([self.model._flat[1]]) if world > 1 else None
-        gen = torch.Generator().manual_seed(1234 + rank)
-        self.batches = [torch.randperm(TRIALS, generator=gen)[:batch].to(dev) for _ in range(nsteps)]
+        self.sync = eav_dist.GradSync([self.model._flat[1]], group=group) if world > 1 else None
+        if shard is None:
+            gen = torch.Generator().manual_seed(1234 + rank)
+            self.batches = [torch.randperm(TRIALS, generator=gen)[:batch].to(dev) for _ in range(nsteps)]
+        else:
+            i, n = shard
+            gen = torch.Generator().manual_seed(4321 + (subject or 0))
+            self.batches = [torch.randperm(TRIALS, generator=gen)[:n * batch][i * batch:(i + 1) * batch].to(dev)
+                            for _ in range(nsteps)]
         self.graphs = {}
 
     def reset_model(self, seed):
@@ -854,7 +941,7 @@ class EEGRun:
 
     def step(self, i):
         from eav_amd.eegnet import GraphStep
-        key = (bool(self.model.training), self.model.fir_precision, self.sync is not None)
+        key = (bool(self.model.training), self.sync is not None)
         if key not in self.graphs:       # one captured graph per BatchNorm mode / kernel set, like Trainer_uni
             self.graphs[key] = GraphStep(self.model, self.opt, self.crit, self.xs, self.ys, self.batch, self.sync)
         return self.graphs[key].run(self.batches[i % len(self.batches)])[1]
@@ -892,13 +979,76 @@ class EEGRun:
         return dt, loss
 
 
+def bench_eeg_subjects(dev, rank, world, steps, warmup, solo=None, n_subjects=42, hybrid=True):
+    """The job north_star's multi-GPU sentence describes: n_subjects independent per-subject EEGNet trainings
+    (EEGNet_tor.py:144-181 `for sub in range(1, 43)`), `steps` optimiser steps each at the reference bench batch of 64.
+    Whole rounds of subjects run one per rank with no collective; the n_subjects mod world subjects of the tail are each
+    trained by a group of ranks (batch split, gradient all-reduce inside the group: EEGNet_tor.py:86-88's DataParallel
+    semantics) - eav_amd.dist.SubjectSchedule.  TOTAL work is fixed, so the rate is comparable with the one-GPU step rate.
+    Timed region: barrier + synchronize on both sides, max over ranks; fresh weights / optimiser state per subject inside it,
+    graph capture and data generation outside."""
+    import torch
+    import torch.distributed as dist
+    from eav_amd import dist as eav_dist
+    sched = eav_dist.subject_schedule(world, n_subjects, hybrid=hybrid)
+    groups = sched.make_groups() if world > 1 else {}
+    if solo is None:
+        solo = EEGRun(dev, rank, 1, B_PER_GPU, steps + warmup)
+    keep_sync, solo.sync = solo.sync, None
+    solo.graphs.clear()                                      # no all-reduce in a solo training: its own captured step
+    mine = sched.group_of(rank)
+    grun = None
+    if mine and len(mine[1]) > 1:
+        sub, ranks = mine
+        if B_PER_GPU % len(ranks):
+            raise SystemExit(f"a group of {len(ranks)} ranks cannot split the batch of {B_PER_GPU}")
+        grun = EEGRun(dev, rank, len(ranks), B_PER_GPU // len(ranks), steps + warmup, subject=sub, group=groups[sub],
+                      shard=(ranks.index(rank), len(ranks)))
+    for i in range(max(warmup, 3)):                          # (the third call captures the graph)
+        solo.step(i)
+        if grun is not None:
+            grun.step(i)
+    results = []
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in sched.solo[rank]:
+        solo.reset_model(1000 + s)
+        for i in range(steps):
+            ls = solo.step(i)
+        results.append((s, ls.clone()))
+    torch.cuda.synchronize()
+    t_solo = time.perf_counter() - t0
+    if mine:
+        r = grun if grun is not None else solo
+        r.reset_model(1000 + mine[0])
+        for i in range(steps):
+            ls = r.step(i)
+        results.append((mine[0], ls.clone()))
+    torch.cuda.synchronize()
+    t_all = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    have = torch.zeros(n_subjects, device=dev)
+    for s, ls in results:
+        have[s - 1] = ls.detach()
+    solo.sync = keep_sync
+    solo.graphs.clear()
+    del grun
+    return _subject_job_record(sched, world, n_subjects, steps, B_PER_GPU, [dt, t_solo, t_all - t_solo], have, dev, hybrid)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
-                    help="N > 1: weak = 64 samples per GPU per step (default), strong = global batch 64 split over N")
+    ap.add_argument("--scaling", choices=("subjects", "strong", "weak"), default="subjects",
+                    help="N > 1, what the headline times: subjects = the 42 per-subject trainings sharded over the ranks, "
+                         "total work fixed (default; comparable with the N = 1 value); strong = ONE training, global "
+                         "batch 64 split over N, gradient all-reduce; weak = 64 samples per GPU per step")
     ap.add_argument("--repeats", type=int, default=4, help="extra K-step blocks timed after the headline block")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-encoders", action="store_true", help="skip the AST / ViT / alternative-encoder sections")
@@ -924,45 +1074,51 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    strong = args.scaling == "strong" and world > 1
+    mode = args.scaling if world > 1 else "single"
+    strong = mode == "strong"
     per_gpu = B_PER_GPU // world if strong else B_PER_GPU
     if strong and B_PER_GPU % world:
         raise SystemExit("strong scaling splits the global batch of 64 evenly: --gpus must divide 64")
-    run = EEGRun(dev, rank, world, per_gpu, args.steps + args.warmup)
+    run = EEGRun(dev, rank, world if mode in ("strong", "weak") else 1, per_gpu, args.steps + args.warmup)
     model = run.model
-    for i in range(max(args.warmup, 3)):                     # (the third call captures the graph)
-        run.step(i)
-    dt, loss = run.timed(args.steps, args.warmup)           # THE timed region: exactly K steps
+    subj = None
+    if mode == "subjects":
+        # THE timed region for N > 1: K optimiser steps of EVERY one of the 42 subject models (a job step = one step of
+        # each), subjects sharded over the ranks - fixed total work, so `value` is comparable with the N = 1 value
+        subj = bench_eeg_subjects(dev, rank, world, args.steps, args.warmup, solo=run)
+        dt = subj["seconds"]
+        for i in range(3):
+            loss = run.step(i)
+    else:
+        for i in range(max(args.warmup, 3)):                 # (the third call captures the graph)
+            run.step(i)
+        dt, loss = run.timed(args.steps, args.warmup)       # THE timed region: exactly K steps
     final_loss = float(loss.item())
-    # dominant kernels, timed live with HIP events on the launch stream: the same launches issued eagerly
-    # (the FIR runs as overlap-save FFT blocks at this shape - eav_eegnet_fir_*_fft - or as Toeplitz GEMMs on the fp32 matrix
-    # cores with EAV_FIR_ALGO=mfma; whichever ran has events)
-    timed = ("eav_eegnet_fir_fwd", "eav_eegnet_fir_wgrad", "eav_eegnet_fir_fwd_fft", "eav_eegnet_fir_wgrad_fft",
-             "eav_eegnet_dw_bwd_fused", "eav_eegnet_dw_fwd")
-    model.kernel_events = {k: [] for k in timed}
-    for i in range(min(args.steps, 20)):
+    # every launch of the step, timed live with HIP events on the launch stream: the same launches issued eagerly with the
+    # library's trace hook on (eav_amd._lib.TRACE) - the dominant kernel is picked from ALL of them, not from a list
+    from eav_amd import _lib as eavlib
+    n_eager = min(args.steps, 20)
+    run.eager_step(args.warmup)
+    torch.cuda.synchronize()
+    eavlib.TRACE = {}
+    for i in range(n_eager):
         run.eager_step(args.warmup + i)
     torch.cuda.synchronize()
-    kern_ms = {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in model.kernel_events.items() if v}
-    model.kernel_events = None
-    blocks_ms = [dt / args.steps * 1e3]
-    for _ in range(args.repeats):                            # spread of the same K-step block
+    trace, eavlib.TRACE = eavlib.TRACE, None
+    kern_ms = {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in trace.items() if v}            # per call
+    kern_step_ms = {k: sum(a.elapsed_time(b) for a, b in v) / n_eager for k, v in trace.items() if v}       # per step
+    del trace
+    blocks_ms = [dt / args.steps * 1e3] if subj is None else []
+    for _ in range(args.repeats):                            # spread of the same K-step block (one model, this rank)
         blocks_ms.append(run.timed(args.steps, args.warmup)[0] / args.steps * 1e3)
+    # N = 1: a short subject loop through the SAME code the N > 1 headline runs (fresh weights per subject, K steps each) -
+    # its rate must reproduce the plain step rate, otherwise the N = 1 and N > 1 values would not be comparable
+    subj_check = None
+    if world == 1:
+        subj_check = bench_eeg_subjects(dev, rank, 1, args.steps, 0, solo=run, n_subjects=3)
+        for i in range(3):
+            run.step(i)
     peaks = measured_peaks(dev) if rank == 0 else None
-
-    # the same step with the opt-in split-precision FIR / separableConv kernels (fp16 matrix cores) - beside the headline
-    model.fir_precision = "split"
-    for i in range(3):
-        run.step(i)
-    dts, _ = run.timed(args.steps, args.warmup)
-    split_names = ("eav_eegnet_fir_fwd_split", "eav_eegnet_fir_wgrad_split")
-    model.kernel_events = {k: [] for k in split_names}
-    for i in range(min(args.steps, 20)):
-        run.eager_step(args.warmup + i)
-    torch.cuda.synchronize()
-    split_ms = {k: sum(a.elapsed_time(b) for a, b in v) / max(len(v), 1) for k, v in model.kernel_events.items()}
-    model.kernel_events = None
-    model.fir_precision = "fp32"
 
     # eval-mode training step: what 349 of the reference's 350 epochs run (model.train() is called once, validate()
     # switches to eval mode and nothing switches back: SURVEY Q4, EEGNet_tor.py:97,119) - BatchNorm on running statistics
@@ -976,54 +1132,25 @@ def main():
     run_sync_bytes = 4 * model._flat[1].numel() if world > 1 else 0
     if world > 1:
         multi = {}
-        # ---- the other data-parallel leg (strong when the headline is weak and vice versa)
-        other = B_PER_GPU if strong else (B_PER_GPU // world if B_PER_GPU % world == 0 else None)
-        if other:
-            r2 = EEGRun(dev, rank, world, other, args.steps + args.warmup)
-            for i in range(args.warmup):
+        if subj is not None:
+            multi["subject_sharded"] = subj
+        # ---- Mode G legs: ONE training data-parallel over all ranks, strong (global batch 64 split) and weak (64 per rank)
+        for leg, b_rank in (("strong", B_PER_GPU // world if B_PER_GPU % world == 0 else None), ("weak", B_PER_GPU)):
+            if b_rank is None or leg == mode:
+                continue
+            r2 = EEGRun(dev, rank, world, b_rank, args.steps + args.warmup)
+            for i in range(max(args.warmup, 3)):
                 r2.step(i)
             d2, _ = r2.timed(args.steps, args.warmup)
-            multi["weak" if strong else "strong"] = {
-                "value": round(args.steps * other * world / d2, 2), "unit": "samples/s",
-                "ms_per_step": round(d2 / args.steps * 1e3, 4), "per_gpu_batch": other, "global_batch": other * world,
+            multi[leg] = {
+                "value": round(args.steps * b_rank * world / d2, 2), "unit": "samples/s",
+                "ms_per_step": round(d2 / args.steps * 1e3, 4), "per_gpu_batch": b_rank, "global_batch": b_rank * world,
                 "allreduce_bytes_per_step": 4 * r2.model._flat[1].numel(),
                 "note": f"data parallel, one all-reduce ({eav_dist.backend_name()}) of the flat gradient buffer per step"}
             del r2
             torch.cuda.empty_cache()
-        # ---- Mode S: the 42 per-subject trainings are independent - subjects round-robin over ranks, no collective on
-        # the data path, one all_gather of the per-subject results at the end (Dataload_audio.py:82-115 loop structure)
-        ks = max(2, args.steps // 10)
-        subs = eav_dist.subjects_for_rank(rank, world)
-        results = []
-        run.sync = None
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        run.graphs.clear()                                  # no all-reduce in this leg: its own captured step
-        for s in subs:
-            run.reset_model(1000 + s)
-            for i in range(ks):
-                ls = run.step(i)
-            results.append((s, ls.clone()))
-        torch.cuda.synchronize()
-        ds = time.perf_counter() - t0
-        mine = torch.zeros(42, device=dev)
-        for s, ls in results:
-            mine[s - 1] = ls.detach()
-        gathered = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(gathered, mine)
-        t = torch.tensor([ds], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        ds = float(t.item())
-        losses = torch.stack(gathered).sum(0)
-        multi["subject_sharded"] = {
-            "value": round(42 * ks * B_PER_GPU / ds, 2), "unit": "samples/s", "seconds": round(ds, 4),
-            "subjects": 42, "steps_per_subject": ks, "batch": B_PER_GPU, "subjects_on_busiest_rank": len(
-                eav_dist.subjects_for_rank(0, world)),
-            "scaling": "strong (total work fixed: 42 subjects; ideal speed-up 42 / ceil(42/N))",
-            "all_subjects_reported": bool((losses > 0).all().item()),
-            "note": "independent per-subject trainings, no data-path collective; one all_gather of results"}
+        if subj is None:
+            multi["subject_sharded"] = bench_eeg_subjects(dev, rank, world, args.steps, args.warmup)
 
     encoders = alt = pre = epoch = enc_multi = proxy = ft_epochs = None
     cpu_enc = {}
@@ -1063,7 +1190,6 @@ def main():
             sections["alt_epoch_preprocess_s"] = round(time.perf_counter() - t0, 1)
 
     if rank == 0:
-        dom = max(kern_ms, key=kern_ms.get)
         kname = {"eav_eegnet_fir_fwd": "fir_fwd_kernel", "eav_eegnet_fir_wgrad": "fir_wgrad_kernel",
                  "eav_eegnet_fir_fwd_fft": "fir_fft_fwd_kernel", "eav_eegnet_fir_wgrad_fft": "fir_fft_wgrad_kernel",
                  "eav_eegnet_dw_bwd_fused": "dw_bwd_kernel", "eav_eegnet_dw_fwd": "dw_fwd_kernel"}
@@ -1073,17 +1199,24 @@ def main():
                   "eav_eegnet_fir_wgrad": 17 * el, "eav_eegnet_fir_wgrad_fft": 17 * el,      # y1, g1, x in
                   "eav_eegnet_dw_bwd_fused": int((8 + 8 + 64 / 30 + 16 / 30) * el),          # y1, z, dp2 in, g1 out
                   "eav_eegnet_dw_fwd": int((8 + 64 / 30) * el)}                              # y1 in, z out
-        traffic, traffic_src = None, None
-        try:  # HBM bytes per launch from the separate --pmc passes (tools/pmc_summary.py), if committed
+        # the dominant launch of the step = the library call with the longest mean duration among ALL the calls traced
+        dom = max(kern_ms, key=kern_ms.get)
+        if dom not in abytes:
+            raise SystemExit(f"bench.py: the step's longest call is {dom} - add its algorithmic bytes to `abytes`")
+        traffic, traffic_src, step_prof = None, None, None
+        try:  # HBM bytes per launch / per step from the separate --pmc passes (tools/summarise_profiles.py), if committed
             import glob
             f = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_eegnet_hbm_traffic.json")))[-1]
             tj = json.load(open(f))
-            traffic = tj["kernels"][kname[dom]]["total_bytes"]
+            hit = [v for k, v in tj["kernels"].items() if k.split("<")[0] == kname[dom]]
+            traffic = max(v["total_bytes"] for v in hit) if hit else None
             traffic_src = os.path.relpath(f, ROOT) + (f" (profiled at commit {tj['commit']})" if tj.get("commit") else "")
+            step_prof = tj.get("step")
         except Exception:
             pass
         fir_flop = FIR_FLOP_PER_LAUNCH * per_gpu / B_PER_GPU
-        kms = {kname[k].replace("_kernel", ""): round(v, 4) for k, v in kern_ms.items()}
+        kms = {kname.get(k, k).replace("_kernel", ""): round(v, 4) for k, v in sorted(kern_ms.items(), key=lambda kv: -kv[1])
+               if v >= 0.02}
         if dom in ("eav_eegnet_fir_fwd", "eav_eegnet_fir_wgrad"):       # Toeplitz GEMM on the fp32 matrix cores
             achieved = fir_flop / (kern_ms[dom] * 1e-3) / 1e12
             roofline = {"bound": "mfma", "kernel": kname[dom], "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
@@ -1094,9 +1227,25 @@ def main():
             roofline = {"bound": "hbm", "kernel": kname[dom], "achieved": round(gbps, 1), "peak": 8000.0, "unit": "GB/s",
                         "frac": round(gbps / 8000.0, 4),
                         "frac_of_measured_copy_rate": round(gbps / 1e3 / peaks["hbm_copy_tb_per_s"], 4)}
+        if dom == "eav_eegnet_fir_wgrad_fft":
+            roofline["timed"] = ("the library call = fir_fft_wgrad_kernel + its two small finishing launches (sum, inverse "
+                                 "transform: ~10 us together); traffic = the main kernel's")
         roofline.update({"traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc, gfx950-corrected)",
                          "traffic_source": traffic_src, "algorithmic_bytes": abytes[dom], "flop_per_launch": fir_flop,
-                         "measured_peaks": peaks, "avg_kernel_ms": kms})
+                         "measured_peaks": peaks, "avg_kernel_ms": kms,
+                         "ms_per_step_by_call": {k: round(v, 4) for k, v in sorted(kern_step_ms.items(),
+                                                                                   key=lambda kv: -kv[1])}})
+        # the whole step against the HBM roofline and against SURVEY 8(d)'s fused minimum (3.9 MB per sample)
+        ms_step = statistics.median(blocks_ms) if blocks_ms else dt / args.steps * 1e3
+        fused_min = 3.9e6 * per_gpu
+        roofline["step"] = {"ms_per_step": round(ms_step, 4), "fused_minimum_bytes": int(fused_min),
+                            "frac_if_fused_minimum": round(fused_min / (ms_step * 1e-3) / 8e12, 4)}
+        if step_prof and per_gpu == B_PER_GPU:
+            hb = step_prof["hbm_bytes_per_step"]
+            roofline["step"].update({"hbm_bytes_per_step": int(hb), "achieved": round(hb / (ms_step * 1e-3) / 1e9, 1),
+                                     "peak": 8000.0, "unit": "GB/s", "frac": round(hb / (ms_step * 1e-3) / 8e12, 4),
+                                     "ratio_to_fused_minimum": round(hb / fused_min, 1),
+                                     "source": traffic_src})
         # the K = 300 FIR in direct form is 92.16 GFLOP per pass: what the FFT kernels deliver in those terms
         fir = {}
         for k in ("eav_eegnet_fir_fwd_fft", "eav_eegnet_fir_wgrad_fft", "eav_eegnet_fir_fwd", "eav_eegnet_fir_wgrad"):
@@ -1107,44 +1256,54 @@ def main():
                                  "hbm_gbps_algorithmic": round(abytes[k] / (kern_ms[k] * 1e-3) / 1e9, 1)}
         roofline["fir_kernels"] = fir
         cpu_eeg = cpu_baseline_eegnet() if (world == 1 and not args.no_cpu_baseline) else None
-        value = round(args.steps * per_gpu * world / dt, 2)
+        bk = eav_dist.backend_name()
+        via = f"torch.distributed backend '{bk}'" + (" = RCCL" if bk == "nccl" else "")
+        if subj is not None:
+            value = subj["value"]
+            gb, scaling = subj["subjects"] * B_PER_GPU, "strong"
+            workload = (f"{subj['subjects']} independent per-subject trainings of EEGNet_tor(5, Chans=30, Samples=10000, "
+                        f"kernLength=300, F1=8, D=8, F2=64), {args.steps} optimiser steps each on x[64,1,30,10000] fp32 "
+                        f"(BASELINE.json configs[1] per subject, configs[4] across GPUs); a step = one optimiser step of "
+                        f"every subject model")
+            sch = subj["schedule"]
+            par = (f"subjects over {world} ranks: {sch['rounds']} whole rounds one subject per rank, no collective"
+                   + (f"; the {len(sch['groups'])} remaining subjects on groups of {sch['group_size']} ranks (batch split, "
+                      f"gradient all-reduce inside the group, {via})" if sch["groups"] else "")
+                   + f"; ideal speed-up {subj['ideal_speedup']}")
+        else:
+            value = round(args.steps * per_gpu * world / dt, 2)
+            gb, scaling = per_gpu * world, ("strong" if strong else "weak")
+            workload = ("EEGNet_tor(5, Chans=30, Samples=10000, kernLength=300, F1=8, D=8, F2=64) "
+                        f"train step on x[{per_gpu},1,30,10000] fp32 per GPU (BASELINE.json configs[1])")
+            par = f"dp{world}" + (f" (ONE training, gradient all-reduce over {via})" if world > 1 else "")
         out = {
             "metric": "EEGNet training samples/sec (fwd+CE+bwd+Adam), whole job",
             "value": value, "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "EEGNet_tor(5, Chans=30, Samples=10000, kernLength=300, F1=8, D=8, F2=64) "
-                                   f"train step on x[{per_gpu},1,30,10000] fp32 per GPU (BASELINE.json configs[1])",
-                       "global_batch": per_gpu * world, "per_gpu_batch": per_gpu,
-                       "parallelism": f"dp{world}" + (f" (gradient all-reduce over torch.distributed backend "
-                                                      f"'{eav_dist.backend_name()}'" + (" = RCCL)" if
-                                                      eav_dist.backend_name() == "nccl" else ")") if world > 1 else ""),
+            "config": {"workload": workload, "global_batch": gb, "per_gpu_batch": per_gpu, "parallelism": par,
                        "optimizer": "Adam lr=1e-5", "dropout": 0.5, "final_loss": round(final_loss, 5),
                        "launch": "hipGraph replay of the whole step (Trainer_uni's own path: GraphStep)"},
             "repeat_blocks": {"ms_per_step": [round(v, 4) for v in blocks_ms],
                               "median_ms_per_step": round(statistics.median(blocks_ms), 4),
                               "min_ms_per_step": round(min(blocks_ms), 4),
-                              "note": f"{len(blocks_ms)} blocks of {args.steps} steps; `value` is the first block"},
+                              "note": f"{len(blocks_ms)} blocks of {args.steps} steps of ONE model on this rank" +
+                                      ("; `value` is the first block" if subj is None else "")},
             "roofline": roofline,
         }
+        if subj is not None:
+            out["speedup_vs_ideal"] = subj.get("speedup_vs_ideal")
+            out["ideal_speedup"] = subj["ideal_speedup"]
+        if subj_check is not None:
+            plain = B_PER_GPU / (statistics.median(blocks_ms) * 1e-3)
+            out["subject_loop_check"] = dict(subj_check, plain_step_rate=round(plain, 2),
+                                             ratio_to_plain_step_rate=round(subj_check["value"] / plain, 4),
+                                             note="3 subjects x K steps through the code path of the N > 1 headline "
+                                                  "(bench_eeg_subjects) on this one GPU")
         if cpu_eeg is not None:
             out["cpu_baseline"] = cpu_eeg
-        y1_bytes = per_gpu * 8 * CHANS * SAMPLES * 4
-        wg_bytes = 2 * y1_bytes + per_gpu * CHANS * SAMPLES * 4
-        out["split_precision"] = {
-            "note": "opt-in EEGNet_tor.fir_precision='split': the FIR and separableConv products (forward, data and weight "
-                    "gradients) on the fp16 matrix cores with two-piece operands (hi + 2^-11 lo, 3 MFMAs per product, fp32 "
-                    "accumulate); measured error vs float64 below the exact-fp32 kernels'; same workload, same parity "
-                    "bounds; not the headline value",
-            "value": round(args.steps * per_gpu * world / dts, 2), "unit": "samples/s",
-            "ms_per_step": round(dts / args.steps * 1e3, 4),
-            "avg_kernel_ms": {k.replace("eav_eegnet_", ""): round(v, 4) for k, v in split_ms.items()},
-            "roofline": {"bound": "hbm", "kernel": "fir_wgrad_split_kernel", "algorithmic_bytes": wg_bytes,
-                         "achieved": round(wg_bytes / (split_ms["eav_eegnet_fir_wgrad_split"] * 1e-3) / 1e9, 1),
-                         "peak": 8000.0, "unit": "GB/s",
-                         "frac": round(wg_bytes / (split_ms["eav_eegnet_fir_wgrad_split"] * 1e-3) / 8e12, 4)}}
         out["eval_mode_training"] = {
             "note": "the same step with the model in eval mode (BatchNorm on running statistics, no dropout) - what epochs "
                     "2..N of the reference's Trainer_uni.train() execute (SURVEY Q4)",

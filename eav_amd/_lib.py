@@ -63,9 +63,6 @@ SIGNATURES = {
     "eav_gather_i64": [_p, _p, _p, _i, _p],
     "eav_gemm_f32": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64, _f, _p,
                      _i, _p, _p, _i, _i, _p],
-    "eav_gemm_bf16": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64, _f, _p,
-                      _i, _p, _p, _i, _i, _p],
-    "eav_gemm_bf16_splitk": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "eav_gemm_f32_splitk": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "eav_sp_absmax": [_p, _i, _i, _i64, _p, _p],
     "eav_sp_convert": [_p, _i, _i, _i64, _p, _p, _p, _p],
@@ -116,15 +113,6 @@ SIGNATURES = {
     "eav_ast_fbank": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _d, _d, _f, _f, _p],
     "eav_decimate_fir_f64": [_p, _p, _p, _i, _i64, _i64, _i, _i, _i, _p],
     "eav_sosfilt_f64": [_p, _p, _p, _p, _p, _p, _p, _i, _i64, _i, _i, _p],
-    "eav_conv64_fwd_split": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
-    "eav_conv64_wgrad_split": [_p, _p, _p, _p, _p, _i, _i, _i, _p],
-    "eav_absmax_scale": [_p, _i64, _f, _p, _p, _p],
-    "eav_eegnet_fir_fwd_split": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
-    "eav_fir_dy_scale": [_p, _p, _i, _p, _i, _p, _p],
-    "eav_absmax_finish": [_p, _i, _f, _p, _p],
-    "eav_bn_elu_pool_fwd_absmax": [_p, _p, _p, _p, _i, _i, _i, _i, _f, _u64, _p, _p, _p],
-    "eav_bn_elu_pool_bwd_apply_absmax": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _u64, _p, _p, _p],
-    "eav_eegnet_fir_wgrad_split": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "eav_eegnet_block1_infer": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "eav_tconv_fwd": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "eav_tconv_wgrad": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
@@ -165,8 +153,6 @@ PLAIN = {
     "eav_tconv_fwd_nparts": ([_i, _i, _i, _i, _i], _i),
     "eav_shallow_embed_nparts": ([_i, _i], _i),
     "eav_colstats_nparts": ([_i64], _i),
-    "eav_absmax_scale_nparts": ([_i64], _i),
-    "eav_eegnet_fir_wgrad_split_nparts": ([_i, _i, _i], _i),
     "eav_tconv_wgrad_nparts": ([_i, _i, _i, _i, _i], _i),
     "eav_spatial_nparts": ([_i, _i], _i),
     "eav_dconv_fwd_nparts": ([_i, _i], _i),
@@ -186,6 +172,15 @@ PLAIN = {
 }
 
 EXPORTS = sorted(list(SIGNATURES) + list(PLAIN))
+
+# Comparison-only kernels (include/eav_hip_extras.h, `make BENCH_EXTRAS=1` -> libeav_extras.so): bench.py's literal-bf16 leg.
+EXTRAS_PATH = os.path.join(_HERE, "libeav_extras.so")
+EXTRAS = {
+    "eav_gemm_bf16": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64, _f, _p,
+                      _i, _p, _p, _i, _i, _p],
+    "eav_gemm_bf16_splitk": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+}
+_extras = None
 
 _lib = None
 
@@ -226,9 +221,43 @@ def stream_ptr():
     return torch.cuda.current_stream().cuda_stream
 
 
+def have_extras():
+    return os.path.exists(EXTRAS_PATH)
+
+
+def load_extras():
+    global _extras
+    if _extras is None:
+        if not have_extras():
+            raise EavError(f"{EXTRAS_PATH} is missing - {sorted(EXTRAS)} are comparison-only kernels: build them with "
+                           "`make -C eav_amd/csrc BENCH_EXTRAS=1`")
+        load()
+        lib = C.CDLL(EXTRAS_PATH)
+        for name, args in EXTRAS.items():
+            fn = getattr(lib, name)
+            fn.argtypes = args
+            fn.restype = _i
+        lib.eav_last_error.restype = C.c_char_p
+        _extras = lib
+    return _extras
+
+
+# bench.py / tools: set to a dict to have EVERY library call bracketed by HIP events on the current stream
+# ({entry point: [(start, end), ...]}); None (default) costs one comparison per call.  Never set by the package itself.
+TRACE = None
+
+
 def call(name, *args):
-    lib = load()
-    rc = getattr(lib, name)(*args)
+    lib = load_extras() if name in EXTRAS else load()
+    if TRACE is not None:
+        import torch
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        rc = getattr(lib, name)(*args)
+        b.record()
+        TRACE.setdefault(name, []).append((a, b))
+    else:
+        rc = getattr(lib, name)(*args)
     if rc != 0:
         raise EavError(f"{name} failed ({rc}): {lib.eav_last_error().decode()}")
 

@@ -164,23 +164,12 @@ __global__ __launch_bounds__(NT) void dw_fwd_kernel(const float* __restrict__ y1
 
 // ------------------------------------------------------------------------------------ pool_fwd
 // one block per (b, ch) row: out[b,ch,to] = drop * mean_{j<P} ELU(scale*in[b,ch,to*P+j] + shift)
-// block-wide maximum of |v| written to part[row] (the split-precision kernels derive their fp16 operand scale from it)
-__device__ __forceinline__ void block_absmax_store(float m, float* __restrict__ dst) {
-  __shared__ float mred[4];
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-  if ((threadIdx.x & 63) == 0) mred[threadIdx.x >> 6] = m;
-  __syncthreads();
-  if (threadIdx.x == 0) *dst = fmaxf(fmaxf(mred[0], mred[1]), fmaxf(mred[2], mred[3]));
-}
-
 template <int P>
 __global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__ in, const float* __restrict__ bn,
                                                        float* __restrict__ out, int CH, int T, float drop_p,
                                                        uint64_t seed_in,
-    const uint8_t* __restrict__ mask, const uint64_t* __restrict__ seed_dev, float* __restrict__ absmax_part) {
+    const uint8_t* __restrict__ mask, const uint64_t* __restrict__ seed_dev) {
   const uint64_t seed = dropout_seed(seed_in, seed_dev);
-  float amax = 0.f;
   const int row = blockIdx.x, ch = row % CH;
   const float sc = bn[2 * CH + ch], sh = bn[3 * CH + ch];
   const int To = T / P;
@@ -196,11 +185,8 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__
       for (int e = 0; e < 4; ++e) s += elu_f(sc * v[e] + sh);
     }
     const uint64_t oi = (uint64_t)row * To + to;
-    const float r = s * (1.0f / P) * dropout_mult_row(drop_p, seed, mask, oi, (uint64_t)row);
-    out[oi] = r;
-    amax = fmaxf(amax, fabsf(r));
+    out[oi] = s * (1.0f / P) * dropout_mult_row(drop_p, seed, mask, oi, (uint64_t)row);
   }
-  if (absmax_part) block_absmax_store(amax, absmax_part + row);
 }
 
 // ------------------------------------------------------------------------------------ pool_bwd
@@ -247,12 +233,11 @@ __global__ __launch_bounds__(256) void pool_bwd_apply_kernel(const float* __rest
                                                              const float* __restrict__ bn,
                                                              const float* __restrict__ m12, float* __restrict__ du,
                                                              int CH, int T, float drop_p, uint64_t seed_in,
-    const uint8_t* __restrict__ mask, const uint64_t* __restrict__ seed_dev, float* __restrict__ absmax_part) {
+    const uint8_t* __restrict__ mask, const uint64_t* __restrict__ seed_dev) {
   const uint64_t seed = dropout_seed(seed_in, seed_dev);
   const int row = blockIdx.x, ch = row % CH;
   const float mean = bn[ch], invstd = bn[CH + ch], sc = bn[2 * CH + ch], sh = bn[3 * CH + ch];
   const float m1 = m12[ch], m2 = m12[CH + ch];
-  float amax = 0.f;
   const int To = T / P;
   const float* src = u + (int64_t)row * T;
   float* dst = du + (int64_t)row * T;
@@ -274,13 +259,7 @@ __global__ __launch_bounds__(256) void pool_bwd_apply_kernel(const float* __rest
       o[e] = sc * (g - m1 - (v[e] - mean) * invstd * m2);
     }
     st4(dst, t, T, vec, o);
-    if (t + 3 < T) amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
-    else
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (t + e < T) amax = fmaxf(amax, fabsf(o[e]));
   }
-  if (absmax_part) block_absmax_store(amax, absmax_part + row);
 }
 
 // -------------------------------------------------------------------------------------- dw_bwd
@@ -474,21 +453,15 @@ extern "C" int eav_eegnet_dw_bwd_fused(const float* y1, const float* z, const fl
 
 extern "C" int eav_bn_elu_pool_fwd(const float* in, const float* bn, float* out, int B, int CH, int T, int P,
                                    float drop_p, uint64_t seed, const uint8_t* mask, const uint64_t* seed_dev, void* stream) {
-  return eav_bn_elu_pool_fwd_absmax(in, bn, out, nullptr, B, CH, T, P, drop_p, seed, mask, seed_dev, stream);
-}
-
-extern "C" int eav_bn_elu_pool_fwd_absmax(const float* in, const float* bn, float* out, float* absmax_part, int B,
-                                          int CH, int T, int P, float drop_p, uint64_t seed, const uint8_t* mask,
-                                          const uint64_t* seed_dev, void* stream) {
   EAV_REQUIRE(in && bn && out && B > 0 && CH > 0 && T >= P, "eav_bn_elu_pool_fwd: bad arguments");
   EAV_REQUIRE(P == 4 || P == 8, "eav_bn_elu_pool_fwd: pool %d not in {4,8}", P);
   EAV_REQUIRE(drop_p > -1.f && drop_p < 1.f, "eav_bn_elu_pool_fwd: dropout %f outside (-1,1)", drop_p);
   if (P == 4)
     hipLaunchKernelGGL(pool_fwd_kernel<4>, dim3(B * CH), dim3(256), 0, (hipStream_t)stream, in, bn, out, CH, T,
-                       drop_p, seed, mask, seed_dev, absmax_part);
+                       drop_p, seed, mask, seed_dev);
   else
     hipLaunchKernelGGL(pool_fwd_kernel<8>, dim3(B * CH), dim3(256), 0, (hipStream_t)stream, in, bn, out, CH, T,
-                       drop_p, seed, mask, seed_dev, absmax_part);
+                       drop_p, seed, mask, seed_dev);
   EAV_CHECK_LAUNCH("eav_bn_elu_pool_fwd");
   return EAV_OK;
 }
@@ -511,21 +484,14 @@ extern "C" int eav_bn_elu_pool_bwd_reduce(const float* dp, const float* u, const
 extern "C" int eav_bn_elu_pool_bwd_apply(const float* dp, const float* u, const float* bn, const float* m12,
                                          float* du, int B, int CH, int T, int P, float drop_p, uint64_t seed,
                                          const uint8_t* mask, const uint64_t* seed_dev, void* stream) {
-  return eav_bn_elu_pool_bwd_apply_absmax(dp, u, bn, m12, du, nullptr, B, CH, T, P, drop_p, seed, mask, seed_dev, stream);
-}
-
-extern "C" int eav_bn_elu_pool_bwd_apply_absmax(const float* dp, const float* u, const float* bn, const float* m12,
-                                                float* du, float* absmax_part, int B, int CH, int T, int P,
-                                                float drop_p, uint64_t seed, const uint8_t* mask,
-                                                const uint64_t* seed_dev, void* stream) {
   EAV_REQUIRE(dp && u && bn && m12 && du && B > 0 && CH > 0 && T >= P, "eav_bn_elu_pool_bwd_apply: bad arguments");
   EAV_REQUIRE(P == 4 || P == 8, "eav_bn_elu_pool_bwd_apply: pool %d not in {4,8}", P);
   if (P == 4)
     hipLaunchKernelGGL(pool_bwd_apply_kernel<4>, dim3(B * CH), dim3(256), 0, (hipStream_t)stream, dp, u, bn, m12, du,
-                       CH, T, drop_p, seed, mask, seed_dev, absmax_part);
+                       CH, T, drop_p, seed, mask, seed_dev);
   else
     hipLaunchKernelGGL(pool_bwd_apply_kernel<8>, dim3(B * CH), dim3(256), 0, (hipStream_t)stream, dp, u, bn, m12, du,
-                       CH, T, drop_p, seed, mask, seed_dev, absmax_part);
+                       CH, T, drop_p, seed, mask, seed_dev);
   EAV_CHECK_LAUNCH("eav_bn_elu_pool_bwd_apply");
   return EAV_OK;
 }

@@ -10,7 +10,7 @@
 // Tile 128 x BN x 32, 4 waves (2x2), LDS images [row][k] bf16 with an 80-byte row stride: every
 // ds_read_b128 fragment read (8 consecutive k of one row) is conflict-free across its 16-lane groups.
 #include "eav_common.h"
-#include "../../include/eav_hip.h"
+#include "../../../include/eav_hip_extras.h"
 
 namespace {
 
@@ -259,13 +259,24 @@ extern "C" int eav_gemm_bf16(const float* A, const float* B, float* C, int M, in
   return EAV_OK;
 }
 
+// slice count: the formula of eav_gemm_f32_splitk_plan (gemm_f32.hip), which the caller sizes `ws` with - this file is linked
+// into its own library (libeav_extras.so), so it carries its own copy
+static int splitk_plan(int M, int N, int K) {
+  const int tiles = cdiv(M, 128) * cdiv(N, N <= 64 ? 64 : 128);
+  int ns = cdiv(1024, tiles);
+  const int maxs = cdiv(K, 256);
+  if (ns > maxs) ns = maxs;
+  if (ns > 64) ns = 64;
+  return ns < 1 ? 1 : ns;
+}
+
 extern "C" int eav_gemm_bf16_splitk(const float* A, const float* B, float* C, float* ws, int M, int N, int K, int lda,
                                     int ldb, int transA, int transB, void* stream) {
   EAV_REQUIRE(A && B && C && ws && M > 0 && N > 0 && K > 0, "eav_gemm_bf16_splitk: bad arguments");
   EAV_REQUIRE((lda & 3) == 0 && (ldb & 3) == 0 && (N & 3) == 0 &&
                   (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)ws) & 15) == 0,
               "eav_gemm_bf16_splitk: operands must be 16-byte aligned, leading dimensions and N multiples of 4");
-  const int nsplit = eav_gemm_f32_splitk_plan(M, N, K);
+  const int nsplit = splitk_plan(M, N, K);
   GemmArgs g;
   g.A = A; g.B = B; g.C = nsplit > 1 ? ws : C; g.bias = nullptr; g.resid = nullptr; g.pre = nullptr;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = N; g.ldr = 0; g.H = 1;

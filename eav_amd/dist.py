@@ -11,6 +11,11 @@ stay per replica, which is DataParallel's behaviour too.
 
 Subject-level sharding (42 independent per-subject trainings, SURVEY 8e level 1)
 needs no collective at all: ``subjects_for_rank`` assigns subjects round-robin.
+``subject_schedule`` composes the two levels: whole rounds of subjects run one per
+rank, and the ``n_subjects mod world`` subjects that would leave most ranks idle in
+a last round are each trained by a GROUP of ranks with the batch split among them
+(gradient all-reduce inside the group only) - 42 subjects on 8 GPUs: 5 rounds + two
+4-rank groups instead of a sixth round on two GPUs.
 """
 from __future__ import annotations
 
@@ -44,6 +49,66 @@ def init_from_env(backend=None, force=False):
 def subjects_for_rank(rank, world, n_subjects=42, first=1):
     """Static round-robin partition of the per-subject loop (for sub in range(1, 43))."""
     return [s for s in range(first, first + n_subjects) if (s - first) % world == rank]
+
+
+class SubjectSchedule:
+    """Static plan of the per-subject loop (Dataload_audio.py:82, EEGNet_tor.py:146, Transformer_Vision.py:136:
+    `for sub in range(1, 43)`) on `world` ranks.
+
+    solo[r]   subjects rank r trains alone, full batch, no collective (whole rounds, round-robin)
+    groups    [(subject, [ranks])] for the remainder: every listed rank holds a replica and 1 / len(ranks) of each batch,
+              one gradient all-reduce per step inside the group (GradSync(group=...)); ranks in no group idle for that
+              tail.  A group of one rank is a plain solo training.
+    """
+
+    def __init__(self, world, n_subjects=42, first=1, hybrid=True):
+        if world < 1 or n_subjects < 0:
+            raise ValueError("subject_schedule: world >= 1 and n_subjects >= 0")
+        self.world, self.n_subjects, self.first, self.hybrid = world, n_subjects, first, hybrid
+        self.rounds, rem = divmod(n_subjects, world)
+        self.solo = [[first + k * world + r for k in range(self.rounds)] for r in range(world)]
+        tail = [first + self.rounds * world + j for j in range(rem)]
+        gsize = (world // rem) if (rem and hybrid) else 1
+        self.group_size = gsize if rem else 0
+        self.groups = [(s, list(range(j * gsize, (j + 1) * gsize))) for j, s in enumerate(tail)]
+
+    def group_of(self, rank):
+        """(subject, ranks) of the group `rank` belongs to, or None."""
+        for s, ranks in self.groups:
+            if rank in ranks:
+                return s, ranks
+        return None
+
+    def subjects_of(self, rank):
+        """Every subject this rank takes part in (solo first, then its group's)."""
+        g = self.group_of(rank)
+        return self.solo[rank] + ([g[0]] if g else [])
+
+    def rounds_of_work(self, group_step_cost=None):
+        """Length of the plan in units of one solo training: whole rounds + the tail.  group_step_cost: time of a group
+        training relative to a solo one (default: perfect scaling inside the group, 1 / group_size)."""
+        if not self.groups:
+            return float(self.rounds)
+        cost = (1.0 / self.group_size) if group_step_cost is None else float(group_step_cost)
+        return self.rounds + cost
+
+    def ideal_speedup(self, group_step_cost=None):
+        """n_subjects solo trainings on one rank against this plan."""
+        r = self.rounds_of_work(group_step_cost)
+        return self.n_subjects / r if r > 0 else 0.0
+
+    def make_groups(self):
+        """Create the process sub-groups (every rank must call this, in the same order - torch.distributed.new_group is
+        collective) and return {subject: group} for the groups of more than one rank."""
+        out = {}
+        for s, ranks in self.groups:
+            if len(ranks) > 1:
+                out[s] = dist.new_group(ranks=ranks)
+        return out
+
+
+def subject_schedule(world, n_subjects=42, first=1, hybrid=True):
+    return SubjectSchedule(world, n_subjects, first, hybrid)
 
 
 class GradSync:

@@ -46,7 +46,7 @@ class _Workspace:
         nchunk = (S + 1023) // 1024
         self.nchunk = nchunk
         self.y1, self.g1 = f(B, 8, C, S), f(B, 8, C, S)
-        self.z, self.dz = f(B, 64, S), f(B, 64, S)
+        self.z = f(B, 64, S)
         self.p2, self.dp2 = f(B, 64, T2), f(B, 64, T2)
         self.u3, self.du3 = f(B, 64, T2), f(B, 64, T2)
         self.p3, self.dp3 = f(B, 64 * T3), f(B, 64 * T3)
@@ -68,13 +68,6 @@ class _Workspace:
         self.part_fw = f(self.np_fw, 8 * klen)
         self.np_cw = _lib.plain("eav_conv64_wgrad_nparts", B, T2)
         self.part_cw = f(self.np_cw, 64 * 1024)
-        # split-precision FIR (EEGNet_tor.fir_precision = "split"): power-of-two operand scales and their reductions
-        self.scale_x, self.scale_w, self.scale_dy = f(4), f(4), f(4)
-        self.scale_p2, self.scale_w3, self.scale_du3 = f(4), f(4), f(4)
-        self.part_amax = torch.zeros(1032, dtype=torch.float32, device=dev)   # [0] = the kernel's self-resetting counter
-        self.rowmax_p2, self.rowmax_du3, self.rowmax_dz = f(B * 64), f(B * 64), f(B * 64)   # maxima emitted by producers
-        self.np_fws = _lib.plain("eav_eegnet_fir_wgrad_split_nparts", B, C, S)
-        self.part_fws = None       # allocated on first use of the split mode ([np_fws, 8*klen])
 
 
 class _GenericWorkspace:
@@ -198,10 +191,8 @@ class EEGNet_tor(nn.Module):
         self._dropout_masks = None             # tests: (mask1 uint8 [B,64,S/4], mask2 uint8 [B,64,S/32])
         self.apply_max_norm = True
         self.kernel_events = None              # bench: {kernel name: [(start_event, end_event), ...]}
-        # "fp32": exact-fp32 MFMA kernels (default).  "split": the FIR products and the separableConv forward / data
-        # gradient on the fp16 matrix cores with two-piece operands and fp32 accumulation (csrc/eegnet_fir_split.hip,
-        # eegnet_conv64_split.hip) - measured error against float64 below the fp32 kernels', 2-3x faster kernels;
-        # opt-in because its arithmetic is not a plain fp32 fma chain
+        # (the round-2 "split" mode - FIR / separableConv products on the fp16 matrix cores with two-piece operands - was
+        # retired in round 5: with the FFT FIR and the frequency-domain separableConv it was the slower path)
         self.fir_precision = "fp32"
         # How the exact-fp32 firstConv and its weight gradient are evaluated.  "fft": overlap-save blocks of 1024-point
         # FFTs (csrc/eegnet_fir_fft.hip: ~350 flops per output sample for the 8 filters together instead of 4800 - the two
@@ -232,7 +223,7 @@ class EEGNet_tor(nn.Module):
         `conv_algo` / EAV_CONV_ALGO: "auto" (default), "fft", "mfma"."""
         if self.conv_algo not in ("auto", "fft", "mfma"):
             raise ValueError(f"conv_algo {self.conv_algo!r}: expected 'auto', 'fft' or 'mfma'")
-        if self.conv_algo == "mfma" or self.fir_precision != "fp32":
+        if self.conv_algo == "mfma":
             return False
         return self.conv_algo == "fft" or B * (self.Samples // 4) >= 40000
 
@@ -270,14 +261,13 @@ class EEGNet_tor(nn.Module):
 
     def forward_indexed(self, data, idx):
         """forward(data[idx]) without materialising data[idx] (Trainer_uni's per-step batch assembly,
-        EEGNet_tor.py:100-101): `data` [N,1,Chans,Samples] fp32 contiguous on the device, `idx` device int64 [B].  The
-        split-precision FIR path needs the batch's own maximum first and keeps the gathered copy."""
+        EEGNet_tor.py:100-101): `data` [N,1,Chans,Samples] fp32 contiguous on the device, `idx` device int64 [B]."""
         if data.dim() != 4 or data.shape[1] != 1 or data.shape[2] != self.Chans or data.shape[3] != self.Samples or \
                 not data.is_cuda or data.dtype != torch.float32 or not data.is_contiguous():
             raise ValueError(f"expected a contiguous fp32 device array [N,1,{self.Chans},{self.Samples}]")
         if idx.dtype != torch.int64 or idx.device != data.device or idx.dim() != 1:
             raise ValueError("idx must be a 1-D int64 tensor on the data's device")
-        if self.fir_precision != "fp32" or self._generic:
+        if self._generic:
             out = torch.empty((idx.numel(),) + tuple(data.shape[1:]), dtype=torch.float32, device=data.device)
             _lib.call("eav_gather_rows", data.data_ptr(), idx.data_ptr(), out.data_ptr(), idx.numel(), data[0].numel(),
                       _lib.stream_ptr())
@@ -339,11 +329,10 @@ class EEGNet_tor(nn.Module):
             L("eav_bn_finalize", P(part), nparts, nch, float(count), gw, gb, P(bn.running_mean), P(bn.running_var),
               int(training), float(bn.momentum), float(bn.eps), b0, b0 + 4 * nch, b0 + 8 * nch, b0 + 12 * nch, st)
 
-        if self.fir_precision not in ("fp32", "split"):
-            raise ValueError(f"fir_precision {self.fir_precision!r}: expected 'fp32' or 'split'")
-        split = self.fir_precision == "split"
+        if self.fir_precision != "fp32":
+            raise ValueError(f"fir_precision {self.fir_precision!r}: only 'fp32' exists (the split mode was retired)")
         counters = [cnt] + ([P(bn.num_batches_tracked) for bn in (bn1, bn2, bn3)] if training else [None] * 3)
-        if split or not self._use_conv_fft(B):    # (the frequency-domain separableConv takes the weight tensor as it is)
+        if not self._use_conv_fft(B):    # (the frequency-domain separableConv takes the weight tensor as it is)
             # per-step prologue, one launch: the transposed separableConv weights of the direct kernels + the dropout step
             # counter and the three BatchNorm step counters (nn.BatchNorm2d's num_batches_tracked)
             L("eav_eegnet_step_prologue", w3, P(ws.wTf), P(ws.wTb), *counters, st)
@@ -351,7 +340,7 @@ class EEGNet_tor(nn.Module):
             # library kernels, no torch op inside a captured step
             L("eav_counter_inc4", *counters, st)
         np_fir = ws.np_fir
-        infer = self.fused_eval and self._infer and not training and not split and S % 4 == 0
+        infer = self.fused_eval and self._infer and not training and S % 4 == 0
         if infer:
             # validate(): x -> block-1 output in ONE kernel (FIR -> firstBN -> ELU -> depthwiseConv -> depthwiseBN -> ELU ->
             # AvgPool4; BatchNorms on running statistics): y1 (614 MB at [64,1,30,10000]) and z are never written
@@ -361,11 +350,6 @@ class EEGNet_tor(nn.Module):
                 L("eav_eegnet_block1_infer", P(x.data), P(x.idx), w1, P(ws.bn1), w2, P(ws.bn2), P(ws.p2), B, C, S, K, st)
             else:
                 L("eav_eegnet_block1_infer", P(x), None, w1, P(ws.bn1), w2, P(ws.bn2), P(ws.p2), B, C, S, K, st)
-        elif split:
-            L("eav_absmax_scale", P(x), B * C * S, 1.0, P(ws.part_amax), P(ws.scale_x), st)
-            L("eav_absmax_scale", w1, 8 * K, 1.0, P(ws.part_amax), P(ws.scale_w), st)
-            L("eav_eegnet_fir_fwd_split", P(x), w1, P(ws.scale_x), P(ws.scale_w), P(ws.y1), P(ws.part_fir), B, C, S, K,
-              st)
         elif self._use_fft():
             np_fir = ws.np_fir_fft
             if isinstance(x, IndexedBatch):
@@ -381,15 +365,9 @@ class EEGNet_tor(nn.Module):
             bnfin(ws.part_fir, np_fir, 8, B * C * S, g1w, g1b, bn1, ws.bn1)
             L("eav_eegnet_dw_fwd", P(ws.y1), P(ws.bn1), w2, P(ws.z), P(ws.part_dw), B, C, S, st)
             bnfin(ws.part_dw, B * ws.nchunk, 64, B * S, g2w, g2b, bn2, ws.bn2)
-            L("eav_bn_elu_pool_fwd_absmax", P(ws.z), P(ws.bn2), P(ws.p2), P(ws.rowmax_p2) if split else None, B, 64, S, 4,
-              drop, seed1, m1, cnt, st)
+            L("eav_bn_elu_pool_fwd", P(ws.z), P(ws.bn2), P(ws.p2), B, 64, S, 4, drop, seed1, m1, cnt, st)
         np_c3 = ws.np_c3
-        if split:
-            L("eav_absmax_finish", P(ws.rowmax_p2), B * 64, 1.0, P(ws.scale_p2), st)
-            L("eav_absmax_scale", w3, 64 * 1024, 1.0, P(ws.part_amax), P(ws.scale_w3), st)
-            L("eav_conv64_fwd_split", P(ws.p2), P(ws.wTf), P(ws.scale_p2), P(ws.scale_w3), P(ws.u3), P(ws.part_c3), B,
-              ws.T2, 7, st)
-        elif self._use_conv_fft(B):
+        if self._use_conv_fft(B):
             if ws.c64_ws is None:
                 ws.c64_ws = torch.zeros(_lib.plain("eav_conv64_fft_ws_floats", B, ws.T2), dtype=torch.float32,
                                         device=ws.y1.device)
@@ -403,7 +381,7 @@ class EEGNet_tor(nn.Module):
         L("eav_dense_softmax_fwd", P(ws.p3), wd, bd, None, P(probs), B, ws.NF, nb, st)
         if self.apply_max_norm:  # the forward hooks of the reference (:33-34, :47-48), intended meaning: one launch
             L("eav_renorm_rows2", w2, 64, C, wd, nb, ws.NF, self.norm_rate, st)
-        self._saved = (self._token, x, training, drop, seed1, seed2, masks, cnt, split, ws, probs)
+        self._saved = (self._token, x, training, drop, seed1, seed2, masks, cnt, ws, probs)
         return self._token
 
     # ------------------------------------------------------------------ generic widths (csrc/eegnet_canon.hip)
@@ -416,8 +394,6 @@ class EEGNet_tor(nn.Module):
         B, C, S, K, nb = x.shape[0], self.Chans, self.Samples, self.kernLength, self.nb_classes
         F1, D, F2 = self.F1, self.D, self.F2
         C2 = F1 * D
-        if self.fir_precision != "fp32":
-            raise ValueError("fir_precision='split' exists for the reference configuration (F1=8, D=8, F2=64) only")
         key = ("generic", B, C, S, str(x.device))
         ws = self._ws = cached_workspace(self._wss, key, lambda: _GenericWorkspace(self, B, x.device))
         training = bool(self.training)
@@ -510,7 +486,7 @@ class EEGNet_tor(nn.Module):
         if self._generic:
             return self._launch_backward_generic(dprobs)
         L, P, st = self._call, _lib.ptr, _lib.stream_ptr()
-        _, x, training, drop, seed1, seed2, masks, cnt, split, ws, probs = self._saved
+        _, x, training, drop, seed1, seed2, masks, cnt, ws, probs = self._saved
         B, C, S, K, nb = x.shape[0], self.Chans, self.Samples, self.kernLength, self.nb_classes
         T2, NF = ws.T2, ws.NF
         flat, gflat, offs = self._flat
@@ -527,23 +503,15 @@ class EEGNet_tor(nn.Module):
         L("eav_bn_elu_pool_bwd_reduce", P(ws.dp3), P(ws.u3), b3, P(ws.part_pb), B, 64, T2, 8, drop, seed2, m2, cnt, st)
         L("eav_bn_bwd_finalize", P(ws.part_pb), B, 64, float(B * T2), tr, P(g["separableBN.weight"]),
           P(g["separableBN.bias"]), b3 + 4 * 256, b3 + 4 * 320, st)
-        L("eav_bn_elu_pool_bwd_apply_absmax", P(ws.dp3), P(ws.u3), b3, b3 + 4 * 256, P(ws.du3),
-          P(ws.rowmax_du3) if split else None, B, 64, T2, 8, drop, seed2, m2, cnt, st)
+        L("eav_bn_elu_pool_bwd_apply", P(ws.dp3), P(ws.u3), b3, b3 + 4 * 256, P(ws.du3), B, 64, T2, 8, drop, seed2, m2,
+          cnt, st)
         # separableConv: data gradient (flipped/transposed taps, pad 8) and weight gradient
-        if split:
-            L("eav_absmax_finish", P(ws.rowmax_du3), B * 64, 1.0, P(ws.scale_du3), st)
-            L("eav_conv64_fwd_split", P(ws.du3), P(ws.wTb), P(ws.scale_du3), P(ws.scale_w3), P(ws.dp2), None, B, T2,
-              8, st)
-        elif self._use_conv_fft(B):
+        if self._use_conv_fft(B):
             # (bwd = 2: the filter spectra of the data gradient were prepared by this step's forward call)
             L("eav_conv64_fft_fwd", P(ws.du3), P(self.separableConv.weight), P(ws.dp2), None, P(ws.c64_ws), B, T2, 2, st)
         else:
             L("eav_conv64_fwd", P(ws.du3), P(ws.wTb), P(ws.dp2), None, B, T2, 8, st)
-        if split:
-            L("eav_conv64_wgrad_split", P(ws.du3), P(ws.p2), P(ws.scale_du3), P(ws.scale_p2), P(ws.part_cw), B, T2, 7,
-              st)
-            L("eav_reduce_partials", P(ws.part_cw), ws.np_cw, 65536, 65536, 1.0, P(g["separableConv.weight"]), st)
-        elif self._use_conv_fft(B):
+        if self._use_conv_fft(B):
             L("eav_conv64_fft_wgrad", P(ws.du3), P(g["separableConv.weight"]), P(ws.c64_ws), B, T2, st)
         else:
             L("eav_conv64_wgrad", P(ws.du3), P(ws.p2), P(ws.part_cw), B, T2, 7, st)
@@ -555,25 +523,14 @@ class EEGNet_tor(nn.Module):
           P(g["depthwiseBN.bias"]), b2 + 4 * 256, b2 + 4 * 320, st)
         # depthwiseConv <- ELU <- firstBN (uses the post-renorm depthwise weight, Q2)
         b1 = P(ws.bn1)
-        if split:     # the split FIR weight gradient needs max |dz| per row: separate apply pass
-            L("eav_bn_elu_pool_bwd_apply_absmax", P(ws.dp2), P(ws.z), b2, b2 + 4 * 256, P(ws.dz), P(ws.rowmax_dz), B, 64,
-              S, 4, drop, seed1, m1, cnt, st)
-            L("eav_eegnet_dw_bwd", P(ws.y1), P(ws.dz), b1, w2, P(ws.g1), P(ws.part_dst), P(ws.part_dw2), B, C, S, st)
-        else:         # dz = backward of BN2 -> ELU -> pool -> dropout is formed inside dw_bwd: no dz tensor in HBM
-            L("eav_eegnet_dw_bwd_fused", P(ws.y1), P(ws.z), P(ws.dp2), b2, b1, w2, P(ws.g1), P(ws.part_dst),
-              P(ws.part_dw2), B, C, S, drop, seed1, m1, cnt, st)
+        # dz = backward of BN2 -> ELU -> pool -> dropout is formed inside dw_bwd: no dz tensor in HBM
+        L("eav_eegnet_dw_bwd_fused", P(ws.y1), P(ws.z), P(ws.dp2), b2, b1, w2, P(ws.g1), P(ws.part_dst),
+          P(ws.part_dw2), B, C, S, drop, seed1, m1, cnt, st)
         L("eav_reduce_partials", P(ws.part_dw2), B * ws.nchunk, 64 * C, 64 * C, 1.0, P(g["depthwiseConv.weight"]), st)
         L("eav_bn_bwd_finalize", P(ws.part_dst), B * ws.nchunk, 8, float(B * C * S), tr, P(g["firstBN.weight"]),
           P(g["firstBN.bias"]), b1 + 4 * 32, b1 + 4 * 40, st)
         # firstConv weight gradient (BN backward folded into the operand staging)
-        if split:
-            if ws.part_fws is None:
-                ws.part_fws = torch.empty(ws.np_fws, 8 * K, dtype=torch.float32, device=x.device)
-            L("eav_fir_dy_scale", b1, P(ws.rowmax_dz), B * 64, w2, C, P(ws.scale_dy), st)
-            L("eav_eegnet_fir_wgrad_split", P(x), P(ws.y1), P(ws.g1), b1, P(ws.scale_x), P(ws.scale_dy),
-              P(ws.part_fws), B, C, S, K, st)
-            L("eav_reduce_partials", P(ws.part_fws), ws.np_fws, 8 * K, 8 * K, 1.0, P(g["firstConv.weight"]), st)
-        elif self._use_fft():
+        if self._use_fft():
             if ws.fft_ws is None:
                 ws.fft_ws = torch.empty(_lib.plain("eav_eegnet_fir_wgrad_fft_ws_floats", B, C, S), dtype=torch.float32,
                                         device=ws.y1.device)

@@ -85,23 +85,6 @@ int eav_eegnet_fir_fwd_indexed(const float* x, const int64_t* xidx, const float*
                                int C, int S, int klen, void* stream);
 int eav_eegnet_fir_wgrad_indexed(const float* x, const int64_t* xidx, const float* y1, const float* g1,
                                  const float* bn_params, float* part, int B, int C, int S, int klen, void* stream);
-/* Opt-in fp32-grade fast path of the same two products on the fp16 matrix cores with split operands
- * (v = hi + 2^-11 lo, three MFMAs per product, fp32 accumulate; csrc/eegnet_fir_split.hip).  scale_x / scale_w: device
- * float[3] = {sigma, 1/sigma, max|v|} from eav_absmax_scale (power-of-two pre-scales keeping the pieces in fp16 range). */
-int eav_absmax_scale_nparts(int64_t n);   /* floats of `part` (<= 1025); zero it once: part[0] is a self-resetting counter */
-int eav_absmax_scale(const float* v, int64_t n, float extra, float* part, float* scale, void* stream);
-int eav_eegnet_fir_fwd_split(const float* x, const float* w1, const float* scale_x, const float* scale_w, float* y1,
-                             float* stat_part, int B, int C, int S, int klen, void* stream);
-/* scale from per-block maxima that a producing kernel emitted (eav_bn_elu_pool_*_absmax): no pass over the tensor. */
-int eav_absmax_finish(const float* part, int nparts, float extra, float* scale, void* stream);
-/* scale for dy = scale_f (g - m1_f - xhat m2_f), g = ELU' * sum_d w2 * dz: bound from max |dz| (per-row maxima of
- * eav_bn_elu_pool_bwd_apply_absmax), the depthwise weights w2 [64,C] and the BatchNorm-backward coefficients. */
-int eav_fir_dy_scale(const float* bn_params, const float* dzmax_part, int nparts, const float* w2, int C, float* out,
-                     void* stream);
-int eav_eegnet_fir_wgrad_split_nparts(int B, int C, int S);
-int eav_eegnet_fir_wgrad_split(const float* x, const float* y1, const float* g1, const float* bn_params,
-                               const float* scale_x, const float* scale_dy, float* part, int B, int C, int S, int klen,
-                               void* stream);
 /* firstBN -> ELU -> depthwiseConv (EEGNet_tor.py:52-54): y1 -> z [B,64,S];
  * stat_part [B*ceil(S/1024)][128]. */
 int eav_eegnet_dw_fwd(const float* y1, const float* bn1, const float* w2, float* z, float* stat_part, int B, int C,
@@ -127,13 +110,6 @@ int eav_eegnet_dw_bwd_fused(const float* y1, const float* z, const float* dp2, c
  * so that a captured hipGraph draws a fresh mask on every replay. */
 int eav_bn_elu_pool_fwd(const float* in, const float* bn, float* out, int B, int CH, int T, int P, float drop_p,
                         uint64_t seed, const uint8_t* mask, const uint64_t* seed_dev, void* stream);
-/* same as eav_bn_elu_pool_fwd / _bwd_apply, also writing absmax_part [B*CH] = max |output| per (b, ch) row */
-int eav_bn_elu_pool_fwd_absmax(const float* in, const float* bn, float* out, float* absmax_part, int B, int CH, int T,
-                               int P, float drop_p, uint64_t seed, const uint8_t* mask, const uint64_t* seed_dev,
-                               void* stream);
-int eav_bn_elu_pool_bwd_apply_absmax(const float* dp, const float* u, const float* bn, const float* m12, float* du,
-                                     float* absmax_part, int B, int CH, int T, int P, float drop_p, uint64_t seed,
-                                     const uint8_t* mask, const uint64_t* seed_dev, void* stream);
 int eav_bn_elu_pool_bwd_reduce(const float* dp, const float* u, const float* bn, float* part /*[B][2*CH]*/, int B,
                                int CH, int T, int P, float drop_p, uint64_t seed, const uint8_t* mask,
                                const uint64_t* seed_dev, void* stream);
@@ -169,14 +145,6 @@ int eav_conv64_fft_wgrad(const float* du, float* dW, float* ws, int B, int T, vo
 int eav_conv64_wgrad_nparts(int B, int T);
 /* part [nparts][64*64*16]; sum over parts = dL/dW[o,i,k]. */
 int eav_conv64_wgrad(const float* du, const float* in, float* part, int B, int T, int padl, void* stream);
-
-/* split-precision form of eav_conv64_fwd (fp16 matrix cores, two-piece operands, fp32 accumulate;
- * csrc/eegnet_conv64_split.hip); scale_x / scale_w: device float[3] from eav_absmax_scale over `in` / the weights. */
-int eav_conv64_fwd_split(const float* in, const float* wT, const float* scale_x, const float* scale_w, float* out,
-                         float* stat_part, int B, int T, int padl, void* stream);
-/* split-precision form of eav_conv64_wgrad; part [eav_conv64_wgrad_nparts(B,T)][64*64*16]. */
-int eav_conv64_wgrad_split(const float* du, const float* in, const float* scale_du, const float* scale_in, float* part,
-                           int B, int T, int padl, void* stream);
 
 /* ---- canonical EEGNet (CNN_torch/CNN_EEG.py:7-67): run-time F1<=16, D<=8, F2<=64, K1<=512, K2<=32 ----------- */
 /* block1[0] nn.Conv2d(1,F1,(1,K),padding='same',bias=False) (CNN_EEG.py:22): x [B,C,S] -> y1 [B,F1,C,S];
@@ -266,14 +234,6 @@ int eav_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, 
 int eav_gemm_f32_splitk_plan(int M, int N, int K);
 int eav_gemm_f32_splitk(const float* A, const float* B, float* C, float* ws, int M, int N, int K, int lda, int ldb,
                         int transA, int transB, void* stream);
-/* Same contracts with bf16 MFMA operands (fp32 in memory, rounded to bf16 while staging; fp32 accumulate and
- * output).  Opt-in fast mode: outside north_star's 1e-3 logit bound. */
-int eav_gemm_bf16(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
-                  int transA, int transB, int batch, int heads, int64_t sAb, int64_t sAh, int64_t sBb, int64_t sBh,
-                  int64_t sCb, int64_t sCh, float alpha, const float* bias, int gelu, float* pre, const float* resid,
-                  int ldr, int accumulate, void* stream);
-int eav_gemm_bf16_splitk(const float* A, const float* B, float* C, float* ws, int M, int N, int K, int lda, int ldb,
-                         int transA, int transB, void* stream);
 /* fp32-grade GEMM on the fp16 matrix cores with split operands (csrc/gemm_sp.hip) - the same call sites as eav_gemm_f32
  * (nn.Linear forward / data gradient / weight gradient inside HF's ASTLayer / ViTLayer, Transformer_Audio.py:72,
  * Transformer_Vision.py:92).  Operands are "sp16 planes": X[R,K] with the contraction index along K stored as

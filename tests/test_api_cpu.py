@@ -268,3 +268,46 @@ def test_bench_headline_is_compact_and_complete():
     assert set(head["modalities"]) == {"eegnet", "ast", "vit"} and "workload" in head["config"]
     for m in head["modalities"].values():
         assert {"value", "ms_per_step", "batch", "roofline", "cpu_baseline"} <= set(m)
+
+
+def test_bench_subject_job_record_and_multi_gpu_headline():
+    """The N > 1 headline of bench.py: a fixed-total-work (42 subjects) rate comparable with the N = 1 step rate.  The record
+    arithmetic on CPU: value = subjects x steps x batch / seconds (doubling the time of the busiest rank halves it), the
+    ideal speed-up of the hybrid schedule at 8 ranks is 8.0 (7.0 for plain round-robin), speed-up against this run's own
+    one-GPU step rate; the compact line says `scaling: strong` and carries the ideal and the measured fraction of it."""
+    import importlib.util
+    import json
+    import torch
+    from eav_amd.dist import subject_schedule
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    have = torch.ones(42)
+    s1 = subject_schedule(1)
+    r1 = bench._subject_job_record(s1, 1, 42, 50, 64, [42 * 50 * 1.5e-3, 42 * 50 * 1.5e-3, 0.0], have, torch.device("cpu"), True)
+    assert abs(r1["value"] - 64 / 1.5e-3) < 1 and r1["ideal_speedup"] == 1.0 and r1["all_subjects_reported"]
+    assert abs(r1["speedup_vs_one_gpu_rate_of_this_run"] - 1.0) < 1e-3
+    r2 = bench._subject_job_record(s1, 1, 42, 50, 64, [2 * 42 * 50 * 1.5e-3, 2 * 42 * 50 * 1.5e-3, 0.0], have,
+                                   torch.device("cpu"), True)
+    assert abs(r2["value"] - r1["value"] / 2) < 1                      # one rank doing twice the work: half the rate
+    # an 8-rank record as rank 0 would assemble it (world = 1 here: no process group on CPU; the schedule is the 8-rank one)
+    s8 = subject_schedule(8)
+    t_solo, t_tail = 5 * 50 * 1.5e-3, 50 * 0.6e-3
+    r8 = bench._subject_job_record(s8, 1, 42, 50, 64, [t_solo + t_tail, t_solo, t_tail], have, torch.device("cpu"), True)
+    assert r8["ideal_speedup"] == 8.0 and r8["ideal_speedup_round_robin"] == 7.0 and r8["schedule"]["group_size"] == 4
+    assert 7.6 < r8["speedup_vs_one_gpu_rate_of_this_run"] < 8.0 and 0.95 < r8["speedup_vs_ideal"] < 1.0
+    assert r8["scaling"].startswith("strong")
+    detail = json.load(open(os.path.join(root, "profiles", "r03_bench_line.json")))
+    detail.update({"n_gpus": 8, "scaling": "strong", "value": r8["value"], "ideal_speedup": r8["ideal_speedup"],
+                   "speedup_vs_ideal": r8["speedup_vs_ideal"],
+                   "multi_gpu": {"backend": "nccl", "rccl_ranks": 8, "subject_sharded": r8,
+                                 "strong": {"value": 1.0}, "weak": {"value": 2.0}}})
+    detail.pop("predicted_strong_scaling", None)
+    head = bench.compact_headline(detail)
+    line = json.dumps(head, separators=(",", ":"))
+    assert len(line) < 4096, len(line)
+    assert head["scaling"] == "strong" and head["ideal_speedup"] == 8.0 and head["speedup_vs_ideal"] == r8["speedup_vs_ideal"]
+    mg = head["multi_gpu"]
+    assert mg["eegnet_subject_sharded"] == r8["value"] and mg["eegnet_strong"] == 1.0 and mg["eegnet_weak"] == 2.0
+    assert mg["eegnet_subjects_ideal_speedup"] == 8.0 and "predicted_strong_scaling_at_8" not in head

@@ -341,122 +341,6 @@ def test_gather_rows(L):
         assert torch.equal(d.cpu(), torch.from_numpy(arr)[idx.cpu()]) and torch.equal(t.cpu(), torch.from_numpy(y)[idx.cpu()])
 
 
-# ----------------------------------------------------------------------------- split-precision FIR (opt-in fast path)
-def _f64_fir(x, w, K):
-    xd = x.double().reshape(-1, 1, x.shape[-1])
-    padl = (K - 1) // 2
-    y = torch.nn.functional.conv1d(torch.nn.functional.pad(xd, (padl, K - 1 - padl)), w.double().reshape(8, 1, K))
-    return y.reshape(x.shape[0], x.shape[1], 8, x.shape[2]).permute(0, 2, 1, 3)
-
-
-@pytest.mark.parametrize("B,C,S,K,amp", [(2, 30, 10000, 300, 1.0), (3, 7, 1001, 64, 1.0), (2, 5, 333, 130, 1.0),
-                                         (2, 30, 2000, 300, 3.0e4), (2, 30, 2000, 300, 2.0e-5)])
-def test_fir_fwd_split_is_fp32_grade(L, B, C, S, K, amp):
-    """eav_eegnet_fir_fwd_split against a float64 convolution: its error must not exceed the exact-fp32 MFMA kernel's
-    (plus one part in 1e7 of the output range), for unit-scale, very large and very small input amplitudes (the
-    power-of-two pre-scale keeps the fp16 pieces in range)."""
-    _lib = L
-    x = torch.from_numpy(synth.normal(11, (B, C, S))).cuda() * amp
-    w = torch.from_numpy(synth.uniform(12, (8, K), -0.06, 0.06)).cuda()
-    P, st = _lib.ptr, _lib.stream_ptr()
-    npart = _lib.plain("eav_eegnet_fir_fwd_nparts", B, C, S)
-    ya, yb = torch.empty(B, 8, C, S, device="cuda"), torch.empty(B, 8, C, S, device="cuda")
-    pa, pb = torch.zeros(npart, 16, device="cuda"), torch.zeros(npart, 16, device="cuda")
-    sx, sw, pp = torch.empty(4, device="cuda"), torch.empty(4, device="cuda"), torch.zeros(1032, device="cuda")
-    _lib.call("eav_eegnet_fir_fwd", P(x), P(w), P(ya), P(pa), B, C, S, K, st)
-    _lib.call("eav_absmax_scale", P(x), x.numel(), 1.0, P(pp), P(sx), st)
-    _lib.call("eav_absmax_scale", P(w), w.numel(), 1.0, P(pp), P(sw), st)
-    _lib.call("eav_eegnet_fir_fwd_split", P(x), P(w), P(sx), P(sw), P(yb), P(pb), B, C, S, K, st)
-    torch.cuda.synchronize()
-    ref = _f64_fir(x.cpu(), w.cpu(), K)
-    ea = (ya.cpu().double() - ref).abs().max().item()
-    eb = (yb.cpu().double() - ref).abs().max().item()
-    rng = ref.abs().max().item()
-    assert eb <= 1.25 * ea + 1e-7 * rng, (ea, eb, rng)
-    # BatchNorm partial statistics of the two kernels agree
-    sa, sb = pa.double().sum(0).cpu(), pb.double().sum(0).cpu()
-    assert torch.allclose(sa, sb, rtol=1e-5, atol=1e-5 * float(sa.abs().max()))
-
-
-@pytest.mark.parametrize("B,C,S,K,gamp", [(4, 30, 10000, 300, 1e-4), (3, 7, 1001, 64, 1.0), (2, 5, 333, 130, 1e-9),
-                                          (2, 9, 777, 300, 50.0)])
-def test_fir_wgrad_split_is_fp32_grade(L, B, C, S, K, gamp):
-    _lib = L
-    x = torch.from_numpy(synth.normal(21, (B, C, S))).cuda()
-    y1 = torch.from_numpy(synth.normal(22, (B, 8, C, S))).cuda() * 0.7 + 0.1
-    g1 = torch.from_numpy(synth.normal(23, (B, 8, C, S))).cuda() * gamp
-    bn = torch.from_numpy(synth.uniform(24, (6, 8), 0.5, 1.5)).cuda().contiguous()
-    bn[4] *= 0.1 * gamp
-    bn[5] *= 0.1 * gamp
-    P, st = _lib.ptr, _lib.stream_ptr()
-    na = _lib.plain("eav_eegnet_fir_wgrad_nparts", B, C, S)
-    nb = _lib.plain("eav_eegnet_fir_wgrad_split_nparts", B, C, S)
-    pa, pb = torch.empty(na, 8 * K, device="cuda"), torch.empty(nb, 8 * K, device="cuda")
-    da, db = torch.empty(8, K, device="cuda"), torch.empty(8, K, device="cuda")
-    sx, sg, sdy = (torch.empty(4, device="cuda") for _ in range(3))
-    pp = torch.zeros(1032, device="cuda")
-    _lib.call("eav_eegnet_fir_wgrad", P(x), P(y1), P(g1), P(bn), P(pa), B, C, S, K, st)
-    _lib.call("eav_reduce_partials", P(pa), na, 8 * K, 8 * K, 1.0, P(da), st)
-    _lib.call("eav_absmax_scale", P(x), x.numel(), 1.0, P(pp), P(sx), st)
-    _lib.call("eav_absmax_scale", P(g1), g1.numel(), 1.0, P(pp), P(sg), st)
-    # dy-scale bound: max|g| enters as "max|dz| times the depthwise row norm"; a unit-norm stand-in weight makes it max|g|
-    w2u = torch.zeros(64, C, device="cuda")
-    w2u[:, 0] = 0.125
-    _lib.call("eav_fir_dy_scale", P(bn), P(sg) + 8, 1, P(w2u), C, P(sdy), st)
-    _lib.call("eav_eegnet_fir_wgrad_split", P(x), P(y1), P(g1), P(bn), P(sx), P(sdy), P(pb), B, C, S, K, st)
-    _lib.call("eav_reduce_partials", P(pb), nb, 8 * K, 8 * K, 1.0, P(db), st)
-    torch.cuda.synchronize()
-    mean, invstd, sc, _, m1, m2 = (bn[i].double().view(1, 8, 1, 1) for i in range(6))
-    dy = sc * (g1.double() - m1 - (y1.double() - mean) * invstd * m2)
-    padl = (K - 1) // 2
-    xp = torch.nn.functional.pad(x.double(), (padl, K - 1 - padl))
-    ref = torch.zeros(8, K, dtype=torch.float64, device="cuda")
-    for b in range(B):
-        ref += torch.einsum("fcs,csk->fk", dy[b], xp[b].unfold(-1, K, 1))
-    ea, eb = (da.double() - ref).abs().max().item(), (db.double() - ref).abs().max().item()
-    rng = ref.abs().max().item()
-    assert eb <= 1.25 * ea + 1e-7 * rng, (ea, eb, rng)
-
-
-@pytest.mark.parametrize("B,T,padl", [(8, 2500, 7), (3, 333, 8), (2, 125, 7)])
-def test_conv64_split_is_fp32_grade(L, B, T, padl):
-    """eav_conv64_fwd_split / eav_conv64_wgrad_split against float64: not worse than the exact-fp32 MFMA kernels."""
-    _lib = L
-    x = torch.from_numpy(synth.normal(31, (B, 64, T))).cuda()
-    du = torch.from_numpy(synth.normal(32, (B, 64, T))).cuda() * 3e-5
-    w = torch.from_numpy(synth.uniform(33, (64, 64, 16), -0.03, 0.03)).cuda()
-    P, st = _lib.ptr, _lib.stream_ptr()
-    wTf, wTb = torch.empty(1024, 64, device="cuda"), torch.empty(1024, 64, device="cuda")
-    _lib.call("eav_conv64_prep_weights", P(w), P(wTf), P(wTb), st)
-    sx, sw, sd = (torch.empty(4, device="cuda") for _ in range(3))
-    pp = torch.zeros(1032, device="cuda")
-    for t, s in ((x, sx), (w, sw), (du, sd)):
-        _lib.call("eav_absmax_scale", P(t), t.numel(), 1.0, P(pp), P(s), st)
-    npf = _lib.plain("eav_conv64_fwd_nparts", B, T)
-    ya, yb = torch.empty(B, 64, T, device="cuda"), torch.empty(B, 64, T, device="cuda")
-    pa, pb = torch.zeros(npf, 128, device="cuda"), torch.zeros(npf, 128, device="cuda")
-    _lib.call("eav_conv64_fwd", P(x), P(wTf), P(ya), P(pa), B, T, padl, st)
-    _lib.call("eav_conv64_fwd_split", P(x), P(wTf), P(sx), P(sw), P(yb), P(pb), B, T, padl, st)
-    npw = _lib.plain("eav_conv64_wgrad_nparts", B, T)
-    qa, qb = torch.empty(npw, 65536, device="cuda"), torch.empty(npw, 65536, device="cuda")
-    da, db = torch.empty(64, 64, 16, device="cuda"), torch.empty(64, 64, 16, device="cuda")
-    _lib.call("eav_conv64_wgrad", P(du), P(x), P(qa), B, T, padl, st)
-    _lib.call("eav_reduce_partials", P(qa), npw, 65536, 65536, 1.0, P(da), st)
-    _lib.call("eav_conv64_wgrad_split", P(du), P(x), P(sd), P(sx), P(qb), B, T, padl, st)
-    _lib.call("eav_reduce_partials", P(qb), npw, 65536, 65536, 1.0, P(db), st)
-    torch.cuda.synchronize()
-    xp = torch.nn.functional.pad(x.double(), (padl, 15 - padl))
-    ref = torch.nn.functional.conv1d(xp.cpu(), w.double().cpu())
-    ea, eb = (ya.cpu().double() - ref).abs().max().item(), (yb.cpu().double() - ref).abs().max().item()
-    assert eb <= 1.25 * ea + 1e-7 * ref.abs().max().item(), (ea, eb)
-    assert torch.allclose(pa.double().sum(0), pb.double().sum(0), rtol=1e-5, atol=1e-5 * float(pa.double().sum(0).abs().max()))
-    refw = torch.zeros(64, 64, 16, dtype=torch.float64, device="cuda")
-    for b in range(B):
-        refw += torch.einsum("ot,itk->oik", du[b].double(), xp[b].unfold(-1, 16, 1))
-    ea, eb = (da.double() - refw).abs().max().item(), (db.double() - refw).abs().max().item()
-    assert eb <= 1.25 * ea + 1e-7 * refw.abs().max().item(), (ea, eb)
-
-
 def test_cross_entropy_rejects_labels_outside_the_class_range():
     """torch's CrossEntropyLoss asserts on a class index outside [0, classes); here such a label never indexes anything
     and check() raises - e.g. the reference's raw EEG labels 1,3,5,7,9 fed to a 5-class head."""

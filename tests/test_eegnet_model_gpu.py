@@ -47,17 +47,15 @@ def build(S, sd, drop=0.0, dropout_type="Dropout", arch=None):
     return m.cuda()
 
 
-@pytest.mark.parametrize("fir_precision", ["fp32", "split"])
 @pytest.mark.parametrize("case", ["s500_train", "s500_eval", "s500_maxnorm", "s500_dropout", "s500_dropout2d"])
-def test_steps_match_reference_golden(golden_dir, case, fir_precision):
-    """fir_precision="split" (the FIR products on the fp16 matrix cores with two-piece operands) is held to exactly the
-    same bounds as the exact-fp32 kernels."""
+def test_steps_match_reference_golden(golden_dir, case):
+    """Two optimiser steps from the reference's own state: probabilities, loss, every gradient, the parameters and the
+    BatchNorm running statistics after each step against the values captured from the imported reference."""
     from eav_amd.optim import CrossEntropyLoss, FusedAdam
     g = np.load(os.path.join(golden_dir, f"eegnet_{case}.npz"))
     B, S, lr = int(g["B"]), int(g["S"]), float(g["lr"])
     model = build(S, eegnet_weights(int(g["wseed"]), S, scale=float(g["wscale"])), float(g["drop_p"]),
                   "SpatialDropout2D" if case.endswith("2d") else "Dropout")   # the reference's nn.Dropout2d branch (:21)
-    model.fir_precision = fir_precision
     model.train(bool(int(g["train_mode"])))
     crit, opt = CrossEntropyLoss(), FusedAdam(model.parameters(), lr=lr)
     for s in range(int(g["steps"])):
@@ -193,8 +191,7 @@ def test_s10000_matches_reference_golden_and_oracle(golden_dir):
         close(named[k].grad, ref, 1e-3, 1e-3 * np.abs(ref).max(), f"grad.{k}")
 
 
-@pytest.mark.parametrize("fir_precision", ["fp32", "split"])
-def test_full_size_batch_against_oracle(fir_precision):
+def test_full_size_batch_against_oracle():
     """BASELINE config 2 shape: B=64, [64,1,30,10000] fp32 - probabilities, loss and
     gradients against the CPU oracle (a few seconds of host time)."""
     from eav_amd.optim import CrossEntropyLoss
@@ -202,7 +199,6 @@ def test_full_size_batch_against_oracle(fir_precision):
     B, S = 64, 10000
     sd = eegnet_weights(31, S)
     model = build(S, sd)
-    model.fir_precision = fir_precision
     model.train()
     x, y = synth.eeg_batch(311, B, 30, S)
     scores = model(torch.from_numpy(x).cuda())
@@ -222,7 +218,6 @@ def test_full_size_batch_against_oracle(fir_precision):
     # determinism: the same step twice is bit-identical (no float atomics anywhere)
     g1 = {k: named[k].grad.clone() for k in PN}
     model2 = build(S, sd)
-    model2.fir_precision = fir_precision
     model2.train()
     s2 = model2(torch.from_numpy(x).cuda())
     CrossEntropyLoss()(s2, torch.from_numpy(y).cuda()).backward()
@@ -308,8 +303,7 @@ def test_ragged_shapes_against_oracle(B, C, S, K, train_mode):
 
 
 @pytest.mark.parametrize("drop", [0.0, 0.5])
-@pytest.mark.parametrize("fir_precision", ["fp32", "split"])
-def test_graph_replay_equals_eager(drop, fir_precision):
+def test_graph_replay_equals_eager(drop):
     """hipGraph replay of the whole training step == the eager schedule, bit for bit: parameters, BN running
     statistics and the dropout stream (device-resident counters) after 6 steps on changing batches."""
     from eav_amd.eegnet import EEGNet_tor, GraphStep
@@ -322,7 +316,6 @@ def test_graph_replay_equals_eager(drop, fir_precision):
     finals = []
     for use_graph in (False, True):
         m = build(S, sd, drop).train()
-        m.fir_precision = fir_precision      # the split mode's operand scales are device-resident: capturable too
         opt, crit = FusedAdam(m.parameters(), lr=1e-3, capturable=True), CrossEntropyLoss()
         losses = []
         if use_graph:
@@ -346,8 +339,7 @@ def test_graph_replay_equals_eager(drop, fir_precision):
     assert len(set(finals[0][0])) == len(finals[0][0])       # the batches (and masks) really changed
 
 
-@pytest.mark.parametrize("fir_precision", ["fp32", "split"])
-def test_forty_step_trajectory_stays_within_tolerance(fir_precision):
+def test_forty_step_trajectory_stays_within_tolerance():
     """40 optimiser steps (20 in train mode, 20 in eval mode as the reference does from epoch 2, Q4) on changing
     batches: the HIP trajectory and the CPU oracle's stay within north_star's 1e-3 on the model output, and make
     the same predictions ("5-class acc parity")."""
@@ -357,7 +349,6 @@ def test_forty_step_trajectory_stays_within_tolerance(fir_precision):
     sd = eegnet_weights(77, S)
     x, y = synth.eeg_batch(770, n, 30, S)
     model = build(S, sd, 0.0).train()
-    model.fir_precision = fir_precision
     opt, crit = FusedAdam(model.parameters(), lr=1e-3), CrossEntropyLoss()
     P = {k: torch.from_numpy(sd[k].copy()) for k in orc.PARAM_NAMES}
     Bf = {k: torch.from_numpy(sd[k].copy()) for k in orc.BUFFER_NAMES}
@@ -419,8 +410,7 @@ def test_trainer_graph_replay_survives_other_batch_sizes(capsys):
         assert torch.equal(finals[0][0][k], finals[1][0][k]), k
 
 
-@pytest.mark.parametrize("fir_precision", ["fp32", "split"])
-def test_generated_spatial_dropout_is_per_feature_map(fir_precision):
+def test_generated_spatial_dropout_is_per_feature_map():
     """dropoutType != 'Dropout' is nn.Dropout2d in the reference (EEGNet_tor.py:21): the generated masks drop whole
     (sample, channel) maps, about half of them, differently on every step, and the backward regenerates the same masks
     (probabilities and gradients equal the oracle's when it is handed the masks read back from the workspace)."""
@@ -429,7 +419,6 @@ def test_generated_spatial_dropout_is_per_feature_map(fir_precision):
     S, B = 500, 16
     sd = eegnet_weights(21, S)
     model = build(S, sd, 0.5, "SpatialDropout2D").train()
-    model.fir_precision = fir_precision
     x, y = synth.eeg_batch(211, B, 30, S)
     seen = []
     for step in range(2):

@@ -86,6 +86,8 @@ def _bf16_round(a):
 
 @pytest.mark.parametrize("M,N,K", [(300, 200, 100), (1214, 64, 1214), (130, 3072, 768), (9, 5, 12)])
 @pytest.mark.parametrize("tA,tB", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.skipif(not __import__("eav_amd._lib", fromlist=["x"]).have_extras(),
+                    reason="comparison-only kernel: build with `make -C eav_amd/csrc BENCH_EXTRAS=1`")
 def test_gemm_bf16_operands(L, M, N, K, tA, tB):
     """bf16-MFMA variant == the fp64 product of the bf16-rounded (RNE) operands, up to fp32 accumulation."""
     pad = lambda v: (v + 3) // 4 * 4  # noqa: E731

@@ -143,6 +143,8 @@ def test_hf_checkpoint_roundtrip(tmp_path):
         assert np.array_equal(sd[k].numpy().reshape(W[k].shape), W[k])
 
 
+@pytest.mark.skipif(not __import__("eav_amd._lib", fromlist=["x"]).have_extras(),
+                    reason="comparison-only bf16 GEMM: build with `make -C eav_amd/csrc BENCH_EXTRAS=1`")
 @pytest.mark.parametrize("kind", ["ast", "vit"])
 def test_reduced_precision_modes(golden_dir, kind):
     """Opt-in fast modes.  bf16_bwd keeps the forward exact (logits identical to the fp32 mode) and only the

@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-EEG="python3 $R/bench.py --no-encoders --no-cpu-baseline --steps 20 --warmup 3 --repeats 0"
+EEG="python3 $R/tools/eeg_steps.py 20"          # 3 eager + 20 graph-replayed train steps, nothing else
 if [ "$ONLY" != "enc" ]; then
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/eeg_trace -o eeg -- $EEG > $OUT/eeg_trace.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/eeg_fetch -o eeg -- $EEG > $OUT/eeg_fetch.log 2>&1

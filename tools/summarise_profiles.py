@@ -59,6 +59,16 @@ for run in ("eeg", "ast", "vit"):
     write = counters(os.path.join(src, f"{run}_write", f"{run}_counter_collection.csv"))
     mfma = counters(os.path.join(src, f"{run}_mfma", f"{run}_counter_collection.csv"))
     total = sum(sum(v) for v in dur.values())
+    # whole-step figures (EEGNet run = tools/eeg_steps.py: train steps only): every launch of every kernel, divided by the
+    # number of optimiser steps (= adam_kernel launches)
+    step = None
+    nsteps = sum(len(v) for k, v in dur.items() if k.startswith("adam_kernel"))
+    if run == "eeg" and nsteps:
+        fb = sum(sum(c.get("FETCH_SIZE", [])) for c in fetch.values())
+        wb = sum(sum(c.get("WRITE_SIZE", [])) for c in write.values())
+        step = {"steps_profiled": nsteps, "hbm_bytes_per_step": round((2.0 * fb + wb) * 1024 / nsteps),
+                "hbm_read_bytes_per_step": round(2.0 * fb * 1024 / nsteps), "hbm_write_bytes_per_step": round(wb * 1024 / nsteps),
+                "kernel_ms_per_step": round(total / 1e6 / nsteps, 4), "launches_per_step": round(sum(len(v) for v in dur.values()) / nsteps, 1)}
     out = {}
     for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
         if sum(v) < 0.002 * total:
@@ -96,7 +106,7 @@ for run in ("eeg", "ast", "vit"):
                     e["mfma_pipe_busy_single_stream"] = round(e["mfma_pipe_busy"] * e["avg_us"] / e["avg_us_single_stream"], 4)
                 if "hbm_gb_per_s" in e:
                     e["hbm_gb_per_s_single_stream"] = round(e["hbm_gb_per_s"] * e["avg_us"] / e["avg_us_single_stream"], 1)
-    json.dump({"note": note, "commit": commit, "total_kernel_ms": round(total / 1e6, 3), "kernels": out},
+    json.dump({"note": note, "commit": commit, "total_kernel_ms": round(total / 1e6, 3), "step": step, "kernels": out},
               open(os.path.join(dst, f"{tag}_{run}_pmc.json"), "w"), indent=1)
     print(run, "total kernel ms", round(total / 1e6, 2))
     for k, e in list(out.items())[:14]:
@@ -113,5 +123,5 @@ if os.path.exists(p):
     for k in list(ker):            # bare template names too ("fir_wgrad_kernel<10, false>" -> "fir_wgrad_kernel")
         b = k.split("<")[0]
         ker.setdefault(b, ker[k])
-    json.dump({"note": d["note"], "commit": d.get("commit"), "kernels": ker},
+    json.dump({"note": d["note"], "commit": d.get("commit"), "step": d.get("step"), "kernels": ker},
               open(os.path.join(dst, f"{tag}_eegnet_hbm_traffic.json"), "w"), indent=1)

@@ -80,6 +80,39 @@ __device__ __forceinline__ v2f cmulc(v2f a, v2f b) {      // a conj(b)
   return fma2(a.yy, swp(b), (a.xx * (v2f){1.f, -1.f}) * b);
 }
 #endif
+#ifndef FFTV_NO_ASM_CMUL
+// Two complex products a0 b0, a1 b1 (CONJ: a conj(b)) in FOUR packed instructions: what hipcc cannot select is one
+// v_pk_fma_f32 with a swapped AND half-negated operand (it builds the pair with a third instruction).  The two products are
+// interleaved so that no packed result is consumed by the next instruction (gfx950 needs one wait state there); the
+// leading s_nop covers a packed producer of an input directly in front of the block.
+template <bool CONJ>
+__device__ __forceinline__ void cmul2(v2f a0, v2f b0, v2f a1, v2f b1, v2f& r0, v2f& r1) {
+  if (CONJ)
+    asm("s_nop 0\n\t"
+        "v_pk_mul_f32 %0, %2, %3 op_sel_hi:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %1, %4, %5 op_sel_hi:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %2, %3, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %1, %4, %5, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1]"
+        : "=&v"(r0), "=&v"(r1) : "v"(a0), "v"(b0), "v"(a1), "v"(b1));
+  else
+    asm("s_nop 0\n\t"
+        "v_pk_mul_f32 %0, %2, %3 op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %1, %4, %5 op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %2, %3, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"
+        "v_pk_fma_f32 %1, %4, %5, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"
+        : "=&v"(r0), "=&v"(r1) : "v"(a0), "v"(b0), "v"(a1), "v"(b1));
+}
+// acc0 += a0 conj(b0), acc1 += a1 conj(b1): four packed fmas, the accumulators interleaved for the same reason
+__device__ __forceinline__ void cmacc2_conj(v2f a0, v2f b0, v2f a1, v2f b1, v2f& acc0, v2f& acc1) {
+  asm("s_nop 0\n\t"
+      "v_pk_fma_f32 %0, %2, %3, %0 op_sel_hi:[0,1,1] neg_hi:[0,1,0]\n\t"
+      "v_pk_fma_f32 %1, %4, %5, %1 op_sel_hi:[0,1,1] neg_hi:[0,1,0]\n\t"
+      "v_pk_fma_f32 %0, %2, %3, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %1, %4, %5, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1]"
+      : "+v"(acc0), "+v"(acc1) : "v"(a0), "v"(b0), "v"(a1), "v"(b1));
+}
+#endif
+
 // a w (forward) / a conj(w) (inverse) for a twiddle w: the w-only factors are loop invariants the compiler keeps in
 // registers, which leaves two instructions per product
 template <bool INV>
@@ -258,8 +291,14 @@ __device__ __forceinline__ void fft1024(v2f (&v)[16], v2f* __restrict__ xb, int 
   const v2f* t1 = twl + lane;
   const v2f* t2 = twl + 1024 + (lane >> 4);
   dft16<INV>(v);
+#ifndef FFTV_NO_ASM_CMUL
+  v[1] = twmul<INV>(v[1], lds_ld(t1 + 64));
+#pragma unroll
+  for (int k = 2; k < 16; k += 2) cmul2<INV>(v[k], lds_ld(t1 + 64 * k), v[k + 1], lds_ld(t1 + 64 * k + 64), v[k], v[k + 1]);
+#else
 #pragma unroll
   for (int k = 1; k < 16; ++k) v[k] = twmul<INV>(v[k], lds_ld(t1 + 64 * k));
+#endif
 #pragma unroll
   for (int k = 0; k < 16; ++k) xb[XP * k + lane] = v[k];
   FFT_ORDER();
@@ -270,8 +309,14 @@ __device__ __forceinline__ void fft1024(v2f (&v)[16], v2f* __restrict__ xb, int 
   }
   FFT_ORDER();
   dft16<INV>(v);
+#ifndef FFTV_NO_ASM_CMUL
+  v[1] = twmul<INV>(v[1], lds_ld(t2 + 4));
+#pragma unroll
+  for (int k = 2; k < 16; k += 2) cmul2<INV>(v[k], lds_ld(t2 + 4 * k), v[k + 1], lds_ld(t2 + 4 * k + 4), v[k], v[k + 1]);
+#else
 #pragma unroll
   for (int k = 1; k < 16; ++k) v[k] = twmul<INV>(v[k], lds_ld(t2 + 4 * k));
+#endif
   // lane 16 n3 + k1 holds k2 = 4 m + r in register 4 m + r; the 4 x 4 transposes put n3 into the register index:
   // lane 16 r + k1, register 4 m + n3
   v2f o[16];
@@ -386,10 +431,18 @@ __global__ __launch_bounds__(64 * NWF, 1) void fir_fft_fwd_kernel(const float* _
     for (int f = 0; f < F1; ++f) {
       const v2f* hp = Hs + f * HB + lane;       // bins lane + 64 j, j < 8
       const v2f* hm = Hs + f * HB - lane;       // bins 1024 - (lane + 64 j), j >= 8: the conjugates
+#ifndef FFTV_NO_ASM_CMUL
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) cmul2<false>(z[j], lds_ld(hp + 64 * j), z[j + 1], lds_ld(hp + 64 * j + 64), v[j], v[j + 1]);
+#pragma unroll
+      for (int j = 8; j < 16; j += 2)
+        cmul2<true>(z[j], lds_ld(hm + (NF - 64 * j)), z[j + 1], lds_ld(hm + (NF - 64 * j - 64)), v[j], v[j + 1]);
+#else
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = cmul(z[j], lds_ld(hp + 64 * j));
 #pragma unroll
       for (int j = 8; j < 16; ++j) v[j] = cmulc(z[j], lds_ld(hm + (NF - 64 * j)));
+#endif
       fft1024<true>(v, xb, lane, tw);
       float* dst = y1 + (((int64_t)b * F1 + f) * C + c0) * S + t0 + lane;
       float a1, a2;
@@ -541,8 +594,13 @@ __global__ __launch_bounds__(512, 1) void fir_fft_wgrad_kernel(const float* __re
       for (int j = NROW; j < 16; ++j) v[j] = (v2f){0.f, 0.f};
       fft1024<false>(v, xb, lane, tw);
       const v2f* zp = zb + uu * NF + lane;
+#ifndef FFTV_NO_ASM_CMUL
+#pragma unroll
+      for (int j = 0; j < 16; j += 2) cmacc2_conj(lds_ld(zp + 64 * j), v[j], lds_ld(zp + 64 * j + 64), v[j + 1], acc[j], acc[j + 1]);
+#else
 #pragma unroll
       for (int j = 0; j < 16; ++j) acc[j] += cmulc(lds_ld(zp + 64 * j), v[j]);
+#endif
 #pragma unroll
       for (int j = 0; j < NROW; ++j) {       // (after the transform: the copy is what waits for the loads)
         cg[j] = ng[j];

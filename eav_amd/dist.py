@@ -193,14 +193,15 @@ def backend_name():
     return dist.get_backend() if dist.is_initialized() else "none"
 
 
-def attach(trainer, force=False):
+def attach(trainer, force=False, group=None):
     """Give a Trainer_uni (or any trainer exposing .model with a flat gradient buffer) a gradient
-    all-reduce when running under torchrun with WORLD_SIZE > 1 (force: also in a one-rank group)."""
-    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
+    all-reduce when running under torchrun with WORLD_SIZE > 1 (force: also in a one-rank group).
+    group: a process sub-group (SubjectSchedule.make_groups) - the replicas of ONE subject's training."""
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
         return trainer
     model = trainer.model
     model._ensure_flat()
-    trainer.grad_sync = GradSync([model._flat[1]], force=force)
+    trainer.grad_sync = GradSync([model._flat[1]], group=group, force=force)
     if hasattr(model, "grad_ready_hook"):
         model.grad_ready_hook = trainer.grad_sync.bucket     # overlap the all-reduce with the backward
     # hipGraph replay stays on (Trainer_uni / GraphStep): with a grad_sync the step is captured as TWO graphs - batch

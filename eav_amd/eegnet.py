@@ -682,6 +682,15 @@ class DeviceLoader:
             return self.x[idx[0]:idx[-1] + 1], self.y[idx[0]:idx[-1] + 1]
         return gather_batch(self.x, self.y, torch.as_tensor(idx, dtype=torch.long, device=self.device))
 
+    def gather_labels(self, idx):
+        """The labels of a batch only (a step that already holds the batch's features needs no copy of x)."""
+        if idx[-1] - idx[0] == len(idx) - 1 and all(b - a == 1 for a, b in zip(idx, idx[1:])):
+            return self.y[idx[0]:idx[-1] + 1]
+        i = torch.as_tensor(idx, dtype=torch.long, device=self.device)
+        out = torch.empty(len(idx), dtype=torch.long, device=self.device)
+        _lib.call("eav_gather_i64", self.y.data_ptr(), i.data_ptr(), out.data_ptr(), len(idx), _lib.stream_ptr())
+        return out
+
     def __iter__(self):
         for idx in self.index_batches():
             yield self.gather(idx)

@@ -84,11 +84,12 @@ class FineTuneBase:
         seen, nb = 0, len(dl)
         fc = getattr(self, "_feat_cache", None)
         for k, idx in enumerate(dl.index_batches(), start=1):
-            xb, tb = dl.gather(idx)
             self.optimizer.zero_grad()
-            if fc is not None and fc["have_train"]:
+            if fc is not None and fc["have_train"]:       # cached features: only the labels of the batch are gathered
+                tb = dl.gather_labels(idx)
                 logits = self.model.head(fc["train"][self._index(idx)]).logits
             else:
+                xb, tb = dl.gather(idx)
                 logits = self.model(xb).logits
                 if fc is not None:
                     fc["train"][self._index(idx)] = self.model.last_features()
@@ -121,10 +122,11 @@ class FineTuneBase:
         spans, pos = [], 0
         with torch.no_grad():
             for k, idx in enumerate(dl.index_batches()):
-                xb, tb = dl.gather(idx)
                 if fc is not None and fc["have_test"]:
+                    tb = dl.gather_labels(idx)
                     logits = self.model.head(fc["test"][pos:pos + len(idx)]).logits
                 else:
+                    xb, tb = dl.gather(idx)
                     logits = self.model(xb).logits
                     if fc is not None:
                         fc["test"][pos:pos + len(idx)] = self.model.last_features()

@@ -223,7 +223,11 @@ class Encoder(nn.Module):
         # "bf16" (bf16 MFMA operands everywhere, fp32 accumulate: ~5e-3 logit drift) or "bf16_bwd" (fp32 forward -
         # logits unchanged - and bf16 operands for the backward products only).  EAV_ENCODER_PRECISION overrides.
         self.precision = os.environ.get("EAV_ENCODER_PRECISION", DEFAULT_PRECISION)
-        self.overlap_wgrad = True     # split mode: weight-gradient GEMMs on a side stream (see _wgrad_sp)
+        # split mode: weight-gradient GEMMs on a side stream (see _wgrad_sp).  "auto" (default): two streams from 8192 token
+        # rows per step on, one stream below - at the per-rank batches of a data-parallel group (ViT B = 16: 3152 rows) the
+        # ~100 events / waits of the two-stream schedule cost more host time than the overlap returns (20.1 -> 13.1 ms;
+        # AST B = 4 21.1 -> 16.8 ms; ViT B = 128 49.2 two streams / 51.3 one: tools/encoder_graph_step.py).  True / False pin it.
+        self.overlap_wgrad = "auto"
         # split mode, backward GEMMs only (data and weight gradients): 3 = the fp32-grade three-term product (default),
         # 1 = the hi.hi term alone - operands rounded to fp16 under the planes' scales (11-bit mantissas; fp32
         # accumulation), i.e. classic fp16 mixed-precision gradients: 3e-4 relative gradient error instead of 3e-7, a
@@ -530,7 +534,7 @@ class Encoder(nn.Module):
         # the side stream - idle during the forward - in layer order, one event per matrix; the main stream waits for a
         # matrix's event right before the first GEMM that reads its planes (_wp), so only the patch projection's
         # conversion is ever on the critical path.
-        side = self._side_stream(dev) if (stale and self.overlap_wgrad and self.kernel_events is None) else None
+        side = self._side_stream(dev) if (stale and self._two_streams() and self.kernel_events is None) else None
         self._wready = {}
         self._wnorm_ready = None
         if side is not None:
@@ -617,6 +621,14 @@ class Encoder(nn.Module):
                     self._wready[k] = ev
         self._wplanes_key = key
 
+    def _two_streams(self):
+        """Whether this step runs its weight gradients / final reductions beside the main stream (overlap_wgrad)."""
+        o = self.overlap_wgrad
+        if o == "auto":
+            ws = getattr(self, "_ws", None)
+            return ws is not None and ws.B * self.cfg.ntok >= 8192
+        return bool(o)
+
     def _cur_stream(self):
         """The stream the current launch sequence runs on (cached by _launch_forward / _launch_backward / the head functions:
         torch.cuda.current_stream() costs tens of microseconds per call, and the step waits on ~50 events)."""
@@ -654,7 +666,7 @@ class Encoder(nn.Module):
         It gets its OWN stream (not the weight-gradient stream): a 24-block kernel queued in order between persistent GEMMs
         waits for a CU whose LDS is not taken by two GEMM workgroups, and held the weight gradients behind it back by
         ~130 us per launch at ViT B=128 (9.6 ms of side-stream time per step)."""
-        if not (self.overlap_wgrad and self.kernel_events is None):
+        if not (self._two_streams() and self.kernel_events is None):
             self._call("eav_reduce_partials", _lib.ptr(buf) + off_bytes, nparts, stride, n, 1.0, out, self._st)
             return
         if self._aux is None or self._aux.device != buf.device:
@@ -682,7 +694,7 @@ class Encoder(nn.Module):
         # flags: backward products with grad_terms = 1 run on the hi.hi term alone (see the class attribute); the backward's
         # data gradients share the GPU with the side stream's weight gradients (EAV_GEMM_SHARED_GPU: see csrc/gemm_sp.hip)
         bwd = self._phase == "bwd"
-        flags = (1 if (self.grad_terms if bwd else self.fwd_terms) == 1 else 0) | (2 if bwd and self.overlap_wgrad else 0) \
+        flags = (1 if (self.grad_terms if bwd else self.fwd_terms) == 1 else 0) | (2 if bwd and self._two_streams() else 0) \
             | (0 if blockmax else 8)
         self._call("eav_gemm_sp_ex", A, B, C, slotA, slotB, M, N, K, ldc, batch, sA, sC, float(alpha), bias, gelu, pre,
                    resid, ldr, acc, amax, None, None, None, flags, self._st)
@@ -698,7 +710,7 @@ class Encoder(nn.Module):
         produced A; the main stream waits for a weight gradient only before it overwrites that gradient's A planes
         (one layer later) and at the end of the backward."""
         name = "eav_gemm_sp_splitk_x1" if self.grad_terms == 1 else "eav_gemm_sp_splitk"
-        if not self.overlap_wgrad or (self.kernel_events is not None and name in self.kernel_events):
+        if not self._two_streams() or (self.kernel_events is not None and name in self.kernel_events):
             self._call(name, _lib.ptr(AT), _lib.ptr(BT), C, _lib.ptr(self._ws.splitk), slotA, slotB, M,
                        N, K, 0, self._st)
             return
@@ -973,10 +985,14 @@ class Encoder(nn.Module):
                 # the attention output leaves as the planes of the o-proj products (scale: qkv's own, |O| <= max|V|); its
                 # fp32 copy is written only when a backward will read it
                 # (... and only by the unfused gradient flow: the fused one forms delta = dO . O from these planes)
-                need_ao = ws.full and not (self.fused_dqkv and self.grad_terms != 1)
+                # (recorded on the workspace: the backward forms delta from ws.aop ONLY if THIS kernel wrote them - its
+                # planes carry one tensor-wide scale; eav_sp_convert's planes below have per-row-block boosts)
+                ws.delta_from_planes = self.fused_dqkv and self.grad_terms != 1
+                need_ao = ws.full and not ws.delta_from_planes
                 L("eav_attn_fwd_sp_planes", P(ws.qkvrow[j]), None, s_qkv, P(ao) if need_ao else None,
                   P(ws.lse[j]), None, P(ws.aop[j]), s_ao, ws.B, H, N, hd, scale, st)
             else:
+                ws.delta_from_planes = False
                 L("eav_attn_fwd_sp", P(ws.qkvrow[j]), None, s_qkv, P(ao), P(ws.lse[j]), s_ao, ws.B, H, N, hd,
                   scale, st)
         else:
@@ -1050,7 +1066,7 @@ class Encoder(nn.Module):
               1.13 * float(np.sqrt(D)), st)
             self._before_overwrite(ws.dactp)
             part = self._part_buf("part_cs2_pool")
-            flags = (1 if self.grad_terms == 1 else 0) | (2 if self.overlap_wgrad else 0)
+            flags = (1 if self.grad_terms == 1 else 0) | (2 if self._two_streams() else 0)
             L("eav_gemm_sp_ex", P(ws.dhp), wpl, None, b_dh2, wsl, M, FF, D, FF, 1, 0, 0, 1.0, None, 2, P(ws.pre[i]), None, 0,
               0, None, P(ws.dactp), b_dact, P(part), flags, st)
             self._reduce_async(part, 0, ws.np_cs2, FF, FF, gp(f"{Lk}.mlp.fc1.bias"))
@@ -1081,7 +1097,12 @@ class Encoder(nn.Module):
         # attention core
         if ws.fused:
             L("eav_attn_sp_prep", dao, b_dao, P(ws.dorow), None, ws.B, N, D, D, 0, st)
-            if self.fused_dqkv and self.grad_terms != 1:      # (hi.hi-only gradient products need the tight measured scale)
+            # dqkv as planes straight from the attention backward, delta = dO . O from the planes of O - only when the
+            # forward of THIS step wrote those planes with eav_attn_fwd_sp_planes (EAV_FUSED_AO=0 / EAV_FUSED_PLANES=0 runs
+            # convert a fp32 O with per-row-block boosts the planes-delta kernel does not read); hi.hi-only gradient
+            # products need the tight measured scale
+            fused_bwd = bool(getattr(ws, "delta_from_planes", False)) and self.fused_dqkv and self.grad_terms != 1
+            if fused_bwd:
                 self._before_overwrite(ws.dqkvp)
                 part = self._part_buf("part_attn_pool")
                 # (delta = dO . O from the planes of dO and of the attention output: no fp32 attention output in the step)
@@ -1108,7 +1129,7 @@ class Encoder(nn.Module):
         # fused q/k/v projection
         if not ws.fused:
             self._call("eav_sp_absmax", dqkv, M, 3 * D, 3 * D, b_dqkv, st)
-        if not (ws.fused and self.fused_dqkv and self.grad_terms != 1):
+        if not (ws.fused and fused_bwd):
             self._to_planes_bias(dqkv, M, 3 * D, b_dqkv, ws.dqkvp, gp(f"{Lk}.attention.q_proj.bias"))
         self._wgrad_sp(ws.dqkvp, b_dqkv, ws.y1p[i], s_y1, gp(f"{Lk}.attention.q_proj.weight"), 3 * D, D, M)
         wpl, wsl = self._wp(f"qkv{i}", transposed=True)

@@ -385,3 +385,53 @@ def test_training_step_after_an_evaluation_forward_keeps_the_weight_norms(kind):
             continue
         scale = float(g0[k].abs().max())
         assert float((g1[k] - g0[k]).abs().max()) <= 2e-5 * scale + 1e-12, (k, float((g1[k] - g0[k]).abs().max()), scale)
+
+
+@pytest.mark.parametrize("switch", ["fused_ao", "fused_planes"])
+def test_ab_switches_keep_the_attention_backward_consistent(switch):
+    """EAV_FUSED_AO=0 / EAV_FUSED_PLANES=0 (the documented A/B switches) with the fused dqkv backward left on: the forward
+    then converts a fp32 attention output into planes with per-32-row-block boosts, which the planes-delta kernel does not
+    read - the backward must fall back to the fp32 O / dO path (round-4 advisor finding).  A batch whose second image is
+    constant has an attention output below 2^-8 of the tensor maximum on six whole row blocks of layer 0 (identical tokens, value
+    projection made almost orthogonal to them): the boosted blocks exist, and every gradient still agrees with the
+    exact-fp32 kernels."""
+    from eav_amd import transformer as T
+    from eav_amd.optim import CrossEntropyLoss
+    kw = dict(hidden=128, layers=2, heads=2, ff=256)       # head_dim 64: the fused attention kernels
+    cfg = T.make_config("vit", **kw)
+    W = _weights("vit", 77, 0.08, **kw)
+    p = cfg.prefix
+    W[f"{p}.embeddings.position_embeddings"] = np.zeros_like(W[f"{p}.embeddings.position_embeddings"])
+    b = W[f"{p}.embeddings.patch_embeddings.projection.bias"] = synth.normal(5, (128,), 0.0, 1.0)
+    W[f"{p}.embeddings.cls_token"] = b.reshape(1, 1, 128).copy()          # a constant image: every token row equals b
+    g, be = W[f"{p}.layers.0.layernorm_before.weight"], W[f"{p}.layers.0.layernorm_before.bias"]
+    bd = b.astype(np.float64)
+    yhat = g * ((bd - bd.mean()) / np.sqrt(bd.var() + cfg.eps)) + be     # LayerNorm of that row
+    Wv = W[f"{p}.layers.0.attention.v_proj.weight"].astype(np.float64)
+    Wv -= (1.0 - 2.0 ** -14) * np.outer(Wv @ yhat, yhat) / float(yhat @ yhat)
+    W[f"{p}.layers.0.attention.v_proj.weight"] = Wv.astype(np.float32)
+    W[f"{p}.layers.0.attention.v_proj.bias"] = np.zeros(128, np.float32)
+    x, y = synth.frame_batch(3, 2, cfg.H)
+    x[1] = 0.0
+    xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    grads = {}
+    for mode in ("fp32", "split"):
+        model = T.Encoder(cfg, W).cuda().train()
+        model.precision = mode
+        if mode == "split":
+            setattr(model, switch, False)
+            assert model.fused_dqkv
+        out = model(xd)
+        CrossEntropyLoss()(out.logits, yd).backward()
+        grads[mode] = {k: q.grad.detach().clone() for k, q in model.named_parameters()}
+        if mode == "split":
+            ws = model._ws
+            assert ws.delta_from_planes is False
+            assert ws.fused
+            ao = ws.ao[0].view(2, cfg.ntok, 128)
+            assert float(ao[1].abs().max()) < 2.0 ** -8 * float(ao[0].abs().max())      # the boosted row blocks exist
+    for k, ref in grads["fp32"].items():
+        if k.endswith("k_proj.bias"):
+            continue
+        rel = float((grads["split"][k] - ref).norm() / ref.norm().clamp_min(1e-30))
+        assert rel < 1e-3, (k, rel)

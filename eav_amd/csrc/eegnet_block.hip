@@ -365,6 +365,9 @@ __global__ __launch_bounds__(NT) void dw_bwd_kernel(const float* __restrict__ y1
       r[d] = (dzv[d][0] * a[0] + dzv[d][1] * a[1]) + (dzv[d][2] * a[2] + dzv[d][3] * a[3]);
     // step xor 1: keep 4 values; xor 2: keep 2; xor 4: keep 1; then plain reduce over the rest
     float r4[4], r2[2], r1;
+#ifdef DWB_ABL_NORED      // timing-only ablation (results garbage): the pass without its cross-lane reductions
+    r1 = r[0] + r[1] + r[2] + r[3] + r[4] + r[5] + r[6] + r[7];
+#else
     {
       const bool hi = lane & 1;
 #pragma unroll
@@ -389,6 +392,7 @@ __global__ __launch_bounds__(NT) void dw_bwd_kernel(const float* __restrict__ y1
     r1 += __shfl_xor(r1, 8, 64);
     r1 += __shfl_xor(r1, 16, 64);
     r1 += __shfl_xor(r1, 32, 64);
+#endif
     // lane l (l < 8) now holds the wave total of d = 4*(l&1) + 2*((l>>1)&1) + ((l>>2)&1)
     if (lane < 8) {
       const int d = 4 * (lane & 1) + 2 * ((lane >> 1) & 1) + ((lane >> 2) & 1);

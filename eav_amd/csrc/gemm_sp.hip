@@ -37,7 +37,8 @@
 #include "../../include/eav_hip.h"
 
 // timing-only ablation of the main loop (tools/probes/tr_ablate.sh builds variants; results are garbage): 1 = no fragment
-// reads, 2 = no LDS-DMA, 4 = no MFMAs, 16 / 32 = every tile streams the A / B rows of tile 0 (L2-hot operand)
+// reads, 2 = no LDS-DMA, 4 = no MFMAs, 16 / 32 = every tile streams the A / B rows of tile 0 (L2-hot operand), 64 = no
+// epilogue at all (the K loop alone: what bias / GELU / planes / maxima / stores cost a short-K product)
 #ifndef EAV_ABL
 #define EAV_ABL 0
 #endif
@@ -124,6 +125,17 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   return (x < 0.f ? hq : 1.0f - hq) + x * e * 0.3989422804014327f;
 }
 
+// v summed over the lanes l ^ 8, l ^ 16, l ^ 32 combinations (the 8 lanes that share l & 7) without LDS round trips:
+// row_ror:8 pairs l with l ^ 8 inside a row of 16; v_permlane16_swap / v_permlane32_swap of the value with a copy of
+// itself leave {even rows, odd rows} / {lower half, upper half} side by side in two registers (tools/probes/permlane_probe)
+__device__ __forceinline__ float sum_over_lane_bits_3_4_5(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, true));
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
 // Four consecutive values of one row -> this lane's half of the 8-value hi / lo pieces; the partner lane (the other half of
 // the group of 8 columns) gets the halves exchanged so that each lane stores one whole 16-byte piece: `first` (the lane
 // holding columns 0-3 of the group) the hi piece, the other one the lo piece.  xorm = lane distance of the partner.
@@ -134,8 +146,13 @@ __device__ __forceinline__ uint4 plane_piece4(float t0, float t1, float t2, floa
   const uint2 hh = *reinterpret_cast<const uint2*>(h), ll = *reinterpret_cast<const uint2*>(l);
   const uint2 send = first ? ll : hh;
   uint2 recv;
-  recv.x = __shfl_xor(send.x, xorm, 64);
-  recv.y = __shfl_xor(send.y, xorm, 64);
+  if (xorm == 1) {      // neighbouring lanes: a DPP quad permutation [1,0,3,2] - no LDS round trip (ds_bpermute) in the epilogue
+    recv.x = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send.x, 0xB1, 0xf, 0xf, true);
+    recv.y = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send.y, 0xB1, 0xf, 0xf, true);
+  } else {
+    recv.x = __shfl_xor(send.x, xorm, 64);
+    recv.y = __shfl_xor(send.y, xorm, 64);
+  }
   return first ? make_uint4(hh.x, hh.y, recv.x, recv.y) : make_uint4(recv.x, recv.y, ll.x, ll.y);
 }
 
@@ -178,6 +195,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+#if defined(EAV_STAGGER) && EAV_STAGGER > 0
+  // experiment: the second resident workgroup of every CU starts EAV_STAGGER x ~3.4 us late, so that the write bursts of
+  // the epilogues of the two halves of the grid do not coincide
+  if (!TR && g.kt_per_split == 0 && blockIdx.x >= gridDim.x / 2 && gridDim.x >= 512)
+    for (int i = 0; i < EAV_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
 
   // ---- persistent workgroups: tile ids blockIdx.x, blockIdx.x + gridDim.x, ... (gridDim.x is a multiple of 8 whenever a
   // workgroup gets more than one tile, so a workgroup stays on its XCD).  tile id -> tile: XCD-contiguous, then groups
@@ -726,11 +749,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
           if (g.colsum) {     // lane = rows prow + 8 k, columns 4 pc4 .. + 3: four rows in the lane, then the 8 lanes of a column group
             float4 t = make_float4((v[0] + v[4]) + (v[8] + v[12]), (v[1] + v[5]) + (v[9] + v[13]),
                                    (v[2] + v[6]) + (v[10] + v[14]), (v[3] + v[7]) + (v[11] + v[15]));
-#pragma unroll
-            for (int o = 8; o < 64; o <<= 1) {
-              t.x += __shfl_xor(t.x, o, 64); t.y += __shfl_xor(t.y, o, 64);
-              t.z += __shfl_xor(t.z, o, 64); t.w += __shfl_xor(t.w, o, 64);
-            }
+            t.x = sum_over_lane_bits_3_4_5(t.x); t.y = sum_over_lane_bits_3_4_5(t.y);
+            t.z = sum_over_lane_bits_3_4_5(t.z); t.w = sum_over_lane_bits_3_4_5(t.w);
             cs4.x += t.x; cs4.y += t.y; cs4.z += t.z; cs4.w += t.w;
           }
           __builtin_amdgcn_sched_barrier(0);
@@ -742,8 +762,19 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
     const bool aligned = (((uintptr_t)C | (uintptr_t)pre | (uintptr_t)g.resid | (uintptr_t)g.bias | (uintptr_t)g.planes |
                            (uintptr_t)g.colsum) & 15) == 0 &&
                          ((g.ldc | g.ldr | (int)(g.sC & 3) | (g.colsum ? N : 0)) & 3) == 0;
-    if (aligned && m0 + BM <= M && n0 + BN <= N) epilogue_linear();
-    else epilogue_elements();
+    if constexpr ((EAV_ABL & 64) != 0) {       // keep the accumulators alive, write nothing
+      float sacc = 0.f;
+#pragma unroll
+      for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
+      if (sacc == 12345.678f && C) C[0] = alf[0][0] + psig + (pre ? 1.f : 0.f);
+    } else {
+      if (aligned && m0 + BM <= M && n0 + BN <= N) epilogue_linear();
+      else epilogue_elements();
+    }
     if (g.amax) {
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));

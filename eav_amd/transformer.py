@@ -233,6 +233,11 @@ class Encoder(nn.Module):
         # accumulation), i.e. classic fp16 mixed-precision gradients: 3e-4 relative gradient error instead of 3e-7, a
         # third of the backward's matrix work.  The forward - the logits - always runs on three terms.
         self.grad_terms = int(os.environ.get("EAV_GRAD_TERMS", "3"))
+        # per-kind overrides of grad_terms (None: follow it): the weight-gradient products (their rounding stays in that
+        # tensor's update) and the data-gradient products (their rounding travels down the layers) priced separately -
+        # tools/encoder_trajectory.py, profiles/r05_term_budget.txt
+        self.wgrad_terms = int(os.environ["EAV_WGRAD_TERMS"]) if os.environ.get("EAV_WGRAD_TERMS") else None
+        self.dgrad_terms = int(os.environ["EAV_DGRAD_TERMS"]) if os.environ.get("EAV_DGRAD_TERMS") else None
         # the same switch for the forward products (comparison only: 16-bit matrix operands everywhere - the logits then
         # move by a few 1e-3, outside north_star's bound; bench.py reports the leg beside the literal bf16 one)
         self.fwd_terms = int(os.environ.get("EAV_FWD_TERMS", "3"))
@@ -621,6 +626,16 @@ class Encoder(nn.Module):
                     self._wready[k] = ev
         self._wplanes_key = key
 
+    def _terms(self, kind):
+        """MFMA terms of the backward products of `kind` ("dgrad" | "wgrad"): 3 = fp32-grade, 1 = hi.hi only."""
+        t = self.wgrad_terms if kind == "wgrad" else self.dgrad_terms
+        return self.grad_terms if t is None else int(t)
+
+    def _bwd_three_terms(self):
+        """Every backward product on three terms: the producers may then write gradient planes under loose a-priori
+        bounds (a hi.hi-only product needs the tight measured scale of its operands)."""
+        return self._terms("dgrad") != 1 and self._terms("wgrad") != 1
+
     def _two_streams(self):
         """Whether this step runs its weight gradients / final reductions beside the main stream (overlap_wgrad)."""
         o = self.overlap_wgrad
@@ -694,7 +709,7 @@ class Encoder(nn.Module):
         # flags: backward products with grad_terms = 1 run on the hi.hi term alone (see the class attribute); the backward's
         # data gradients share the GPU with the side stream's weight gradients (EAV_GEMM_SHARED_GPU: see csrc/gemm_sp.hip)
         bwd = self._phase == "bwd"
-        flags = (1 if (self.grad_terms if bwd else self.fwd_terms) == 1 else 0) | (2 if bwd and self._two_streams() else 0) \
+        flags = (1 if (self._terms("dgrad") if bwd else self.fwd_terms) == 1 else 0) | (2 if bwd and self._two_streams() else 0) \
             | (0 if blockmax else 8)
         self._call("eav_gemm_sp_ex", A, B, C, slotA, slotB, M, N, K, ldc, batch, sA, sC, float(alpha), bias, gelu, pre,
                    resid, ldr, acc, amax, None, None, None, flags, self._st)
@@ -709,7 +724,7 @@ class Encoder(nn.Module):
         tails of its own GEMMs.  Ordering: the side stream waits for the event recorded after the conversion that
         produced A; the main stream waits for a weight gradient only before it overwrites that gradient's A planes
         (one layer later) and at the end of the backward."""
-        name = "eav_gemm_sp_splitk_x1" if self.grad_terms == 1 else "eav_gemm_sp_splitk"
+        name = "eav_gemm_sp_splitk_x1" if self._terms("wgrad") == 1 else "eav_gemm_sp_splitk"
         if not self._two_streams() or (self.kernel_events is not None and name in self.kernel_events):
             self._call(name, _lib.ptr(AT), _lib.ptr(BT), C, _lib.ptr(self._ws.splitk), slotA, slotB, M,
                        N, K, 0, self._st)
@@ -987,7 +1002,7 @@ class Encoder(nn.Module):
                 # (... and only by the unfused gradient flow: the fused one forms delta = dO . O from these planes)
                 # (recorded on the workspace: the backward forms delta from ws.aop ONLY if THIS kernel wrote them - its
                 # planes carry one tensor-wide scale; eav_sp_convert's planes below have per-row-block boosts)
-                ws.delta_from_planes = self.fused_dqkv and self.grad_terms != 1
+                ws.delta_from_planes = self.fused_dqkv and self._bwd_three_terms()
                 need_ao = ws.full and not ws.delta_from_planes
                 L("eav_attn_fwd_sp_planes", P(ws.qkvrow[j]), None, s_qkv, P(ao) if need_ao else None,
                   P(ws.lse[j]), None, P(ws.aop[j]), s_ao, ws.B, H, N, hd, scale, st)
@@ -1050,7 +1065,7 @@ class Encoder(nn.Module):
         dh, dy, dao, dact, dqkv = P(ws.dh), P(ws.dy), P(ws.dao), P(ws.dact), P(ws.dqkv)
         s_y1, s_qkv, s_ao, s_y2, s_act = (fslot(1 + self.FS * i + k) for k in range(5))
         b_dh2, b_dact, b_dh1, b_dao, b_ds, b_dqkv, b_dy2, b_dy1 = (bslot(1 + self.BS * i + k) for k in range(8))
-        fdh = self.fused_dh and self.grad_terms != 1      # (hi.hi-only gradient products need the tight measured scales)
+        fdh = self.fused_dh and self._bwd_three_terms()      # (hi.hi-only gradient products need the tight measured scales)
         # fc2: h_out = h_mid + act.W2^T + b2.  max|dh| is already in b_dh2 (left there by the producer of dh); every
         # conversion pass also yields the bias gradient of its tensor.  (fused_dh: the layer above's LayerNorm backward
         # already wrote these planes and the bias-gradient partials - only the top layer's dh comes from the head)
@@ -1066,7 +1081,7 @@ class Encoder(nn.Module):
               1.13 * float(np.sqrt(D)), st)
             self._before_overwrite(ws.dactp)
             part = self._part_buf("part_cs2_pool")
-            flags = (1 if self.grad_terms == 1 else 0) | (2 if self._two_streams() else 0)
+            flags = (1 if self._terms("dgrad") == 1 else 0) | (2 if self._two_streams() else 0)
             L("eav_gemm_sp_ex", P(ws.dhp), wpl, None, b_dh2, wsl, M, FF, D, FF, 1, 0, 0, 1.0, None, 2, P(ws.pre[i]), None, 0,
               0, None, P(ws.dactp), b_dact, P(part), flags, st)
             self._reduce_async(part, 0, ws.np_cs2, FF, FF, gp(f"{Lk}.mlp.fc1.bias"))
@@ -1101,7 +1116,7 @@ class Encoder(nn.Module):
             # forward of THIS step wrote those planes with eav_attn_fwd_sp_planes (EAV_FUSED_AO=0 / EAV_FUSED_PLANES=0 runs
             # convert a fp32 O with per-row-block boosts the planes-delta kernel does not read); hi.hi-only gradient
             # products need the tight measured scale
-            fused_bwd = bool(getattr(ws, "delta_from_planes", False)) and self.fused_dqkv and self.grad_terms != 1
+            fused_bwd = bool(getattr(ws, "delta_from_planes", False)) and self.fused_dqkv and self._bwd_three_terms()
             if fused_bwd:
                 self._before_overwrite(ws.dqkvp)
                 part = self._part_buf("part_attn_pool")

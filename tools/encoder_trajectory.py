@@ -26,28 +26,36 @@ for kind, B in (("vit", 32), ("ast", 8)):
     hx, _ = (synth.mel_batch(999, B) if kind == "ast" else synth.frame_batch(999, B))
     hx = torch.from_numpy(hx).cuda()
     runs = {}
-    for name, prec, terms in (("fp32", "fp32", 3), ("split", "split", 3), ("split, grad_terms=1", "split", 1)):
+    for name, prec, terms, wt, dt in (("fp32", "fp32", 3, None, None), ("split", "split", 3, None, None),
+                                      ("split, wgrad_terms=1", "split", 3, 1, None),
+                                      ("split, dgrad_terms=1", "split", 3, None, 1),
+                                      ("split, grad_terms=1", "split", 1, None, None)):
         model = T.Encoder(cfg).cuda().train()
         model.load_state_dict(init)
-        model.precision, model.grad_terms = prec, terms
+        model.precision, model.grad_terms, model.wgrad_terms, model.dgrad_terms = prec, terms, wt, dt
         opt, crit = FusedAdam(model.parameters(), lr=lr, weight_decay=0.01, decoupled=True), CrossEntropyLoss()
         losses = []
+        import time
+        t_steps = []
         for i in range(steps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
             x, y = batches[i % len(batches)]
             opt.zero_grad()
             loss = crit(model(x).logits, y)
             loss.backward()
             opt.step()
             losses.append(float(loss))
+            t_steps.append(time.perf_counter() - t0)
         model.eval()
         with torch.no_grad():
             held = model(hx).logits.float().cpu().numpy()
-        runs[name] = (np.array(losses), held)
+        runs[name] = (np.array(losses), held, float(np.median(t_steps[5:])) * 1e3)
         del model, opt
         torch.cuda.empty_cache()
-    ref_l, ref_h = runs["fp32"]
+    ref_l, ref_h, _ = runs["fp32"]
     print(f"== {kind} B={B}, {steps} AdamW steps at lr {lr:g}: loss {ref_l[0]:.4f} -> {ref_l[-1]:.4f} (exact-fp32 kernels)")
-    for name in ("split", "split, grad_terms=1"):
-        l, h = runs[name]
-        print(f"   {name:22s} max |loss - fp32 loss| over the run {np.abs(l - ref_l).max():.2e} (final {abs(l[-1] - ref_l[-1]):.2e}); "
+    for name in ("split", "split, wgrad_terms=1", "split, dgrad_terms=1", "split, grad_terms=1"):
+        l, h, ms = runs[name]
+        print(f"   {name:22s} {ms:6.2f} ms/step  max |loss - fp32 loss| over the run {np.abs(l - ref_l).max():.2e} (final {abs(l[-1] - ref_l[-1]):.2e}); "
               f"held-out logits after training: max |diff| {np.abs(h - ref_h).max():.2e} (logit range {np.abs(ref_h).max():.2f})")

@@ -38,7 +38,9 @@
 
 // timing-only ablation of the main loop (tools/probes/tr_ablate.sh builds variants; results are garbage): 1 = no fragment
 // reads, 2 = no LDS-DMA, 4 = no MFMAs, 16 / 32 = every tile streams the A / B rows of tile 0 (L2-hot operand), 64 = no
-// epilogue at all (the K loop alone: what bias / GELU / planes / maxima / stores cost a short-K product)
+// epilogue at all (the K loop alone: what bias / GELU / planes / maxima / stores cost a short-K product), 128 = the linear
+// epilogue without its global stores (arithmetic, LDS patch and loads stay), 256 = its stores wrapped into a 1-MB window of
+// the output (L2-resident: store issue and acknowledgement without the HBM write stream)
 #ifndef EAV_ABL
 #define EAV_ABL 0
 #endif
@@ -660,6 +662,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
     // wave's LDS patch (16-byte slots XOR-swizzled by row: conflict-free both ways) and comes back with lane l owning
     // columns 4 (l & 7) .. + 3 of rows (l >> 3) + 8 k - every global access of a wave instruction is then 8 whole
     // 128-byte row segments instead of 32 rows x 32 bytes (the planes conversion gained 25 % from the same change).
+    // (EAV_ABL store ablations of the linear epilogue)
+    auto st_off = [&](int64_t o) -> int64_t { return (EAV_ABL & 256) ? (o & ((int64_t)(1 << 18) - 1)) : o; };      // floats
+    auto st_offb = [&](int64_t o) -> int64_t { return (EAV_ABL & 256) ? (o & ((int64_t)(1 << 20) - 1)) : o; };     // bytes
     auto epilogue_linear = [&]() {
       float* patch = reinterpret_cast<float*>(smem + 2 * STAGE + wave * 4096);
       const int prow = lane >> 3, pc4 = lane & 7;
@@ -695,10 +700,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
               v[4 * k] *= gelu_erf_grad(p4.x); v[4 * k + 1] *= gelu_erf_grad(p4.y);
               v[4 * k + 2] *= gelu_erf_grad(p4.z); v[4 * k + 3] *= gelu_erf_grad(p4.w);
             }
-          } else if (pre) {
+          } else if (pre && !(EAV_ABL & 128)) {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-              *reinterpret_cast<float4*>(pre + o + (int64_t)8 * k * g.ldc) =
+              *reinterpret_cast<float4*>(pre + st_off(o + (int64_t)8 * k * g.ldc)) =
                   make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
           }
           if (g.gelu == 1) {
@@ -728,17 +733,18 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
               v[4 * k] += c4[k].x; v[4 * k + 1] += c4[k].y; v[4 * k + 2] += c4[k].z; v[4 * k + 3] += c4[k].w;
             }
           }
-          if (g.C) {
+          if (g.C && !(EAV_ABL & 128)) {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-              *reinterpret_cast<float4*>(C + o + (int64_t)8 * k * g.ldc) =
+              *reinterpret_cast<float4*>(C + st_off(o + (int64_t)8 * k * g.ldc)) =
                   make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
           }
           if (g.planes) {     // neighbouring lanes hold the two halves of a group of 8 columns: 16-byte piece stores
-            unsigned char* pp = g.planes + (int64_t)(rowb + prow) * g.ldp + (int64_t)((colb + 4 * pc4) >> 3) * 32 + (pc4 & 1) * 16;
+            const int64_t po = (int64_t)(rowb + prow) * g.ldp + (int64_t)((colb + 4 * pc4) >> 3) * 32 + (pc4 & 1) * 16;
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-              *reinterpret_cast<uint4*>(pp + (int64_t)8 * k * g.ldp) =
+              *reinterpret_cast<uint4*>((EAV_ABL & 128) ? reinterpret_cast<unsigned char*>(patch) + 64 * lane
+                                                        : g.planes + st_offb(po + (int64_t)8 * k * g.ldp)) =
                   plane_piece4(v[4 * k] * psig, v[4 * k + 1] * psig, v[4 * k + 2] * psig, v[4 * k + 3] * psig, g.lomul,
                                (pc4 & 1) == 0, 1);
           }

@@ -86,10 +86,6 @@ SIGNATURES = {
     "eav_rownorm_max": [_p, _i, _i, _i64, _p, _p],
     "eav_tf_forward_scales": [_p, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _i64, _i, _i, _i, _p],
     "eav_gemm_sp_splitk": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
-    "eav_gemm_sp_set_tile": [_i],
-    "eav_gemm_sp_set_splitk": [_i],
-    "eav_sp_set_convert_blocks": [_i],
-    "eav_attn_sp_set_nw4_above": [_i],
     "eav_attn_sp_prep": [_p, _p, _p, _p, _i, _i, _i, _i, C.c_uint, _p],
     "eav_attn_fwd_sp": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
     "eav_tf_forward_scales_qkv": [_p, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _i64, _i, _i, _i, _i, _p],
@@ -173,6 +169,10 @@ PLAIN = {
 
 EXPORTS = sorted(list(SIGNATURES) + list(PLAIN))
 
+# test / tuning overrides (include/eav_hip_tuning.h): process-global, never called by the package
+TUNING = {"eav_gemm_sp_set_tile": [_i], "eav_gemm_sp_set_splitk": [_i], "eav_sp_set_convert_blocks": [_i],
+          "eav_attn_sp_set_nw4_above": [_i]}
+
 # Comparison-only kernels (include/eav_hip_extras.h, `make BENCH_EXTRAS=1` -> libeav_extras.so): bench.py's literal-bf16 leg.
 EXTRAS_PATH = os.path.join(_HERE, "libeav_extras.so")
 EXTRAS = {
@@ -207,6 +207,10 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = res
+    for name, args in TUNING.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = _i
     _lib = lib
     return lib
 

@@ -25,6 +25,7 @@
 
 #include "eav_common.h"
 #include "../../include/eav_hip.h"
+#include "../../include/eav_hip_tuning.h"
 
 namespace {
 

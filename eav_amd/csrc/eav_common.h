@@ -29,7 +29,11 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // ELU(alpha=1) as torch computes it (expm1 for v<=0) and its derivative.
+#ifdef EAV_ABL_ELU      // timing-only ablation: the passes without their expm1 (results garbage)
+__device__ __forceinline__ float elu_f(float v) { return v > 0.f ? v : 0.5f * v; }
+#else
 __device__ __forceinline__ float elu_f(float v) { return v > 0.f ? v : expm1f(v); }
+#endif
 __device__ __forceinline__ float elu_grad_from_out(float v, float a) { return v > 0.f ? 1.f : a + 1.f; }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -270,6 +270,12 @@ __global__ __launch_bounds__(256) void pool_bwd_apply_kernel(const float* __rest
 // FUSED: dz is not read from memory but formed in the prologue from z (depthwiseConv output), dp2 (gradient of the pooled
 // block-1 output) and the depthwiseBN backward coefficients - the arithmetic of pool_bwd_apply_kernel<4>, whose launch
 // and whose dz round trip through HBM (2 x 164 MB at the bench shape) disappear.
+// DPP move of src under control CTRL into the lanes of the banks in BANK_MASK (the others keep `old`)
+template <int CTRL, int BANK_MASK>
+__device__ __forceinline__ float dpp_f(float old, float src) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, 0xf, BANK_MASK, false));
+}
+
 struct DwFuse {
   const float* z; const float* dp2; const float* bn2;   // bn2: mean, invstd, scale, shift, m1, m2 (64 each)
   float drop_p; uint64_t seed; const uint8_t* mask; const uint64_t* seed_dev;
@@ -368,12 +374,14 @@ __global__ __launch_bounds__(NT) void dw_bwd_kernel(const float* __restrict__ y1
 #ifdef DWB_ABL_NORED      // timing-only ablation (results garbage): the pass without its cross-lane reductions
     r1 = r[0] + r[1] + r[2] + r[3] + r[4] + r[5] + r[6] + r[7];
 #else
+    // (the partner values travel by DPP quad permutations / masked row shifts / v_permlane swaps: the same pairs and the same
+    // order of additions as the __shfl_xor butterfly this replaces - ten dependent ds_bpermute round trips per channel)
     {
       const bool hi = lane & 1;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         float mine = hi ? r[4 + k] : r[k], other = hi ? r[k] : r[4 + k];
-        r4[k] = mine + __shfl_xor(other, 1, 64);
+        r4[k] = mine + dpp_f<0xB1, 0xf>(0.f, other);                 // quad_perm:[1,0,3,2] = lane ^ 1
       }
     }
     {
@@ -381,17 +389,23 @@ __global__ __launch_bounds__(NT) void dw_bwd_kernel(const float* __restrict__ y1
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         float mine = hi ? r4[2 + k] : r4[k], other = hi ? r4[k] : r4[2 + k];
-        r2[k] = mine + __shfl_xor(other, 2, 64);
+        r2[k] = mine + dpp_f<0x4E, 0xf>(0.f, other);                 // quad_perm:[2,3,0,1] = lane ^ 2
       }
     }
     {
       const bool hi = lane & 4;
       float mine = hi ? r2[1] : r2[0], other = hi ? r2[0] : r2[1];
-      r1 = mine + __shfl_xor(other, 4, 64);
+      float part = dpp_f<0x104, 0x5>(0.f, other);                    // row_shl:4 into lanes 0-3 / 8-11 of every row
+      part = dpp_f<0x114, 0xA>(part, other);                         // row_shr:4 into lanes 4-7 / 12-15: lane ^ 4
+      r1 = mine + part;
     }
-    r1 += __shfl_xor(r1, 8, 64);
-    r1 += __shfl_xor(r1, 16, 64);
-    r1 += __shfl_xor(r1, 32, 64);
+    r1 += dpp_f<0x128, 0xf>(0.f, r1);                                // row_ror:8 = lane ^ 8
+    {
+      auto q = __builtin_amdgcn_permlane16_swap(__float_as_uint(r1), __float_as_uint(r1), false, false);
+      r1 = __uint_as_float(q[0]) + __uint_as_float(q[1]);            // own + lane ^ 16 (the two rows side by side)
+      auto h = __builtin_amdgcn_permlane32_swap(__float_as_uint(r1), __float_as_uint(r1), false, false);
+      r1 = __uint_as_float(h[0]) + __uint_as_float(h[1]);            // own + lane ^ 32
+    }
 #endif
     // lane l (l < 8) now holds the wave total of d = 4*(l&1) + 2*((l>>1)&1) + ((l>>2)&1)
     if (lane < 8) {

@@ -35,6 +35,7 @@
 
 #include "eav_common.h"
 #include "../../include/eav_hip.h"
+#include "../../include/eav_hip_tuning.h"
 
 // timing-only ablation of the main loop (tools/probes/tr_ablate.sh builds variants; results are garbage): 1 = no fragment
 // reads, 2 = no LDS-DMA, 4 = no MFMAs, 16 / 32 = every tile streams the A / B rows of tile 0 (L2-hot operand), 64 = no

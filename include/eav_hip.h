@@ -9,7 +9,8 @@
  * eav_last_error(), thread-local).  All pointers are caller-owned DEVICE pointers unless said
  * otherwise; nothing is allocated inside; `stream` is a hipStream_t (NULL = default stream);
  * launches are asynchronous.  Tensors are dense, row-major, fp32 unless noted.
- * The only process-wide state are the eav_*_set_* tuning hooks (tile shape, resident-block caps): plain globals read at
+ * The only process-wide state are the eav_*_set_* tuning hooks of include/eav_hip_tuning.h (tile shape, resident-block caps;
+ * test / benchmark use only, declared apart from this product ABI): plain globals read at
  * launch time, meant to be set once before work is issued (benchmarks / experiments), not synchronised across threads.
  */
 #ifndef EAV_HIP_H
@@ -364,18 +365,13 @@ int eav_gemm_sp_ex(const void* A, const void* B, float* C, const float* slotA, c
                    const float* planes_slot, float* colsum_part, int flags, void* stream);
 int eav_gemm_sp_splitk_x1(const void* A, const void* B, float* C, float* ws, const float* slotA, const float* slotB, int M,
                           int N, int T, int accumulate, void* stream);
-/* TEST / TUNING ONLY - process-global state, not part of the drop-in boundary: the trainers never call these; the kernel
- * benchmarks under tools/ and tests/test_split_kernels_gpu.py use them to A/B tile shapes inside one process. */
-int eav_gemm_sp_set_tile(int which);   /* 0 heuristic, 1 = 128x128 tiles, 2 = 256x128, +4 single accumulator, +8 non-persistent */
-int eav_gemm_sp_set_splitk(int slices);  /* eav_gemm_sp_splitk: forced slice count (0 = the plan; ws must hold it) */
-int eav_sp_set_convert_blocks(int n);  /* resident-block cap of eav_sp_convert (default 512; 0 = one block per tile) */
+/* (the process-global tile / slice-count overrides the kernel benchmarks use are NOT part of this header: eav_hip_tuning.h) */
 /* The same fused attention on the fp16 matrix cores with split operands (csrc/attention_sp.hip; fp32-grade, 3 MFMAs per
  * product).  eav_attn_sp_prep converts an fp32 activation src [B*N, ncols] (qkv or dO; slot holds its max|x| shards, see
  * EAV_SP_SLOT) into row planes [B*N][ncols/8][2][8] f16 and, for the column sections (of secw columns) selected by
  * tmask, per-head transposed planes [B][ncols/64][64][Npad/8][2][8] (Npad = eav_attn_sp_npad(N), zero beyond N); here
  * lo = fp16(sigma x - hi) without the 2^11 lift of the GEMM planes.  amax_slot (optional) receives max|output| shards. */
 int eav_attn_sp_npad(int N);
-int eav_attn_sp_set_nw4_above(int n);   /* TEST / TUNING ONLY (as eav_gemm_sp_set_tile): 128-row (4-wave) workgroups for N > n (default 128); n < 0: the software-pipelined forward from N >= -n (default 512) */
 int eav_attn_sp_prep(const float* src, float* slot, void* rowp, void* tp, int B, int N, int ncols, int secw,
                      unsigned tmask, void* stream);
 /* Since round 3 the three attention kernels take their token-contracting operands (V in the forward, K in the dQ kernel,

@@ -12,8 +12,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_symbols():
-    text = open(os.path.join(ROOT, "include", "eav_hip.h")).read()
+def _declared_symbols(header="eav_hip.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(eav_[a-z0-9_]+)\s*\(", text)))
 
@@ -27,6 +27,16 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in include/eav_hip.h but not exported"
     assert sorted(_lib.EXPORTS) == names, set(_lib.EXPORTS) ^ set(names)
     assert lib.eav_abi_version() == 3
+    # the process-global test / tuning overrides live in their own header, apart from the product ABI
+    tuning = _declared_symbols("eav_hip_tuning.h")
+    assert tuning == sorted(_lib.TUNING) and not set(tuning) & set(names)
+    for n in tuning:
+        assert hasattr(lib, n)
+    # every exported eav_* symbol is declared in one of the two headers
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = sorted({ln.split()[-1] for ln in out.splitlines() if " T eav_" in ln})
+    assert exported == sorted(names + tuning), set(exported) ^ set(names + tuning)
 
 
 def test_argument_validation_without_gpu():

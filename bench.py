@@ -819,7 +819,9 @@ def compact_headline(out):
         short = {"backend": mg.get("backend"), "rccl_ranks": mg.get("rccl_ranks")}
         for leg in ("strong", "weak", "subject_sharded"):
             if leg in mg:
-                short["eegnet_" + leg] = mg[leg]["value"]
+                short["eegnet_" + leg] = mg[leg].get("value")
+                if mg[leg].get("error"):
+                    short["eegnet_" + leg + "_error"] = mg[leg]["error"][:120]
         ss = mg.get("subject_sharded") or {}
         for k in ("ideal_speedup", "ideal_speedup_round_robin", "speedup_vs_one_gpu_rate_of_this_run", "speedup_vs_ideal",
                   "solo_ms_per_step", "tail_ms_per_step", "steps_per_subject"):
@@ -829,6 +831,8 @@ def compact_headline(out):
             for leg in ("strong", "subject_sharded"):
                 if kind in mg and leg in mg[kind]:
                     short[f"{kind}_{leg}"] = mg[kind][leg]["value"]
+            if (mg.get(kind) or {}).get("error"):
+                short[f"{kind}_error"] = mg[kind]["error"][:120]
             e = (mg.get(kind) or {}).get("subject_sharded") or {}
             if e.get("speedup_vs_ideal") is not None:
                 short[f"{kind}_subjects_speedup_vs_ideal"] = e["speedup_vs_ideal"]
@@ -991,7 +995,14 @@ def bench_eeg_subjects(dev, rank, world, steps, warmup, solo=None, n_subjects=42
     import torch.distributed as dist
     from eav_amd import dist as eav_dist
     sched = eav_dist.subject_schedule(world, n_subjects, hybrid=hybrid)
-    groups = sched.make_groups() if world > 1 else {}
+    groups = {}
+    if world > 1:
+        try:
+            groups = sched.make_groups()
+        except Exception as e:             # a backend that cannot form sub-groups: plain round-robin, every rank alike
+            print(f"bench.py: process sub-groups unavailable ({e!r}): round-robin schedule", file=sys.stderr)
+            hybrid = False
+            sched = eav_dist.subject_schedule(world, n_subjects, hybrid=False)
     if solo is None:
         solo = EEGRun(dev, rank, 1, B_PER_GPU, steps + warmup)
     keep_sync, solo.sync = solo.sync, None
@@ -1138,16 +1149,19 @@ def main():
         for leg, b_rank in (("strong", B_PER_GPU // world if B_PER_GPU % world == 0 else None), ("weak", B_PER_GPU)):
             if b_rank is None or leg == mode:
                 continue
-            r2 = EEGRun(dev, rank, world, b_rank, args.steps + args.warmup)
-            for i in range(max(args.warmup, 3)):
-                r2.step(i)
-            d2, _ = r2.timed(args.steps, args.warmup)
-            multi[leg] = {
-                "value": round(args.steps * b_rank * world / d2, 2), "unit": "samples/s",
-                "ms_per_step": round(d2 / args.steps * 1e3, 4), "per_gpu_batch": b_rank, "global_batch": b_rank * world,
-                "allreduce_bytes_per_step": 4 * r2.model._flat[1].numel(),
-                "note": f"data parallel, one all-reduce ({eav_dist.backend_name()}) of the flat gradient buffer per step"}
-            del r2
+            try:       # (a side leg must not cost the headline: its failure is reported in its place)
+                r2 = EEGRun(dev, rank, world, b_rank, args.steps + args.warmup)
+                for i in range(max(args.warmup, 3)):
+                    r2.step(i)
+                d2, _ = r2.timed(args.steps, args.warmup)
+                multi[leg] = {
+                    "value": round(args.steps * b_rank * world / d2, 2), "unit": "samples/s",
+                    "ms_per_step": round(d2 / args.steps * 1e3, 4), "per_gpu_batch": b_rank, "global_batch": b_rank * world,
+                    "allreduce_bytes_per_step": 4 * r2.model._flat[1].numel(),
+                    "note": f"data parallel, one all-reduce ({eav_dist.backend_name()}) of the flat gradient buffer per step"}
+                del r2
+            except Exception as e:
+                multi[leg] = {"value": None, "error": repr(e)[:300]}
             torch.cuda.empty_cache()
         if subj is None:
             multi["subject_sharded"] = bench_eeg_subjects(dev, rank, world, args.steps, args.warmup)
@@ -1169,7 +1183,12 @@ def main():
                                                         runs=(("unfrozen", False, "split"),))["unfrozen"]
         sections["encoders_s"] = round(time.perf_counter() - t0, 1)
         if world > 1:
-            enc_multi = {k: bench_encoder_multi(k, dev, rank, world) for k in ("ast", "vit")}
+            enc_multi = {}
+            for k in ("ast", "vit"):
+                try:
+                    enc_multi[k] = bench_encoder_multi(k, dev, rank, world)
+                except Exception as e:
+                    enc_multi[k] = {"error": repr(e)[:300]}
         if world == 1 and rank == 0 and not args.no_cpu_baseline:
             t0 = time.perf_counter()
             cpu_enc = {k: cpu_baseline_encoder(k) for k in ("ast", "vit")}

@@ -39,6 +39,12 @@ m = d["modalities"]
 rf = d["roofline"]
 v["EEG_V"], v["EEG_MS"] = fmt(d["value"]), f"{d['ms_per_step']:.3f}"
 v["EEG_RF"] = f"{rf['achieved']:.0f} / {rf['peak']:.0f} {rf['unit']} = {rf['frac']:.2f}"
+v["EEG_DOM"] = rf["kernel"]
+st = rf.get("step") or {}
+v["STEP_GB"] = f"{st.get('hbm_bytes_per_step', 0) / 1e9:.2f}"
+v["STEP_GBPS"] = f"{st.get('achieved', 0):.0f}"
+v["STEP_FRAC"] = f"{st.get('frac', 0):.2f}"
+v["STEP_RATIO"] = f"{st.get('ratio_to_fused_minimum', 0):.0f}"
 v["EEG_CPU"] = f"{d['cpu_baseline']['value']:.1f}"
 v["EEG_X"] = fmt(d["value"] / d["cpu_baseline"]["value"])
 for k, K in (("ast", "AST"), ("vit", "VIT")):

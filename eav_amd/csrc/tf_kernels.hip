@@ -152,6 +152,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         old = fmaxf(old, __shfl_xor(old, o, 64));
         dmx = fmaxf(dmx, __shfl_xor(dmx, o, 64));
       }
+      if (rmx == 0.f) {      // the slot was not written by the matching forward LayerNorm (rstd > 0 always): never trust a
+                             // zero - walk the saved rstd instead (slow path, the same value in every wave)
+        for (int i = lane; i < M; i += 64) rmx = fmaxf(rmx, rstd_i[i]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) rmx = fmaxf(rmx, __shfl_xor(rmx, o, 64));
+      }
       const float bound = (old + (2.f + sqrtf((float)D)) * gmx * rmx * dmx) * 1.0001f;
       psg = sigma_of_bound(bound);
       if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -888,6 +894,16 @@ __global__ __launch_bounds__(256) void layernorm_bwd_bound_kernel(float* __restr
   }
   if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = gmx; red[4 + (threadIdx.x >> 6)] = rmx; }
   __syncthreads();
+  if (slot_rstd && rstd && fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7])) == 0.f) {
+    // the slot's word 1 was never written by the matching forward (rstd > 0 always): walk the saved rstd instead
+    __syncthreads();
+    rmx = 0.f;
+    for (int i = threadIdx.x; i < M; i += 256) rmx = fmaxf(rmx, rstd[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) rmx = fmaxf(rmx, __shfl_xor(rmx, o, 64));
+    if ((threadIdx.x & 63) == 0) red[4 + (threadIdx.x >> 6)] = rmx;
+    __syncthreads();
+  }
   if (threadIdx.x == 0) {
     gmx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     rmx = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));

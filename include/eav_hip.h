@@ -266,7 +266,11 @@ typedef struct EavPlaneJob {
   int R, C;
 } EavPlaneJob;
 int eav_sp_refresh_planes(const void* jobs, int n, int maxR, int maxC, void* stream);
-/* producers that also accumulate max|output| into an operand-scale slot (zeroed by the caller) */
+/* producers that also accumulate max|output| into an operand-scale slot (zeroed by the caller).  Both LayerNorm forward forms
+ * that take a slot (amax_slot here, scale_slot of eav_layernorm_fwd_planes) ALSO WRITE max(rstd) into word 1 of the slot's 64
+ * shard lines (atomicMax of the float bits): the slot is an output of the forward in that respect even where it is declared
+ * const, and eav_layernorm_bwd_planes / _bound read it through slot_rstd (a slot whose word 1 is still zero is not trusted:
+ * the backward then walks rstd[M]). */
 int eav_layernorm_fwd_amax(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                            int M, int D, float eps, float* amax_slot, void* stream);
 int eav_layernorm_bwd_amax(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,

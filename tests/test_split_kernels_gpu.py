@@ -441,6 +441,15 @@ def test_layernorm_backward_writes_the_operand_planes_itself(M, D):
     _lib.call("eav_layernorm_bwd_planes", P(dy), P(x), P(g), P(mean), P(rstd), P(dx4), 1, P(part4), M, D, P(s4), P(pl4), P(s_old),
               P(s_dy), P(s_f), None)
     assert float(s4[2048]) == sig and float(s4[2049]) == 1.0 / sig and torch.equal(dx4, dx2) and torch.equal(part4, part2)
+    # a slot_rstd the matching forward never wrote (word 1 still zero) is not trusted: both forms walk rstd[M] instead and
+    # arrive at the same bound - a zero max(rstd) would shrink it to max|dx_old| and overflow the fp16 pieces (advisor r4)
+    s_z, s5, s6 = (torch.zeros(SLOT, device="cuda") for _ in range(3))
+    _lib.call("eav_layernorm_bwd_bound", P(s5), P(s_old), P(s_dy), P(g), P(rstd), M, D, P(s_z), None)
+    assert float(s5[2048]) == sig
+    dx6, part6, pl6 = old.clone(), torch.zeros(npart, 3 * D, device="cuda"), torch.zeros_like(pl)
+    _lib.call("eav_layernorm_bwd_planes", P(dy), P(x), P(g), P(mean), P(rstd), P(dx6), 1, P(part6), M, D, P(s6), P(pl6), P(s_old),
+              P(s_dy), P(s_z), None)
+    assert float(s6[2048]) == sig and torch.equal(dx6, dx2) and torch.equal(pl6[:M, :2 * D], pl[:M, :2 * D])
     assert torch.equal(dx2, dx1)
     assert torch.equal(pl4[:M, :2 * D], pl[:M, :2 * D])
     assert torch.equal(part2[:, :2 * D], part1)

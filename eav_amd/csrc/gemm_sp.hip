@@ -804,6 +804,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
 
 int g_order = 0;
 int g_force_tile = 0;   // test / tuning hook: 0 = heuristic, 1 = 128x128, 2 = 256x128
+int g_small_tile = 0;   // test / tuning hook: 0 = heuristic, 1 = 64x128 wherever it applies, 2 = never
 // 11 (default): lo = fp16((t - hi) 2^11), cross terms in a second accumulator folded in with 2^-11 - both pieces stay
 // normal fp16 numbers for elements down to 2^-29 of the tensor maximum.  0: lo = fp16(t - hi), one accumulator (64 fewer
 // VGPRs, same speed at 2 waves per SIMD; full precision only down to 2^-15 of the maximum) - kept as a tuning hook.
@@ -823,8 +824,11 @@ bool launch(SpArgs& g, int nz, hipStream_t st, int terms = 3) {
   const int resident = (WM * WN <= 4 ? 2 : 1) * 256 * (g_persist ? 1 : 1 << 20);
   const int nb = g.tm * g.tn, gx = nb <= resident ? nb : resident;
   if (terms == 1) {
-    hipLaunchKernelGGL((gemm_sp_kernel<WM, WN, RM, RN, false, TR, 1, NS>), dim3(gx, 1, nz), dim3(64 * WM * WN), 0, st, g);
-    return true;
+    if constexpr (RM * RN >= 4) {      // (the one-term form has too few MFMA slots per K-step for the chunks of a 64-row tile)
+      hipLaunchKernelGGL((gemm_sp_kernel<WM, WN, RM, RN, false, TR, 1, NS>), dim3(gx, 1, nz), dim3(64 * WM * WN), 0, st, g);
+      return true;
+    }
+    return false;
   } else if (g_loshift) {
     if constexpr (RM * RN <= 4) {
       hipLaunchKernelGGL((gemm_sp_kernel<WM, WN, RM, RN, true, TR, 3, NS>), dim3(gx, 1, nz), dim3(64 * WM * WN), 0, st, g);
@@ -851,6 +855,12 @@ bool dispatch(SpArgs& g, int nz, hipStream_t st, int terms = 3, bool shared_gpu 
   const bool big = g_force_tile == 2 || (g_force_tile == 0 && shared_gpu && cdiv(g.M, 256) * cdiv(g.N, 128) >= 256);
   if (g_force_tile == 3) return launch<2, 4, 2, 2, false, 3>(g, nz, st, terms);
   if (big) return launch<4, 2, 2, 2, false, 3>(g, nz, st, terms);
+  // Fewer 128 x 128 tiles than CUs (the N = 768 products at the per-rank batches of a data-parallel group: ViT B = 16 is
+  // 25 x 6 = 150 tiles, a launch then lasts one tile's K loop on 150 of 256 CUs): 64 x 128 tiles, four waves of 32 x 64 -
+  // twice the workgroups of half the length.  (Not with column sums: their partial rows are per 64 output rows of ONE wave.)
+  if (g_force_tile == 0 && g_small_tile != 2 && terms == 3 && g_loshift && !g.colsum && g.M > 64 &&
+      (g_small_tile == 1 || cdiv(g.M, 128) * cdiv(g.N, 128) * nz <= 256))
+    return launch<2, 2, 1, 2>(g, nz, st, terms);
   return launch<2, 2, 2, 2>(g, nz, st, terms);
 }
 
@@ -1177,6 +1187,7 @@ extern "C" int eav_gemm_sp_set_splitk(int slices) {
 
 extern "C" int eav_gemm_sp_set_tile(int which) {
   g_force_tile = which & 3;
+  g_small_tile = (which >> 6) & 3;      // +64: the 64 x 128 form wherever it applies, +128: never
   g_order = (which >> 4) & 3;      // +16: groups of 8 tile-rows, +32: row-major, 0: by shape
   g_loshift = (which & 4) ? 0 : 11;
   g_persist = (which & 8) ? 0 : 1;

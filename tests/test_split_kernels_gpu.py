@@ -70,11 +70,22 @@ def test_planes_encode_the_tensor():
     assert torch.equal(recT[:, :77], rec[:, :100].t())
 
 
+@pytest.fixture
+def tile_hook():
+    """eav_gemm_sp_set_tile for one test (process-global tuning hook, include/eav_hip_tuning.h): restored afterwards."""
+    def set_tile(v):
+        _lib.call("eav_gemm_sp_set_tile", int(v))
+    yield set_tile
+    _lib.call("eav_gemm_sp_set_tile", 0)
+
+
 @pytest.mark.parametrize("shape", [(512, 384, 768), (1000, 200, 100), (9712, 768, 3072), (300, 130, 40), (64, 5, 36),
                                    (9712, 2304, 768)])     # the last one: 1368 tiles on 512 persistent workgroups
 @pytest.mark.parametrize("amp", [(1.0, 0.02), (2e-5, 3e4)])
-def test_gemm_sp_is_fp32_grade(shape, amp):
+@pytest.mark.parametrize("tile", [0, 64, 128])      # heuristic / the 64 x 128 form wherever it applies / never
+def test_gemm_sp_is_fp32_grade(shape, amp, tile, tile_hook):
     M, N, K = shape
+    tile_hook(tile)
     torch.manual_seed(M + N + K)
     A = torch.randn(M, K, device="cuda") * amp[0]
     B = torch.randn(N, K, device="cuda") * amp[1]
@@ -331,10 +342,12 @@ def test_attention_sp_is_fp32_grade(cfg):
 @pytest.mark.parametrize("opts", [dict(bias=True), dict(bias=True, gelu=1, pre=True), dict(bias=True, resid=True),
                                   dict(gelu=1, resid=True, acc=True, pre=True), dict(acc=True), dict(gelu=2),
                                   dict(bias=True, gelu=2, resid=True)])
-def test_gemm_sp_epilogue_option_matrix(shape, opts):
+@pytest.mark.parametrize("tile", [64, 128])         # 64 x 128 tiles (these launches are far below one tile per CU) / 128 x 128
+def test_gemm_sp_epilogue_option_matrix(shape, opts, tile, tile_hook):
     """Every epilogue option combination on tiles inside the matrix (16-byte path) and ragged ones (element path),
     against float64: C = [accumulate C0 +] [resid +] act(alpha A.B^T + bias), act = GELU or . x gelu'(pre)."""
     M, N, K = shape
+    tile_hook(tile)
     torch.manual_seed(M + N + len(opts))
     A = torch.randn(M, K, device="cuda")
     B = torch.randn(N, K, device="cuda") * 0.2

@@ -42,6 +42,7 @@ SIGNATURES = {
     "eav_eegnet_fir_wgrad_fft": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "eav_eegnet_fir_wgrad_indexed": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "eav_eegnet_dw_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _p],
+    "eav_eegnet_dw_fwd_pool_eval": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     "eav_eegnet_dw_bwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     "eav_eegnet_dw_bwd_fused": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _u64, _p, _p, _p],
     "eav_bn_elu_pool_fwd": [_p, _p, _p, _i, _i, _i, _i, _f, _u64, _p, _p, _p],

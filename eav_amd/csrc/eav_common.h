@@ -32,7 +32,17 @@ static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 #ifdef EAV_ABL_ELU      // timing-only ablation: the passes without their expm1 (results garbage)
 __device__ __forceinline__ float elu_f(float v) { return v > 0.f ? v : 0.5f * v; }
 #else
+// (branch-free: `v > 0 ? v : expm1f(v)` compiles to an exec-masked branch around every call - the lanes of a wave diverge on the
+// sign, so nothing is skipped, and the four calls per channel of the depthwise passes sit in four basic blocks that cannot be
+// interleaved.  Same values bit for bit: expm1f of the clamped argument, selected.)
+#ifdef EAV_ELU_BRANCHY
 __device__ __forceinline__ float elu_f(float v) { return v > 0.f ? v : expm1f(v); }
+#else
+__device__ __forceinline__ float elu_f(float v) {
+  const float e = expm1f(fminf(v, 0.f));
+  return v > 0.f ? v : e;
+}
+#endif
 #endif
 __device__ __forceinline__ float elu_grad_from_out(float v, float a) { return v > 0.f ? 1.f : a + 1.f; }
 

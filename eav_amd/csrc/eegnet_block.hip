@@ -86,7 +86,8 @@ __device__ __forceinline__ void block_sum_nt(float (&v)[NV], float* red) {
 template <int CG, int NT>
 __global__ __launch_bounds__(NT) void dw_fwd_kernel(const float* __restrict__ y1, const float* __restrict__ bn1,
                                                      const float* __restrict__ w2, float* __restrict__ z,
-                                                     float* __restrict__ part, int C, int S) {
+                                                     float* __restrict__ part, int C, int S,
+                                                     const float* __restrict__ bn2, float* __restrict__ p2) {
   __shared__ float wsh[DD * CHMAX];
   __shared__ float red[NT / 64 * 16];
   __shared__ float xsum[CG > 1 ? (CG - 1) * DD * 4 * (NT / CG) : 1];
@@ -152,6 +153,17 @@ __global__ __launch_bounds__(NT) void dw_fwd_kernel(const float* __restrict__ y1
     st[d] = s;
     st[8 + d] = q;
     if (mine && t < S) st4s(z + ((int64_t)b * F1 * DD + f * DD + d) * S, t, S, vec, acc[d]);
+    // eval-mode forward (bn2 = depthwiseBN on its RUNNING statistics, known before this launch; no dropout): the thread's four
+    // samples are exactly one AvgPool(1,4) window, so depthwiseBN -> ELU -> pool leaves here too - pool_fwd_kernel<4> and its
+    // read of z (164 MB at the bench shape) disappear from eval-mode steps.  The same arithmetic as pool_fwd_kernel<4>.
+    if (p2 && mine && t + 3 < S) {
+      const int ch = f * DD + d, CH = F1 * DD;
+      const float sc2 = bn2[2 * CH + ch], sh2 = bn2[3 * CH + ch];
+      float ps = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ps += elu_f(sc2 * acc[d][e] + sh2);
+      p2[((int64_t)b * CH + ch) * (S / 4) + t / 4] = ps * 0.25f;
+    }
   }
   block_sum_nt<NT, 16>(st, red);
   if (threadIdx.x < 16) {
@@ -427,18 +439,39 @@ __global__ __launch_bounds__(NT) void dw_bwd_kernel(const float* __restrict__ y1
 
 }  // namespace
 
+static int dw_fwd_launch(const float* y1, const float* bn1, const float* w2, float* z, float* stat_part, int B, int C,
+                         int S, const float* bn2, float* p2, void* stream) {
+  dim3 grid(cdiv(S, 1024), F1, B);
+  if (S <= 256)         // short rows: channel groups (see the kernel)
+    hipLaunchKernelGGL((dw_fwd_kernel<4, 256>), grid, dim3(256), 0, (hipStream_t)stream, y1, bn1, w2, z, stat_part, C, S,
+                       bn2, p2);
+  else if (S <= 512)
+    hipLaunchKernelGGL((dw_fwd_kernel<4, 512>), grid, dim3(512), 0, (hipStream_t)stream, y1, bn1, w2, z, stat_part, C, S,
+                       bn2, p2);
+  else
+    hipLaunchKernelGGL((dw_fwd_kernel<1, 256>), grid, dim3(256), 0, (hipStream_t)stream, y1, bn1, w2, z, stat_part, C, S,
+                       bn2, p2);
+  return EAV_OK;
+}
+
 extern "C" int eav_eegnet_dw_fwd(const float* y1, const float* bn1, const float* w2, float* z, float* stat_part,
                                  int B, int C, int S, void* stream) {
   EAV_REQUIRE(y1 && bn1 && w2 && z && stat_part && B > 0 && C > 0 && C <= CHMAX && S > 0,
               "eav_eegnet_dw_fwd: bad arguments (Chans must be <= %d)", CHMAX);
-  dim3 grid(cdiv(S, 1024), F1, B);
-  if (S <= 256)         // short rows: channel groups (see the kernel)
-    hipLaunchKernelGGL((dw_fwd_kernel<4, 256>), grid, dim3(256), 0, (hipStream_t)stream, y1, bn1, w2, z, stat_part, C, S);
-  else if (S <= 512)
-    hipLaunchKernelGGL((dw_fwd_kernel<4, 512>), grid, dim3(512), 0, (hipStream_t)stream, y1, bn1, w2, z, stat_part, C, S);
-  else
-    hipLaunchKernelGGL((dw_fwd_kernel<1, 256>), grid, dim3(256), 0, (hipStream_t)stream, y1, bn1, w2, z, stat_part, C, S);
+  dw_fwd_launch(y1, bn1, w2, z, stat_part, B, C, S, nullptr, nullptr, stream);
   EAV_CHECK_LAUNCH("eav_eegnet_dw_fwd");
+  return EAV_OK;
+}
+
+// eav_eegnet_dw_fwd that also leaves p2 [B,64,S/4] = AvgPool(1,4)(ELU(depthwiseBN(z))) (EEGNet_tor.py:55-57) for a
+// depthwiseBN in EVAL mode: bn2 = its finalised parameter block (eav_bn_finalize with training = 0: scale / shift from the
+// running statistics), no dropout (nn.Dropout is the identity in eval mode).  S % 4 == 0.
+extern "C" int eav_eegnet_dw_fwd_pool_eval(const float* y1, const float* bn1, const float* w2, float* z, float* stat_part,
+                                           const float* bn2, float* p2, int B, int C, int S, void* stream) {
+  EAV_REQUIRE(y1 && bn1 && w2 && z && stat_part && bn2 && p2 && B > 0 && C > 0 && C <= CHMAX && S > 0 && (S & 3) == 0,
+              "eav_eegnet_dw_fwd_pool_eval: bad arguments (Chans <= %d, Samples %% 4 == 0)", CHMAX);
+  dw_fwd_launch(y1, bn1, w2, z, stat_part, B, C, S, bn2, p2, stream);
+  EAV_CHECK_LAUNCH("eav_eegnet_dw_fwd_pool_eval");
   return EAV_OK;
 }
 

@@ -382,6 +382,7 @@ constexpr int NWF = 12;
 #endif
 constexpr int HB = 520;         // float2 slots per filter: bins 0 .. 512, padded to a multiple of 64 bytes
 
+template <bool STATS>
 __global__ __launch_bounds__(64 * NWF, 1) void fir_fft_fwd_kernel(const float* __restrict__ x, const int64_t* __restrict__ xidx,
                                                                   const float* __restrict__ w1, float* __restrict__ y1,
                                                                   float* __restrict__ part, int C, int S, int klen, int padl,
@@ -446,6 +447,25 @@ __global__ __launch_bounds__(64 * NWF, 1) void fir_fft_fwd_kernel(const float* _
       fft1024<true>(v, xb, lane, tw);
       float* dst = y1 + (((int64_t)b * F1 + f) * C + c0) * S + t0 + lane;
       float a1, a2;
+      if (!STATS) {      // firstBN in eval mode: no batch statistics to collect (STATS = false: stat_part is not written)
+        a1 = a2 = 0.f;
+        if (has1 && t0 + LB <= S) {
+#pragma unroll
+          for (int j = 0; j < NROW; ++j) {
+            EAV_STG(dst + 64 * j, v[j].x);
+            EAV_STG(dst + S + 64 * j, v[j].y);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < NROW; ++j) {
+            if (t0 + lane + 64 * j < S) {
+              EAV_STG(dst + 64 * j, v[j].x);
+              if (has1) EAV_STG(dst + S + 64 * j, v[j].y);
+            }
+          }
+        }
+        continue;
+      }
       if (has1 && t0 + LB <= S) {      // a whole block of a full pair (14 of 15): no predicates
         v2f s1 = (v2f){0.f, 0.f}, s2 = (v2f){0.f, 0.f};
 #pragma unroll
@@ -479,7 +499,7 @@ __global__ __launch_bounds__(64 * NWF, 1) void fir_fft_fwd_kernel(const float* _
       if (lane == 8 + f) sacc += a2;
     }
   }
-  if (lane < 16) part[wgid * 16 + lane] = sacc;      // (a wave without units writes its zeros)
+  if (STATS && lane < 16) part[wgid * 16 + lane] = sacc;      // (a wave without units writes its zeros)
 }
 
 // ---------------------------------------------------------------------------------------------------------------- wgrad
@@ -679,15 +699,20 @@ extern "C" int eav_eegnet_fir_fwd_fft_nparts(int B, int C, int S) {
 }
 
 // y1 [B,8,C,S] = firstConv(x) for the batch x[xidx[0..B)] (xidx NULL: x itself), 'same' padding, klen <= 321 taps;
-// stat_part [eav_eegnet_fir_fwd_fft_nparts][16]: per-wave sums / sums of squares per filter (input of eav_bn_finalize).
+// stat_part [eav_eegnet_fir_fwd_fft_nparts][16]: per-wave sums / sums of squares per filter (input of eav_bn_finalize); NULL:
+// none (firstBN in eval mode takes its running statistics - the sums, their wave totals and the partial rows are skipped).
 extern "C" int eav_eegnet_fir_fwd_fft(const float* x, const int64_t* xidx, const float* w1, float* y1, float* stat_part,
                                       int B, int C, int S, int klen, void* stream) {
-  EAV_REQUIRE(x && w1 && y1 && stat_part && B > 0 && C > 0 && S > 0, "eav_eegnet_fir_fwd_fft: bad arguments");
+  EAV_REQUIRE(x && w1 && y1 && B > 0 && C > 0 && S > 0, "eav_eegnet_fir_fwd_fft: bad arguments");
   EAV_REQUIRE(klen >= 1 && klen <= MAXK, "eav_eegnet_fir_fwd_fft: kernLength %d outside [1,%d]", klen, MAXK);
   int npair, nblk;
   const int nunits = fft_units(B, C, S, &npair, &nblk);
-  hipLaunchKernelGGL(fir_fft_fwd_kernel, dim3(fft_grid(nunits, NWF)), dim3(64 * NWF), 0, (hipStream_t)stream, x, xidx, w1, y1,
-                     stat_part, C, S, klen, (klen - 1) / 2, npair, nblk, nunits);
+  if (stat_part)
+    hipLaunchKernelGGL(fir_fft_fwd_kernel<true>, dim3(fft_grid(nunits, NWF)), dim3(64 * NWF), 0, (hipStream_t)stream, x, xidx,
+                       w1, y1, stat_part, C, S, klen, (klen - 1) / 2, npair, nblk, nunits);
+  else      // firstBN in eval mode: running statistics, nothing to collect
+    hipLaunchKernelGGL(fir_fft_fwd_kernel<false>, dim3(fft_grid(nunits, NWF)), dim3(64 * NWF), 0, (hipStream_t)stream, x, xidx,
+                       w1, y1, stat_part, C, S, klen, (klen - 1) / 2, npair, nblk, nunits);
   EAV_CHECK_LAUNCH("eav_eegnet_fir_fwd_fft");
   return EAV_OK;
 }

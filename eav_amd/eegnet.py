@@ -352,10 +352,11 @@ class EEGNet_tor(nn.Module):
                 L("eav_eegnet_block1_infer", P(x), None, w1, P(ws.bn1), w2, P(ws.bn2), P(ws.p2), B, C, S, K, st)
         elif self._use_fft():
             np_fir = ws.np_fir_fft
+            pf = P(ws.part_fir) if training else None      # eval mode: firstBN needs no batch statistics
             if isinstance(x, IndexedBatch):
-                L("eav_eegnet_fir_fwd_fft", P(x.data), P(x.idx), w1, P(ws.y1), P(ws.part_fir), B, C, S, K, st)
+                L("eav_eegnet_fir_fwd_fft", P(x.data), P(x.idx), w1, P(ws.y1), pf, B, C, S, K, st)
             else:
-                L("eav_eegnet_fir_fwd_fft", P(x), None, w1, P(ws.y1), P(ws.part_fir), B, C, S, K, st)
+                L("eav_eegnet_fir_fwd_fft", P(x), None, w1, P(ws.y1), pf, B, C, S, K, st)
         else:
             if isinstance(x, IndexedBatch):
                 L("eav_eegnet_fir_fwd_indexed", P(x.data), P(x.idx), w1, P(ws.y1), P(ws.part_fir), B, C, S, K, st)
@@ -363,9 +364,17 @@ class EEGNet_tor(nn.Module):
                 L("eav_eegnet_fir_fwd", P(x), w1, P(ws.y1), P(ws.part_fir), B, C, S, K, st)
         if not infer:
             bnfin(ws.part_fir, np_fir, 8, B * C * S, g1w, g1b, bn1, ws.bn1)
-            L("eav_eegnet_dw_fwd", P(ws.y1), P(ws.bn1), w2, P(ws.z), P(ws.part_dw), B, C, S, st)
-            bnfin(ws.part_dw, B * ws.nchunk, 64, B * S, g2w, g2b, bn2, ws.bn2)
-            L("eav_bn_elu_pool_fwd", P(ws.z), P(ws.bn2), P(ws.p2), B, 64, S, 4, drop, seed1, m1, cnt, st)
+            if not training and drop == 0.0 and m1 is None and S % 4 == 0:
+                # eval-mode step (what 349 of the reference's 350 epochs run, Q4): depthwiseBN's scale / shift come from the
+                # running statistics, i.e. they are known BEFORE the depthwise pass - which then leaves the pooled block-1
+                # output too (z is still written: the backward forms dz from it); one launch and one pass over z less
+                bnfin(ws.part_dw, B * ws.nchunk, 64, B * S, g2w, g2b, bn2, ws.bn2)
+                L("eav_eegnet_dw_fwd_pool_eval", P(ws.y1), P(ws.bn1), w2, P(ws.z), P(ws.part_dw), P(ws.bn2), P(ws.p2), B, C, S,
+                  st)
+            else:
+                L("eav_eegnet_dw_fwd", P(ws.y1), P(ws.bn1), w2, P(ws.z), P(ws.part_dw), B, C, S, st)
+                bnfin(ws.part_dw, B * ws.nchunk, 64, B * S, g2w, g2b, bn2, ws.bn2)
+                L("eav_bn_elu_pool_fwd", P(ws.z), P(ws.bn2), P(ws.p2), B, 64, S, 4, drop, seed1, m1, cnt, st)
         np_c3 = ws.np_c3
         if self._use_conv_fft(B):
             if ws.c64_ws is None:

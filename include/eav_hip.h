@@ -72,7 +72,8 @@ int eav_eegnet_fir_wgrad(const float* x, const float* y1, const float* g1, const
  * eav_eegnet_fir_fwd / eav_eegnet_fir_wgrad (nn.Conv2d(1, 8, (1, kernLength), padding='same', bias=False) and autograd's
  * weight gradient of it, CNN_torch/EEGNet_tor.py:24,51,109) in ~13 x fewer flops - HBM-bound instead of MFMA-bound; up to
  * eav_eegnet_fir_fft_max_taps() = 321 taps, any C / S.  xidx (optional): the batch is x[xidx[0..B)].
- * fwd: stat_part [eav_eegnet_fir_fwd_fft_nparts(B,C,S)][16] (8 sums, 8 sums of squares per row) for eav_bn_finalize.
+ * fwd: stat_part [eav_eegnet_fir_fwd_fft_nparts(B,C,S)][16] (8 sums, 8 sums of squares per row) for eav_bn_finalize; NULL:
+ * no statistics are collected (firstBN in eval mode uses its running statistics).
  * wgrad: dW [8, klen] is WRITTEN (no partials to reduce); ws: eav_eegnet_fir_wgrad_fft_ws_floats(B,C,S) floats;
  * y1 = NULL selects BatchNorm in eval mode (dy = scale g).  Bit-reproducible run to run. */
 int eav_eegnet_fir_fft_max_taps(void);
@@ -90,6 +91,12 @@ int eav_eegnet_fir_wgrad_indexed(const float* x, const int64_t* xidx, const floa
  * stat_part [B*ceil(S/1024)][128]. */
 int eav_eegnet_dw_fwd(const float* y1, const float* bn1, const float* w2, float* z, float* stat_part, int B, int C,
                       int S, void* stream);
+/* eav_eegnet_dw_fwd that also leaves p2 [B,64,S/4] = AvgPool(1,4)(ELU(depthwiseBN(z))) (EEGNet_tor.py:55-57) when
+ * depthwiseBN is in EVAL mode: bn2 = its parameter block as eav_bn_finalize(training = 0) leaves it (scale / shift from the
+ * running statistics, known before the launch); no dropout (identity in eval mode).  Saves eav_bn_elu_pool_fwd's pass over
+ * z in the eval-mode training steps the reference runs from its second epoch on.  S % 4 == 0. */
+int eav_eegnet_dw_fwd_pool_eval(const float* y1, const float* bn1, const float* w2, float* z, float* stat_part,
+                                const float* bn2, float* p2, int B, int C, int S, void* stream);
 /* backward of the above: g1 [B,8,C,S] = dL/d(firstBN out); stat_part [B*ceil(S/1024)][16];
  * w_part [B*ceil(S/1024)][64*C]. */
 int eav_eegnet_dw_bwd(const float* y1, const float* dz, const float* bn1, const float* w2, float* g1,

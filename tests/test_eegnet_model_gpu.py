@@ -227,6 +227,45 @@ def test_full_size_batch_against_oracle():
         assert torch.equal(n2[k].grad, g1[k]), k
 
 
+@pytest.mark.parametrize("B,S", [(4, 2816), (3, 10000)])
+def test_eval_mode_training_step_on_the_fft_path_against_oracle(B, S):
+    """What epochs 2 .. 350 of the reference run (Q4: the model stays in eval mode after the first validate()): BatchNorm on
+    running statistics, no dropout, WITH a backward.  On the FFT path this step takes three eval-only shortcuts - firstConv
+    collects no statistics, depthwiseBN -> ELU -> AvgPool4 leaves the depthwise pass itself (eav_eegnet_dw_fwd_pool_eval), the
+    weight gradient skips y1 - all held to the train-mode bounds against the oracle, with non-trivial running statistics."""
+    from eav_amd.optim import CrossEntropyLoss
+    from oracle import eegnet_oracle as orc
+    sd = eegnet_weights(37, S)
+    rng = np.random.default_rng(5)
+    for k in list(sd):                      # running statistics a trained model would have (the defaults are 0 / 1)
+        if k.endswith("running_mean"):
+            sd[k] = (0.05 * rng.standard_normal(sd[k].shape)).astype(np.float32)
+        if k.endswith("running_var"):
+            sd[k] = (0.5 + rng.random(sd[k].shape)).astype(np.float32)
+    model = build(S, sd)
+    model.eval()
+    assert model._use_fft()
+    x, y = synth.eeg_batch(411, B, 30, S)
+    scores = model(torch.from_numpy(x).cuda())
+    loss = CrossEntropyLoss()(scores, torch.from_numpy(y).cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    P = {k: torch.from_numpy(sd[k].copy()) for k in orc.PARAM_NAMES}
+    Bf = {k: torch.from_numpy(sd[k].copy()) for k in orc.BUFFER_NAMES}
+    st = orc.Stepper(P, Bf, lr=1e-3, drop_p=0.5)
+    probs, lref, grads = st.step(torch.from_numpy(x), torch.from_numpy(y), False, None)
+    close(scores, probs.numpy(), 1e-4, 2e-5, "probs")
+    close(loss, lref.numpy(), 1e-5, 1e-5, "loss")
+    named = dict(model.named_parameters())
+    for k in PN:
+        ref = grads[k].numpy()
+        close(named[k].grad, ref, 2e-3, 2e-3 * np.abs(ref).max(), f"grad.{k}")
+    # the running statistics are untouched by an eval-mode step
+    for k in orc.BUFFER_NAMES:
+        if "running" in k:
+            assert np.array_equal(dict(model.named_buffers())[k].cpu().numpy(), sd[k]), k
+
+
 def test_trainer_loop_matches_reference(golden_dir):
     """Trainer_uni.train() for 2 epochs (epoch 2 trains in eval mode, Q4), replaying
     the reference's recorded shuffle order; compares the printed lines' numbers,

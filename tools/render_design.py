@@ -40,6 +40,7 @@ rf = d["roofline"]
 v["EEG_V"], v["EEG_MS"] = fmt(d["value"]), f"{d['ms_per_step']:.3f}"
 v["EEG_RF"] = f"{rf['achieved']:.0f} / {rf['peak']:.0f} {rf['unit']} = {rf['frac']:.2f}"
 v["EEG_DOM"] = rf["kernel"]
+v["EVAL_MS"] = f"{d.get('eval_mode_training', {}).get('ms_per_step', float('nan')):.3f}"
 st = rf.get("step") or {}
 v["STEP_GB"] = f"{st.get('hbm_bytes_per_step', 0) / 1e9:.2f}"
 v["STEP_GBPS"] = f"{st.get('achieved', 0):.0f}"

@@ -38,6 +38,20 @@ want = t.clone()
 w = dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
 w.wait()
 assert torch.equal(t, want)
+# a process SUB-group over RCCL (the tail groups of eav_amd.dist.SubjectSchedule are torch.distributed.new_group communicators):
+# created, reduced in, and a GradSync bound to it - identity on one rank, bit for bit
+sub = dist.new_group(ranks=[0])
+t2 = torch.arange(4096, dtype=torch.float32, device=dev) * 0.5
+dist.all_reduce(t2, op=dist.ReduceOp.SUM, group=sub)
+torch.cuda.synchronize()
+assert torch.equal(t2, torch.arange(4096, dtype=torch.float32, device=dev) * 0.5)
+gs = ed.GradSync([t2], group=sub, force=True)
+gs.bucket(100, 2000)
+gs()
+torch.cuda.synchronize()
+assert gs.world == 1 and gs.collectives == 3 and torch.equal(t2, torch.arange(4096, dtype=torch.float32, device=dev) * 0.5)
+sched = ed.subject_schedule(1, 3)
+assert sched.make_groups() == {} and sched.solo == [[1, 2, 3]] and sched.ideal_speedup() == 1.0
 big = torch.randn(86_192_645, device=dev)              # the AST gradient buffer: 345 MB in one call
 ref = big.clone()
 dist.all_reduce(big)

@@ -4,10 +4,12 @@
     python tools/run_eeg_subjects.py [--subjects 42] [--epochs 3] [--samples 500]
     python -m torch.distributed.run --nproc-per-node 8 tools/run_eeg_subjects.py ...
 
-Each rank trains its share of the 42 independent subjects (round-robin, no gradient traffic - SURVEY.md section 8e
-level 1) with the reference's hyper-parameters (lr 1e-5, batch 32) on synthetic recordings
-(eav_amd.synth.eeg_subject -> EAVDataSplit -> EEGNet_tor -> Trainer_uni), then the per-subject test accuracies
-are gathered on rank 0.  With real data, replace `synthetic_subject` by DataLoadEEG(...).prepare_data().
+Each rank trains its share of the 42 independent subjects with the reference's hyper-parameters (lr 1e-5, batch 32) on
+synthetic recordings (eav_amd.synth.eeg_subject -> EAVDataSplit -> EEGNet_tor -> Trainer_uni), then the per-subject test
+accuracies are gathered on rank 0.  Placement: eav_amd.dist.SubjectSchedule - whole rounds one subject per rank with no
+gradient traffic (SURVEY.md section 8e level 1), the 42 mod N remaining subjects on groups of ranks (every member a replica on
+every n-th training trial with 1 / n of the batch, gradients all-reduced inside the group: the reference's DataParallel
+wrap, EEGNet_tor.py:86-88); --no-hybrid: plain round-robin.  With real data, replace `synthetic_subject` by DataLoadEEG(...).prepare_data().
 """
 import argparse
 import contextlib
@@ -37,24 +39,38 @@ def main():
     ap.add_argument("--epochs", type=int, default=3)
     ap.add_argument("--samples", type=int, default=500)
     ap.add_argument("--quiet", action="store_true")
+    ap.add_argument("--no-hybrid", action="store_true", help="plain round-robin: the remainder one subject per rank")
     args = ap.parse_args()
-    rank, world, local = eav_dist.init_from_env()
+    if "EAV_FORCE_DEVICE" in os.environ:                      # several ranks on one GPU (logic runs on a 1-GPU box)
+        os.environ["LOCAL_RANK"] = os.environ["EAV_FORCE_DEVICE"]
+    rank, world, local = eav_dist.init_from_env(os.environ.get("EAV_DIST_BACKEND"))
     torch.cuda.set_device(local)
-    mine = eav_dist.subjects_for_rank(rank, world, args.subjects)
+    sched = eav_dist.subject_schedule(world, args.subjects, hybrid=not args.no_hybrid)
+    groups = sched.make_groups() if world > 1 else {}
+    grp = sched.group_of(rank)
+    plan = [(s, None) for s in sched.solo[rank]] + ([grp] if grp else [])
+    mine = [s for s, _ in plan]
     results, t0 = {}, time.perf_counter()
-    for sub in mine:
+    for sub, ranks in plan:
         x, y = synthetic_subject(sub, args.samples)
         tr_x, tr_y, te_x, te_y = EAVDataSplit(x, y).get_split()               # h_idx = 40 -> 200 / 200
+        n = len(ranks) if ranks else 1
+        if n > 1:                                             # this replica's share of the training trials
+            i = ranks.index(rank)
+            tr_x, tr_y = tr_x[i::n], tr_y[i::n]
         data = [torch.from_numpy(tr_x).float().unsqueeze(1), tr_y, torch.from_numpy(te_x).float().unsqueeze(1), te_y]
         torch.manual_seed(sub)
         model = EEGNet_tor(nb_classes=5, D=8, F2=64, Chans=30, kernLength=300, Samples=args.samples, dropoutRate=0.5)
-        trainer = Trainer_uni(model=model, data=data, lr=1e-5, batch_size=32, num_epochs=args.epochs)
+        trainer = Trainer_uni(model=model, data=data, lr=1e-5, batch_size=max(1, 32 // n), num_epochs=args.epochs)
+        if n > 1:
+            eav_dist.attach(trainer, group=groups[sub])       # gradient all-reduce inside the group
         with contextlib.redirect_stdout(io.StringIO() if args.quiet else sys.stdout):
             trainer.train()
         model.eval()
         with torch.no_grad():
             pred = model(trainer.test_dataloader.x).argmax(dim=1)
-            results[sub] = float((pred == trainer.test_dataloader.y).float().mean().item())
+            if n == 1 or ranks[0] == rank:                    # one report per subject
+                results[sub] = float((pred == trainer.test_dataloader.y).float().mean().item())
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     gathered = [None] * world

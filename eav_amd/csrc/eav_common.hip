@@ -233,8 +233,25 @@ __global__ void renorm_rows_kernel(float* __restrict__ w, int rows, int cols, fl
     cols = cols_b;
   }
   float* row = w + (int64_t)r * cols;
+  // long rows (the dense layer's 5 x 19 968): 16 bytes per lane and four loads in flight - one block per row is a chain of
+  // load latencies (78 dependent trips of 4 bytes took 10 us of the EEGNet step)
+  const bool vec = (cols & 3) == 0 && (reinterpret_cast<uintptr_t>(row) & 15) == 0;
   float v[1] = {0.f};
-  for (int i = threadIdx.x; i < cols; i += 256) v[0] += row[i] * row[i];
+  if (vec) {
+    const float4* row4 = reinterpret_cast<const float4*>(row);
+    const int n4 = cols >> 2;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i0 = threadIdx.x; i0 < n4; i0 += 1024) {
+      float4 q[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) q[u] = i0 + 256 * u < n4 ? row4[i0 + 256 * u] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a[u] += (q[u].x * q[u].x + q[u].y * q[u].y) + (q[u].z * q[u].z + q[u].w * q[u].w);
+    }
+    v[0] = (a[0] + a[1]) + (a[2] + a[3]);
+  } else {
+    for (int i = threadIdx.x; i < cols; i += 256) v[0] += row[i] * row[i];
+  }
   block_sum_256<1>(v, red);
   __shared__ float sc;
   if (threadIdx.x == 0) {
@@ -243,8 +260,21 @@ __global__ void renorm_rows_kernel(float* __restrict__ w, int rows, int cols, fl
   }
   __syncthreads();
   float s = sc;
-  if (s != 1.f)
+  if (s == 1.f) return;
+  if (vec) {
+    float4* row4 = reinterpret_cast<float4*>(row);
+    const int n4 = cols >> 2;
+    for (int i0 = threadIdx.x; i0 < n4; i0 += 1024) {
+      float4 q[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) q[u] = i0 + 256 * u < n4 ? row4[i0 + 256 * u] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (i0 + 256 * u < n4) row4[i0 + 256 * u] = make_float4(q[u].x * s, q[u].y * s, q[u].z * s, q[u].w * s);
+    }
+  } else {
     for (int i = threadIdx.x; i < cols; i += 256) row[i] *= s;
+  }
 }
 
 extern "C" int eav_renorm_rows(float* w, int rows, int cols, float maxnorm, void* stream) {

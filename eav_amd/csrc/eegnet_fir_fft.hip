@@ -634,20 +634,27 @@ __global__ __launch_bounds__(512, 1) void fir_fft_wgrad_kernel(const float* __re
   for (int j = 0; j < 16; ++j) *reinterpret_cast<v2f*>(out + 2 * (j * 64 + lane)) = acc[j];
 }
 
-// Finish in two small launches.  (1) 64 workgroups = (filter, slice of 128 bins): 4 thread groups each sum every fourth
-// per-workgroup spectrum of their bins in order, the 4 group sums are added in group order - a fixed order, bit-reproducible -
-// and the total goes to row `nparts` of the workspace.  (2) One wave per filter transforms the total back and keeps the real
-// parts of lags 0 .. klen - 1.  (One workgroup per filter doing both took 30 us at 225 partials: 1.8 MB read by 8 waves.)
+// Finish in two small launches.  (1) 256 workgroups = (filter, slice of 32 bins): 16 thread groups each sum every sixteenth
+// per-workgroup spectrum of their bins in order (at 225 partials: 14 or 15 loads per thread, all in flight together), the
+// 16 group sums are added as a fixed tree - bit-reproducible - and the total goes to row `nparts` of the workspace.
+// (2) One wave per filter transforms the total back and keeps the real parts of lags 0 .. klen - 1.  (One workgroup per
+// filter doing both took 30 us at 225 partials; 64 workgroups of 4 groups 16.6 us: a chain of 56 loads per thread.)
 __global__ __launch_bounds__(512) void fir_fft_wgrad_sum_kernel(float* __restrict__ spec, int nparts) {
   __shared__ v2f red[512];
-  const int f = blockIdx.x >> 3, bin = (blockIdx.x & 7) * 128 + (threadIdx.x & 127), grp = threadIdx.x >> 7;
+  const int f = blockIdx.x >> 5, bin = (blockIdx.x & 31) * 32 + (threadIdx.x & 31), grp = threadIdx.x >> 5;
   const v2f* src = reinterpret_cast<const v2f*>(spec) + (int64_t)f * NF + bin;
   v2f a = (v2f){0.f, 0.f};
-  for (int p = grp; p < nparts; p += 4) a += src[(int64_t)p * F1 * NF];
+#pragma unroll 4
+  for (int p = grp; p < nparts; p += 16) a += src[(int64_t)p * F1 * NF];
   red[threadIdx.x] = a;
   __syncthreads();
-  if (grp == 0) {
+  if (threadIdx.x < 128) {                 // groups g, g + 4, g + 8, g + 12
     a = (red[threadIdx.x] + red[threadIdx.x + 128]) + (red[threadIdx.x + 256] + red[threadIdx.x + 384]);
+    red[threadIdx.x] = a;
+  }
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    a = (red[threadIdx.x] + red[threadIdx.x + 32]) + (red[threadIdx.x + 64] + red[threadIdx.x + 96]);
     reinterpret_cast<v2f*>(spec)[((int64_t)nparts * F1 + f) * NF + bin] = a;
   }
 }
@@ -743,7 +750,7 @@ extern "C" int eav_eegnet_fir_wgrad_fft(const float* x, const int64_t* xidx, con
     hipLaunchKernelGGL(fir_fft_wgrad_kernel<true>, dim3(grid), dim3(512), 0, st, x, xidx, y1, g1, bn_params, ws, C, S,
                        (klen - 1) / 2, npair, nblk, nunits);
   EAV_CHECK_LAUNCH("eav_eegnet_fir_wgrad_fft");
-  hipLaunchKernelGGL(fir_fft_wgrad_sum_kernel, dim3(F1 * 8), dim3(512), 0, st, ws, grid);
+  hipLaunchKernelGGL(fir_fft_wgrad_sum_kernel, dim3(F1 * 32), dim3(512), 0, st, ws, grid);
   EAV_CHECK_LAUNCH("eav_eegnet_fir_wgrad_fft(sum)");
   hipLaunchKernelGGL(fir_fft_wgrad_finish_kernel, dim3(F1), dim3(64), 0, st, ws, grid, dW, klen);
   EAV_CHECK_LAUNCH("eav_eegnet_fir_wgrad_fft(finish)");

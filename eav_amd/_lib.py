@@ -45,9 +45,11 @@ SIGNATURES = {
     "eav_eegnet_dw_fwd_pool_eval": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     "eav_eegnet_dw_bwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     "eav_eegnet_dw_bwd_fused": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _u64, _p, _p, _p],
+    "eav_eegnet_dw_bwd_fused_eval": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _u64, _p, _p, _p],
     "eav_bn_elu_pool_fwd": [_p, _p, _p, _i, _i, _i, _i, _f, _u64, _p, _p, _p],
     "eav_bn_elu_pool_bwd_reduce": [_p, _p, _p, _p, _i, _i, _i, _i, _f, _u64, _p, _p, _p],
     "eav_bn_elu_pool_bwd_apply": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _u64, _p, _p, _p],
+    "eav_bn_elu_pool_bwd_eval": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _u64, _p, _p, _p],
     "eav_conv64_prep_weights": [_p, _p, _p, _p],
     "eav_conv64_fwd": [_p, _p, _p, _p, _i, _i, _i, _p],
     "eav_conv64_wgrad": [_p, _p, _p, _i, _i, _i, _p],

@@ -239,17 +239,21 @@ __global__ __launch_bounds__(256) void pool_bwd_reduce_kernel(const float* __res
 }
 
 // pass 2: du = scale*(g - m1 - uhat*m2) for every t < T (tail included: g = 0 there)
+// m12 NULL (BatchNorm on its running statistics: m1 = m2 = 0, du = scale g needs no sums first): the ONE pass of an eval-mode
+// step - the sums of pass 1 (the gradients of the BatchNorm weight and bias) go to `part` from here.
 template <int P>
 __global__ __launch_bounds__(256) void pool_bwd_apply_kernel(const float* __restrict__ dp,
                                                              const float* __restrict__ u,
                                                              const float* __restrict__ bn,
                                                              const float* __restrict__ m12, float* __restrict__ du,
                                                              int CH, int T, float drop_p, uint64_t seed_in,
-    const uint8_t* __restrict__ mask, const uint64_t* __restrict__ seed_dev) {
+    const uint8_t* __restrict__ mask, const uint64_t* __restrict__ seed_dev, float* __restrict__ part) {
   const uint64_t seed = dropout_seed(seed_in, seed_dev);
+  __shared__ float red[8];
   const int row = blockIdx.x, ch = row % CH;
   const float mean = bn[ch], invstd = bn[CH + ch], sc = bn[2 * CH + ch], sh = bn[3 * CH + ch];
-  const float m1 = m12[ch], m2 = m12[CH + ch];
+  const float m1 = m12 ? m12[ch] : 0.f, m2 = m12 ? m12[CH + ch] : 0.f;
+  float st[2] = {0.f, 0.f};
   const int To = T / P;
   const float* src = u + (int64_t)row * T;
   float* dst = du + (int64_t)row * T;
@@ -269,8 +273,16 @@ __global__ __launch_bounds__(256) void pool_bwd_apply_kernel(const float* __rest
       const float pre = sc * v[e] + sh;
       const float g = go * elu_grad_from_out(pre, elu_f(pre));
       o[e] = sc * (g - m1 - (v[e] - mean) * invstd * m2);
+      if (t + e < T) {                       // (go = 0 on the dropped tail: it adds nothing, as in pass 1)
+        st[0] += g;
+        st[1] += g * ((v[e] - mean) * invstd);
+      }
     }
     st4(dst, t, T, vec, o);
+  }
+  if (part) {
+    block_sum_256<2>(st, red);
+    if (threadIdx.x < 2) part[(int64_t)(row / CH) * 2 * CH + threadIdx.x * CH + ch] = st[0];
   }
 }
 
@@ -288,21 +300,40 @@ __device__ __forceinline__ float dpp_f(float old, float src) {
   return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, 0xf, BANK_MASK, false));
 }
 
+// Sum of a over the wave, wave-uniform, by DPP only (in-row inclusive scan, the two row broadcasts, lane 63): no LDS round
+// trips and no barrier (eegnet_fir_fft.hip's wave_total)
+template <int CTRL, int ROW_MASK, bool BOUND>
+__device__ __forceinline__ float dpp_row(float src) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(src), CTRL, ROW_MASK, 0xf, BOUND));
+}
+__device__ __forceinline__ float wave_total_dpp(float a) {
+  a += dpp_row<0x111, 0xf, true>(a);      // row_shr:1
+  a += dpp_row<0x112, 0xf, true>(a);      // row_shr:2
+  a += dpp_row<0x114, 0xf, true>(a);      // row_shr:4
+  a += dpp_row<0x118, 0xf, true>(a);      // row_shr:8
+  a += dpp_row<0x142, 0xa, false>(a);     // row_bcast:15 into rows 1 and 3
+  a += dpp_row<0x143, 0xc, false>(a);     // row_bcast:31 into rows 2 and 3
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), 63));
+}
+
 struct DwFuse {
   const float* z; const float* dp2; const float* bn2;   // bn2: mean, invstd, scale, shift, m1, m2 (64 each)
   float drop_p; uint64_t seed; const uint8_t* mask; const uint64_t* seed_dev;
+  float* part2;     // eval-mode step (depthwiseBN on its running statistics: m1 = m2 = 0): the sums of pool_bwd_reduce_kernel<4>
+                    // leave from here, part2[(b * nchunk + chunk)][2 * 64] - that launch and its read of z and dp2 disappear
 };
 
 // CG: channel groups for short rows, as in dw_fwd_kernel - every group forms dz for the row's samples (the same loads: L1
 // hits), group j walks channels j, j + CG, ...; g1 and the depthwise weight gradient are per channel, the two statistics
 // are block sums anyway.
-template <bool FUSED, int CG, int NT>
+template <bool FUSED, int CG, int NT, bool SUMS2 = false>      // SUMS2: the eval-mode form (fu.part2)
 __global__ __launch_bounds__(NT) void dw_bwd_kernel(const float* __restrict__ y1, const float* __restrict__ dz,
                                                      const float* __restrict__ bn1, const float* __restrict__ w2,
                                                      float* __restrict__ g1, float* __restrict__ part_st,
                                                      float* __restrict__ part_w, int C, int S, DwFuse fu) {
   __shared__ float wsh[DD * CHMAX];
   __shared__ float red[NT / 64 * 8];
+  __shared__ float red2[SUMS2 ? NT / 64 * 2 * DD : 1];
   __shared__ float wacc[NT / 64 * DD * CHMAX];
   constexpr int TPG = NT / CG;            // threads per channel group (a multiple of the wave size)
   const int chunk = blockIdx.x, f = blockIdx.y, b = blockIdx.z;
@@ -317,6 +348,9 @@ __global__ __launch_bounds__(NT) void dw_bwd_kernel(const float* __restrict__ y1
   const int t = chunk * (4 * TPG) + tl * 4;
   float dzv[DD][4];
   if (FUSED) {
+    float st2[2 * DD];
+#pragma unroll
+    for (int k = 0; k < 2 * DD; ++k) st2[k] = 0.f;
     const uint64_t seed = dropout_seed(fu.seed, fu.seed_dev);
     const int To = S / 4, to = t / 4;
 #pragma unroll
@@ -324,7 +358,7 @@ __global__ __launch_bounds__(NT) void dw_bwd_kernel(const float* __restrict__ y1
       const int ch = f * DD + d, CH = F1 * DD;
       const int64_t row = (int64_t)b * CH + ch;
       const float mean2 = fu.bn2[ch], invstd2 = fu.bn2[CH + ch], sc2 = fu.bn2[2 * CH + ch], sh2 = fu.bn2[3 * CH + ch];
-      const float m1 = fu.bn2[4 * CH + ch], m2 = fu.bn2[5 * CH + ch];
+      const float m1 = SUMS2 ? 0.f : fu.bn2[4 * CH + ch], m2 = SUMS2 ? 0.f : fu.bn2[5 * CH + ch];
       float go = 0.f;
       if (to < To) {
         const uint64_t oi = (uint64_t)row * To + to;
@@ -337,6 +371,20 @@ __global__ __launch_bounds__(NT) void dw_bwd_kernel(const float* __restrict__ y1
         const float pre = sc2 * v[e] + sh2;
         const float g = go * elu_grad_from_out(pre, elu_f(pre));
         dzv[d][e] = (t + e < S) ? sc2 * (g - m1 - (v[e] - mean2) * invstd2 * m2) : 0.f;
+        if (SUMS2 && t + e < S) {
+          st2[d] += g;
+          st2[DD + d] += g * ((v[e] - mean2) * invstd2);
+        }
+      }
+    }
+    if constexpr (SUMS2) {
+      // wave sums by DPP into this wave's LDS row - no barrier here (one in front of the y1 loads below cost 40 us of the
+      // 310: the loads could no longer start under the prologue); the rows are added at the end of the kernel.  With
+      // channel groups every group formed the same dz: the waves of group 0 are the ones summed.
+#pragma unroll
+      for (int k = 0; k < 2 * DD; ++k) {
+        const float tot = wave_total_dpp(st2[k]);
+        if (lane == 0) red2[wave * 2 * DD + k] = tot;
       }
     }
   } else {
@@ -428,6 +476,15 @@ __global__ __launch_bounds__(NT) void dw_bwd_kernel(const float* __restrict__ y1
   block_sum_nt<NT, 2>(st, red);
   if (threadIdx.x < 2) part_st[((int64_t)b * gridDim.x + chunk) * 16 + threadIdx.x * 8 + f] = st[0];
   __syncthreads();
+  if (FUSED && SUMS2 && threadIdx.x < 2 * DD) {      // (red2 was written before the barriers above)
+    constexpr int NWG = NT / 64 / CG;                   // waves of channel group 0: threads 0 .. NT / CG - 1
+    float t = red2[threadIdx.x];
+#pragma unroll
+    for (int w = 1; w < NWG; ++w) t += red2[w * 2 * DD + threadIdx.x];
+    const int nch = F1 * DD;
+    float* dst2 = fu.part2 + ((int64_t)b * gridDim.x + chunk) * 2 * nch;
+    dst2[(threadIdx.x < DD ? 0 : nch) + f * DD + (threadIdx.x & (DD - 1))] = t;
+  }
   float* dst = part_w + ((int64_t)b * gridDim.x + chunk) * (F1 * DD * C) + f * DD * C;
   for (int i = threadIdx.x; i < DD * C; i += NT) {
     float w = (wacc[i] + wacc[DD * CHMAX + i]) + (wacc[2 * DD * CHMAX + i] + wacc[3 * DD * CHMAX + i]);
@@ -488,26 +545,51 @@ extern "C" int eav_eegnet_dw_bwd(const float* y1, const float* dz, const float* 
 
 // dw_bwd with the depthwiseBN -> ELU -> AvgPool(1,4) -> Dropout backward folded into its prologue (see DwFuse): takes z and
 // dp2 [B,64,S/4] instead of dz.  bn2: mean, invstd, scale, shift, m1, m2 (64 floats each, m1/m2 from eav_bn_bwd_finalize).
+static int dw_bwd_fused_launch(const char* name, const float* y1, const float* z, const float* dp2, const float* bn2,
+                               const float* bn1, const float* w2, float* g1, float* stat_part, float* w_part, float* bn2_part,
+                               int B, int C, int S, float drop_p, uint64_t seed, const uint8_t* mask,
+                               const uint64_t* seed_dev, void* stream) {
+  EAV_REQUIRE(y1 && z && dp2 && bn2 && bn1 && w2 && g1 && stat_part && w_part && B > 0 && C > 0 && C <= CHMAX && S >= 4,
+              "%s: bad arguments (Chans must be <= %d)", name, CHMAX);
+  EAV_REQUIRE(drop_p > -1.f && drop_p < 1.f, "%s: dropout %f outside (-1,1)", name, drop_p);
+  dim3 grid(cdiv(S, 1024), F1, B);
+  DwFuse fu{z, dp2, bn2, drop_p, seed, mask, seed_dev, bn2_part};
+#define DWB_LAUNCH(CG, NT, SUMS)                                                                                        \
+  hipLaunchKernelGGL((dw_bwd_kernel<true, CG, NT, SUMS>), grid, dim3(NT), 0, (hipStream_t)stream, y1, nullptr, bn1, w2, g1, \
+                     stat_part, w_part, C, S, fu)
+  if (bn2_part) {
+    if (S <= 256) DWB_LAUNCH(4, 256, true);
+    else if (S <= 512) DWB_LAUNCH(4, 512, true);
+    else DWB_LAUNCH(1, 256, true);
+  } else {
+    if (S <= 256) DWB_LAUNCH(4, 256, false);
+    else if (S <= 512) DWB_LAUNCH(4, 512, false);
+    else DWB_LAUNCH(1, 256, false);
+  }
+#undef DWB_LAUNCH
+  EAV_CHECK_LAUNCH(name);
+  return EAV_OK;
+}
+
 extern "C" int eav_eegnet_dw_bwd_fused(const float* y1, const float* z, const float* dp2, const float* bn2,
                                        const float* bn1, const float* w2, float* g1, float* stat_part, float* w_part,
                                        int B, int C, int S, float drop_p, uint64_t seed, const uint8_t* mask,
                                        const uint64_t* seed_dev, void* stream) {
-  EAV_REQUIRE(y1 && z && dp2 && bn2 && bn1 && w2 && g1 && stat_part && w_part && B > 0 && C > 0 && C <= CHMAX && S >= 4,
-              "eav_eegnet_dw_bwd_fused: bad arguments (Chans must be <= %d)", CHMAX);
-  EAV_REQUIRE(drop_p > -1.f && drop_p < 1.f, "eav_eegnet_dw_bwd_fused: dropout %f outside (-1,1)", drop_p);
-  dim3 grid(cdiv(S, 1024), F1, B);
-  DwFuse fu{z, dp2, bn2, drop_p, seed, mask, seed_dev};
-  if (S <= 256)
-    hipLaunchKernelGGL((dw_bwd_kernel<true, 4, 256>), grid, dim3(256), 0, (hipStream_t)stream, y1, nullptr, bn1, w2, g1,
-                       stat_part, w_part, C, S, fu);
-  else if (S <= 512)
-    hipLaunchKernelGGL((dw_bwd_kernel<true, 4, 512>), grid, dim3(512), 0, (hipStream_t)stream, y1, nullptr, bn1, w2, g1,
-                       stat_part, w_part, C, S, fu);
-  else
-    hipLaunchKernelGGL((dw_bwd_kernel<true, 1, 256>), grid, dim3(256), 0, (hipStream_t)stream, y1, nullptr, bn1, w2, g1,
-                       stat_part, w_part, C, S, fu);
-  EAV_CHECK_LAUNCH("eav_eegnet_dw_bwd_fused");
-  return EAV_OK;
+  return dw_bwd_fused_launch("eav_eegnet_dw_bwd_fused", y1, z, dp2, bn2, bn1, w2, g1, stat_part, w_part, nullptr, B, C, S,
+                             drop_p, seed, mask, seed_dev, stream);
+}
+
+// The same with depthwiseBN on its RUNNING statistics (an eval-mode step): dz = scale2 g needs no batch sums first, so the
+// sums themselves (sum g, sum g zhat per channel: the BatchNorm weight / bias gradients) leave from this pass -
+// bn2_part[(b * ceil(S / 1024) + chunk)][2 * 64], to be finished by eav_bn_bwd_finalize(training = 0) AFTER this launch; no
+// eav_bn_elu_pool_bwd_reduce pass.  bn2's m1 / m2 slots are not read.
+extern "C" int eav_eegnet_dw_bwd_fused_eval(const float* y1, const float* z, const float* dp2, const float* bn2,
+                                            const float* bn1, const float* w2, float* g1, float* stat_part, float* w_part,
+                                            float* bn2_part, int B, int C, int S, float drop_p, uint64_t seed,
+                                            const uint8_t* mask, const uint64_t* seed_dev, void* stream) {
+  EAV_REQUIRE(bn2_part, "eav_eegnet_dw_bwd_fused_eval: bad arguments");
+  return dw_bwd_fused_launch("eav_eegnet_dw_bwd_fused_eval", y1, z, dp2, bn2, bn1, w2, g1, stat_part, w_part, bn2_part, B, C,
+                             S, drop_p, seed, mask, seed_dev, stream);
 }
 
 extern "C" int eav_bn_elu_pool_fwd(const float* in, const float* bn, float* out, int B, int CH, int T, int P,
@@ -540,17 +622,35 @@ extern "C" int eav_bn_elu_pool_bwd_reduce(const float* dp, const float* u, const
   return EAV_OK;
 }
 
+static int pool_bwd_apply_launch(const char* name, const float* dp, const float* u, const float* bn, const float* m12,
+                                 float* du, float* part, int B, int CH, int T, int P, float drop_p, uint64_t seed,
+                                 const uint8_t* mask, const uint64_t* seed_dev, void* stream) {
+  EAV_REQUIRE(dp && u && bn && (m12 || part) && du && B > 0 && CH > 0 && T >= P, "%s: bad arguments", name);
+  EAV_REQUIRE(P == 4 || P == 8, "%s: pool %d not in {4,8}", name, P);
+  if (P == 4)
+    hipLaunchKernelGGL(pool_bwd_apply_kernel<4>, dim3(B * CH), dim3(256), 0, (hipStream_t)stream, dp, u, bn, m12, du,
+                       CH, T, drop_p, seed, mask, seed_dev, part);
+  else
+    hipLaunchKernelGGL(pool_bwd_apply_kernel<8>, dim3(B * CH), dim3(256), 0, (hipStream_t)stream, dp, u, bn, m12, du,
+                       CH, T, drop_p, seed, mask, seed_dev, part);
+  EAV_CHECK_LAUNCH(name);
+  return EAV_OK;
+}
+
 extern "C" int eav_bn_elu_pool_bwd_apply(const float* dp, const float* u, const float* bn, const float* m12,
                                          float* du, int B, int CH, int T, int P, float drop_p, uint64_t seed,
                                          const uint8_t* mask, const uint64_t* seed_dev, void* stream) {
-  EAV_REQUIRE(dp && u && bn && m12 && du && B > 0 && CH > 0 && T >= P, "eav_bn_elu_pool_bwd_apply: bad arguments");
-  EAV_REQUIRE(P == 4 || P == 8, "eav_bn_elu_pool_bwd_apply: pool %d not in {4,8}", P);
-  if (P == 4)
-    hipLaunchKernelGGL(pool_bwd_apply_kernel<4>, dim3(B * CH), dim3(256), 0, (hipStream_t)stream, dp, u, bn, m12, du,
-                       CH, T, drop_p, seed, mask, seed_dev);
-  else
-    hipLaunchKernelGGL(pool_bwd_apply_kernel<8>, dim3(B * CH), dim3(256), 0, (hipStream_t)stream, dp, u, bn, m12, du,
-                       CH, T, drop_p, seed, mask, seed_dev);
-  EAV_CHECK_LAUNCH("eav_bn_elu_pool_bwd_apply");
-  return EAV_OK;
+  EAV_REQUIRE(m12, "eav_bn_elu_pool_bwd_apply: bad arguments");
+  return pool_bwd_apply_launch("eav_bn_elu_pool_bwd_apply", dp, u, bn, m12, du, nullptr, B, CH, T, P, drop_p, seed, mask,
+                               seed_dev, stream);
+}
+
+// BatchNorm on its running statistics (an eval-mode step): du = scale g and the sums of eav_bn_elu_pool_bwd_reduce
+// (part [B][2*CH], finished by eav_bn_bwd_finalize(training = 0)) in ONE pass over u and dp.
+extern "C" int eav_bn_elu_pool_bwd_eval(const float* dp, const float* u, const float* bn, float* du, float* part, int B,
+                                        int CH, int T, int P, float drop_p, uint64_t seed, const uint8_t* mask,
+                                        const uint64_t* seed_dev, void* stream) {
+  EAV_REQUIRE(part, "eav_bn_elu_pool_bwd_eval: bad arguments");
+  return pool_bwd_apply_launch("eav_bn_elu_pool_bwd_eval", dp, u, bn, nullptr, du, part, B, CH, T, P, drop_p, seed, mask,
+                               seed_dev, stream);
 }

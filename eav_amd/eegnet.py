@@ -509,11 +509,19 @@ class EEGNet_tor(nn.Module):
           P(ws.dp3), B, NF, nb, st)
         # block 2: Dropout <- AvgPool8 <- ELU <- separableBN
         b3 = P(ws.bn3)
-        L("eav_bn_elu_pool_bwd_reduce", P(ws.dp3), P(ws.u3), b3, P(ws.part_pb), B, 64, T2, 8, drop, seed2, m2, cnt, st)
-        L("eav_bn_bwd_finalize", P(ws.part_pb), B, 64, float(B * T2), tr, P(g["separableBN.weight"]),
-          P(g["separableBN.bias"]), b3 + 4 * 256, b3 + 4 * 320, st)
-        L("eav_bn_elu_pool_bwd_apply", P(ws.dp3), P(ws.u3), b3, b3 + 4 * 256, P(ws.du3), B, 64, T2, 8, drop, seed2, m2,
-          cnt, st)
+        if training:
+            L("eav_bn_elu_pool_bwd_reduce", P(ws.dp3), P(ws.u3), b3, P(ws.part_pb), B, 64, T2, 8, drop, seed2, m2, cnt, st)
+            L("eav_bn_bwd_finalize", P(ws.part_pb), B, 64, float(B * T2), tr, P(g["separableBN.weight"]),
+              P(g["separableBN.bias"]), b3 + 4 * 256, b3 + 4 * 320, st)
+            L("eav_bn_elu_pool_bwd_apply", P(ws.dp3), P(ws.u3), b3, b3 + 4 * 256, P(ws.du3), B, 64, T2, 8, drop, seed2, m2,
+              cnt, st)
+        else:
+            # eval-mode step (Q4: every epoch after the first): BatchNorm backward is a plain scale, so the gradient and the
+            # sums for the BatchNorm weight / bias leave from ONE pass over u3 / dp3
+            L("eav_bn_elu_pool_bwd_eval", P(ws.dp3), P(ws.u3), b3, P(ws.du3), P(ws.part_pb), B, 64, T2, 8, drop, seed2, m2,
+              cnt, st)
+            L("eav_bn_bwd_finalize", P(ws.part_pb), B, 64, float(B * T2), tr, P(g["separableBN.weight"]),
+              P(g["separableBN.bias"]), b3 + 4 * 256, b3 + 4 * 320, st)
         # separableConv: data gradient (flipped/transposed taps, pad 8) and weight gradient
         if self._use_conv_fft(B):
             # (bwd = 2: the filter spectra of the data gradient were prepared by this step's forward call)
@@ -527,14 +535,22 @@ class EEGNet_tor(nn.Module):
             L("eav_reduce_partials", P(ws.part_cw), ws.np_cw, 65536, 65536, 1.0, P(g["separableConv.weight"]), st)
         # block 1 tail: Dropout <- AvgPool4 <- ELU <- depthwiseBN
         b2 = P(ws.bn2)
-        L("eav_bn_elu_pool_bwd_reduce", P(ws.dp2), P(ws.z), b2, P(ws.part_pb), B, 64, S, 4, drop, seed1, m1, cnt, st)
-        L("eav_bn_bwd_finalize", P(ws.part_pb), B, 64, float(B * S), tr, P(g["depthwiseBN.weight"]),
-          P(g["depthwiseBN.bias"]), b2 + 4 * 256, b2 + 4 * 320, st)
         # depthwiseConv <- ELU <- firstBN (uses the post-renorm depthwise weight, Q2)
         b1 = P(ws.bn1)
         # dz = backward of BN2 -> ELU -> pool -> dropout is formed inside dw_bwd: no dz tensor in HBM
-        L("eav_eegnet_dw_bwd_fused", P(ws.y1), P(ws.z), P(ws.dp2), b2, b1, w2, P(ws.g1), P(ws.part_dst),
-          P(ws.part_dw2), B, C, S, drop, seed1, m1, cnt, st)
+        if training:
+            L("eav_bn_elu_pool_bwd_reduce", P(ws.dp2), P(ws.z), b2, P(ws.part_pb), B, 64, S, 4, drop, seed1, m1, cnt, st)
+            L("eav_bn_bwd_finalize", P(ws.part_pb), B, 64, float(B * S), tr, P(g["depthwiseBN.weight"]),
+              P(g["depthwiseBN.bias"]), b2 + 4 * 256, b2 + 4 * 320, st)
+            L("eav_eegnet_dw_bwd_fused", P(ws.y1), P(ws.z), P(ws.dp2), b2, b1, w2, P(ws.g1), P(ws.part_dst),
+              P(ws.part_dw2), B, C, S, drop, seed1, m1, cnt, st)
+        else:
+            # eval-mode step: no sums are needed before dz = scale2 g - they leave from the depthwise pass itself (no reduce
+            # launch, no extra read of z and dp2)
+            L("eav_eegnet_dw_bwd_fused_eval", P(ws.y1), P(ws.z), P(ws.dp2), b2, b1, w2, P(ws.g1), P(ws.part_dst),
+              P(ws.part_dw2), P(ws.part_dw), B, C, S, drop, seed1, m1, cnt, st)
+            L("eav_bn_bwd_finalize", P(ws.part_dw), B * ws.nchunk, 64, float(B * S), tr, P(g["depthwiseBN.weight"]),
+              P(g["depthwiseBN.bias"]), b2 + 4 * 256, b2 + 4 * 320, st)
         L("eav_reduce_partials", P(ws.part_dw2), B * ws.nchunk, 64 * C, 64 * C, 1.0, P(g["depthwiseConv.weight"]), st)
         L("eav_bn_bwd_finalize", P(ws.part_dst), B * ws.nchunk, 8, float(B * C * S), tr, P(g["firstBN.weight"]),
           P(g["firstBN.bias"]), b1 + 4 * 32, b1 + 4 * 40, st)

@@ -109,6 +109,15 @@ int eav_eegnet_dw_bwd_fused(const float* y1, const float* z, const float* dp2, c
                             const float* w2, float* g1, float* stat_part, float* w_part, int B, int C, int S,
                             float drop_p, uint64_t seed, const uint8_t* mask, const uint64_t* seed_dev, void* stream);
 
+/* the same for an eval-mode step (depthwiseBN on its running statistics, what the reference's loop runs from its second
+ * epoch on: model.eval() in validate(), EEGNet_tor.py:118, is never undone): dz = scale2 g needs no batch sums first, so the
+ * sums themselves (the depthwiseBN weight / bias gradients) leave from this pass - bn2_part [B*ceil(S/1024)][2*64], finished
+ * by eav_bn_bwd_finalize(training = 0) AFTER this launch; no eav_bn_elu_pool_bwd_reduce pass; bn2's m1 / m2 are not read. */
+int eav_eegnet_dw_bwd_fused_eval(const float* y1, const float* z, const float* dp2, const float* bn2, const float* bn1,
+                                 const float* w2, float* g1, float* stat_part, float* w_part, float* bn2_part, int B, int C,
+                                 int S, float drop_p, uint64_t seed, const uint8_t* mask, const uint64_t* seed_dev,
+                                 void* stream);
+
 /* ---- BN -> ELU -> AvgPool(1,P) -> Dropout (EEGNet_tor.py:55-58, 60-63), P in {4,8} -------- */
 /* bn = mean, invstd, scale, shift (CH each).  mask: optional uint8 keep-mask [B,CH,T/P]
  * (NULL = counter-based generator keyed by seed); drop_p = 0 disables dropout; drop_p < 0 = nn.Dropout2d with
@@ -124,6 +133,11 @@ int eav_bn_elu_pool_bwd_reduce(const float* dp, const float* u, const float* bn,
 int eav_bn_elu_pool_bwd_apply(const float* dp, const float* u, const float* bn, const float* m12 /*m1[CH],m2[CH]*/,
                               float* du, int B, int CH, int T, int P, float drop_p, uint64_t seed,
                               const uint8_t* mask, const uint64_t* seed_dev, void* stream);
+/* BatchNorm on its running statistics (eval-mode step): du = scale g and the sums of eav_bn_elu_pool_bwd_reduce (part
+ * [B][2*CH], to be finished by eav_bn_bwd_finalize(training = 0)) in ONE pass over u and dp. */
+int eav_bn_elu_pool_bwd_eval(const float* dp, const float* u, const float* bn, float* du, float* part /*[B][2*CH]*/, int B,
+                             int CH, int T, int P, float drop_p, uint64_t seed, const uint8_t* mask,
+                             const uint64_t* seed_dev, void* stream);
 
 /* ---- separableConv: dense 64->64, 16 taps, 'same' (EEGNet_tor.py:37,59) ------------------- */
 int eav_conv64_prep_weights(const float* w /*[64,64,16]*/, float* wT_fwd /*[1024,64]*/, float* wT_bwd, void* stream);

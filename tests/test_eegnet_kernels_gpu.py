@@ -173,6 +173,17 @@ def test_pool_fwd_bwd(L, B, T, P, drop):
     close(s[CH:], (g_ref * uhat).sum((0, 2)), 1e-4, 1e-4, "sum g uhat")
     du_ref = bc(scale) * (g_ref - bc(m1) - uhat * bc(m2))
     close(du, du_ref, 1e-4, 1e-6, "du")
+    # eval-mode step (BatchNorm on its running statistics, m1 = m2 = 0): gradient and sums from ONE pass
+    du2 = torch.full((B, CH, T), float("nan"), device="cuda")
+    part2 = torch.full((B, 2 * CH), float("nan"), device="cuda")
+    L.call("eav_bn_elu_pool_bwd_eval", dpd.data_ptr(), ud.data_ptr(), bn.data_ptr(), du2.data_ptr(), part2.data_ptr(), B, CH,
+           T, P, drop, 0, mp, None, None)
+    torch.cuda.synchronize()
+    close(du2, bc(scale) * g_ref, 1e-4, 1e-6, "du (eval)")
+    s2 = part2.sum(0).cpu().double().numpy()
+    close(s2[:CH], g_ref.sum((0, 2)), 1e-4, 1e-4, "sum g (eval)")
+    close(s2[CH:], (g_ref * uhat).sum((0, 2)), 1e-4, 1e-4, "sum g uhat (eval)")
+    close(part2, part, 1e-4, 1e-5 * float(part.abs().max()), "per-sample sums, one pass against two")
 
 
 def test_dropout_generator_statistics(L):
@@ -635,3 +646,23 @@ def test_dw_bwd_fused_matches_apply_then_dw_bwd(L, B, C, S, drop):
     close(gb, ga, 1e-5, 1e-6 * float(ga.abs().max()), "g1")
     close(sb, sa, 1e-4, 1e-5 * float(sa.abs().max()), "sum g, sum g*yhat")
     close(wb, wa, 1e-4, 1e-5 * float(wa.abs().max()), "dW2")
+    # eval-mode step: depthwiseBN on its running statistics (m1 = m2 = 0 whatever the slots hold) and its two sums from the
+    # same pass - against the fused kernel on a buffer with zeroed m1 / m2 and against eav_bn_elu_pool_bwd_reduce
+    b2z = b2.clone()
+    b2z[4 * 64:] = 0.0
+    g1z = torch.empty(B, 8, C, S, device="cuda")
+    pstz, pwz = torch.empty(B * nchunk, 16, device="cuda"), torch.empty(B * nchunk, 64 * C, device="cuda")
+    L.call("eav_eegnet_dw_bwd_fused", y1d.data_ptr(), zd.data_ptr(), dpd.data_ptr(), b2z.data_ptr(), b1.data_ptr(),
+           w2d.data_ptr(), g1z.data_ptr(), pstz.data_ptr(), pwz.data_ptr(), B, C, S, drop, 77, None, None, None)
+    g1e = torch.full((B, 8, C, S), float("nan"), device="cuda")
+    pste, pwe = torch.full((B * nchunk, 16), float("nan"), device="cuda"), torch.full((B * nchunk, 64 * C), float("nan"), device="cuda")
+    p2e = torch.full((B * nchunk, 128), float("nan"), device="cuda")
+    L.call("eav_eegnet_dw_bwd_fused_eval", y1d.data_ptr(), zd.data_ptr(), dpd.data_ptr(), b2.data_ptr(), b1.data_ptr(),
+           w2d.data_ptr(), g1e.data_ptr(), pste.data_ptr(), pwe.data_ptr(), p2e.data_ptr(), B, C, S, drop, 77, None, None, None)
+    pr = torch.empty(B, 128, device="cuda")
+    L.call("eav_bn_elu_pool_bwd_reduce", dpd.data_ptr(), zd.data_ptr(), b2.data_ptr(), pr.data_ptr(), B, 64, S, 4, drop, 77,
+           None, None, None)
+    torch.cuda.synchronize()
+    assert torch.equal(g1e, g1z) and torch.equal(pste, pstz) and torch.equal(pwe, pwz)
+    got, want = p2e.double().sum(0), pr.double().sum(0)
+    close(got, want, 1e-4, 1e-5 * float(want.abs().max()), "depthwiseBN sums from the depthwise pass")

@@ -87,6 +87,8 @@ def avg(name):
     if name in es:
         return es[name][1]
     hits = [v[1] for k, v in es.items() if k.split("<")[0] == name]      # a templated kernel named without its arguments
+    if not hits and name.endswith(">"):                                # ... or with the first of its arguments only
+        hits = [v[1] for k, v in es.items() if k.startswith(name[:-1] + ",")]
     return max(hits) if hits else float("nan")
 
 

@@ -336,7 +336,13 @@ __global__ __launch_bounds__(NT) void dw_bwd_kernel(const float* __restrict__ y1
   __shared__ float red2[SUMS2 ? NT / 64 * 2 * DD : 1];
   __shared__ float wacc[NT / 64 * DD * CHMAX];
   constexpr int TPG = NT / CG;            // threads per channel group (a multiple of the wave size)
+  // samples in DESCENDING order (the FFT weight-gradient kernel behind this one walks them ascending): measured -3 .. -8 us
+  // on the step on one box, alternating runs (profiles/r05_eeg_variants.txt); dw_fwd walking backwards costs +5 us
+#ifdef DWB_ASC
   const int chunk = blockIdx.x, f = blockIdx.y, b = blockIdx.z;
+#else
+  const int chunk = blockIdx.x, f = blockIdx.y, b = gridDim.z - 1 - blockIdx.z;
+#endif
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int cg = CG > 1 ? threadIdx.x / TPG : 0, tl = CG > 1 ? threadIdx.x % TPG : threadIdx.x;
   for (int i = threadIdx.x; i < DD * C; i += NT) wsh[i] = w2[f * DD * C + i];

@@ -28,21 +28,47 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
-// ELU(alpha=1) as torch computes it (expm1 for v<=0) and its derivative.
+// ELU(alpha=1) as torch computes it (expm1 for v <= 0) and its derivative (EEGNet_tor.py:53,56,61: nn.ELU()).
 #ifdef EAV_ABL_ELU      // timing-only ablation: the passes without their expm1 (results garbage)
 __device__ __forceinline__ float elu_f(float v) { return v > 0.f ? v : 0.5f * v; }
-#else
-// (branch-free: `v > 0 ? v : expm1f(v)` compiles to an exec-masked branch around every call - the lanes of a wave diverge on the
-// sign, so nothing is skipped, and the four calls per channel of the depthwise passes sit in four basic blocks that cannot be
-// interleaved.  Same values bit for bit: expm1f of the clamped argument, selected.)
-#ifdef EAV_ELU_BRANCHY
-__device__ __forceinline__ float elu_f(float v) { return v > 0.f ? v : expm1f(v); }
-#else
+#elif defined(EAV_ELU_LIBM)
+// round 5: libm expm1f of the clamped argument, selected (22 instructions per call + clamp + select; `v > 0 ? v :
+// expm1f(v)` compiles to an exec-masked branch around every call - the lanes of a wave diverge on the sign, so nothing is
+// skipped, and the four calls per channel of the depthwise passes sit in four basic blocks that cannot be interleaved)
 __device__ __forceinline__ float elu_f(float v) {
   const float e = expm1f(fminf(v, 0.f));
-  return v > 0.f ? v : e;
+  return v <= 0.f ? e : v;
 }
-#endif
+#else
+// expm1 on [-17.5, 0] (below, expm1 rounds to -1 in fp32) in 13 branch-free VALU instructions:
+//   t = x log2(e) + 1.5 2^23        the sum's low mantissa bits hold n = rint(x log2 e), no conversion instruction
+//   r = x - n ln2_hi - n ln2_lo     |r| <= ln2 / 2, two fmas (ln2_hi has 15 mantissa bits: n ln2_hi is exact)
+//   p = r + r^2 q(r)                q = degree-4 fit of (expm1(r) - r) / r^2 (tools/probes/expm1_fit.py)
+//   s = 2^n                         (bits(t) << 23) + bits(1.0f): one v_lshl_add_u32
+//   expm1(x) = fma(p, s, s - 1)     s - 1 is exact; n = 0 returns p itself
+// Max error 0.97 ulp against float64 expm1 over 8 M arguments (the probe emulates this sequence in fp32 arithmetic) - the
+// accuracy class of libm's expm1f, which torch's CPU ELU calls.  elu_f: NaN in, NaN out; -inf gives -1.
+__device__ __forceinline__ float expm1_neg(float x) {       // x in [-17.5, 0]
+#pragma clang fp contract(off)
+  const float t = __builtin_fmaf(x, 1.4426950408889634f, 12582912.f);
+  const float n = t - 12582912.f;
+  float r = __builtin_fmaf(n, -0.693145751953125f, x);
+  r = __builtin_fmaf(n, -1.42860682030941723212e-6f, r);
+  float q = 1.394644962e-03f;
+  q = __builtin_fmaf(q, r, 8.366583847e-03f);
+  q = __builtin_fmaf(q, r, 4.166628048e-02f);
+  q = __builtin_fmaf(q, r, 1.666654348e-01f);
+  q = __builtin_fmaf(q, r, 0.5f);
+  const float p = __builtin_fmaf(r * r, q, r);
+  const float s = __uint_as_float((__float_as_uint(t) << 23) + 0x3f800000u);
+  return __builtin_fmaf(p, s, s - 1.f);
+}
+__device__ __forceinline__ float elu_f(float v) {
+  // v_med3_f32 clamps in one instruction (and maps a NaN to a bound: the select below hands the NaN itself through,
+  // as torch's F.elu does - `v <= 0` is false for it)
+  const float e = expm1_neg(__builtin_amdgcn_fmed3f(v, -17.5f, 0.f));
+  return v <= 0.f ? e : v;
+}
 #endif
 __device__ __forceinline__ float elu_grad_from_out(float v, float a) { return v > 0.f ? 1.f : a + 1.f; }
 

@@ -84,7 +84,9 @@ __device__ __forceinline__ v2f cmulc(v2f a, v2f b) {      // a conj(b)
 // Two complex products a0 b0, a1 b1 (CONJ: a conj(b)) in FOUR packed instructions: what hipcc cannot select is one
 // v_pk_fma_f32 with a swapped AND half-negated operand (it builds the pair with a third instruction).  The two products are
 // interleaved so that no packed result is consumed by the next instruction (gfx950 needs one wait state there); the
-// leading s_nop covers a packed producer of an input directly in front of the block.
+// leading s_nop covers a packed producer of an input directly in front of the block, the trailing `s_nop 1` a consumer
+// hipcc schedules directly behind it (the hazard recogniser does not see into inline asm: a v_permlane*_swap of the last
+// result needs two wait states after the VALU write, a packed consumer one).
 template <bool CONJ>
 __device__ __forceinline__ void cmul2(v2f a0, v2f b0, v2f a1, v2f b1, v2f& r0, v2f& r1) {
   if (CONJ)
@@ -92,14 +94,16 @@ __device__ __forceinline__ void cmul2(v2f a0, v2f b0, v2f a1, v2f b1, v2f& r0, v
         "v_pk_mul_f32 %0, %2, %3 op_sel_hi:[0,1] neg_hi:[0,1]\n\t"
         "v_pk_mul_f32 %1, %4, %5 op_sel_hi:[0,1] neg_hi:[0,1]\n\t"
         "v_pk_fma_f32 %0, %2, %3, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1]\n\t"
-        "v_pk_fma_f32 %1, %4, %5, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1]"
+        "v_pk_fma_f32 %1, %4, %5, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1]\n\t"
+        "s_nop 1"
         : "=&v"(r0), "=&v"(r1) : "v"(a0), "v"(b0), "v"(a1), "v"(b1));
   else
     asm("s_nop 0\n\t"
         "v_pk_mul_f32 %0, %2, %3 op_sel_hi:[0,1]\n\t"
         "v_pk_mul_f32 %1, %4, %5 op_sel_hi:[0,1]\n\t"
         "v_pk_fma_f32 %0, %2, %3, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"
-        "v_pk_fma_f32 %1, %4, %5, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"
+        "v_pk_fma_f32 %1, %4, %5, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"
+        "s_nop 1"
         : "=&v"(r0), "=&v"(r1) : "v"(a0), "v"(b0), "v"(a1), "v"(b1));
 }
 // acc0 += a0 conj(b0), acc1 += a1 conj(b1): four packed fmas, the accumulators interleaved for the same reason
@@ -108,7 +112,8 @@ __device__ __forceinline__ void cmacc2_conj(v2f a0, v2f b0, v2f a1, v2f b1, v2f&
       "v_pk_fma_f32 %0, %2, %3, %0 op_sel_hi:[0,1,1] neg_hi:[0,1,0]\n\t"
       "v_pk_fma_f32 %1, %4, %5, %1 op_sel_hi:[0,1,1] neg_hi:[0,1,0]\n\t"
       "v_pk_fma_f32 %0, %2, %3, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1]\n\t"
-      "v_pk_fma_f32 %1, %4, %5, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1]"
+      "v_pk_fma_f32 %1, %4, %5, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1]\n\t"
+      "s_nop 1"
       : "+v"(acc0), "+v"(acc1) : "v"(a0), "v"(b0), "v"(a1), "v"(b1));
 }
 #endif

@@ -209,6 +209,25 @@ def attach(trainer, force=False, group=None):
     return trainer
 
 
+def replica_shard(n_items, batch_size, i, n):
+    """Training items and batch size of member i of an n-rank group that trains ONE model through a per-replica data loader
+    (tools/run_*_subjects.py): (slice over the items, per-member batch size).  Every member gets the SAME number of items
+    (the n_items mod n last ones are dropped, like a DistributedSampler with drop_last) and the same batch size
+    batch_size / n, hence the same number of optimiser steps - members that disagree on the step count dead-lock in the
+    gradient all-reduce - and equal-weight averaging (GradSync's default 1 / n) is then exact for every batch.  A group larger
+    than the batch, or one that does not divide it, would silently change the global batch: refused."""
+    if n < 1 or not 0 <= i < n:
+        raise ValueError("replica_shard: member index outside the group")
+    if n == 1:
+        return slice(0, n_items), batch_size
+    if batch_size % n:
+        raise ValueError(f"replica_shard: a group of {n} ranks cannot split the batch of {batch_size} evenly")
+    per = n_items // n
+    if per == 0:
+        raise ValueError(f"replica_shard: {n_items} items for {n} ranks")
+    return slice(i, i + per * n, n), batch_size // n
+
+
 def shard_batch(n_items, rank, world):
     """Contiguous shard [lo, hi) of a global batch of n_items for this rank."""
     per = (n_items + world - 1) // world

@@ -22,6 +22,32 @@ def test_subject_and_batch_sharding():
         assert cover == list(range(70))
 
 
+def test_replica_shard_gives_every_group_member_the_same_step_count():
+    """eav_amd.dist.replica_shard (tools/run_*_subjects.py): equal shard lengths and batch sizes on every member - members
+    that disagree on the number of optimiser steps dead-lock in the gradient all-reduce (200 trials on 41 ranks gave 5
+    against 4 steps with plain i::n slicing) - and a group that does not divide the batch is refused, not silently run
+    with a different global batch."""
+    import numpy as np
+    import pytest
+    from eav_amd.dist import replica_shard
+    items = np.arange(200)
+    for n, bs in ((1, 32), (2, 32), (4, 32), (8, 32), (16, 32), (32, 32), (4, 8), (4, 128)):
+        shards = [items[replica_shard(200, bs, i, n)[0]] for i in range(n)]
+        sizes = {len(s_) for s_ in shards}
+        assert len(sizes) == 1 and sizes.pop() == 200 // n
+        assert len(np.unique(np.concatenate(shards))) == (200 // n) * n          # disjoint
+        per = {replica_shard(200, bs, i, n)[1] for i in range(n)}
+        assert per == {bs // n}
+        steps = {-(-len(s_) // (bs // n)) for s_ in shards}
+        assert len(steps) == 1
+    assert replica_shard(200, 32, 0, 1) == (slice(0, 200), 32)
+    for n, bs in ((41, 32), (3, 32), (64, 32)):
+        with pytest.raises(ValueError):
+            replica_shard(200, bs, 0, n)
+    with pytest.raises(ValueError):
+        replica_shard(200, 32, 4, 4)
+
+
 def test_subject_schedule_composes_rounds_and_groups():
     """SubjectSchedule: whole rounds one subject per rank + the remainder on groups of ranks (42 = 5 x 8 + 2 -> two 4-rank
     groups); every subject exactly once, ideal speed-ups as DESIGN.md section 7 states them."""
@@ -101,6 +127,109 @@ def test_subject_groups_gloo_world4(tmp_path):
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert all((tmp_path / f"ok_{{k}}".format(k=k)).exists() for k in range(4)), r.stdout + r.stderr
+
+
+def test_subject_schedule_gloo_world8_two_groups_of_four(tmp_path):
+    """The EXACT topology of the 8-GPU job (BASELINE configs[4]): subject_schedule(8, 42) = five whole rounds + subjects 41
+    and 42 on two 4-RANK groups.  Eight gloo ranks: inside a group GradSync.weight = 1/4 and shard_batch(64, i, 4) = 16 rows
+    per member; every element of the group gradient is BIT-equal to a sum of the four pre-scaled shard gradients in one of the
+    ring's orders, identical on all four members, and equal (fp32
+    rounding) to the undivided batch's; the two groups reduce at the same time and nothing of group B reaches group A (their
+    data differ by seed, and a poisoned buffer reduced inside B must not show up in A); every one of the 42 subjects is
+    reported exactly once after one all_gather; an uneven LAST batch (37 rows: 10/10/10/7) is weighted n_r / n.  A rank that fails exits non-zero and torchrun tears the job down (second launch below)."""
+    script = tmp_path / "w8.py"
+    script.write_text(textwrap.dedent(f"""
+        import os, sys
+        sys.path.insert(0, {ROOT!r})
+        import torch, torch.distributed as dist
+        from eav_amd import dist as ed
+        rank, world, local = ed.init_from_env("gloo")
+        assert world == 8
+        if os.environ.get("EAV_TEST_FAIL_RANK") == str(rank):
+            raise SystemExit(3)                                # (d): a failing rank must end the whole job non-zero
+        sched = ed.subject_schedule(world, 42)
+        assert sched.rounds == 5 and sched.group_size == 4
+        assert sched.groups == [(41, [0, 1, 2, 3]), (42, [4, 5, 6, 7])]
+        assert sched.solo[rank] == [1 + rank + 8 * k for k in range(5)]
+        groups = sched.make_groups()
+        assert sorted(groups) == [41, 42]
+        sub, ranks = sched.group_of(rank)
+        assert sub == (41 if rank < 4 else 42) and rank in ranks
+        i = ranks.index(rank)
+        B = 64
+        torch.manual_seed(1000 + sub)                          # members of a group: same data, same weights
+        X, w, t = torch.randn(B, 24), torch.randn(24), torch.randn(B)
+        grad = lambda Xs, ts: (2.0 / len(ts)) * ((Xs @ w - ts)[:, None] * Xs).sum(0)   # gradient of the MEAN loss over the rows
+        lo, hi = ed.shard_batch(B, i, 4)
+        assert (lo, hi) == (16 * i, 16 * i + 16)
+        g = grad(X[lo:hi], t[lo:hi])
+        sync = ed.GradSync([g], group=groups[sub])
+        assert sync.world == 4 and sync.weight == 0.25 and sync.enabled
+        sync()
+        parts = [grad(X[16 * j:16 * j + 16], t[16 * j:16 * j + 16]) for j in range(4)]
+        ref = ((0.25 * parts[0] + 0.25 * parts[1]) + 0.25 * parts[2]) + 0.25 * parts[3]
+        full = grad(X, t)
+        assert torch.allclose(g, full, rtol=2e-6, atol=2e-6), (g - full).abs().max()
+        # all four members hold the same bits (an all-reduce result is identical on every member)
+        same = [torch.empty_like(g) for _ in range(4)]
+        dist.all_gather(same, g, group=groups[sub])
+        assert all(torch.equal(same[0], s_) for s_ in same)
+        # ... and those bits are a fixed-order sum of the pre-scaled shard gradients (gloo: ring order may differ from the
+        # left-to-right one, so compare against every association of the four terms)
+        import itertools
+        sc = [0.25 * p_ for p_ in parts]
+        cands = []
+        for perm in itertools.permutations(range(4)):
+            a, b, c, d = (sc[k] for k in perm)
+            cands += [((a + b) + c) + d, (a + b) + (c + d)]
+        # (a ring all-reduce sums each CHUNK of the buffer in its own rotation of the ring: element-wise membership)
+        assert bool(torch.stack([g == c_ for c_ in cands]).any(0).all()), (g - ref).abs().max()
+        # isolation: group B reduces a poisoned buffer while group A reduces zeros - A must still see zeros
+        probe = torch.full((8,), 1e30 if sub == 42 else 0.0)
+        ed.GradSync([probe], group=groups[sub])()
+        assert float(probe.max()) == (float(torch.tensor(1e30)) if sub == 42 else 0.0) and float(probe.min()) == float(probe.max())
+        # ragged last batch of 37 rows over 4 members: 10 / 10 / 10 / 7 rows, weights n_r / n
+        lo, hi = ed.shard_batch(37, i, 4)
+        n_r = hi - lo
+        assert n_r == (10, 10, 10, 7)[i]
+        g2 = grad(X[lo:hi], t[lo:hi])
+        s2 = ed.GradSync([g2], group=groups[sub])
+        s2.set_batch(n_r, 37)
+        s2()
+        assert torch.allclose(g2, grad(X[:37], t[:37]), rtol=2e-6, atol=2e-6)
+        # results of the whole job: 42 subjects, each reported by exactly one rank (a group reports through its first member)
+        have = torch.zeros(42)
+        for s_ in sched.solo[rank]:
+            have[s_ - 1] += 1.0
+        if ranks[0] == rank:
+            have[sub - 1] += 1.0
+        out = [torch.empty_like(have) for _ in range(world)]
+        dist.all_gather(out, have)
+        assert torch.equal(torch.stack(out).sum(0), torch.ones(42))
+        assert abs(sched.ideal_speedup() - 8.0) < 1e-12
+        dist.barrier()
+        dist.destroy_process_group()
+        open({str(tmp_path)!r} + f"/ok_{{rank}}", "w").write("ok")
+    """))
+    import socket
+
+    def run(extra_env):
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", **extra_env)
+        return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8",
+                               "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                              capture_output=True, text=True, env=env, timeout=600)
+
+    r = run({})
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert all((tmp_path / f"ok_{k}").exists() for k in range(8)), r.stdout + r.stderr
+    for k in range(8):
+        (tmp_path / f"ok_{k}").unlink()
+    r = run({"EAV_TEST_FAIL_RANK": "5"})          # one rank dies before the first collective: the job must not hang or pass
+    assert r.returncode != 0
+    assert not any((tmp_path / f"ok_{k}").exists() for k in range(8))
 
 
 def test_grad_allreduce_gloo_world2(tmp_path):

@@ -186,6 +186,33 @@ def test_pool_fwd_bwd(L, B, T, P, drop):
     close(part2, part, 1e-4, 1e-5 * float(part.abs().max()), "per-sample sums, one pass against two")
 
 
+def test_elu_is_expm1_to_an_ulp_and_propagates_nan(L):
+    """elu_f (csrc/eav_common.h: branch-free 13-instruction expm1 on the clamped argument) through eav_bn_elu_pool_fwd with an
+    identity BatchNorm and four equal samples per pool window (their mean is exact): within 1.5 ulp of float64 expm1 for
+    v <= 0 (libm's class; nn.ELU = expm1, EEGNet_tor.py:53,56,61), v itself for v > 0, NaN in -> NaN out (torch.nn.functional
+    .elu propagates it: a diverged run must stay visible to loss / NaN checks), -inf -> -1, +inf -> +inf."""
+    CH, n = 64, 4096
+    x = np.concatenate([-np.logspace(-38, np.log10(40.0), CH * n - 4096 - 8), np.linspace(-20, 6, 4096),
+                        [0.0, -0.0, -17.5, -17.4999, -88.0, 1e-30, 3.0, -1e-45]]).astype(np.float32)
+    x[5] = np.nan
+    x[6] = -np.inf
+    x[7] = np.inf
+    u = np.repeat(x.reshape(1, CH, n), 4, axis=2)
+    one, zero = np.ones(CH, np.float32), np.zeros(CH, np.float32)
+    bn = bn_buf(CH, zero, one, one, zero)
+    out = torch.empty(1, CH, n, device="cuda")
+    L.call("eav_bn_elu_pool_fwd", dev(u).data_ptr(), bn.data_ptr(), out.data_ptr(), 1, CH, 4 * n, 4, 0.0, 0, None, None, None)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().reshape(-1)
+    assert np.isnan(got[5]) and got[6] == -1.0 and got[7] == np.inf
+    ok = np.isfinite(x)
+    ref = np.where(x[ok] > 0, x[ok].astype(np.float64), np.expm1(x[ok].astype(np.float64)))
+    ulp = np.spacing(np.abs(ref.astype(np.float32))).astype(np.float64)
+    err = np.abs(got[ok].astype(np.float64) - ref) / ulp
+    assert err.max() <= 1.5, f"ELU: {err.max():.2f} ulp at v = {x[ok][err.argmax()]!r}"
+    assert (got[ok][x[ok] > 0] == x[ok][x[ok] > 0]).all()
+
+
 def test_dropout_generator_statistics(L):
     B, CH, T, P = 4, 64, 4000, 4
     u = np.ones((B, CH, T), np.float32)

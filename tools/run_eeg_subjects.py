@@ -55,13 +55,14 @@ def main():
         x, y = synthetic_subject(sub, args.samples)
         tr_x, tr_y, te_x, te_y = EAVDataSplit(x, y).get_split()               # h_idx = 40 -> 200 / 200
         n = len(ranks) if ranks else 1
-        if n > 1:                                             # this replica's share of the training trials
-            i = ranks.index(rank)
-            tr_x, tr_y = tr_x[i::n], tr_y[i::n]
+        # this replica's share of the training trials: equal shard lengths and batch sizes on every member, hence equal
+        # step counts (eav_amd.dist.replica_shard refuses a group that does not divide the batch of 32)
+        sl, bs = eav_dist.replica_shard(len(tr_x), 32, ranks.index(rank) if n > 1 else 0, n)
+        tr_x, tr_y = tr_x[sl], tr_y[sl]
         data = [torch.from_numpy(tr_x).float().unsqueeze(1), tr_y, torch.from_numpy(te_x).float().unsqueeze(1), te_y]
         torch.manual_seed(sub)
         model = EEGNet_tor(nb_classes=5, D=8, F2=64, Chans=30, kernLength=300, Samples=args.samples, dropoutRate=0.5)
-        trainer = Trainer_uni(model=model, data=data, lr=1e-5, batch_size=max(1, 32 // n), num_epochs=args.epochs)
+        trainer = Trainer_uni(model=model, data=data, lr=1e-5, batch_size=bs, num_epochs=args.epochs)
         if n > 1:
             eav_dist.attach(trainer, group=groups[sub])       # gradient all-reduce inside the group
         with contextlib.redirect_stdout(io.StringIO() if args.quiet else sys.stdout):

@@ -82,17 +82,18 @@ def main():
         for sub, ranks in plan:
             data = synthetic_subject(args.kind, sub, args.small)
             n = len(ranks) if ranks else 1
-            if n > 1:                                         # this rank's replica sees every n-th training item
-                i = ranks.index(rank)
-                data = [data[0][i::n], data[1][i::n], data[2], data[3]]
+            # this rank's replica sees every n-th training item: equal shard lengths and batch sizes on every member,
+            # hence equal step counts (eav_amd.dist.replica_shard)
+            sl, bsz = eav_dist.replica_shard(len(data[0]), bs, ranks.index(rank) if n > 1 else 0, n)
+            data = [data[0][sl], data[1][sl], data[2], data[3]]
             torch.manual_seed(sub)                            # the fresh head: identical on every member of a group
             with contextlib.redirect_stdout(sys.stdout if args.verbose else io.StringIO()):
                 if audio:
                     tr = AudioModelTrainer(data, model_path=path, sub=f"subject_{sub:02d}", num_classes=5,
-                                           weight_decay=1e-5, lr=0.005, batch_size=max(1, bs // n))
+                                           weight_decay=1e-5, lr=0.005, batch_size=bsz)
                 else:
                     tr = ImageClassifierTrainer(data, model_path=path, sub=f"subject_{sub:02d}", num_labels=5, lr=5e-5,
-                                                batch_size=max(1, bs // n))
+                                                batch_size=bsz)
                 if n > 1:
                     eav_dist.attach(tr, group=groups[sub])
                 tr.train(epochs=args.frozen_epochs, lr=5e-4, freeze=True)

@@ -118,7 +118,8 @@ if os.path.exists(p):
     d = json.load(open(p))
     ker = {k if k.endswith("_kernel") or "<" in k else k: {"read_bytes": e.get("hbm_read_bytes"),
                                                             "write_bytes": e.get("hbm_write_bytes"),
-                                                            "total_bytes": (e.get("hbm_read_bytes") or 0) + (e.get("hbm_write_bytes") or 0)}
+                                                            "total_bytes": (e.get("hbm_read_bytes") or 0) + (e.get("hbm_write_bytes") or 0),
+                                                            "avg_us": e.get("avg_us"), "calls": e.get("calls")}
            for k, e in d["kernels"].items() if "hbm_read_bytes" in e}
     for k in list(ker):            # bare template names too ("fir_wgrad_kernel<10, false>" -> "fir_wgrad_kernel")
         b = k.split("<")[0]

@@ -87,6 +87,11 @@ __device__ __forceinline__ v2f cmulc(v2f a, v2f b) {      // a conj(b)
 // leading s_nop covers a packed producer of an input directly in front of the block, the trailing `s_nop 1` a consumer
 // hipcc schedules directly behind it (the hazard recogniser does not see into inline asm: a v_permlane*_swap of the last
 // result needs two wait states after the VALU write, a packed consumer one).
+#ifdef EAV_FIR_NO_TRAILING_NOP      // (A/B only: round 5's blocks, correct by scheduling luck)
+#define EAV_ASM_TAIL "s_nop 0"
+#else
+#define EAV_ASM_TAIL "s_nop 1"
+#endif
 template <bool CONJ>
 __device__ __forceinline__ void cmul2(v2f a0, v2f b0, v2f a1, v2f b1, v2f& r0, v2f& r1) {
   if (CONJ)
@@ -95,7 +100,7 @@ __device__ __forceinline__ void cmul2(v2f a0, v2f b0, v2f a1, v2f b1, v2f& r0, v
         "v_pk_mul_f32 %1, %4, %5 op_sel_hi:[0,1] neg_hi:[0,1]\n\t"
         "v_pk_fma_f32 %0, %2, %3, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1]\n\t"
         "v_pk_fma_f32 %1, %4, %5, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1]\n\t"
-        "s_nop 1"
+        EAV_ASM_TAIL
         : "=&v"(r0), "=&v"(r1) : "v"(a0), "v"(b0), "v"(a1), "v"(b1));
   else
     asm("s_nop 0\n\t"
@@ -103,7 +108,7 @@ __device__ __forceinline__ void cmul2(v2f a0, v2f b0, v2f a1, v2f b1, v2f& r0, v
         "v_pk_mul_f32 %1, %4, %5 op_sel_hi:[0,1]\n\t"
         "v_pk_fma_f32 %0, %2, %3, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"
         "v_pk_fma_f32 %1, %4, %5, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"
-        "s_nop 1"
+        EAV_ASM_TAIL
         : "=&v"(r0), "=&v"(r1) : "v"(a0), "v"(b0), "v"(a1), "v"(b1));
 }
 // acc0 += a0 conj(b0), acc1 += a1 conj(b1): four packed fmas, the accumulators interleaved for the same reason
@@ -113,7 +118,7 @@ __device__ __forceinline__ void cmacc2_conj(v2f a0, v2f b0, v2f a1, v2f b1, v2f&
       "v_pk_fma_f32 %1, %4, %5, %1 op_sel_hi:[0,1,1] neg_hi:[0,1,0]\n\t"
       "v_pk_fma_f32 %0, %2, %3, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1]\n\t"
       "v_pk_fma_f32 %1, %4, %5, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1]\n\t"
-      "s_nop 1"
+      EAV_ASM_TAIL
       : "+v"(acc0), "+v"(acc1) : "v"(a0), "v"(b0), "v"(a1), "v"(b1));
 }
 #endif

@@ -45,6 +45,10 @@
 #ifndef EAV_ABL
 #define EAV_ABL 0
 #endif
+// start-up stagger of the dynamic tile walk: units | phases << 8 (profiles/r06_gemm_sched_ab.txt)
+#ifndef EAV_SCHED_DEFAULT_STAGGER
+#define EAV_SCHED_DEFAULT_STAGGER (6 | (2 << 8))
+#endif
 
 
 namespace {
@@ -90,6 +94,9 @@ struct SpArgs {
   int order;                // tile order inside an XCD (see tile_origin)
   int kt_per_split;         // > 0: split-K, slice z covers K-tiles [z*kt_per_split, ...), C[z] = partial slab
   int tm, tn;
+  unsigned* sched;          // dynamic tile walk: this launch's 8 per-XCD tile counters + exit counter (zero; reset by the
+                            // last workgroup to leave), or null = static walk (tile ids blockIdx.x + k gridDim.x)
+  int stagger;              // start-up stagger: units | phases << 8 (workgroup b sleeps (b phases / gridDim.x) x units x ~3.4 us)
 };
 
 // erf-GELU without the libm erff (two divergent branches, ~60 instructions): with z = |x| / sqrt 2,
@@ -172,7 +179,11 @@ __device__ __forceinline__ uint4 plane_piece4(float t0, float t1, float t2, floa
 //
 // TERMS = 3: the fp32-grade product above.  TERMS = 1: hi.hi only - a plain fp16 product of the scaled operands (11-bit
 // operand mantissas, fp32 accumulation), a third of the MFMA work on the same planes; the opt-in mode of the backward
-// products (Encoder.grad_terms = 1; the forward - the logits - stays on three terms).
+// products (Encoder.grad_terms = 1; the forward - the logits - stays on three terms).  TERMS = 2 (token-contracting form
+// only): hi_A.hi_B + lo_A.hi_B - operand B rounded to fp16, operand A at full split precision.  In a weight gradient A is the
+// GRADIENT tensor (loosely scaled a-priori planes: it needs its lo piece) and B the ACTIVATION: two thirds of the matrix
+// work, B's lo pieces are not even read from LDS, and the producers' fused gradient planes stay usable (a hi.hi-only product
+// needs tightly scaled operands on BOTH sides, which switches them off: profiles/r05_term_budget.txt).
 //
 // NS = LDS stages.  2: a stage is in flight for one K-tile period.  3 (the 256 x 128 / 8-wave form, one workgroup per CU;
 // the epilogue patches then alias stage 2): two periods, and 96 KB instead of 64 KB in flight per CU - the loop is bound by
@@ -186,24 +197,33 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
   constexpr int CPW = NCH / NW;           // chunks per wave
   constexpr int NT = RM * RN;             // MFMA tiles per wave
   constexpr int NMF = TERMS * NT;         // MFMAs per K-step of 16
-  constexpr int NRD = (TR ? 2 : 1) * (TERMS == 1 ? 1 : 2) * (RM + RN);      // fragment reads per K-step (hi pieces first)
-  static_assert(TERMS == 3 || (TERMS == 1 && !TWOACC), "three terms, or the hi.hi term alone in one accumulator");
+  // fragment reads per K-step, in the order ah[], bh[], al[], bl[] (TERMS = 2 stops in front of bl)
+  constexpr int NRD = (TR ? 2 : 1) * (TERMS == 1 ? RM + RN : TERMS == 2 ? 2 * RM + RN : 2 * (RM + RN));
+  static_assert(TERMS == 3 || (TERMS == 1 && !TWOACC) || (TERMS == 2 && TWOACC && TR),
+                "three terms, the hi.hi term alone in one accumulator, or hi.hi + lo_A.hi_B of the token-contracting form");
   static_assert(NCH % NW == 0 && CPW <= 2 * NMF && NRD <= (TR ? 2 : 1) * NMF,
                 "stage chunks / fragment reads must fit the MFMA slots");
   static_assert(!TR || (BM == 128 && BN == 128 && RM == 2 && RN == 2), "the token-major image is laid out for 128 x 128");
   static_assert(NS == 2 || (NS == 3 && NW * 4096 <= STAGE), "two stages, or three with the patches inside the third");
   // + one 32 x 32 fp32 patch per wave: the epilogue turns accumulator blocks into row-linear order through it
   // (at offset 2 STAGE in both forms; NS = 3: that is stage 2, free while the epilogue runs)
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[NS == 2 ? 2 * STAGE + NW * 4096 : 3 * STAGE];
+  // (+ 16 bytes in the three-stage form: the next-tile word of the dynamic tile walk; the two-stage form sits exactly at
+  // the 80 KB that let two workgroups share a CU and keeps that word in wave 0's patch, see s_next)
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[NS == 2 ? 2 * STAGE + NW * 4096 : 3 * STAGE + 16];
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-#if defined(EAV_STAGGER) && EAV_STAGGER > 0
-  // experiment: the second resident workgroup of every CU starts EAV_STAGGER x ~3.4 us late, so that the write bursts of
-  // the epilogues of the two halves of the grid do not coincide
-  if (!TR && g.kt_per_split == 0 && blockIdx.x >= gridDim.x / 2 && gridDim.x >= 512)
-    for (int i = 0; i < EAV_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
-#endif
+  // Start-up stagger (with the dynamic tile walk below): the persistent workgroups otherwise run in lock-step - every
+  // epilogue of a round bursts at the same time (ViT qkv forward: 232 MB of stores at 3.3 TB/s, 70 of 331 us, overlapped with
+  // nothing; the bias / GELU / plane arithmetic of both workgroups of a CU in the same window, the matrix pipes idle).
+  // Workgroups of the later phases start late, so that one phase's epilogues fall into the other phases' K loops.
+  // Round 5 measured the stagger alone (static walk): the late half of the grid also FINISHES late (-11 % ... +14 %);
+  // with tiles handed out dynamically the tail evens out.
+  if (g.stagger) {
+    const int units = g.stagger & 255, phases = g.stagger >> 8;
+    const int ph = (int)((unsigned)blockIdx.x * (unsigned)phases / gridDim.x);
+    for (int i = 0; i < ph * units; ++i) __builtin_amdgcn_s_sleep(127);
+  }
 
   // ---- persistent workgroups: tile ids blockIdx.x, blockIdx.x + gridDim.x, ... (gridDim.x is a multiple of 8 whenever a
   // workgroup gets more than one tile, so a workgroup stays on its XCD).  tile id -> tile: XCD-contiguous, then groups
@@ -238,32 +258,40 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
   const int nk = kt1 - kt0;
   if (nk <= 0) return;
 
-  // ---- per-lane global source pointers of this wave's chunks (row clamped: ragged tiles re-read the last row)
-  const unsigned char* gp[CPW];
-  int64_t gstep[TR ? CPW : 1];                           // TR: bytes from one K-tile (32 tokens) to the next
+  // ---- operand sources: one SCALAR base per operand (the tile's first row at the first K-tile of this workgroup's K range)
+  // and one 32-bit byte offset per lane and chunk - the saddr form of the LDS-DMA.  (Round 5 kept a 64-bit pointer per lane
+  // and chunk and advanced each one by a VALU add pair per K-tile: 2 CPW registers and 2 CPW VALU instructions per K-tile
+  // that the scalar unit now carries.)  Rows are clamped: ragged tiles re-read the last row.
+  constexpr int ACH = BM / (8 * NW);                     // chunks wave + NW i with i < ACH belong to the A tile
+  static_assert(BM % (8 * NW) == 0, "a wave's chunk i is an A chunk for every wave or for none");
+  unsigned voff[CPW];
+  const unsigned char *baseA = Ab, *baseB = g.B;
   auto set_sources = [&](int m0, int n0) {
+    if constexpr (TR) {
+      baseA = Ab + (int64_t)kt0 * 32 * g.ldA;
+      baseB = g.B + (int64_t)kt0 * 32 * g.ldB;
+    } else {
+      if (EAV_ABL & 16) m0 = 0;
+      if (EAV_ABL & 32) n0 = 0;
+      baseA = Ab + (int64_t)m0 * g.ldA + (int64_t)kt0 * 128;
+      baseB = g.B + (int64_t)n0 * g.ldB + (int64_t)kt0 * 128;
+    }
 #pragma unroll
     for (int i = 0; i < CPW; ++i) {
       const int c = wave + NW * i;                       // wave-uniform chunk id
+      const bool isA = i < ACH;
       if constexpr (TR) {
-        const bool isA = 8 * c < BM;
         const int tk = 2 * (isA ? c : c - BM / 8) + (lane >> 5);          // token within the K-tile
         const int w = (lane & 31) ^ ((tk & 1) | ((tk & 2) << 2));          // piece held by this lane's slot
         const int fg = w >> 1, hl = w & 1;
-        const int64_t ld = isA ? g.ldA : g.ldB;
-        const int grp = min((isA ? m0 : n0) / 8 + fg, (int)(ld >> 5) - 1);  // ragged feature tiles re-read the last group
-        gp[i] = (isA ? Ab : g.B) + ((int64_t)kt0 * 32 + tk) * ld + (int64_t)grp * 32 + hl * 16;
-        gstep[i] = 32 * ld;
+        const int ld = (int)(isA ? g.ldA : g.ldB);
+        const int grp = min((isA ? m0 : n0) / 8 + fg, (ld >> 5) - 1);      // ragged feature tiles re-read the last group
+        voff[i] = (unsigned)(tk * ld + grp * 32 + hl * 16);
       } else {
         const int row = 8 * c + (lane >> 3);               // row in the combined [A tile; B tile] image
         const int p = (lane & 7) ^ ((row >> 1) & 7);       // piece held by this lane's slot
-        if (8 * c < BM) {
-          const int gr = min(((EAV_ABL & 16) ? 0 : m0) + row, g.M - 1);
-          gp[i] = Ab + (int64_t)gr * g.ldA + (int64_t)kt0 * 128 + p * 16;
-        } else {
-          const int gr = min(((EAV_ABL & 32) ? 0 : n0) + row - BM, g.N - 1);
-          gp[i] = g.B + (int64_t)gr * g.ldB + (int64_t)kt0 * 128 + p * 16;
-        }
+        if (isA) voff[i] = (unsigned)(min(row, g.M - 1 - m0) * (int)g.ldA + p * 16);
+        else voff[i] = (unsigned)(min(row - BM, g.N - 1 - n0) * (int)g.ldB + p * 16);
       }
     }
   };
@@ -273,12 +301,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
   // TR loop (each DMA was waited for right after its issue) and the epilogue's patch reads (the next tile's first stages
   // were drained before the epilogue could start).  An asm DMA is invisible to that pass; the waits that order DMA and
   // fragment reads are the explicit ones of this kernel (mid-tile vmcnt + barrier, tile start).
-  auto issue1 = [&](int buf, int i) {
+  // kt: K-tile (relative to this workgroup's K range) the stage holds.
+  auto issue1 = [&](int buf, int i, int kt) {
     const int c = wave + NW * i;
+    const bool isA = i < ACH;
     const unsigned dst = lds0 + buf * STAGE + c * 1024;
-    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gp[i]), "s"(dst) : "memory");   // (m0 is a reserved register: nothing hipcc emits for gfx950 in this kernel depends on it)
-    if constexpr (TR) gp[i] += gstep[i];
-    else gp[i] += 128;
+    const unsigned char* sb = (isA ? baseA : baseB) + (int64_t)kt * (TR ? 32 * (isA ? g.ldA : g.ldB) : (int64_t)128);
+    asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff[i]), "s"(sb), "s"(dst) : "memory");   // (m0 is a reserved register: nothing hipcc emits for gfx950 in this kernel depends on it)
   };
 
   // ---- fragment addressing
@@ -386,7 +415,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
 #pragma unroll
       for (int j = 0; j < RN; ++j) {
         f.bh[j] *= sb;
-        if constexpr (TERMS > 1) f.bl[j] *= sb;
+        if constexpr (TERMS == 3) f.bl[j] *= sb;
       }
     }
   };
@@ -445,35 +474,51 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
           if (more && m < NRD) read_frag(f0, sa2, sb2, 0, m);
         }
       }
-      if (more2 && m < CPW && !(EAV_ABL & 2)) issue1(buf, m);
-      if (more2 && m + NMF < CPW && !(EAV_ABL & 2)) issue1(buf, m + NMF);          // (one term: 4 slots for 8 chunks)
+      if (more2 && m < CPW && !(EAV_ABL & 2)) issue1(buf, m, t + NS);
+      if (more2 && m + NMF < CPW && !(EAV_ABL & 2)) issue1(buf, m + NMF, t + NS);          // (one term: 4 slots for 8 chunks)
       if (!more && next_m0 >= 0) {
-        if (m < CPW) issue1(0, m);
-        else if (m < 2 * CPW && nk > 1) issue1(1, m - CPW);
+        if (m < CPW) issue1(0, m, 0);
+        else if (m < 2 * CPW && nk > 1) issue1(1, m - CPW, 1);
       }
       SB();
     }
     if (!more && next_m0 >= 0) {                 // the rest of the next tile's first two stages (2 CPW may exceed the slots)
 #pragma unroll
       for (int m = NMF; m < 2 * CPW; ++m) {
-        if (m < CPW) issue1(0, m);
-        else if (nk > 1) issue1(1, m - CPW);
+        if (m < CPW) issue1(0, m, 0);
+        else if (nk > 1) issue1(1, m - CPW, 1);
       }
     }
   };
 
+  // Tile walk.  Static: ids blockIdx.x + k gridDim.x.  Dynamic (g.sched): the first tile is static, every further one is
+  // popped from the workgroup's XCD counter (id = xcd + 8 j keeps a workgroup's tiles on its XCD and the XCD-contiguous tile
+  // order of tile_origin): wave 0 pops one tile AHEAD at the start of a tile (the atomic's round trip hides under the K
+  // loop), leaves the id in LDS at the end of the tile, and every wave picks it up behind the next tile-start barrier.
+  // s_next: NS = 2 - the first word of wave 0's epilogue patch (written after wave 0's epilogue, read by every wave right
+  // behind the next tile-start barrier, i.e. before the K-tile barrier that precedes wave 0's next epilogue); NS = 3 - a word
+  // of its own (the patches alias stage 2, which is re-filled between the two tile-start barriers)
+  int& s_next = *reinterpret_cast<int*>(smem + (NS == 2 ? 2 * STAGE : 3 * STAGE));
+  const bool dyn = g.sched != nullptr;
+  const bool popper = dyn && wave == 0 && lane == 0;
+  auto pop = [&]() -> int { return (tl0 & 7) + (int)tstep + 8 * (int)atomicAdd(g.sched + (tl0 & 7), 1u); };
+  int pend = 0;
+  if (popper) {
+    s_next = pop();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
   bool primed = false;
-  for (int tl = tl0; tl < nb; tl += tstep) {
+  int nxt = tl0 + tstep;
+  for (int tl = tl0; tl < nb; tl = nxt) {
     int m0, n0, nm0 = -1, nn0 = -1;
     tile_origin(tl, m0, n0);
-    if (tl + tstep < nb) tile_origin(tl + tstep, nm0, nn0);
     if (!primed) {
       set_sources(m0, n0);
 #pragma unroll
-      for (int i = 0; i < CPW; ++i) issue1(0, i);
+      for (int i = 0; i < CPW; ++i) issue1(0, i, 0);
       if (nk > 1) {
 #pragma unroll
-        for (int i = 0; i < CPW; ++i) issue1(1, i);
+        for (int i = 0; i < CPW; ++i) issue1(1, i, 1);
       }
       primed = true;
     }
@@ -491,7 +536,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
       __builtin_amdgcn_s_barrier();          // every wave is done with its epilogue patch (inside stage 2)
       if (nk > 2) {
 #pragma unroll
-        for (int i = 0; i < CPW; ++i) issue1(2, i);
+        for (int i = 0; i < CPW; ++i) issue1(2, i, 2);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CPW) : "memory");
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -500,6 +545,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
+    if (dyn) {
+      nxt = __builtin_amdgcn_readfirstlane(*(volatile int*)&s_next);
+      if (popper) pend = pop();
+    } else {
+      nxt = tl + tstep;
+    }
+    if (nxt < nb) tile_origin(nxt, nm0, nn0);
 #pragma unroll
     for (int r = 0; r < NRD; ++r) {
       if constexpr (TR) read_frag_tr(f0, smem, 0, r);
@@ -522,6 +574,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
     }
 
     // ---- epilogue of this tile (the next tile's first stages are in flight)
+    // The epilogue's per-lane index arithmetic is tile-invariant: left alone, hipcc hoists it out of the persistent tile loop
+    // and - the main loop sits at the 256-register budget - spills it once at kernel entry to reload it in every epilogue
+    // (36-196 bytes of scratch per lane in round 5, none of it inside the K loop).  A laundered lane id makes it tile-local:
+    // a handful of VALU instructions per tile instead of scratch traffic.
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const int lane = lane_e, r32 = lane_e & 31, kh = lane_e >> 5;
     if (TWOACC) {
 #pragma unroll
       for (int i = 0; i < RM; ++i)
@@ -797,9 +856,47 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
         }
       }
     }
+    if (popper) {              // (read by the other waves behind the NEXT tile-start barrier; their last read of s_next was
+      s_next = pend;           //  behind this tile's)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
+  if (popper) {
+    // the last workgroup to leave re-arms the counters for the launch that takes this slot of the ring next
+    if (atomicAdd(g.sched + 8, 1u) == gridDim.x - 1) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) __hip_atomic_store(g.sched + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 #undef MM
 #undef SB
+}
+
+// Counter slots of the dynamic tile walk: a ring of 16-word slots (8 per-XCD counters + the exit counter), zero at rest - the
+// last workgroup of a launch re-arms its slot.  A slot is taken per launch, round-robin: two launches share one only 4096
+// launches apart (concurrent streams, or kernels captured into different hipGraphs, never collide in practice; replays of ONE
+// graph are ordered).  Allocated on first use; if that fails (or happens inside a stream capture) the walk stays static.
+constexpr int SCHED_RING = 4096;
+unsigned* g_sched_ring = nullptr;
+int g_sched_state = 0;            // 0 = not tried, 1 = usable, -1 = unavailable
+unsigned g_sched_seq = 0;
+int g_sched_dynamic = 1;          // tuning hook (eav_gemm_sp_set_sched): 0 = static tile walk everywhere
+int g_sched_stagger = -1;         // tuning hook: -1 = by shape (launch), else units | phases << 8
+
+unsigned* sched_slot() {
+  if (g_sched_state == 0) {
+    void* p = nullptr;
+    if (hipMalloc(&p, SCHED_RING * 16 * sizeof(unsigned)) == hipSuccess &&
+        hipMemset(p, 0, SCHED_RING * 16 * sizeof(unsigned)) == hipSuccess) {
+      g_sched_ring = (unsigned*)p;
+      g_sched_state = 1;
+    } else {
+      (void)hipGetLastError();
+      g_sched_state = -1;
+    }
+  }
+  if (g_sched_state != 1) return nullptr;
+  return g_sched_ring + 16 * (__atomic_fetch_add(&g_sched_seq, 1u, __ATOMIC_RELAXED) % SCHED_RING);
 }
 
 int g_order = 0;
@@ -823,9 +920,19 @@ bool launch(SpArgs& g, int nz, hipStream_t st, int terms = 3) {
   // that every workgroup's tiles stay on one XCD; fewer tiles than that: one workgroup per tile
   const int resident = (WM * WN <= 4 ? 2 : 1) * 256 * (g_persist ? 1 : 1 << 20);
   const int nb = g.tm * g.tn, gx = nb <= resident ? nb : resident;
+  // more tiles than resident workgroups: tiles handed out dynamically behind a staggered start (see the kernel)
+  g.sched = (g_sched_dynamic && nz == 1 && nb > gx) ? sched_slot() : nullptr;
+  g.stagger = g.sched ? (g_sched_stagger >= 0 ? g_sched_stagger : (EAV_SCHED_DEFAULT_STAGGER)) : 0;
   if (terms == 1) {
     if constexpr (RM * RN >= 4) {      // (the one-term form has too few MFMA slots per K-step for the chunks of a 64-row tile)
       hipLaunchKernelGGL((gemm_sp_kernel<WM, WN, RM, RN, false, TR, 1, NS>), dim3(gx, 1, nz), dim3(64 * WM * WN), 0, st, g);
+      return true;
+    }
+    return false;
+  } else if (terms == 2) {
+    if constexpr (TR) {
+      if (!g_loshift) return false;
+      hipLaunchKernelGGL((gemm_sp_kernel<WM, WN, RM, RN, true, true, 2, NS>), dim3(gx, 1, nz), dim3(64 * WM * WN), 0, st, g);
       return true;
     }
     return false;
@@ -1185,6 +1292,12 @@ extern "C" int eav_gemm_sp_set_splitk(int slices) {
   return EAV_OK;
 }
 
+extern "C" int eav_gemm_sp_set_sched(int dynamic, int stagger) {
+  g_sched_dynamic = dynamic;
+  g_sched_stagger = stagger;
+  return EAV_OK;
+}
+
 extern "C" int eav_gemm_sp_set_tile(int which) {
   g_force_tile = which & 3;
   g_small_tile = (which >> 6) & 3;      // +64: the 64 x 128 form wherever it applies, +128: never
@@ -1343,6 +1456,13 @@ static int gemm_sp_splitk_impl(const void* A, const void* B, float* C, float* ws
 extern "C" int eav_gemm_sp_splitk(const void* A, const void* B, float* C, float* ws, const float* slotA,
                                   const float* slotB, int M, int N, int T, int accumulate, void* stream) {
   return gemm_sp_splitk_impl(A, B, C, ws, slotA, slotB, M, N, T, accumulate, stream, 3);
+}
+
+// eav_gemm_sp_splitk on two terms, hi_A.hi_B + lo_A.hi_B: B (the activation operand of a weight gradient) rounded to fp16, A
+// (the gradient operand) at full split precision - two thirds of the matrix work of eav_gemm_sp_splitk
+extern "C" int eav_gemm_sp_splitk_x2(const void* A, const void* B, float* C, float* ws, const float* slotA,
+                                     const float* slotB, int M, int N, int T, int accumulate, void* stream) {
+  return gemm_sp_splitk_impl(A, B, C, ws, slotA, slotB, M, N, T, accumulate, stream, 2);
 }
 
 // eav_gemm_sp_splitk with the hi.hi term only (see eav_gemm_sp_x1)

@@ -627,7 +627,9 @@ class Encoder(nn.Module):
         self._wplanes_key = key
 
     def _terms(self, kind):
-        """MFMA terms of the backward products of `kind` ("dgrad" | "wgrad"): 3 = fp32-grade, 1 = hi.hi only."""
+        """MFMA terms of the backward products of `kind` ("dgrad" | "wgrad"): 3 = fp32-grade, 1 = hi.hi only; wgrad also 2 =
+        hi.hi + lo_grad.hi_act (the activation operand rounded to fp16, the gradient operand at full split precision -
+        the producers' a-priori gradient planes stay on)."""
         t = self.wgrad_terms if kind == "wgrad" else self.dgrad_terms
         return self.grad_terms if t is None else int(t)
 
@@ -724,7 +726,7 @@ class Encoder(nn.Module):
         tails of its own GEMMs.  Ordering: the side stream waits for the event recorded after the conversion that
         produced A; the main stream waits for a weight gradient only before it overwrites that gradient's A planes
         (one layer later) and at the end of the backward."""
-        name = "eav_gemm_sp_splitk_x1" if self._terms("wgrad") == 1 else "eav_gemm_sp_splitk"
+        name = {1: "eav_gemm_sp_splitk_x1", 2: "eav_gemm_sp_splitk_x2"}.get(self._terms("wgrad"), "eav_gemm_sp_splitk")
         if not self._two_streams() or (self.kernel_events is not None and name in self.kernel_events):
             self._call(name, _lib.ptr(AT), _lib.ptr(BT), C, _lib.ptr(self._ws.splitk), slotA, slotB, M,
                        N, K, 0, self._st)

@@ -390,6 +390,11 @@ int eav_gemm_sp_ex(const void* A, const void* B, float* C, const float* slotA, c
                    const float* planes_slot, float* colsum_part, int flags, void* stream);
 int eav_gemm_sp_splitk_x1(const void* A, const void* B, float* C, float* ws, const float* slotA, const float* slotB, int M,
                           int N, int T, int accumulate, void* stream);
+/* eav_gemm_sp_splitk on TWO terms, hi_A.hi_B + lo_A.hi_B: operand B rounded to fp16 (its lo pieces are not read), operand A
+ * at full split precision.  For weight gradients with A = the gradient tensor and B = the activation (autograd of
+ * Transformer_Audio.py:74-79 / Transformer_Vision.py:94-99 through the HF nn.Linear layers): two thirds of the matrix work. */
+int eav_gemm_sp_splitk_x2(const void* A, const void* B, float* C, float* ws, const float* slotA, const float* slotB, int M,
+                          int N, int T, int accumulate, void* stream);
 /* (the process-global tile / slice-count overrides the kernel benchmarks use are NOT part of this header: eav_hip_tuning.h) */
 /* The same fused attention on the fp16 matrix cores with split operands (csrc/attention_sp.hip; fp32-grade, 3 MFMAs per
  * product).  eav_attn_sp_prep converts an fp32 activation src [B*N, ncols] (qkv or dO; slot holds its max|x| shards, see

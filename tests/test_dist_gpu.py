@@ -136,26 +136,131 @@ open(os.path.join(OUT, f"ok_{rank}"), "w").write("ok")
 """
 
 
-def test_two_ranks_on_one_gpu(tmp_path):
+WORKER4 = r"""
+import os, sys
+sys.path.insert(0, ROOT)
+import numpy as np, torch, torch.distributed as dist
+from eav_amd import dist as ed, synth
+from eav_amd.eegnet import EEGNet_tor, GraphStep, gather_batch
+from eav_amd.optim import CrossEntropyLoss, FusedAdam
+
+rank, world, _ = ed.init_from_env("gloo")
+assert world == 4
+torch.cuda.set_device(0)
+# the tail group of the 8-GPU job in miniature: ONE subject left over for four ranks -> one 4-rank group, formed by the
+# schedule code the bench and the subject drivers use (SubjectSchedule.make_groups -> GradSync(group=...))
+sched = ed.subject_schedule(world, 1)
+assert sched.rounds == 0 and sched.group_size == 4 and sched.groups == [(1, [0, 1, 2, 3])]
+groups = sched.make_groups()
+sub, ranks = sched.group_of(rank)
+i, n = ranks.index(rank), len(ranks)
+S, TR, GB = 1408, 80, 64                       # FFT FIR path; global batch 64 = the bench batch -> 16 rows per rank
+lo, hi = ed.shard_batch(GB, i, n)
+assert (lo, hi) == (16 * i, 16 * i + 16)
+x, y = synth.eeg_subject(sub, TR, 30, S)
+xs, ys = torch.from_numpy(x).unsqueeze(1).cuda(), torch.from_numpy(y).cuda()
+crit = CrossEntropyLoss()
+
+
+def fresh(drop):
+    torch.manual_seed(7)                       # identical replicas on every member
+    return EEGNet_tor(nb_classes=5, Chans=30, Samples=S, dropoutRate=drop).cuda().train()
+
+
+def grads_of(model):
+    return {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+
+
+# (a) the group's gradient = the mean of the four shard gradients (BatchNorm statistics per replica: nn.DataParallel's
+# behaviour, EEGNet_tor.py:86-88), every member computes all four shards itself to compare
+gen = torch.Generator().manual_seed(99)
+gidx = torch.randperm(TR, generator=gen)[:GB].cuda()
+per = []
+for r in range(n):
+    m = fresh(0.0)
+    d, t = gather_batch(xs, ys, gidx[16 * r:16 * r + 16])
+    crit(m(d), t).backward()
+    per.append(grads_of(m))
+m = fresh(0.0)
+m._ensure_flat()
+sync = ed.GradSync([m._flat[1]], group=groups[sub])
+assert sync.world == 4 and sync.weight == 0.25 and sync.enabled
+d, t = gather_batch(xs, ys, gidx[lo:hi])
+crit(m(d), t).backward()
+sync()
+for k, g in grads_of(m).items():
+    want = 0.25 * (per[0][k] + per[1][k] + per[2][k] + per[3][k])
+    assert (g - want).abs().max().item() <= 2e-6 * want.abs().max().item() + 1e-10, k
+
+# (b) GraphStep at B = 16 per rank: compute graph -> eager all-reduce inside the group -> update graph, bit-equal to the
+# eager schedule (dropout 0.5 active: the counter-based generator is part of the captured step), replicas stay identical
+finals, losses = [], []
+for use_graph in (False, True):
+    model = fresh(0.5)
+    opt = FusedAdam(model.parameters(), lr=1e-3, capturable=True)
+    model._ensure_flat()
+    sync = ed.GradSync([model._flat[1]], group=groups[sub])
+    gen = torch.Generator().manual_seed(4321)
+    batches = [torch.randperm(TR, generator=gen)[:GB][lo:hi] for _ in range(6)]
+    ls = []
+    gs = GraphStep(model, opt, crit, xs, ys, hi - lo, sync)
+    for b in batches:
+        if use_graph:
+            ls.append(gs.run(b)[1].clone())
+        else:                                  # the same launches issued one by one: compute -> all-reduce -> update
+            gs.idx.copy_(b)
+            ls.append(gs._eager()[1].detach().clone())
+    if use_graph:
+        assert gs.graph is not None and gs.graph_update is not None        # two graphs with the all-reduce between them
+    else:
+        assert gs.graph is None
+    torch.cuda.synchronize()
+    assert sync.collectives == len(batches)
+    finals.append(model._flat[0].clone())
+    losses.append(torch.stack(ls))
+assert torch.equal(finals[0], finals[1]), "graph replay vs eager schedule (parameters)"
+assert torch.equal(losses[0], losses[1]), "graph replay vs eager schedule (losses)"
+both = [torch.empty_like(finals[1]) for _ in range(n)]
+dist.all_gather(both, finals[1], group=groups[sub])
+assert all(torch.equal(both[0], b) for b in both), "replicas diverged"
+dist.barrier()
+dist.destroy_process_group()
+open(os.path.join(OUT, f"ok_{rank}"), "w").write("ok")
+"""
+
+
+def _run_workers(tmp_path, worker, nproc):
     script = tmp_path / "worker.py"
-    body = textwrap.indent(textwrap.dedent(WORKER), "    ")
+    body = textwrap.indent(textwrap.dedent(worker), "    ")
     script.write_text(f"ROOT = {ROOT!r}\nOUT = {str(tmp_path)!r}\nimport os, traceback\ntry:\n{body}\nexcept BaseException:\n"
                       "    open(os.path.join(OUT, 'err_' + os.environ.get('RANK', '0')), 'w').write(traceback.format_exc())\n"
                       "    raise\n")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="4", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = None
-    for attempt in range(2):      # the worker takes seconds; a rendezvous that never completes (seen once on a pool box) gets one retry
+    for attempt in range(2):      # a rendezvous that never completes (seen once on a pool box) gets one retry
         with socket.socket() as sock:
             sock.bind(("127.0.0.1", 0))
             port = sock.getsockname()[1]
         try:
-            r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+            r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
                                 "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
-                               capture_output=True, text=True, env=env, timeout=400, cwd=str(tmp_path))
+                               capture_output=True, text=True, env=env, timeout=500, cwd=str(tmp_path))
             break
         except subprocess.TimeoutExpired:
             if attempt == 1:
                 raise
     errs = "".join(open(tmp_path / f).read() for f in sorted(os.listdir(tmp_path)) if f.startswith("err_"))
     assert r.returncode == 0, (errs or (r.stdout[-3000:] + r.stderr[-6000:]))
-    assert (tmp_path / "ok_0").exists() and (tmp_path / "ok_1").exists(), r.stdout[-3000:] + r.stderr[-3000:]
+    assert all((tmp_path / f"ok_{k}").exists() for k in range(nproc)), r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def test_four_rank_group_on_one_gpu(tmp_path):
+    """The 4-rank tail group of SubjectSchedule(8, 42) - GradSync.weight 1/4, shard_batch(64, i, 4) = 16 rows per rank, a
+    GraphStep captured at B = 16 in two graphs with the in-group all-reduce between them - with real EEGNet backwards, four
+    processes sharing the one MI355X of the test box (gloo carries the collective; the 8-GPU node runs the same code over
+    RCCL)."""
+    _run_workers(tmp_path, WORKER4, 4)
+
+
+def test_two_ranks_on_one_gpu(tmp_path):
+    _run_workers(tmp_path, WORKER, 2)

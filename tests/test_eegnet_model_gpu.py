@@ -227,12 +227,15 @@ def test_full_size_batch_against_oracle():
         assert torch.equal(n2[k].grad, g1[k]), k
 
 
-@pytest.mark.parametrize("B,S", [(4, 2816), (3, 10000)])
-def test_eval_mode_training_step_on_the_fft_path_against_oracle(B, S):
+@pytest.mark.parametrize("B,S,fir", [(4, 2816, "auto"), (3, 10000, "auto"), (5, 256, "auto"), (3, 512, "auto"), (2, 512, "fft"),
+                                     (4, 500, "auto")])
+def test_eval_mode_training_step_on_the_fft_path_against_oracle(B, S, fir):
     """What epochs 2 .. 350 of the reference run (Q4: the model stays in eval mode after the first validate()): BatchNorm on
     running statistics, no dropout, WITH a backward.  On the FFT path this step takes three eval-only shortcuts - firstConv
     collects no statistics, depthwiseBN -> ELU -> AvgPool4 leaves the depthwise pass itself (eav_eegnet_dw_fwd_pool_eval), the
-    weight gradient skips y1 - all held to the train-mode bounds against the oracle, with non-trivial running statistics."""
+    weight gradient skips y1 - all held to the train-mode bounds against the oracle, with non-trivial running statistics.
+    Rows of <= 256 / <= 512 samples take the channel-group instantiations of the two depthwise eval kernels (CG = 4 / 2: only
+    the `mine` group writes p2, only group 0's waves feed the BatchNorm-backward sums), with either FIR algorithm."""
     from eav_amd.optim import CrossEntropyLoss
     from oracle import eegnet_oracle as orc
     sd = eegnet_weights(37, S)
@@ -244,7 +247,8 @@ def test_eval_mode_training_step_on_the_fft_path_against_oracle(B, S):
             sd[k] = (0.5 + rng.random(sd[k].shape)).astype(np.float32)
     model = build(S, sd)
     model.eval()
-    assert model._use_fft()
+    model.fir_algo = fir
+    assert model._use_fft() == (S >= 1408 or fir == "fft")
     x, y = synth.eeg_batch(411, B, 30, S)
     scores = model(torch.from_numpy(x).cuda())
     loss = CrossEntropyLoss()(scores, torch.from_numpy(y).cuda())

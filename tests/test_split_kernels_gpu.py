@@ -714,6 +714,45 @@ def test_one_term_products_are_the_fp16_product_of_the_planes(shape):
     assert torch.equal(W, W2)
 
 
+@pytest.mark.parametrize("T,n1,n2", [(512, 256, 136), (1000, 200, 100), (9712, 768, 384), (25216, 64, 768), (300, 130, 40)])
+def test_two_term_weight_gradient_rounds_only_the_activation_operand(T, n1, n2):
+    """eav_gemm_sp_splitk_x2 (Encoder.wgrad_terms = 2): hi_A.hi_B + lo_A.hi_B - operand A (the gradient tensor of a weight
+    gradient) keeps both pieces, operand B (the activation) is rounded to fp16 under its scale.  EXACTLY (up to summation
+    order) the float64 product of A with the decoded hi pieces of B: within 3e-7 of sum|a||b| - the three-term kernel's
+    accuracy class; against the true product the error is B's fp16 rounding (2^-12 relative per element, random signs), far
+    below the one-term product's, which rounds both operands.  A carries a loose scale (1e-3 of its slot's bound, like the
+    producers' a-priori gradient planes) without loss; bit-reproducible."""
+    torch.manual_seed(T + n1)
+    G = torch.randn(T, n1, device="cuda") * 1e-3 * (1 + torch.arange(n1, device="cuda") % 7)      # "gradient"
+    X = torch.randn(T, n2, device="cuda") * (1 + torch.arange(n2, device="cuda") % 3)              # "activation"
+    sg, pg = row_planes(G)
+    sx, px = row_planes(X)
+    W = torch.empty(n1, n2, device="cuda")
+    ns = _lib.plain("eav_gemm_sp_splitk_plan", n1, n2, T)
+    ws = torch.empty(max(ns, 1) * n1 * n2, device="cuda")
+    _lib.call("eav_gemm_sp_splitk_x2", P(pg), P(px), P(W), P(ws), P(sg), P(sx), n1, n2, T, 0, None)
+    n2p = kpad(n2)
+    Tp = px.numel() // (2 * n2p)
+    xhi = px.view(Tp, n2p // 8, 2, 8)[:T, :, 0, :].reshape(T, n2p)[:, :n2].double() * sx[2049].double()
+    ref_hi = G.double().t() @ xhi
+    den = G.double().abs().t() @ X.double().abs()
+    assert ((W.double() - ref_hi).abs() / den).max().item() < 3e-7
+    ref = G.double().t() @ X.double()
+    e2 = ((W.double() - ref).norm() / ref.norm()).item()
+    W1 = torch.empty_like(W)
+    _lib.call("eav_gemm_sp_splitk_x1", P(pg), P(px), P(W1), P(ws), P(sg), P(sx), n1, n2, T, 0, None)
+    e1 = ((W1.double() - ref).norm() / ref.norm()).item()
+    W3 = torch.empty_like(W)
+    _lib.call("eav_gemm_sp_splitk", P(pg), P(px), P(W3), P(ws), P(sg), P(sx), n1, n2, T, 0, None)
+    e3 = ((W3.double() - ref).norm() / ref.norm()).item()
+    print(f"wgrad T={T} {n1}x{n2}: relative error three terms {e3:.2e}, two terms {e2:.2e}, one term {e1:.2e}")
+    assert e2 < 3e-4 and e2 < 0.85 * e1 and e3 < 1e-6
+    assert ((W.double() - ref).abs() / den).max().item() < 3e-4
+    W2 = torch.empty_like(W)
+    _lib.call("eav_gemm_sp_splitk_x2", P(pg), P(px), P(W2), P(ws), P(sg), P(sx), n1, n2, T, 0, None)
+    assert torch.equal(W, W2)
+
+
 @pytest.mark.parametrize("shape", [(512, 384, 768), (1000, 200, 100), (9712, 768, 3072), (25216, 768, 64), (700, 2304, 96)])
 def test_three_stage_256x128_form_gives_the_same_bits(shape):
     """The 256 x 128 / 8-wave / three-LDS-stage form of the kernel (tuning hook eav_gemm_sp_set_tile(2); epilogue patches

@@ -174,7 +174,7 @@ PLAIN = {
 EXPORTS = sorted(list(SIGNATURES) + list(PLAIN))
 
 # test / tuning overrides (include/eav_hip_tuning.h): process-global, never called by the package
-TUNING = {"eav_gemm_sp_set_tile": [_i], "eav_gemm_sp_set_sched": [_i, _i], "eav_gemm_sp_set_splitk": [_i], "eav_sp_set_convert_blocks": [_i],
+TUNING = {"eav_gemm_sp_set_tile": [_i], "eav_gemm_sp_set_splitk": [_i], "eav_sp_set_convert_blocks": [_i],
           "eav_attn_sp_set_nw4_above": [_i]}
 
 # Comparison-only kernels (include/eav_hip_extras.h, `make BENCH_EXTRAS=1` -> libeav_extras.so): bench.py's literal-bf16 leg.

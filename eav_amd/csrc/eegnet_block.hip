@@ -434,7 +434,9 @@ __global__ __launch_bounds__(NT) void dw_bwd_kernel(const float* __restrict__ y1
     float r[DD];
 #pragma unroll
     for (int d = 0; d < DD; ++d)
-      r[d] = (dzv[d][0] * a[0] + dzv[d][1] * a[1]) + (dzv[d][2] * a[2] + dzv[d][3] * a[3]);
+      // (explicit fmas: left to -ffp-contract, two instantiations of this template may fuse the four products differently
+      // - the eval-mode form must reproduce the train-mode form's bits, tests/test_eegnet_kernels_gpu.py)
+      r[d] = __builtin_fmaf(dzv[d][0], a[0], dzv[d][1] * a[1]) + __builtin_fmaf(dzv[d][2], a[2], dzv[d][3] * a[3]);
     // step xor 1: keep 4 values; xor 2: keep 2; xor 4: keep 1; then plain reduce over the rest
     float r4[4], r2[2], r1;
 #ifdef DWB_ABL_NORED      // timing-only ablation (results garbage): the pass without its cross-lane reductions

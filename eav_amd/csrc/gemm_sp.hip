@@ -45,10 +45,6 @@
 #ifndef EAV_ABL
 #define EAV_ABL 0
 #endif
-// start-up stagger of the dynamic tile walk: units | phases << 8 (profiles/r06_gemm_sched_ab.txt)
-#ifndef EAV_SCHED_DEFAULT_STAGGER
-#define EAV_SCHED_DEFAULT_STAGGER (6 | (2 << 8))
-#endif
 
 
 namespace {
@@ -94,9 +90,6 @@ struct SpArgs {
   int order;                // tile order inside an XCD (see tile_origin)
   int kt_per_split;         // > 0: split-K, slice z covers K-tiles [z*kt_per_split, ...), C[z] = partial slab
   int tm, tn;
-  unsigned* sched;          // dynamic tile walk: this launch's 8 per-XCD tile counters + exit counter (zero; reset by the
-                            // last workgroup to leave), or null = static walk (tile ids blockIdx.x + k gridDim.x)
-  int stagger;              // start-up stagger: units | phases << 8 (workgroup b sleeps (b phases / gridDim.x) x units x ~3.4 us)
 };
 
 // erf-GELU without the libm erff (two divergent branches, ~60 instructions): with z = |x| / sqrt 2,
@@ -207,24 +200,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
   static_assert(NS == 2 || (NS == 3 && NW * 4096 <= STAGE), "two stages, or three with the patches inside the third");
   // + one 32 x 32 fp32 patch per wave: the epilogue turns accumulator blocks into row-linear order through it
   // (at offset 2 STAGE in both forms; NS = 3: that is stage 2, free while the epilogue runs)
-  // (+ 16 bytes in the three-stage form: the next-tile word of the dynamic tile walk; the two-stage form sits exactly at
-  // the 80 KB that let two workgroups share a CU and keeps that word in wave 0's patch, see s_next)
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[NS == 2 ? 2 * STAGE + NW * 4096 : 3 * STAGE + 16];
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[NS == 2 ? 2 * STAGE + NW * 4096 : 3 * STAGE];
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  // Start-up stagger (with the dynamic tile walk below): the persistent workgroups otherwise run in lock-step - every
-  // epilogue of a round bursts at the same time (ViT qkv forward: 232 MB of stores at 3.3 TB/s, 70 of 331 us, overlapped with
-  // nothing; the bias / GELU / plane arithmetic of both workgroups of a CU in the same window, the matrix pipes idle).
-  // Workgroups of the later phases start late, so that one phase's epilogues fall into the other phases' K loops.
-  // Round 5 measured the stagger alone (static walk): the late half of the grid also FINISHES late (-11 % ... +14 %);
-  // with tiles handed out dynamically the tail evens out.
-  if (g.stagger) {
-    const int units = g.stagger & 255, phases = g.stagger >> 8;
-    const int ph = (int)((unsigned)blockIdx.x * (unsigned)phases / gridDim.x);
-    for (int i = 0; i < ph * units; ++i) __builtin_amdgcn_s_sleep(127);
-  }
-
   // ---- persistent workgroups: tile ids blockIdx.x, blockIdx.x + gridDim.x, ... (gridDim.x is a multiple of 8 whenever a
   // workgroup gets more than one tile, so a workgroup stays on its XCD).  tile id -> tile: XCD-contiguous, then groups
   // of 8 tile-rows x all tile-columns, so that each XCD's L2 sees a compact set of operand panels.
@@ -267,6 +246,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
   unsigned voff[CPW];
   const unsigned char *baseA = Ab, *baseB = g.B;
   auto set_sources = [&](int m0, int n0) {
+    int lane = t & 63;                     // (laundered, like the epilogue's: the per-lane terms below are tile-invariant and
+    asm volatile("" : "+v"(lane));         //  would otherwise be hoisted out of the tile loop and spilled around the K loop)
     if constexpr (TR) {
       baseA = Ab + (int64_t)kt0 * 32 * g.ldA;
       baseB = g.B + (int64_t)kt0 * 32 * g.ldB;
@@ -491,27 +472,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
     }
   };
 
-  // Tile walk.  Static: ids blockIdx.x + k gridDim.x.  Dynamic (g.sched): the first tile is static, every further one is
-  // popped from the workgroup's XCD counter (id = xcd + 8 j keeps a workgroup's tiles on its XCD and the XCD-contiguous tile
-  // order of tile_origin): wave 0 pops one tile AHEAD at the start of a tile (the atomic's round trip hides under the K
-  // loop), leaves the id in LDS at the end of the tile, and every wave picks it up behind the next tile-start barrier.
-  // s_next: NS = 2 - the first word of wave 0's epilogue patch (written after wave 0's epilogue, read by every wave right
-  // behind the next tile-start barrier, i.e. before the K-tile barrier that precedes wave 0's next epilogue); NS = 3 - a word
-  // of its own (the patches alias stage 2, which is re-filled between the two tile-start barriers)
-  int& s_next = *reinterpret_cast<int*>(smem + (NS == 2 ? 2 * STAGE : 3 * STAGE));
-  const bool dyn = g.sched != nullptr;
-  const bool popper = dyn && wave == 0 && lane == 0;
-  auto pop = [&]() -> int { return (tl0 & 7) + (int)tstep + 8 * (int)atomicAdd(g.sched + (tl0 & 7), 1u); };
-  int pend = 0;
-  if (popper) {
-    s_next = pop();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  }
   bool primed = false;
-  int nxt = tl0 + tstep;
-  for (int tl = tl0; tl < nb; tl = nxt) {
+  for (int tl = tl0; tl < nb; tl += tstep) {
     int m0, n0, nm0 = -1, nn0 = -1;
     tile_origin(tl, m0, n0);
+    if (tl + tstep < nb) tile_origin(tl + tstep, nm0, nn0);
     if (!primed) {
       set_sources(m0, n0);
 #pragma unroll
@@ -545,13 +510,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
-    if (dyn) {
-      nxt = __builtin_amdgcn_readfirstlane(*(volatile int*)&s_next);
-      if (popper) pend = pop();
-    } else {
-      nxt = tl + tstep;
-    }
-    if (nxt < nb) tile_origin(nxt, nm0, nn0);
 #pragma unroll
     for (int r = 0; r < NRD; ++r) {
       if constexpr (TR) read_frag_tr(f0, smem, 0, r);
@@ -856,47 +814,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_sp_
         }
       }
     }
-    if (popper) {              // (read by the other waves behind the NEXT tile-start barrier; their last read of s_next was
-      s_next = pend;           //  behind this tile's)
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-  }
-  if (popper) {
-    // the last workgroup to leave re-arms the counters for the launch that takes this slot of the ring next
-    if (atomicAdd(g.sched + 8, 1u) == gridDim.x - 1) {
-#pragma unroll
-      for (int i = 0; i < 9; ++i) __hip_atomic_store(g.sched + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
   }
 #undef MM
 #undef SB
-}
-
-// Counter slots of the dynamic tile walk: a ring of 16-word slots (8 per-XCD counters + the exit counter), zero at rest - the
-// last workgroup of a launch re-arms its slot.  A slot is taken per launch, round-robin: two launches share one only 4096
-// launches apart (concurrent streams, or kernels captured into different hipGraphs, never collide in practice; replays of ONE
-// graph are ordered).  Allocated on first use; if that fails (or happens inside a stream capture) the walk stays static.
-constexpr int SCHED_RING = 4096;
-unsigned* g_sched_ring = nullptr;
-int g_sched_state = 0;            // 0 = not tried, 1 = usable, -1 = unavailable
-unsigned g_sched_seq = 0;
-int g_sched_dynamic = 1;          // tuning hook (eav_gemm_sp_set_sched): 0 = static tile walk everywhere
-int g_sched_stagger = -1;         // tuning hook: -1 = by shape (launch), else units | phases << 8
-
-unsigned* sched_slot() {
-  if (g_sched_state == 0) {
-    void* p = nullptr;
-    if (hipMalloc(&p, SCHED_RING * 16 * sizeof(unsigned)) == hipSuccess &&
-        hipMemset(p, 0, SCHED_RING * 16 * sizeof(unsigned)) == hipSuccess) {
-      g_sched_ring = (unsigned*)p;
-      g_sched_state = 1;
-    } else {
-      (void)hipGetLastError();
-      g_sched_state = -1;
-    }
-  }
-  if (g_sched_state != 1) return nullptr;
-  return g_sched_ring + 16 * (__atomic_fetch_add(&g_sched_seq, 1u, __ATOMIC_RELAXED) % SCHED_RING);
 }
 
 int g_order = 0;
@@ -920,9 +840,6 @@ bool launch(SpArgs& g, int nz, hipStream_t st, int terms = 3) {
   // that every workgroup's tiles stay on one XCD; fewer tiles than that: one workgroup per tile
   const int resident = (WM * WN <= 4 ? 2 : 1) * 256 * (g_persist ? 1 : 1 << 20);
   const int nb = g.tm * g.tn, gx = nb <= resident ? nb : resident;
-  // more tiles than resident workgroups: tiles handed out dynamically behind a staggered start (see the kernel)
-  g.sched = (g_sched_dynamic && nz == 1 && nb > gx) ? sched_slot() : nullptr;
-  g.stagger = g.sched ? (g_sched_stagger >= 0 ? g_sched_stagger : (EAV_SCHED_DEFAULT_STAGGER)) : 0;
   if (terms == 1) {
     if constexpr (RM * RN >= 4) {      // (the one-term form has too few MFMA slots per K-step for the chunks of a 64-row tile)
       hipLaunchKernelGGL((gemm_sp_kernel<WM, WN, RM, RN, false, TR, 1, NS>), dim3(gx, 1, nz), dim3(64 * WM * WN), 0, st, g);
@@ -1289,12 +1206,6 @@ extern "C" int eav_sp_set_convert_blocks(int n) { g_convert_blocks = n > 0 ? n :
 
 extern "C" int eav_gemm_sp_set_splitk(int slices) {
   g_splitk_force = slices;
-  return EAV_OK;
-}
-
-extern "C" int eav_gemm_sp_set_sched(int dynamic, int stagger) {
-  g_sched_dynamic = dynamic;
-  g_sched_stagger = stagger;
   return EAV_OK;
 }
 

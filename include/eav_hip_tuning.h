@@ -6,7 +6,6 @@
 extern "C" {
 #endif
 int eav_gemm_sp_set_tile(int which);   /* 0 heuristic, 1 = 128x128 tiles, 2 = 256x128, +4 single accumulator, +8 non-persistent, +64 the 64x128 form wherever it applies, +128 never */
-int eav_gemm_sp_set_sched(int dynamic, int stagger);  /* tile walk of the persistent split GEMM: dynamic = 0 static ids; stagger = -1 by shape, else units | phases << 8 (start-up sleep of phase p: p x units x ~3.4 us) */
 int eav_gemm_sp_set_splitk(int slices);  /* eav_gemm_sp_splitk: forced slice count (0 = the plan; ws must hold it) */
 int eav_sp_set_convert_blocks(int n);  /* resident-block cap of eav_sp_convert (default 512; 0 = one block per tile) */
 int eav_attn_sp_set_nw4_above(int n);   /* 128-row (4-wave) attention workgroups for N > n (default 128); n < 0: the software-pipelined forward from N >= -n (default 512) */

@@ -321,3 +321,22 @@ def test_bench_subject_job_record_and_multi_gpu_headline():
     mg = head["multi_gpu"]
     assert mg["eegnet_subject_sharded"] == r8["value"] and mg["eegnet_strong"] == 1.0 and mg["eegnet_weak"] == 2.0
     assert mg["eegnet_subjects_ideal_speedup"] == 8.0 and "predicted_strong_scaling_at_8" not in head
+
+
+def test_split_gemm_instantiations_are_scratch_free():
+    """Every instantiation of gemm_sp_kernel `dispatch` can pick compiles for gfx950 without scratch (round 5: 36-196 bytes per
+    lane in all the default forms - the epilogue's tile-invariant index arithmetic, hoisted out of the persistent tile loop
+    and spilled around the K loop) and with the register budget of two waves per SIMD; the two-stage forms stay at the 80 KB
+    of LDS that let two workgroups share a CU.  hipcc cross-compiles here: no GPU needed (about a minute)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(root, "tools", "kernel_resources.py"))
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    rows = [r for r in kr.resources(os.path.join(root, "eav_amd", "csrc", "gemm_sp.hip")) if "gemm_sp_kernel" in r["demangled"]]
+    assert len(rows) >= 12, [r["demangled"] for r in rows]
+    for r in rows:
+        assert int(r["ScratchSize"]) == 0, (r["demangled"], r["ScratchSize"])
+        assert int(r["VGPRs"]) <= 256 and int(r["AGPRs"]) == 0 and int(r["Occupancy"]) == 2, r
+        three_stage = r["demangled"].rstrip(">(SpArgs) ").endswith(", 3")
+        assert int(r["LDS Size"]) <= (160 if three_stage else 80) * 1024, r

@@ -27,6 +27,7 @@ for kind, B in (("vit", 32), ("ast", 8)):
     hx = torch.from_numpy(hx).cuda()
     runs = {}
     for name, prec, terms, wt, dt in (("fp32", "fp32", 3, None, None), ("split", "split", 3, None, None),
+                                      ("split, wgrad_terms=2", "split", 3, 2, None),
                                       ("split, wgrad_terms=1", "split", 3, 1, None),
                                       ("split, dgrad_terms=1", "split", 3, None, 1),
                                       ("split, grad_terms=1", "split", 1, None, None)):
@@ -55,7 +56,7 @@ for kind, B in (("vit", 32), ("ast", 8)):
         torch.cuda.empty_cache()
     ref_l, ref_h, _ = runs["fp32"]
     print(f"== {kind} B={B}, {steps} AdamW steps at lr {lr:g}: loss {ref_l[0]:.4f} -> {ref_l[-1]:.4f} (exact-fp32 kernels)")
-    for name in ("split", "split, wgrad_terms=1", "split, dgrad_terms=1", "split, grad_terms=1"):
+    for name in ("split", "split, wgrad_terms=2", "split, wgrad_terms=1", "split, dgrad_terms=1", "split, grad_terms=1"):
         l, h, ms = runs[name]
         print(f"   {name:22s} {ms:6.2f} ms/step  max |loss - fp32 loss| over the run {np.abs(l - ref_l).max():.2e} (final {abs(l[-1] - ref_l[-1]):.2e}); "
               f"held-out logits after training: max |diff| {np.abs(h - ref_h).max():.2e} (logit range {np.abs(ref_h).max():.2f})")

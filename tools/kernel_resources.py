@@ -3,6 +3,7 @@
     python tools/kernel_resources.py eav_amd/csrc/gemm_sp.hip [-D... extra hipcc flags]
 
 Prints one line per kernel: VGPRs, AGPRs, scratch bytes per lane, occupancy, LDS bytes, demangled name.  No GPU needed."""
+import os
 import re
 import subprocess
 import sys
@@ -10,7 +11,7 @@ import sys
 
 def resources(src, extra=()):
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
-           "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", "/dev/null", "-I", "eav_amd/csrc", *extra]
+           "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", "/dev/null", "-I", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "eav_amd", "csrc"), *extra]
     err = subprocess.run(cmd, capture_output=True, text=True).stderr
     rows, cur = [], None
     for line in err.splitlines():

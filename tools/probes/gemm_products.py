@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
-"""Tile walk of the persistent split GEMM, A/B inside one process (eav_gemm_sp_set_sched): static ids (round 5) against tiles
-handed out dynamically, with and without a staggered start, on the products of an encoder layer with the epilogues the
-training step uses - ViT B = 128 (25216 token rows) and AST B = 8 (9712).  Times are interleaved (variant order rotated per
-repeat) medians of 5 x 20 launches.  Also the token-contracting weight gradients on three / two terms.  Run on the GPU box:
-    python3 tools/probes/gemm_sched_ab.py [vit|ast|both] > gpurun_out/gemm_sched_ab.txt"""
+"""The split GEMM on the products of an encoder layer with the epilogues the training step uses - ViT B = 128 (25216 token
+rows) and AST B = 8 (9712): median of 5 x 20 launches per product, the token-contracting weight gradients on three / two /
+one terms.  One library per process (EAV_LIB_PATH selects an A/B build: tools/probes/build_variant.sh), run on ONE box:
+    for so in "" tools/probes/build/libeav_r05gemm.so; do EAV_LIB_PATH=$so python3 tools/probes/gemm_products.py; done
+(Round 6 also ran it with the tile walk switched at run time - static ids against tiles popped from per-XCD counters behind a
+staggered start; that experiment lost and its code is gone: profiles/r06_gemm_sched_ab.txt, commit 63a5f0e.)"""
 import os
 import statistics
 import sys
@@ -19,11 +20,7 @@ from gemm_sp_bench import P, planes, row_planes, timeit, kpad  # noqa: E402
 L = _lib.load()
 SLOT = 4128
 which = sys.argv[1] if len(sys.argv) > 1 else "both"
-VARIANTS = [("static", 0, 0), ("dynamic", 1, 0), ("dyn+3x2", 1, 3 | 2 << 8), ("dyn+6x2", 1, 6 | 2 << 8), ("dyn+10x2", 1, 10 | 2 << 8),
-            ("dyn+3x4", 1, 3 | 4 << 8), ("dyn+2x8", 1, 2 | 8 << 8), ("dyn+1x16", 1, 1 | 16 << 8)]
-if os.environ.get("SCHED_VARIANTS"):
-    keep = os.environ["SCHED_VARIANTS"].split(",")
-    VARIANTS = [v for v in VARIANTS if v[0] in keep]
+VARIANTS = [(os.path.basename(os.environ.get("EAV_LIB_PATH") or "libeav_hip.so")[6:-3] or "hip", 0, 0)]
 print("product".ljust(44) + "".join(f"{n:>10s}" for n, _, _ in VARIANTS) + "   (us per launch; TFLOP/s of the best)")
 tot = {}
 for tag, M in (("vit", 25216), ("ast", 9712)):
@@ -61,12 +58,10 @@ for tag, M in (("vit", 25216), ("ast", 9712)):
             for rep in range(5):
                 order = VARIANTS[rep % len(VARIANTS):] + VARIANTS[:rep % len(VARIANTS)]
                 for n, dyn, stg in order:
-                    L.eav_gemm_sp_set_sched(dyn, stg)
                     ts[n].append(timeit(lambda: _lib.call("eav_gemm_sp_ex", *args), reps=20) * 1e3)
                     if rep == 0:
                         torch.cuda.synchronize()
                         outs[n] = (Cm.clone() if Cm is not None else None, pl.clone() if pl is not None else None)
-            L.eav_gemm_sp_set_sched(1, -1)
             ref = outs[VARIANTS[0][0]]
             for n, o in outs.items():           # the tile walk must not change a bit of the result
                 for a, b in zip(o, ref):

@@ -139,13 +139,17 @@ def bench_encoder(kind, dev, world, sync_factory, steps=4, warmup=2, blocks=3, b
     res = {}
     from eav_amd import _lib as _eavlib
     runs = runs or ((("unfrozen", False, "split"), ("frozen", True, "split"), ("unfrozen_fp32", False, "fp32"),
-                     ("frozen_fp32", True, "fp32"), ("unfrozen_fp16_gradients", False, "split_g1"),
-                     ("unfrozen_fp16", False, "split_11")) +
+                     ("frozen_fp32", True, "fp32"), ("unfrozen_two_term_wgrad", False, "split_w2"),
+                     ("unfrozen_fp16_gradients", False, "split_g1"), ("unfrozen_fp16", False, "split_11")) +
                     # literal bf16 operands: a comparison-only kernel (`make -C eav_amd/csrc BENCH_EXTRAS=1`)
                     ((("unfrozen_bf16", False, "bf16"),) if _eavlib.have_extras() else ()))
     notes = {"split": "fp16 MFMA, operands split into hi + lo fp16 planes, 3 MFMAs per product, fp32 accumulate: "
                       "fp32-grade (not worse than the exact-fp32 kernels against float64; logits within 1e-4 of HF)",
              "fp32": "exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)",
+             "split_w2": "as `split`, weight-gradient GEMMs on two terms (hi_grad.hi_act + lo_grad.hi_act: the activation "
+                         "operand rounded to fp16) - opt-in Encoder.wgrad_terms = 2; logits bit-equal, weight gradients 2-4e-4 "
+                         "relative; 40-step held-out drift 3.9e-5 / 2.3e-5 at lr 5e-6, 5.8e-4 / 1.5e-4 at 5e-5 "
+                         "(profiles/r06_term_budget.txt)",
              "split_g1": "forward as `split` (logits unchanged), backward GEMMs on the hi.hi term alone: fp16-operand "
                          "gradients (11-bit mantissas under per-tensor / per-row-block scales, fp32 accumulate) - opt-in "
                          "Encoder.grad_terms = 1; gradient error ~3e-4 relative (tests/test_transformer_model_gpu.py)",
@@ -158,6 +162,7 @@ def bench_encoder(kind, dev, world, sync_factory, steps=4, warmup=2, blocks=3, b
     for phase, freeze, prec in runs:
         model.precision = "split" if prec.startswith("split") else prec
         model.grad_terms = 1 if prec in ("split_g1", "split_11") else 3
+        model.wgrad_terms = 2 if prec == "split_w2" else None
         model.fwd_terms = 1 if prec == "split_11" else 3
         for k, p in model.named_parameters():
             p.requires_grad = (not freeze) or k.startswith("classifier.")
@@ -193,8 +198,9 @@ def bench_encoder(kind, dev, world, sync_factory, steps=4, warmup=2, blocks=3, b
             per_block.append((time.perf_counter() - t0) / steps)
         dt = statistics.median(per_block)
         # dominant kernel family, timed live with HIP events on the launch stream in a separate pass
-        sp_names = ("eav_gemm_sp", "eav_gemm_sp_ex", "eav_gemm_sp_planes", "eav_gemm_sp_splitk", "eav_gemm_sp_splitk_x1")
-        names = {"split": sp_names, "split_g1": sp_names, "split_11": sp_names,
+        sp_names = ("eav_gemm_sp", "eav_gemm_sp_ex", "eav_gemm_sp_planes", "eav_gemm_sp_splitk", "eav_gemm_sp_splitk_x1",
+                    "eav_gemm_sp_splitk_x2")
+        names = {"split": sp_names, "split_w2": sp_names, "split_g1": sp_names, "split_11": sp_names,
                  "fp32": ("eav_gemm_f32", "eav_gemm_f32_splitk"), "bf16": ("eav_gemm_bf16", "eav_gemm_bf16_splitk")}[prec]
         gemm_ms, gemm_launches = 0.0, 0
         if probe:

@@ -32,6 +32,8 @@ SIGNATURES = {
     "eav_reduce_partials": [_p, _i, _i64, _i, _f, _p, _p],
     "eav_bn_finalize": [_p, _i, _i, _d, _p, _p, _p, _p, _i, _f, _f, _p, _p, _p, _p, _p],
     "eav_bn_bwd_finalize": [_p, _i, _i, _d, _i, _p, _p, _p, _p, _p],
+    "eav_reduce_and_bn_bwd_finalize": [_p, _i, _i64, _i, _p, _p, _i, _i, _d, _i, _p, _p, _p, _p, _p, _i, _i, _d, _i, _p, _p, _p,
+                                       _p, _p],
     "eav_renorm_rows": [_p, _i, _i, _f, _p],
     "eav_renorm_rows2": [_p, _i, _i, _p, _i, _i, _f, _p],
     "eav_eegnet_step_prologue": [_p, _p, _p, _p, _p, _p, _p, _p],
@@ -62,6 +64,7 @@ SIGNATURES = {
     "eav_adam_step": [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _i64, _i, _p, _p],
     "eav_counter_inc": [_p, _p],
     "eav_counter_inc4": [_p, _p, _p, _p, _p],
+    "eav_step_begin": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _p],
     "eav_gather_rows": [_p, _p, _p, _i, _i64, _p],
     "eav_gather_i64": [_p, _p, _p, _i, _p],
     "eav_gemm_f32": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64, _f, _p,

@@ -56,13 +56,12 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
 // lane order: fixed order, bit-reproducible.  (The scalar kernel above read 64-byte segments with one load in flight and
 // ran at 45-80 GB/s on the [~400, 3072] bias-gradient partials of the encoders; this one is latency-bound at a few us.)
 template <int CL>
-__global__ __launch_bounds__(256) void reduce_partials_vec_kernel(const float* __restrict__ part, int nparts,
-                                                                  int64_t stride, int n4, float scale,
-                                                                  float* __restrict__ out) {
+__device__ __forceinline__ void reduce_partials_vec_body(const float* __restrict__ part, int nparts, int64_t stride, int n4,
+                                                         float scale, float* __restrict__ out, int bid) {
   constexpr int PL = 256 / CL;
   __shared__ double sh[PL][4 * CL + 1];
   const int cl = threadIdx.x % CL, pl = threadIdx.x / CL;
-  const int c4 = blockIdx.x * CL + cl;
+  const int c4 = bid * CL + cl;
   double a = 0.0, b = 0.0, c = 0.0, d = 0.0;
   if (c4 < n4) {
     const float* src = part + 4 * (int64_t)c4;
@@ -84,12 +83,19 @@ __global__ __launch_bounds__(256) void reduce_partials_vec_kernel(const float* _
   }
   sh[pl][4 * cl] = a; sh[pl][4 * cl + 1] = b; sh[pl][4 * cl + 2] = c; sh[pl][4 * cl + 3] = d;
   __syncthreads();
-  if (threadIdx.x < 4 * CL && 4 * blockIdx.x * CL + threadIdx.x < 4 * n4) {
+  if (threadIdx.x < 4 * CL && 4 * bid * CL + threadIdx.x < 4 * n4) {
     double t = 0.0;
 #pragma unroll
     for (int k = 0; k < PL; ++k) t += sh[k][threadIdx.x];
-    out[4 * (int64_t)blockIdx.x * CL + threadIdx.x] = (float)(t * (double)scale);
+    out[4 * (int64_t)bid * CL + threadIdx.x] = (float)(t * (double)scale);
   }
+}
+
+template <int CL>
+__global__ __launch_bounds__(256) void reduce_partials_vec_kernel(const float* __restrict__ part, int nparts,
+                                                                  int64_t stride, int n4, float scale,
+                                                                  float* __restrict__ out) {
+  reduce_partials_vec_body<CL>(part, nparts, stride, n4, scale, out, blockIdx.x);
 }
 
 extern "C" int eav_reduce_partials(const float* part, int nparts, int64_t stride, int n, float scale, float* out,
@@ -180,10 +186,9 @@ extern "C" int eav_bn_finalize(const float* part, int nparts, int nch, double co
 // (g = gradient w.r.t. the BN output).  dbeta = sum g, dgamma = sum g*xhat; in training mode the
 // input gradient is scale*(g - m1 - xhat*m2) with m1 = mean g, m2 = mean g*xhat; in eval mode
 // (running statistics are constants) m1 = m2 = 0.
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nparts, int nch, double count,
-                                       int training, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                       float* __restrict__ m1, float* __restrict__ m2) {
-  const int c = blockIdx.x;
+__device__ __forceinline__ void bn_bwd_finalize_body(const float* __restrict__ part, int nparts, int nch, double count,
+                                                     int training, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                     float* __restrict__ m1, float* __restrict__ m2, int c) {
   __shared__ double shs[256], shq[256];
   double s = 0.0, q = 0.0;
   for (int p = threadIdx.x; p < nparts; p += 256) {
@@ -207,6 +212,64 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int npart
   dgamma[c] = (float)q;
   m1[c] = training ? (float)(s / count) : 0.f;
   m2[c] = training ? (float)(q / count) : 0.f;
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nparts, int nch, double count,
+                                       int training, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                       float* __restrict__ m1, float* __restrict__ m2) {
+  bn_bwd_finalize_body(part, nparts, nch, count, training, dgamma, dbeta, m1, m2, blockIdx.x);
+}
+
+// One launch for the small finishing work behind a gradient pass: a fixed-order reduction of partial rows (a weight gradient)
+// and up to two BatchNorm-backward finalisers - the same bodies as eav_reduce_partials / eav_bn_bwd_finalize on disjoint block
+// ranges, hence the same bits.  Each was a graph node of its own at the ~4.7 us floor of a dependent node (EEGNet step:
+// depthwiseConv.weight + firstBN after eav_eegnet_dw_bwd_fused; + depthwiseBN in the eval-mode step).
+struct BnBwdJob {
+  const float* part;
+  int nparts, nch, training;
+  double count;
+  float *dgamma, *dbeta, *m1, *m2;
+};
+
+__global__ __launch_bounds__(256) void finish_jobs_kernel(const float* __restrict__ part, int nparts, int64_t stride, int n4,
+                                                          float scale, float* __restrict__ out, int nred, BnBwdJob a,
+                                                          BnBwdJob b) {
+  const int bid = blockIdx.x;
+  if (bid < nred) {
+    reduce_partials_vec_body<8>(part, nparts, stride, n4, scale, out, bid);
+    return;
+  }
+  const int c = bid - nred;
+  const BnBwdJob& j = c < a.nch ? a : b;
+  bn_bwd_finalize_body(j.part, j.nparts, j.nch, j.count, j.training, j.dgamma, j.dbeta, j.m1, j.m2, c < a.nch ? c : c - a.nch);
+}
+
+extern "C" int eav_reduce_and_bn_bwd_finalize(const float* part, int nparts, int64_t stride, int n, float* out,
+                                              const float* part_a, int nparts_a, int nch_a, double count_a, int training_a,
+                                              float* dgamma_a, float* dbeta_a, float* m1_a, float* m2_a,
+                                              const float* part_b, int nparts_b, int nch_b, double count_b, int training_b,
+                                              float* dgamma_b, float* dbeta_b, float* m1_b, float* m2_b, void* stream) {
+  EAV_REQUIRE(part && out && nparts > 0 && n > 0, "eav_reduce_and_bn_bwd_finalize: bad reduction arguments");
+  EAV_REQUIRE(part_a && nparts_a > 0 && nch_a > 0 && count_a > 0 && dgamma_a && dbeta_a && m1_a && m2_a,
+              "eav_reduce_and_bn_bwd_finalize: bad BatchNorm arguments");
+  EAV_REQUIRE(!part_b || (nparts_b > 0 && nch_b > 0 && count_b > 0 && dgamma_b && dbeta_b && m1_b && m2_b),
+              "eav_reduce_and_bn_bwd_finalize: bad second BatchNorm arguments");
+  const bool vec8 = (n & 3) == 0 && (stride & 3) == 0 && (((uintptr_t)part | (uintptr_t)out) & 15) == 0 && n < 8192;
+  if (!vec8) {      // shapes eav_reduce_partials serves with its other kernels: the separate launches (same results)
+    int rc = eav_reduce_partials(part, nparts, stride, n, 1.f, out, stream);
+    if (rc == EAV_OK)
+      rc = eav_bn_bwd_finalize(part_a, nparts_a, nch_a, count_a, training_a, dgamma_a, dbeta_a, m1_a, m2_a, stream);
+    if (rc == EAV_OK && part_b)
+      rc = eav_bn_bwd_finalize(part_b, nparts_b, nch_b, count_b, training_b, dgamma_b, dbeta_b, m1_b, m2_b, stream);
+    return rc;
+  }
+  BnBwdJob a{part_a, nparts_a, nch_a, training_a, count_a, dgamma_a, dbeta_a, m1_a, m2_a};
+  BnBwdJob b{part_b, nparts_b, part_b ? nch_b : 0, training_b, count_b, dgamma_b, dbeta_b, m1_b, m2_b};
+  const int nred = cdiv(n / 4, 8);
+  hipLaunchKernelGGL(finish_jobs_kernel, dim3(nred + a.nch + b.nch), dim3(256), 0, (hipStream_t)stream, part, nparts, stride,
+                     n / 4, 1.f, out, nred, a, b);
+  EAV_CHECK_LAUNCH("eav_reduce_and_bn_bwd_finalize");
+  return EAV_OK;
 }
 
 extern "C" int eav_bn_bwd_finalize(const float* part, int nparts, int nch, double count, int training,

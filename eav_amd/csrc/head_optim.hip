@@ -343,6 +343,34 @@ __global__ void gather_i64_kernel(const int64_t* __restrict__ src, const int64_t
   if (i < n) out[i] = src[idx[i]];
 }
 
+// The start of a captured training step in ONE launch (EEGNet_tor.py:100-104's batch assembly + the counters nn.BatchNorm2d /
+// the dropout stream / optim.Adam keep): up to five distinct step counters incremented by one thread, and the labels of the
+// batch gathered (out[i] = labels[idx[i]]).  Replaces eav_counter_inc4 + eav_counter_inc + eav_gather_i64: three graph
+// nodes at the ~4.7 us floor of a dependent node.
+__global__ void step_begin_kernel(int64_t* c0, int64_t* c1, int64_t* c2, int64_t* c3, int64_t* c4,
+                                  const int64_t* __restrict__ labels, const int64_t* __restrict__ idx,
+                                  int64_t* __restrict__ out, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i == 0) {
+    if (c0) *c0 += 1;
+    if (c1) *c1 += 1;
+    if (c2) *c2 += 1;
+    if (c3) *c3 += 1;
+    if (c4) *c4 += 1;
+  }
+  if (i < n) out[i] = labels[idx[i]];
+}
+
+extern "C" int eav_step_begin(int64_t* c0, int64_t* c1, int64_t* c2, int64_t* c3, int64_t* c4, const int64_t* labels,
+                              const int64_t* idx, int64_t* out, int n, void* stream) {
+  EAV_REQUIRE(n >= 0 && (n == 0 || (labels && idx && out)), "eav_step_begin: bad arguments");
+  EAV_REQUIRE(c0 || c1 || c2 || c3 || c4 || n > 0, "eav_step_begin: nothing to do");
+  hipLaunchKernelGGL(step_begin_kernel, dim3(n > 0 ? cdiv(n, 256) : 1), dim3(256), 0, (hipStream_t)stream, c0, c1, c2, c3, c4,
+                     labels, idx, out, n);
+  EAV_CHECK_LAUNCH("eav_step_begin");
+  return EAV_OK;
+}
+
 extern "C" int eav_gather_rows(const float* src, const int64_t* idx, float* out, int nrows, int64_t row_elems,
                                void* stream) {
   EAV_REQUIRE(src && idx && out && nrows > 0 && row_elems > 0, "eav_gather_rows: bad arguments");

@@ -203,6 +203,9 @@ class EEGNet_tor(nn.Module):
         self.conv_algo = os.environ.get("EAV_CONV_ALGO", "auto")      # separableConv: see _use_conv_fft
         self._fwd_counter = None               # device uint64: number of training forwards (dropout stream)
         self._infer = False                    # set per call: no-grad eval-mode forward
+        # GraphStep: (optimiser step counter, labels, idx, targets, batch) - raw pointers for eav_step_begin, taken by the next
+        # forward's counter launch (left in place if that forward has none to merge them into)
+        self._step_begin = None
         # validate()'s forward with block 1 as ONE kernel (eav_eegnet_block1_infer: y1 / z never written).  Opt-in: at the
         # benchmark shape [64,1,30,10000] it measures 1.35 ms against 1.30 ms for the training kernels in eval mode - with its
         # 128 z accumulators per lane it runs one wave per SIMD and cannot hide its VALU tail behind another wave's MFMAs
@@ -332,10 +335,15 @@ class EEGNet_tor(nn.Module):
         if self.fir_precision != "fp32":
             raise ValueError(f"fir_precision {self.fir_precision!r}: only 'fp32' exists (the split mode was retired)")
         counters = [cnt] + ([P(bn.num_batches_tracked) for bn in (bn1, bn2, bn3)] if training else [None] * 3)
+        begin, self._step_begin = self._step_begin, None
         if not self._use_conv_fft(B):    # (the frequency-domain separableConv takes the weight tensor as it is)
             # per-step prologue, one launch: the transposed separableConv weights of the direct kernels + the dropout step
             # counter and the three BatchNorm step counters (nn.BatchNorm2d's num_batches_tracked)
             L("eav_eegnet_step_prologue", w3, P(ws.wTf), P(ws.wTb), *counters, st)
+            self._step_begin = begin     # (not taken: GraphStep issues its own launches)
+        elif begin is not None:
+            # ... and, in a captured step (GraphStep), the optimiser's step count and the gather of the batch's labels with them
+            L("eav_step_begin", *counters, *begin, st)
         elif cnt is not None or training:
             # library kernels, no torch op inside a captured step
             L("eav_counter_inc4", *counters, st)
@@ -549,11 +557,15 @@ class EEGNet_tor(nn.Module):
             # launch, no extra read of z and dp2)
             L("eav_eegnet_dw_bwd_fused_eval", P(ws.y1), P(ws.z), P(ws.dp2), b2, b1, w2, P(ws.g1), P(ws.part_dst),
               P(ws.part_dw2), P(ws.part_dw), B, C, S, drop, seed1, m1, cnt, st)
-            L("eav_bn_bwd_finalize", P(ws.part_dw), B * ws.nchunk, 64, float(B * S), tr, P(g["depthwiseBN.weight"]),
-              P(g["depthwiseBN.bias"]), b2 + 4 * 256, b2 + 4 * 320, st)
-        L("eav_reduce_partials", P(ws.part_dw2), B * ws.nchunk, 64 * C, 64 * C, 1.0, P(g["depthwiseConv.weight"]), st)
-        L("eav_bn_bwd_finalize", P(ws.part_dst), B * ws.nchunk, 8, float(B * C * S), tr, P(g["firstBN.weight"]),
-          P(g["firstBN.bias"]), b1 + 4 * 32, b1 + 4 * 40, st)
+        # the finishing work behind the depthwise pass in ONE launch: depthwiseConv.weight (fixed-order sum of the partial
+        # rows), firstBN's backward sums -> its gradients and the m1 / m2 the FIR weight gradient folds in, and - eval-mode
+        # step - depthwiseBN's, which left from the same pass
+        bn2job = (None, 0, 0, 0.0, 0, None, None, None, None) if training else \
+            (P(ws.part_dw), B * ws.nchunk, 64, float(B * S), tr, P(g["depthwiseBN.weight"]), P(g["depthwiseBN.bias"]),
+             b2 + 4 * 256, b2 + 4 * 320)
+        L("eav_reduce_and_bn_bwd_finalize", P(ws.part_dw2), B * ws.nchunk, 64 * C, 64 * C, P(g["depthwiseConv.weight"]),
+          P(ws.part_dst), B * ws.nchunk, 8, float(B * C * S), tr, P(g["firstBN.weight"]), P(g["firstBN.bias"]), b1 + 4 * 32,
+          b1 + 4 * 40, *bn2job, st)
         # firstConv weight gradient (BN backward folded into the operand staging)
         if self._use_fft():
             if ws.fft_ws is None:
@@ -603,10 +615,23 @@ class GraphStep:
 
         def compute():       # batch gather + forward + loss + backward
             if hasattr(model, "forward_indexed") and xs.is_cuda and xs.dim() == 4 and xs.is_contiguous():
-                # EEGNet_tor reads the batch in place through the index vector: only the labels are gathered
+                # EEGNet_tor reads the batch in place through the index vector: only the labels are gathered - by the
+                # model's own step-counter launch where it has one (eav_step_begin: the label gather, the optimiser's step
+                # count and the dropout / BatchNorm counters in ONE graph node instead of three)
                 targets = torch.empty(batch, dtype=torch.long, device=dev)
-                _lib.call("eav_gather_i64", ys.data_ptr(), self.idx.data_ptr(), targets.data_ptr(), batch, _lib.stream_ptr())
-                scores = model.forward_indexed(xs, self.idx)
+                merged = False
+                if hasattr(model, "_step_begin") and not getattr(model, "_generic", False):
+                    cnt = optimizer.device_step_counter()
+                    model._step_begin = (cnt.data_ptr(), ys.data_ptr(), self.idx.data_ptr(), targets.data_ptr(), batch)
+                    scores = model.forward_indexed(xs, self.idx)
+                    merged = model._step_begin is None
+                    model._step_begin = None
+                    if merged:
+                        optimizer.step_counted = True
+                else:
+                    scores = model.forward_indexed(xs, self.idx)
+                if not merged:
+                    _lib.call("eav_gather_i64", ys.data_ptr(), self.idx.data_ptr(), targets.data_ptr(), batch, _lib.stream_ptr())
             else:
                 data, targets = gather_batch(xs, ys, self.idx)
                 scores = model(data)

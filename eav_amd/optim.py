@@ -70,12 +70,24 @@ class FusedAdam(torch.optim.Optimizer):
         self._flat_state = {}
         self.capturable = capturable
         self._dev_step = None
+        # capturable: set by a caller that increments the device step count itself at the start of the step, in a launch
+        # it issues anyway (GraphStep: eav_step_begin) - step() then skips its own eav_counter_inc for that one call
+        self.step_counted = False
 
     def _launch(self, p_ptr, g_ptr, m_ptr, v_ptr, n, group, step):
         b1, b2 = group["betas"]
         _lib.call("eav_adam_step", p_ptr, g_ptr, m_ptr, v_ptr, n, float(group["lr"]), float(b1), float(b2),
                   float(group["eps"]), float(group["weight_decay"]), int(step), int(bool(group["decoupled"])),
                   None if self._dev_step is None else self._dev_step.data_ptr(), _lib.stream_ptr())
+
+    def device_step_counter(self):
+        """The device-resident step count of a capturable optimiser (created on first use)."""
+        if not self.capturable:
+            return None
+        if self._dev_step is None:
+            dev = next(p for g in self.param_groups for p in g["params"]).device
+            self._dev_step = torch.zeros((), dtype=torch.int64, device=dev)
+        return self._dev_step
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -84,7 +96,10 @@ class FusedAdam(torch.optim.Optimizer):
             if self._dev_step is None:
                 dev = next(p for g in self.param_groups for p in g["params"]).device
                 self._dev_step = torch.zeros((), dtype=torch.int64, device=dev)
-            _lib.call("eav_counter_inc", self._dev_step.data_ptr(), _lib.stream_ptr())
+            if self.step_counted:
+                self.step_counted = False
+            else:
+                _lib.call("eav_counter_inc", self._dev_step.data_ptr(), _lib.stream_ptr())
         for group in self.param_groups:
             runs = []  # (p_ptr, g_ptr, m_ptr, v_ptr, numel, step) candidates for merging
             touched = {}

@@ -40,6 +40,14 @@ int eav_bn_finalize(const float* part, int nparts, int nch, double count, const 
 /* BatchNorm backward sums -> dgamma, dbeta and the two means of the input-gradient formula. */
 int eav_bn_bwd_finalize(const float* part, int nparts, int nch, double count, int training, float* dgamma,
                         float* dbeta, float* m1, float* m2, void* stream);
+/* eav_reduce_partials(part, nparts, stride, n, 1, out) and one or two eav_bn_bwd_finalize jobs (part_b = NULL: one) in ONE
+ * launch - the same arithmetic on disjoint block ranges, the same bits (autograd of EEGNet_tor.py:52-54: depthwiseConv.weight
+ * and firstBN - and, in the eval-mode step, depthwiseBN - behind eav_eegnet_dw_bwd_fused). */
+int eav_reduce_and_bn_bwd_finalize(const float* part, int nparts, int64_t stride, int n, float* out,
+                                   const float* part_a, int nparts_a, int nch_a, double count_a, int training_a,
+                                   float* dgamma_a, float* dbeta_a, float* m1_a, float* m2_a,
+                                   const float* part_b, int nparts_b, int nch_b, double count_b, int training_b,
+                                   float* dgamma_b, float* dbeta_b, float* m1_b, float* m2_b, void* stream);
 /* weight.data.renorm_(p=2, dim=0, maxnorm) - the max-norm hooks, EEGNet_tor.py:33-34,47-48. */
 int eav_renorm_rows(float* w, int rows, int cols, float maxnorm, void* stream);
 /* both hooks of EEGNet_tor.forward (depthwiseConv.weight, dense.weight) in one launch */
@@ -238,6 +246,11 @@ int eav_gather_i64(const int64_t* src, const int64_t* idx, int64_t* out, int n, 
 /* *counter += 1 on the stream (device-resident step counters for hipGraph replay). */
 int eav_counter_inc(int64_t* counter, void* stream);
 int eav_counter_inc4(int64_t* c0, int64_t* c1, int64_t* c2, int64_t* c3, void* stream);   /* distinct counters; NULL = skip */
+/* The start of a captured training step in one launch (EEGNet_tor.py:100-104): up to five DISTINCT step counters + 1 (NULL =
+ * skip: dropout stream, the three BatchNorm num_batches_tracked, the optimiser's step count) and out[i] = labels[idx[i]] for
+ * i < n (n = 0: counters only). */
+int eav_step_begin(int64_t* c0, int64_t* c1, int64_t* c2, int64_t* c3, int64_t* c4, const int64_t* labels,
+                   const int64_t* idx, int64_t* out, int n, void* stream);
 
 /* ---- AST / ViT encoders (HF ASTForAudioClassification / ViTForImageClassification as called at
  *      Transformer_Audio.py:22,72 and Transformer_Vision.py:29,92) ------------------------------ */

@@ -634,6 +634,60 @@ def test_step_prologue_is_prep_weights_plus_the_step_counters(L):
     assert torch.equal(ref_f.view(64, 16, 64), w.permute(1, 2, 0))        # wT_fwd[(i*16+k)][o] = W[o][i][k]
 
 
+def test_step_begin_is_the_counters_plus_the_label_gather(L):
+    """eav_step_begin (GraphStep's first node): five distinct counters + 1, NULL ones skipped, labels gathered - what
+    eav_counter_inc4 + eav_counter_inc + eav_gather_i64 did in three launches."""
+    cnt = torch.tensor([5, 0, 41, 7, 100, 9], dtype=torch.int64, device="cuda")
+    c = cnt.data_ptr()
+    labels = torch.arange(200, dtype=torch.int64, device="cuda") % 5
+    idx = torch.randperm(200, generator=torch.Generator().manual_seed(3))[:64].cuda()
+    out = torch.full((64,), -1, dtype=torch.int64, device="cuda")
+    for _ in range(3):
+        L.call("eav_step_begin", c, None, c + 16, c + 24, c + 32, labels.data_ptr(), idx.data_ptr(), out.data_ptr(), 64, None)
+    L.call("eav_step_begin", None, None, None, None, c + 40, None, None, None, 0, None)       # counters only
+    torch.cuda.synchronize()
+    assert cnt.tolist() == [8, 0, 44, 10, 103, 10]
+    assert torch.equal(out, labels[idx])
+    ref = torch.empty_like(out)
+    L.call("eav_gather_i64", labels.data_ptr(), idx.data_ptr(), ref.data_ptr(), 64, None)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    out2 = torch.full((300,), -1, dtype=torch.int64, device="cuda")                              # more than one block of labels
+    idx2 = torch.randint(0, 200, (300,), generator=torch.Generator().manual_seed(4)).cuda()
+    L.call("eav_step_begin", None, None, None, None, None, labels.data_ptr(), idx2.data_ptr(), out2.data_ptr(), 300, None)
+    torch.cuda.synchronize()
+    assert torch.equal(out2, labels[idx2])
+
+
+@pytest.mark.parametrize("nparts,n,two", [(640, 1920, False), (640, 1920, True), (3, 448, True), (20, 64 * 30, False),
+                                           (640, 64 * 128, True), (7, 450, False)])
+def test_reduce_and_bn_bwd_finalize_is_the_separate_launches(L, nparts, n, two):
+    """eav_reduce_and_bn_bwd_finalize (one graph node behind eav_eegnet_dw_bwd_fused) against eav_reduce_partials + one / two
+    eav_bn_bwd_finalize: the same bits - also for the shapes it hands to the separate kernels itself (n >= 8192, n % 4 != 0)."""
+    part = dev(synth.normal(71, (nparts, n)))
+    pa, pb = dev(synth.normal(72, (nparts, 16))), dev(synth.normal(73, (nparts * 2, 128)))
+    ref_out = torch.empty(n, device="cuda")
+    refs = [[torch.empty(ch, device="cuda") for _ in range(4)] for ch in (8, 64)]
+    L.call("eav_reduce_partials", part.data_ptr(), nparts, n, n, 1.0, ref_out.data_ptr(), None)
+    L.call("eav_bn_bwd_finalize", pa.data_ptr(), nparts, 8, 1234.0, 1, *[t.data_ptr() for t in refs[0]], None)
+    L.call("eav_bn_bwd_finalize", pb.data_ptr(), 2 * nparts, 64, 77.0, 0, *[t.data_ptr() for t in refs[1]], None)
+    out = torch.full((n,), float("nan"), device="cuda")
+    got = [[torch.full((ch,), float("nan"), device="cuda") for _ in range(4)] for ch in (8, 64)]
+    jb = (pb.data_ptr(), 2 * nparts, 64, 77.0, 0, *[t.data_ptr() for t in got[1]]) if two else \
+        (None, 0, 0, 0.0, 0, None, None, None, None)
+    L.call("eav_reduce_and_bn_bwd_finalize", part.data_ptr(), nparts, n, n, out.data_ptr(), pa.data_ptr(), nparts, 8, 1234.0, 1,
+           *[t.data_ptr() for t in got[0]], *jb, None)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref_out)
+    for a, b in zip(got[0], refs[0]):
+        assert torch.equal(a, b)
+    if two:
+        for a, b in zip(got[1], refs[1]):
+            assert torch.equal(a, b)
+        assert float(got[1][2].abs().max()) == 0.0          # training = 0: m1 = m2 = 0
+    close(out, part.double().sum(0), 1e-5, 1e-5, "reduced partials")
+
+
 @pytest.mark.parametrize("B,C,S,drop", [(2, 30, 500, 0.5), (3, 30, 200, 0.25), (2, 7, 132, 0.0), (1, 30, 2052, 0.5),
                                         (2, 3, 512, -0.5), (2, 30, 256, 0.5), (1, 5, 516, 0.0)])
 def test_dw_bwd_fused_matches_apply_then_dw_bwd(L, B, C, S, drop):

@@ -326,8 +326,14 @@ struct DwFuse {
 // CG: channel groups for short rows, as in dw_fwd_kernel - every group forms dz for the row's samples (the same loads: L1
 // hits), group j walks channels j, j + CG, ...; g1 and the depthwise weight gradient are per channel, the two statistics
 // are block sums anyway.
+#ifndef DWB_WPE          // A/B builds: minimum waves per SIMD asked of the register allocator (0 = none), rows fetched ahead
+#define DWB_WPE 0
+#endif
+#ifndef DWB_PF
+#define DWB_PF 2
+#endif
 template <bool FUSED, int CG, int NT, bool SUMS2 = false>      // SUMS2: the eval-mode form (fu.part2)
-__global__ __launch_bounds__(NT) void dw_bwd_kernel(const float* __restrict__ y1, const float* __restrict__ dz,
+__global__ __launch_bounds__(NT, DWB_WPE) void dw_bwd_kernel(const float* __restrict__ y1, const float* __restrict__ dz,
                                                      const float* __restrict__ bn1, const float* __restrict__ w2,
                                                      float* __restrict__ g1, float* __restrict__ part_st,
                                                      float* __restrict__ part_w, int C, int S, DwFuse fu) {
@@ -401,7 +407,7 @@ __global__ __launch_bounds__(NT) void dw_bwd_kernel(const float* __restrict__ y1
   const int64_t base = ((int64_t)b * F1 + f) * C * S;
   // y1 rows in flight per thread ahead of the one being worked on (16 bytes each).  (Round 5: 4 / 6 rows ahead measured
   // 399 / 350 us against 349 us with 2 at [64,1,30,10000] - the pass is not limited by bytes in flight.)
-  constexpr int PF = 2;
+  constexpr int PF = DWB_PF;
   float nx[PF][4];
 #pragma unroll
   for (int q = 0; q < PF; ++q)

@@ -543,3 +543,36 @@ def test_no_grad_eval_forward_fuses_block1_and_matches_the_unfused_path(S, B):
     with torch.no_grad():
         model(xd)
         assert not model._infer                            # train mode under no_grad keeps the batch-statistics kernels
+
+
+def test_bench_subject_reset_from_the_device_table_is_the_host_reset():
+    """bench.py's N > 1 job gives every subject a fresh model (EEGNet_tor.py:159-162).  Round 5 built it on the host inside the
+    timed region; EEGRun.prepare_resets now builds the same states BEFORE it into a device table, EEGRun.reset_model copies a
+    row.  Same bits: parameters, BatchNorm buffers, Adam state and the losses of the steps that follow."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_reset", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    run = bench.EEGRun(torch.device("cuda", 0), 0, 1, 16, 8)
+    for i in range(4):                               # (eager, eager, capture, replay: the optimiser state exists and is non-zero)
+        run.step(i)
+    run.prepare_resets([1001, 1002])
+    outs = []
+    for how in ("table", "host", "table"):
+        if how == "table":
+            run.reset_model(1002)
+        else:
+            run._reset_model_host(1002)
+        run.model._fwd_counter.zero_()                 # (the dropout stream's step count is not part of a model's state)
+        torch.cuda.synchronize()
+        state = [run.model._flat[0].clone()] + [b.clone() for b in run.model.buffers()] + \
+                [f[k].clone() for f in run.opt._flat_state.values() for k in ("m", "v")] + [run.opt._dev_step.clone()]
+        losses = torch.stack([run.step(i).clone() for i in range(3)])
+        outs.append((state, losses))
+    assert float(outs[0][0][-1]) == 0.0 and all(float(t.abs().max()) == 0.0 for t in outs[0][0][-3:-1])
+    for a, b in zip(outs[0][0], outs[1][0]):
+        assert torch.equal(a, b)
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][1], outs[2][1])
+    run.reset_model(1001)
+    assert not torch.equal(run.model._flat[0], outs[0][0][0])          # another subject: other weights

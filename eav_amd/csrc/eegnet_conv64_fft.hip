@@ -188,7 +188,10 @@ __global__ __launch_bounds__(256) void c64_pack_fft_kernel(const float* __restri
 // tiles of 32 are staged into LDS (row stride 129: the A-operand reads hit 32 banks), next tile prefetched in registers.
 constexpr int XS = 129;
 
-__global__ __launch_bounds__(256) void c64_bin_gemm_kernel(const float* __restrict__ Z, const float* __restrict__ Bm,
+#ifndef C64V_WPE        // A/B builds: minimum waves per SIMD asked of the register allocator for the per-bin GEMM (0 = none)
+#define C64V_WPE 0
+#endif
+__global__ __launch_bounds__(256, C64V_WPE) void c64_bin_gemm_kernel(const float* __restrict__ Z, const float* __restrict__ Bm,
                                                            float* __restrict__ C, int ncolp) {
   __shared__ float xs[2][32 * XS];
   const int bin = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -3,7 +3,8 @@
 K = 768) with the epilogues the training step really uses, against the same launches from a library built with
 -DEAV_ABL=64 (gemm_sp.hip: the K loop alone, nothing written).  Build first, here:
     tools/probes/build_variant.sh noepi gemm_sp -DEAV_ABL=64
-then on the GPU box:  python tools/probes/gemm_epilogue_share.py   (loads both libraries itself)."""
+then on the GPU box:  python tools/probes/gemm_epilogue_share.py [libeav_noepi.so]   (loads both libraries itself; EAV_LIB_PATH
+selects the full library - e.g. round 5's kernel behind this round's ABI, with its own -DEAV_ABL=64 build as the argument)."""
 import ctypes as C
 import os
 import sys
@@ -23,6 +24,11 @@ sig = [v, v, v, v, v, i32, i32, i32, i32, i32, i64, i64, f32, v, i32, v, v, i32,
 abl.eav_gemm_sp_ex.argtypes = sig
 full = _lib.load()
 SLOT = 4128
+# warm the GPU first (a process's first launches run 10-20 % slow: clocks of a GPU that has been idle)
+_w = torch.randn(8192, 8192, device="cuda")
+for _ in range(40):
+    _w @ _w
+torch.cuda.synchronize()
 print("product                          full us   K loop alone us   epilogue share   algorithmic TFLOP/s (full / K loop alone)")
 for tag, M in (("vit", 25216), ("ast", 9712)):
     for name, N, K, gelu, bias, want_pre, want_c, want_planes, colsum, amax in (

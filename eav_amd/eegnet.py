@@ -620,6 +620,7 @@ class GraphStep:
                 # count and the dropout / BatchNorm counters in ONE graph node instead of three)
                 targets = torch.empty(batch, dtype=torch.long, device=dev)
                 merged = False
+                optimizer.step_counted = False       # (a step that failed between its two halves must not leave the flag set)
                 if hasattr(model, "_step_begin") and not getattr(model, "_generic", False):
                     cnt = optimizer.device_step_counter()
                     model._step_begin = (cnt.data_ptr(), ys.data_ptr(), self.idx.data_ptr(), targets.data_ptr(), batch)

@@ -1,7 +1,7 @@
 // Canonical EEGNet (CNN_torch/CNN_EEG.py:7-67) - the blocks that differ from EEGNet_tor.py:
 //   block1: Conv2d(1,F1,(1,K1),'same') -> BN -> depthwise Conv2d(F1,D*F1,(Chans,1),groups=F1) -> BN -> ELU -> pool4
 //   block2: depthwise Conv2d(C2,C2,(1,K2),'same',groups=C2) -> pointwise Conv2d(C2,F2,1) -> BN -> ELU -> pool8
-// with run-time F1 <= 16, D <= 8, F2 <= 64, K1 <= 512, K2 <= 32, Chans <= 128.  The model is a few MFLOP per sample
+// with run-time F1 <= 16, D <= 8, F2 <= 64, K1 <= 512, K2 <= 32, Chans <= 256 (high-density montages).  The model is a few MFLOP per sample
 // at its default size (64 x 128 input), so these are direct LDS-tiled kernels, not MFMA ones; BN -> ELU -> pool ->
 // dropout and the classifier reuse eegnet_block.hip / head_optim.hip.  Reductions are two-stage and ordered
 // (per-block partials + eav_reduce_partials / eav_bn_finalize): no float atomics, bit-reproducible.
@@ -13,6 +13,7 @@ namespace {
 constexpr int TT = 1024;   // tconv forward: time samples per block
 constexpr int WT = 512;    // tconv wgrad: time samples per work item
 constexpr int KMAX = 512;
+constexpr int CGMAX = 256;   // electrodes of the spatial (depthwise) kernels: their weight rows live in LDS
 constexpr int ST = 128;    // separable conv forward: time samples per block
 constexpr int PT = 64;     // pointwise backward: time samples per work item
 
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(256) void spatial_fwd_kernel(const float* __restric
                                                           const float* __restrict__ wd, float* __restrict__ z,
                                                           float* __restrict__ part, int C, int S, int F1, int D,
                                                           int elu) {
-  __shared__ float wl[8][128];
+  __shared__ float wl[8][CGMAX];
   __shared__ float red[4 * 16];
   const int tile = blockIdx.x, f = blockIdx.y, b = blockIdx.z, tid = threadIdx.x, C2 = F1 * D;
   for (int i = tid; i < 8 * C; i += 256) {
@@ -253,8 +254,8 @@ __global__ __launch_bounds__(256) void spatial_bwd_kernel(const float* __restric
                                                           float* __restrict__ g1, float* __restrict__ stat_part,
                                                           float* __restrict__ w_part, int C, int S, int F1, int D,
                                                           int elu) {
-  __shared__ float wl[8][128];
-  __shared__ float wred[4][8][128];
+  __shared__ float wl[8][CGMAX];
+  __shared__ float wred[4][8][CGMAX];
   __shared__ float red[4 * 2];
   const int tile = blockIdx.x, f = blockIdx.y, b = blockIdx.z, tid = threadIdx.x, C2 = F1 * D;
   const int lane = tid & 63, wave = tid >> 6;
@@ -638,8 +639,8 @@ extern "C" int eav_tconv_wgrad(const float* x, const float* y1, const float* g1,
 }
 
 static int spatial_ok(const char* who, int B, int C, int S, int F1, int D) {
-  if (!(B > 0 && C >= 1 && C <= 128 && S > 0 && F1 >= 1 && F1 <= 16 && D >= 1 && D <= 8))
-    return eav_set_error(EAV_EINVAL, "%s: need Chans<=128, F1<=16, D<=8 (got B=%d C=%d S=%d F1=%d D=%d)", who, B, C,
+  if (!(B > 0 && C >= 1 && C <= CGMAX && S > 0 && F1 >= 1 && F1 <= 16 && D >= 1 && D <= 8))
+    return eav_set_error(EAV_EINVAL, "%s: need Chans<=256, F1<=16, D<=8 (got B=%d C=%d S=%d F1=%d D=%d)", who, B, C,
                          S, F1, D);
   return EAV_OK;
 }

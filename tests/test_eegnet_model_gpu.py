@@ -167,6 +167,40 @@ def test_generic_widths_train_through_trainer_uni_like_the_oracle():
         close(got[k], st.Bf[k].numpy(), 1e-3, 1e-4, k)
 
 
+@pytest.mark.parametrize("chans,F1,D,F2,klen", [(200, 4, 2, 8, 64), (256, 8, 2, 16, 125), (129, 3, 1, 5, 17)])
+def test_generic_path_on_high_density_montages_against_oracle(chans, F1, D, F2, klen):
+    """More than 128 electrodes (round 6: the spatial kernels' LDS weight rows hold 256): one training step - probabilities,
+    loss, every gradient - of the run-time-parametrised path against the CPU oracle, at the bounds of the other generic tests."""
+    from eav_amd.eegnet import EEGNet_tor
+    from eav_amd.optim import CrossEntropyLoss
+    from oracle import eegnet_oracle as orc
+    a = dict(nb=5, chans=chans, klen=klen, F1=F1, D=D, F2=F2)
+    S, B = 256, 6
+    sd = eegnet_weights(43, S, **a)
+    x, y = synth.eeg_batch(430, B, chans, S, 5)
+    m = EEGNet_tor(5, Chans=chans, Samples=S, kernLength=klen, F1=F1, D=D, F2=F2, dropoutRate=0.0)
+    full = m.state_dict()
+    full.update({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+    m.load_state_dict(full)
+    m = m.cuda().train()
+    assert m._generic
+    scores = m(torch.from_numpy(x).cuda())
+    loss = CrossEntropyLoss()(scores, torch.from_numpy(y).cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    st = orc.Stepper({k: torch.from_numpy(sd[k].copy()) for k in orc.PARAM_NAMES},
+                     {k: torch.from_numpy(sd[k].copy()) for k in orc.BUFFER_NAMES}, lr=1e-3, drop_p=0.0)
+    probs, lref, grads = st.step(torch.from_numpy(x), torch.from_numpy(y), True, None)
+    close(scores, probs.numpy(), 1e-4, 2e-5, "probs")
+    close(loss, lref.numpy(), 1e-5, 1e-5, "loss")
+    named = dict(m.named_parameters())
+    for k in PN:
+        ref = grads[k].numpy()
+        close(named[k].grad, ref, 1e-3, 1e-3 * np.abs(ref).max(), f"grad.{k}")
+    with pytest.raises(NotImplementedError):
+        EEGNet_tor(5, Chans=257, Samples=S, kernLength=klen, F1=F1, D=D, F2=F2)
+
+
 def test_s10000_matches_reference_golden_and_oracle(golden_dir):
     from eav_amd.optim import CrossEntropyLoss
     from oracle import eegnet_oracle as orc

@@ -79,10 +79,10 @@ class EEGNet(nn.Module):
     def __init__(self, nb_classes, Chans=64, Samples=128, dropoutRate=0.5, kernLength=64, F1=8, D=2, F2=16,
                  norm_rate=0.25):
         super().__init__()
-        if not (1 <= F1 <= 16 and 1 <= D <= 8 and D * F1 <= 64 and 1 <= F2 <= 64 and 1 <= kernLength <= 512
+        if not (1 <= F1 <= 16 and 1 <= D <= 8 and D * F1 <= 64 and 1 <= F2 <= 64 and 1 <= kernLength <= 1024
                 and 1 <= Chans <= 256 and 1 <= nb_classes <= 16 and Samples >= 32):
             raise NotImplementedError("eav_amd.EEGNet: the gfx950 kernels cover F1<=16, D<=8, D*F1<=64, F2<=64, "
-                                      "kernLength<=512, Chans<=256, nb_classes<=16, Samples>=32")
+                                      "kernLength<=1024, Chans<=256, nb_classes<=16, Samples>=32")
         self.Chans, self.Samples = Chans, Samples
         # the reference's modules at the reference's indices (:20-42): identical state_dict keys and default init
         self.block1 = nn.Sequential(

@@ -1,7 +1,7 @@
 // Canonical EEGNet (CNN_torch/CNN_EEG.py:7-67) - the blocks that differ from EEGNet_tor.py:
 //   block1: Conv2d(1,F1,(1,K1),'same') -> BN -> depthwise Conv2d(F1,D*F1,(Chans,1),groups=F1) -> BN -> ELU -> pool4
 //   block2: depthwise Conv2d(C2,C2,(1,K2),'same',groups=C2) -> pointwise Conv2d(C2,F2,1) -> BN -> ELU -> pool8
-// with run-time F1 <= 16, D <= 8, F2 <= 64, K1 <= 512, K2 <= 32, Chans <= 256 (high-density montages).  The model is a few MFLOP per sample
+// with run-time F1 <= 16, D <= 8, F2 <= 64, K1 <= 1024, K2 <= 32, Chans <= 256 (high-density montages, 2 kHz recordings).  The model is a few MFLOP per sample
 // at its default size (64 x 128 input), so these are direct LDS-tiled kernels, not MFMA ones; BN -> ELU -> pool ->
 // dropout and the classifier reuse eegnet_block.hip / head_optim.hip.  Reductions are two-stage and ordered
 // (per-block partials + eav_reduce_partials / eav_bn_finalize): no float atomics, bit-reproducible.
@@ -12,19 +12,19 @@ namespace {
 
 constexpr int TT = 1024;   // tconv forward: time samples per block
 constexpr int WT = 512;    // tconv wgrad: time samples per work item
-constexpr int KMAX = 512;
+constexpr int KMAX = 1024;
 constexpr int CGMAX = 256;   // electrodes of the spatial (depthwise) kernels: their weight rows live in LDS
 constexpr int ST = 128;    // separable conv forward: time samples per block
 constexpr int PT = 64;     // pointwise backward: time samples per work item
 
 // ------------------------------------------------------------------------------------ tconv_fwd
 // y1[b,f,c,t] = sum_j w[f,j] * x[b,c,t+j-padl]; part[blk][0..F1) = sum y1, [F1..2F1) = sum y1^2 over the block.
-template <int NG>
+template <int NG, int KM = KMAX>      // KM: taps the LDS images are sized for (512: the occupancy of the usual filters)
 __global__ __launch_bounds__(256) void tconv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         float* __restrict__ y1, float* __restrict__ part, int C,
                                                         int S, int F1, int K, int padl) {
-  __shared__ float xs[TT + KMAX + 4];
-  __shared__ __attribute__((aligned(16))) float ws[8 * NG][KMAX + 4];
+  __shared__ float xs[TT + KM + 4];
+  __shared__ __attribute__((aligned(16))) float ws[8 * NG][KM + 4];
   __shared__ float red[4 * 16];
   const int tile = blockIdx.x, c = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
   const int t0 = tile * TT, K4 = (K + 3) & ~3;
@@ -150,24 +150,29 @@ __global__ __launch_bounds__(256) void tconv_wgrad_kernel(const float* __restric
     }
     __syncthreads();
   }
-  // combine the time slices in a fixed order, then one partial row per block
-  float* red = dys;   // 256 * NI * FW floats <= WT * FW
+  // combine the time slices in a fixed order, then one partial row per block - two lag groups at a time: the exchange buffer
+  // (the dy tile, WT * FW floats) holds 256 * 2 * FW
+  float* red = dys;
 #pragma unroll
-  for (int i = 0; i < NI; ++i)
+  for (int ib = 0; ib < NI; ib += 2) {
 #pragma unroll
-    for (int f = 0; f < FW; ++f) red[(i * FW + f) * 256 + tid] = acc[i][f];
-  __syncthreads();
-  if (slice == 0) {
+    for (int i = ib; i < ib + 2 && i < NI; ++i)
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int j = jl + JW * i;
+      for (int f = 0; f < FW; ++f) red[((i - ib) * FW + f) * 256 + tid] = acc[i][f];
+    __syncthreads();
+    if (slice == 0) {
 #pragma unroll
-      for (int f = 0; f < FW; ++f) {
-        float s = 0.f;
-        for (int sl = 0; sl < nsl; ++sl) s += red[(i * FW + f) * 256 + sl * JW + jl];
-        if (f < F1 && j < K) part[(int64_t)blockIdx.x * F1 * K + f * K + j] = s;
+      for (int i = ib; i < ib + 2 && i < NI; ++i) {
+        const int j = jl + JW * i;
+#pragma unroll
+        for (int f = 0; f < FW; ++f) {
+          float s = 0.f;
+          for (int sl = 0; sl < nsl; ++sl) s += red[((i - ib) * FW + f) * 256 + sl * JW + jl];
+          if (f < F1 && j < K) part[(int64_t)blockIdx.x * F1 * K + f * K + j] = s;
+        }
       }
     }
+    if (ib + 2 < NI) __syncthreads();
   }
 }
 
@@ -582,7 +587,7 @@ __global__ __launch_bounds__(256) void dconv_wgrad_kernel(const float* __restric
 // =============================================================================================== C ABI
 static int tconv_ok(const char* who, int B, int C, int S, int F1, int K) {
   if (!(B > 0 && C > 0 && S > 0 && F1 >= 1 && F1 <= 16 && K >= 1 && K <= KMAX))
-    return eav_set_error(EAV_EINVAL, "%s: need F1<=16, kernLength<=512 (got B=%d C=%d S=%d F1=%d K=%d)", who, B, C, S,
+    return eav_set_error(EAV_EINVAL, "%s: need F1<=16, kernLength<=1024 (got B=%d C=%d S=%d F1=%d K=%d)", who, B, C, S,
                          F1, K);
   return EAV_OK;
 }
@@ -603,12 +608,14 @@ extern "C" int eav_tconv_fwd(const float* x, const float* w, float* y1, float* s
   EAV_REQUIRE(C <= 65535 && B <= 65535, "eav_tconv_fwd: grid too large");
   const dim3 grid(cdiv(S, TT), C, B);
   const int padl = (K - 1) / 2;
-  if (F1 <= 8)
-    hipLaunchKernelGGL(tconv_fwd_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, x, w, y1, stat_part, C, S, F1, K,
-                       padl);
-  else
-    hipLaunchKernelGGL(tconv_fwd_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, x, w, y1, stat_part, C, S, F1, K,
-                       padl);
+#define EAV_TF(NG, KM)                                                                                                \
+  hipLaunchKernelGGL((tconv_fwd_kernel<NG, KM>), grid, dim3(256), 0, (hipStream_t)stream, x, w, y1, stat_part, C, S, F1, \
+                     K, padl)
+  if (F1 <= 8 && K <= 512) EAV_TF(1, 512);
+  else if (F1 <= 8) EAV_TF(1, 1024);
+  else if (K <= 512) EAV_TF(2, 512);
+  else EAV_TF(2, 1024);
+#undef EAV_TF
   EAV_CHECK_LAUNCH("eav_tconv_fwd");
   return EAV_OK;
 }
@@ -630,9 +637,11 @@ extern "C" int eav_tconv_wgrad(const float* x, const float* y1, const float* g1,
   hipLaunchKernelGGL((tconv_wgrad_kernel<NG, NI_>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, y1, g1,         \
                      bn_params, part, B, C, S, F1, K, padl, JW, nitems)
   if (F1 <= 8 && NI == 1) EAV_TW(1, 1);
-  else if (F1 <= 8) EAV_TW(1, 2);
+  else if (F1 <= 8 && NI == 2) EAV_TW(1, 2);
+  else if (F1 <= 8) EAV_TW(1, 4);             // (513 .. 1024 taps)
   else if (NI == 1) EAV_TW(2, 1);
-  else EAV_TW(2, 2);
+  else if (NI == 2) EAV_TW(2, 2);
+  else EAV_TW(2, 4);
 #undef EAV_TW
   EAV_CHECK_LAUNCH("eav_tconv_wgrad");
   return EAV_OK;

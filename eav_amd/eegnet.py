@@ -156,10 +156,10 @@ class EEGNet_tor(nn.Module):
         # fp32-MFMA kernels; every other width the reference constructor accepts (:16-17) takes the run-time-parametrised
         # kernels of csrc/eegnet_canon.hip (`_generic`), whose LDS tiles bound it at the sizes below.
         self._generic = not (F1 == 8 and D == 8 and F2 == 64 and 1 <= kernLength <= 300 and 1 <= Chans <= 32)
-        if not (1 <= F1 <= 16 and 1 <= D <= 8 and F1 * D <= 64 and 1 <= F2 <= 64 and 1 <= kernLength <= 512
+        if not (1 <= F1 <= 16 and 1 <= D <= 8 and F1 * D <= 64 and 1 <= F2 <= 64 and 1 <= kernLength <= 1024
                 and 1 <= Chans <= 256 and 1 <= nb_classes <= 16 and Samples >= 32):
             raise NotImplementedError("eav_amd.EEGNet_tor: the gfx950 kernels cover F1<=16, D<=8, F1*D<=64, F2<=64, "
-                                      "kernLength<=512, Chans<=256, nb_classes<=16, Samples>=32")
+                                      "kernLength<=1024, Chans<=256, nb_classes<=16, Samples>=32")
         # same sub-modules in the same construction order as the reference (:21-48): identical
         # state_dict keys and identical consumption of the torch RNG by the default initialisers
         self.dropout = nn.Dropout(dropoutRate) if dropoutType == 'Dropout' else nn.Dropout2d(dropoutRate)

@@ -167,10 +167,12 @@ def test_generic_widths_train_through_trainer_uni_like_the_oracle():
         close(got[k], st.Bf[k].numpy(), 1e-3, 1e-4, k)
 
 
-@pytest.mark.parametrize("chans,F1,D,F2,klen", [(200, 4, 2, 8, 64), (256, 8, 2, 16, 125), (129, 3, 1, 5, 17)])
+@pytest.mark.parametrize("chans,F1,D,F2,klen", [(200, 4, 2, 8, 64), (256, 8, 2, 16, 125), (129, 3, 1, 5, 17), (30, 4, 2, 8, 700),
+                                                 (40, 16, 2, 16, 1024), (30, 8, 8, 64, 513)])
 def test_generic_path_on_high_density_montages_against_oracle(chans, F1, D, F2, klen):
-    """More than 128 electrodes (round 6: the spatial kernels' LDS weight rows hold 256): one training step - probabilities,
-    loss, every gradient - of the run-time-parametrised path against the CPU oracle, at the bounds of the other generic tests."""
+    """More than 128 electrodes (round 6: the spatial kernels' LDS weight rows hold 256) and more than 512 taps (the direct temporal
+    kernels stage up to 1024): one training step - probabilities, loss, every gradient - of the run-time-parametrised path against
+    the CPU oracle, at the bounds of the other generic tests."""
     from eav_amd.eegnet import EEGNet_tor
     from eav_amd.optim import CrossEntropyLoss
     from oracle import eegnet_oracle as orc
@@ -199,6 +201,8 @@ def test_generic_path_on_high_density_montages_against_oracle(chans, F1, D, F2, 
         close(named[k].grad, ref, 1e-3, 1e-3 * np.abs(ref).max(), f"grad.{k}")
     with pytest.raises(NotImplementedError):
         EEGNet_tor(5, Chans=257, Samples=S, kernLength=klen, F1=F1, D=D, F2=F2)
+    with pytest.raises(NotImplementedError):
+        EEGNet_tor(5, Chans=chans, Samples=S, kernLength=1025, F1=F1, D=D, F2=F2)
 
 
 def test_s10000_matches_reference_golden_and_oracle(golden_dir):

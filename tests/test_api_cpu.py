@@ -237,7 +237,8 @@ def test_unsupported_configurations_raise_not_silently_differ():
     ref = __import__("torch").nn
     assert not EEGNet_tor(5)._generic
     for kw in (dict(F1=4), dict(D=2), dict(F2=32), dict(kernLength=301), dict(Chans=33),
-               dict(F1=4, D=2, F2=16, kernLength=64, Chans=64, Samples=256)):
+               dict(F1=4, D=2, F2=16, kernLength=64, Chans=64, Samples=256), dict(kernLength=1024, Samples=2048),
+               dict(Chans=256)):
         m = EEGNet_tor(5, **kw)
         assert m._generic
         full = dict(F1=8, D=8, F2=64, kernLength=300, Chans=30, Samples=500)
@@ -247,7 +248,7 @@ def test_unsupported_configurations_raise_not_silently_differ():
         assert tuple(m.separableConv.weight.shape) == (full["F2"], full["F1"] * full["D"], 1, 16)
         assert tuple(m.dense.weight.shape) == (5, full["F2"] * (full["Samples"] // 32))
         assert isinstance(m.separableBN, ref.BatchNorm2d)
-    for kw in (dict(F1=32), dict(D=16), dict(F1=16, D=8), dict(F2=128), dict(kernLength=513), dict(Chans=129)):
+    for kw in (dict(F1=32), dict(D=16), dict(F1=16, D=8), dict(F2=128), dict(kernLength=1025), dict(Chans=257)):
         with pytest.raises(NotImplementedError):
             EEGNet_tor(5, **kw)
     # every dropoutType other than 'Dropout' is nn.Dropout2d in the reference (:21) - supported (per-map masks)

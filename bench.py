@@ -1080,7 +1080,7 @@ def bench_eeg_subjects(dev, rank, world, steps, warmup, solo=None, n_subjects=42
             raise SystemExit(f"a group of {len(ranks)} ranks cannot split the batch of {B_PER_GPU}")
         grun = EEGRun(dev, rank, len(ranks), B_PER_GPU // len(ranks), steps + warmup, subject=sub, group=groups[sub],
                       shard=(ranks.index(rank), len(ranks)))
-    for i in range(max(warmup, 3)):                          # (the third call captures the graph)
+    for i in range(3):                                       # set-up: two eager steps, the third call captures the graph
         solo.step(i)
         if grun is not None:
             grun.step(i)
@@ -1088,6 +1088,13 @@ def bench_eeg_subjects(dev, rank, world, steps, warmup, solo=None, n_subjects=42
     solo.prepare_resets([1000 + s for s in sched.solo[rank]] + ([1000 + mine[0]] if mine and grun is None else []))
     if grun is not None:
         grun.prepare_resets([1000 + mine[0]])
+    # the W warm-up steps come LAST, right in front of the timed region: the host work above (a second or so of model
+    # construction) leaves the GPU idle, and the first ~12 replays after an idle gap run 3-15 % slow (clocks:
+    # tools/probes/eeg_step_ramp2.py) - round 5's order (warm-up, then the host work) timed exactly those
+    for i in range(warmup):
+        solo.step(i)
+        if grun is not None:
+            grun.step(i)
     results = []
     if world > 1:
         dist.barrier()
@@ -1187,7 +1194,9 @@ def main():
         for i in range(3):
             loss = run.step(i)
     else:
-        for i in range(max(args.warmup, 3)):                 # (the third call captures the graph)
+        for i in range(3):                                   # set-up: two eager steps, the third call captures the graph
+            run.step(i)
+        for i in range(args.warmup):                         # the W warm-up steps: replays, like the K timed ones
             run.step(i)
         dt, loss = run.timed(args.steps, args.warmup)       # THE timed region: exactly K steps
     final_loss = float(loss.item())
@@ -1198,7 +1207,7 @@ def main():
     # its rate must reproduce the plain step rate, otherwise the N = 1 and N > 1 values would not be comparable
     subj_check = None
     if world == 1:
-        subj_check = bench_eeg_subjects(dev, rank, 1, args.steps, 0, solo=run, n_subjects=3)
+        subj_check = bench_eeg_subjects(dev, rank, 1, args.steps, args.warmup, solo=run, n_subjects=3)
         for i in range(3):
             run.step(i)
     peaks = measured_peaks(dev) if rank == 0 else None
@@ -1206,7 +1215,7 @@ def main():
     # eval-mode training step: what 349 of the reference's 350 epochs run (model.train() is called once, validate()
     # switches to eval mode and nothing switches back: SURVEY Q4, EEGNet_tor.py:97,119) - BatchNorm on running statistics
     model.eval()
-    for i in range(3):
+    for i in range(3 + args.warmup):
         run.step(i)
     dte, _ = run.timed(args.steps, args.warmup)
     model.train()
@@ -1223,7 +1232,7 @@ def main():
                 continue
             try:       # (a side leg must not cost the headline: its failure is reported in its place)
                 r2 = EEGRun(dev, rank, world, b_rank, args.steps + args.warmup)
-                for i in range(max(args.warmup, 3)):
+                for i in range(3 + args.warmup):             # set-up (two eager steps + the capture), then the W warm-up replays
                     r2.step(i)
                 d2, _ = r2.timed(args.steps, args.warmup)
                 multi[leg] = {

@@ -1174,6 +1174,9 @@ def main():
     # 1 % slower than the four that followed it (1.369 against 1.355 ms: clocks and caches of a GPU that has run ~10 ms of
     # work) - a training run is in the steady state, and the contract's W warm-up steps still precede the K timed ones
     from eav_amd import _lib as eavlib
+    if mode != "subjects":
+        for i in range(3):                                   # set-up first: two eager steps, the third call captures the graph
+            run.step(i)                                      # (its host work leaves the GPU idle for tens of milliseconds)
     n_eager = min(args.steps, 20)
     run.eager_step(args.warmup)
     torch.cuda.synchronize()
@@ -1194,8 +1197,6 @@ def main():
         for i in range(3):
             loss = run.step(i)
     else:
-        for i in range(3):                                   # set-up: two eager steps, the third call captures the graph
-            run.step(i)
         for i in range(args.warmup):                         # the W warm-up steps: replays, like the K timed ones
             run.step(i)
         dt, loss = run.timed(args.steps, args.warmup)       # THE timed region: exactly K steps
